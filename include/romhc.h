@@ -1,0 +1,147 @@
+/*
+ * romhc.h -- C-ABI of libromhc.so, the MI355X (gfx950) implementation of the
+ * ROMHighContrast snapshot-generation + reduced-basis hot path.
+ *
+ * The reference (agussomacal/ROMHighContrast) has no FFI layer: its boundary for this path is
+ * the Python API of src/lib/SolutionsManagers.py and src/lib/ReducedBasis.py.  Each entry point
+ * below names the reference interface it replaces (file:line, relative to the reference tree).
+ * The Python shim (romhighcontrast_amd/lib, re-exported as src.lib / lib) binds these
+ * with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; rom_last_error() returns a
+ *     thread-local, NUL-terminated description of the last failure on this thread.
+ *   - all floating point is IEEE fp64.  Bulk data lives in device buffers (rom_buf*), created
+ *     and destroyed explicitly; host arrays are caller-owned and only touched by
+ *     rom_buf_upload / rom_buf_download and the few *_host helpers.
+ *   - snapshot matrices are row-major (n_rows, dim): row = one FE vector over the inner
+ *     vertices in row-major (r, c) order -- exactly the reference's `solutions` arrays.
+ *   - parameters `a` are row-major (M, nrb*ncb): a[m][p*ncb+q], p = block row (y), q = block
+ *     column (x) -- the reference's a[m][p][q].
+ *   - all work is enqueued on the context's HIP stream; functions that return host data
+ *     synchronise that stream first.  One context per process per GPU.
+ */
+#ifndef ROMHC_H
+#define ROMHC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rom_ctx rom_ctx; /* one GPU + stream + workspace            */
+typedef struct rom_buf rom_buf; /* fp64 device buffer                      */
+typedef struct rom_fem rom_fem; /* FE space of one (blocks_geometry, N)    */
+
+#define ROM_OK 0
+#define ROM_ERR_INVALID 1  /* bad argument                                              */
+#define ROM_ERR_HIP 2      /* HIP runtime failure (message holds hipGetErrorString)     */
+#define ROM_ERR_NOT_SPD 3  /* a pivot was <= 0: maps to scipy.linalg.LinAlgError         */
+#define ROM_ERR_COMM 4     /* RCCL failure / librccl not loadable                        */
+#define ROM_ERR_NOMEM 5
+
+const char* rom_last_error(void);
+int rom_version(void);
+
+/* ---- context ------------------------------------------------------------------------- */
+int rom_device_count(int* n);
+int rom_init(int device, rom_ctx** out);
+int rom_shutdown(rom_ctx* ctx);
+int rom_synchronize(rom_ctx* ctx);
+/* workspace budget (bytes) for the factor storage of rom_solve_batch; default 24 GiB */
+int rom_set_workspace_limit(rom_ctx* ctx, size_t bytes);
+int rom_device_name(rom_ctx* ctx, char* out, size_t cap);
+
+/* HIP-event stopwatch on the context stream (bench.py's timed region) */
+int rom_timer_start(rom_ctx* ctx);
+int rom_timer_stop(rom_ctx* ctx, double* elapsed_ms);
+
+/* per-kernel HIP-event profiling: when enabled every kernel launch of the library is
+ * bracketed by an event pair on the launch stream; rom_profile_query sums them by name. */
+int rom_profile_enable(rom_ctx* ctx, int on);
+int rom_profile_reset(rom_ctx* ctx);
+int rom_profile_count(rom_ctx* ctx, int* n_kernels);
+int rom_profile_query(rom_ctx* ctx, int idx, char* name, size_t cap, double* total_ms, long* launches,
+                      double* flops, double* bytes);
+
+/* ---- device buffers ------------------------------------------------------------------- */
+int rom_buf_alloc(rom_ctx* ctx, size_t n_doubles, rom_buf** out);
+int rom_buf_free(rom_buf* b);
+int rom_buf_size(rom_buf* b, size_t* n_doubles);
+int rom_buf_upload(rom_buf* b, size_t offset, const double* host, size_t n);
+int rom_buf_download(rom_buf* b, size_t offset, double* host, size_t n);
+int rom_buf_fill(rom_buf* b, size_t offset, size_t n, double value);
+int rom_buf_copy(rom_buf* dst, size_t dst_off, rom_buf* src, size_t src_off, size_t n);
+/* dst[i, :] = src[rows[i], :] for row length `dim` (host index list; used by the greedy) */
+int rom_buf_gather_rows(rom_buf* dst, rom_buf* src, const int64_t* rows, int n_rows, size_t dim);
+
+/* ---- FE space: SolutionsManagerFEM.__init__ (src/lib/SolutionsManagers.py:146-219) ------ */
+/* Builds the parameter-independent tables of the substructured operator on the device
+ * (unit-block sine basis, harmonic-extension matrix, Dirichlet-to-Neumann blocks, symbolic
+ * tile Cholesky of the interface system).  Replaces the dense A_preassembled tensor. */
+int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** out);
+int rom_fem_destroy(rom_fem* fem);
+int rom_fem_dims(rom_fem* fem, int* nr, int* nc, int64_t* dim, int* n_interface, int* n_tiles);
+/* B_total (:177-185): dim doubles, host */
+int rom_fem_load_vector_host(rom_fem* fem, double* B_out);
+
+/* einsum('pqij,pq->ij') in stencil form (:19-23 / :187-215): for each of M parameters the
+ * three stencil arrays diag[M,nr,nc], east[M,nr,nc-1], north[M,nr-1,nc]. */
+int rom_assemble_batch(rom_fem* fem, rom_buf* a, int M, rom_buf* diag, rom_buf* east, rom_buf* north);
+
+/* generate_solutions (:64-68) = map(galerkin (:17-40)) : U[row0+m, :] = A(a_m)^{-1} B_total.
+ * Exact direct method (interface Schur complement + tile Cholesky + harmonic extension). */
+int rom_solve_batch(rom_fem* fem, rom_buf* a, int M, rom_buf* U, int64_t row0);
+/* flops / HBM bytes of the library's own algorithm for one snapshot solve, and the canonical
+ * banded-Cholesky figures of SURVEY.md 8(d) for comparison */
+int rom_solve_work(rom_fem* fem, double* flops_own, double* bytes_own, double* flops_banded,
+                   double* bytes_banded);
+
+/* Y[k,:] = A(coef) X[k,:], K rows.  mode 0: coef = a_one (k doubles, host) general blocks;
+ * mode 1: unit coefficient (A_preassembled4h1_norm, :49).  (the C A_pq contractions, :93-101) */
+int rom_stencil_apply(rom_fem* fem, const double* a_one_host, int unit, rom_buf* X, int64_t x_row0,
+                      int K, rom_buf* Y, int64_t y_row0);
+
+/* H10norm (:56-58): out[k] = sqrt(u_k^T A_1 u_k); out_host has K doubles.
+ * If V != NULL computes the norm of (U[u_row0+k] - V[v_row0+k]) instead (greedy residuals,
+ * src/lib/ReducedBasis.py:129). */
+int rom_h10norm(rom_fem* fem, rom_buf* U, int64_t u_row0, rom_buf* V, int64_t v_row0, int K,
+                double* out_host);
+/* l2norm (:60-62) */
+int rom_l2norm(rom_ctx* ctx, rom_buf* U, int64_t row0, int K, int64_t dim, double* out_host);
+
+/* ---- dense fp64 contractions on MFMA (v_mfma_f64_16x16x4_f64) --------------------------- */
+/* C[m,n] = alpha * sum_k A[m,k] B[n,k] + beta*C   (row-major, "NT": Gram / C A U^T) */
+int rom_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, rom_buf* A, size_t a_off,
+                int64_t lda, rom_buf* B, size_t b_off, int64_t ldb, double beta, rom_buf* C, size_t c_off,
+                int64_t ldc);
+/* C[m,n] = alpha * sum_k A[m,k] B[k,n] + beta*C   (row-major, "NN": lift c_i . basis, :106/:139) */
+int rom_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, rom_buf* A, size_t a_off,
+                int64_t lda, rom_buf* B, size_t b_off, int64_t ldb, double beta, rom_buf* C, size_t c_off,
+                int64_t ldc);
+
+/* batched reduced solves: for m<M: (sum_b w[m,b] * Ahat[b]) c_m = rhs[m or 0]  (n x n SPD).
+ * Ahat: (kb, n, n); w: (M, kb); rhs: (M, n) if rhs_per_system else (n); out c: (M, n).
+ * The reduced `galerkin` calls of generate_fm_solutions (:104-105) and project_solutions
+ * (:135-138). */
+int rom_reduced_solve_batch(rom_ctx* ctx, int n, int kb, int M, rom_buf* Ahat, rom_buf* w, rom_buf* rhs,
+                            int rhs_per_system, rom_buf* c_out);
+
+/* ---- multi-GPU: RCCL all-gather of the snapshot block --------------------- */
+/* id_out: 128 bytes (ncclUniqueId).  librccl is dlopen()ed on first use. */
+int rom_comm_unique_id(char* id_out, size_t cap);
+int rom_comm_init(rom_ctx* ctx, const char* id, size_t id_len, int rank, int nranks);
+int rom_comm_destroy(rom_ctx* ctx);
+/* recv[(r*count) ...] = send of rank r; count doubles per rank */
+int rom_comm_allgather(rom_ctx* ctx, rom_buf* send, size_t send_off, rom_buf* recv, size_t recv_off,
+                       size_t count);
+/* in-place max / sum all-reduce of n host doubles staged through the device (control plane:
+ * barrier + max-over-ranks timing of bench.py) */
+int rom_comm_allreduce_host(rom_ctx* ctx, double* vals, int n, int op /*0=sum,1=max*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROMHC_H */

@@ -1,0 +1,325 @@
+"""ctypes binding of libromhc.so (include/romhc.h).  Thin: prototypes, error mapping, handles.
+
+There is no CPU fallback: if the shared library is missing or no MI355X is visible the import of
+the product modules fails loudly (RomLibraryError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+from scipy.linalg import LinAlgError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libromhc.so")
+
+ROM_OK, ROM_ERR_INVALID, ROM_ERR_HIP, ROM_ERR_NOT_SPD, ROM_ERR_COMM, ROM_ERR_NOMEM = range(6)
+
+
+class RomLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_c_double_p = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/romhc.h declares
+PROTOTYPES = {
+    "rom_last_error": (C.c_char_p, []),
+    "rom_version": (C.c_int, []),
+    "rom_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rom_init": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "rom_shutdown": (C.c_int, [_vp]),
+    "rom_synchronize": (C.c_int, [_vp]),
+    "rom_set_workspace_limit": (C.c_int, [_vp, C.c_size_t]),
+    "rom_device_name": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    "rom_timer_start": (C.c_int, [_vp]),
+    "rom_timer_stop": (C.c_int, [_vp, _c_double_p]),
+    "rom_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "rom_profile_reset": (C.c_int, [_vp]),
+    "rom_profile_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "rom_profile_query": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_size_t, _c_double_p, C.POINTER(C.c_long),
+                                    _c_double_p, _c_double_p]),
+    "rom_buf_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "rom_buf_free": (C.c_int, [_vp]),
+    "rom_buf_size": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
+    "rom_buf_upload": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t]),
+    "rom_buf_download": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t]),
+    "rom_buf_fill": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_double]),
+    "rom_buf_copy": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t]),
+    "rom_buf_gather_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_size_t]),
+    "rom_fem_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "rom_fem_destroy": (C.c_int, [_vp]),
+    "rom_fem_dims": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64),
+                               C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rom_fem_load_vector_host": (C.c_int, [_vp, _vp]),
+    "rom_assemble_batch": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "rom_solve_batch": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64]),
+    "rom_solve_work": (C.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    "rom_stencil_apply": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _vp, C.c_int64]),
+    "rom_h10norm": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, _vp]),
+    "rom_l2norm": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
+    "rom_gemm_nt": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_double, _vp, C.c_size_t, C.c_int64,
+                              _vp, C.c_size_t, C.c_int64, C.c_double, _vp, C.c_size_t, C.c_int64]),
+    "rom_gemm_nn": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_double, _vp, C.c_size_t, C.c_int64,
+                              _vp, C.c_size_t, C.c_int64, C.c_double, _vp, C.c_size_t, C.c_int64]),
+    "rom_reduced_solve_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
+    "rom_comm_unique_id": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "rom_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),
+    "rom_comm_destroy": (C.c_int, [_vp]),
+    "rom_comm_allgather": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t]),
+    "rom_comm_allreduce_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+}
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen libromhc.so and attach prototypes.  No GPU is touched here."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RomLibraryError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C romhighcontrast_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load_library().rom_last_error().decode("utf-8", "replace")
+
+
+def check(status: int):
+    """Map a C status to the exception types the reference raises."""
+    if status == ROM_OK:
+        return
+    msg = last_error()
+    if status == ROM_ERR_NOT_SPD:
+        raise LinAlgError(msg)  # scipy.linalg.solve(assume_a='pos') raises this in the reference
+    if status == ROM_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RomLibraryError(f"libromhc error {status}: {msg}")
+
+
+def _host(arr: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(arr, dtype=np.float64)
+
+
+class Context:
+    """One GPU + stream.  Process-wide singleton per device (``get_context``)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        n = C.c_int(0)
+        try:
+            check(self.lib.rom_device_count(C.byref(n)))
+        except RomLibraryError as e:
+            raise RomLibraryError(f"no usable HIP device: {e}. libromhc needs an MI355X (gfx950).") from None
+        if n.value < 1:
+            raise RomLibraryError("no HIP device visible; libromhc needs an MI355X (gfx950). No CPU fallback.")
+        h = _vp()
+        check(self.lib.rom_init(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    # -- buffers ---------------------------------------------------------------------------
+    def alloc(self, n: int) -> "Buffer":
+        return Buffer(self, int(n))
+
+    def upload(self, arr) -> "Buffer":
+        arr = _host(arr)
+        b = Buffer(self, arr.size)
+        b.upload(arr)
+        return b
+
+    def synchronize(self):
+        check(self.lib.rom_synchronize(self.h))
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        check(self.lib.rom_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def set_workspace_limit(self, nbytes: int):
+        check(self.lib.rom_set_workspace_limit(self.h, int(nbytes)))
+
+    # -- timing ----------------------------------------------------------------------------
+    def timer_start(self):
+        check(self.lib.rom_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_double(0)
+        check(self.lib.rom_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile(self, on: bool):
+        check(self.lib.rom_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.lib.rom_profile_reset(self.h))
+
+    def profile_report(self):
+        n = C.c_int(0)
+        check(self.lib.rom_profile_count(self.h, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name = C.create_string_buffer(128)
+            ms, fl, by = C.c_double(0), C.c_double(0), C.c_double(0)
+            cnt = C.c_long(0)
+            check(self.lib.rom_profile_query(self.h, i, name, 128, C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(by)))
+            out[name.value.decode()] = dict(total_ms=ms.value, launches=cnt.value, flops=fl.value, bytes=by.value)
+        return out
+
+    # -- dense ops ---------------------------------------------------------------------------
+    def gemm_nt(self, m, n, k, A, a_off, lda, B, b_off, ldb, Cb, c_off, ldc, alpha=1.0, beta=0.0):
+        check(self.lib.rom_gemm_nt(self.h, m, n, k, alpha, A.h, a_off, lda, B.h, b_off, ldb, beta, Cb.h, c_off, ldc))
+
+    def gemm_nn(self, m, n, k, A, a_off, lda, B, b_off, ldb, Cb, c_off, ldc, alpha=1.0, beta=0.0):
+        check(self.lib.rom_gemm_nn(self.h, m, n, k, alpha, A.h, a_off, lda, B.h, b_off, ldb, beta, Cb.h, c_off, ldc))
+
+    def reduced_solve_batch(self, n, kb, M, Ahat, w, rhs, rhs_per_system, c_out):
+        check(self.lib.rom_reduced_solve_batch(self.h, n, kb, M, Ahat.h, w.h, rhs.h, 1 if rhs_per_system else 0,
+                                               c_out.h))
+
+    def l2norm(self, U: "Buffer", row0, K, dim) -> np.ndarray:
+        out = np.empty(K)
+        check(self.lib.rom_l2norm(self.h, U.h, row0, K, dim, out.ctypes.data))
+        return out
+
+    # -- RCCL ----------------------------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        check(self.lib.rom_comm_unique_id(buf, 128))
+        return buf.raw
+
+    def comm_init(self, uid: bytes, rank: int, nranks: int):
+        check(self.lib.rom_comm_init(self.h, uid, len(uid), rank, nranks))
+
+    def comm_destroy(self):
+        check(self.lib.rom_comm_destroy(self.h))
+
+    def allgather(self, send: "Buffer", send_off, recv: "Buffer", recv_off, count):
+        check(self.lib.rom_comm_allgather(self.h, send.h, send_off, recv.h, recv_off, count))
+
+    def allreduce_host(self, vals, op="sum") -> np.ndarray:
+        v = _host(np.atleast_1d(vals)).copy()
+        check(self.lib.rom_comm_allreduce_host(self.h, v.ctypes.data, v.size, 1 if op == "max" else 0))
+        return v
+
+
+class Buffer:
+    """fp64 device buffer owned by the library; freed on garbage collection."""
+
+    def __init__(self, ctx: Context, n: int):
+        self.ctx = ctx
+        self.n = int(n)
+        h = _vp()
+        check(ctx.lib.rom_buf_alloc(ctx.h, self.n, C.byref(h)))
+        self.h = h
+
+    def upload(self, arr, offset=0):
+        arr = _host(arr)
+        check(self.ctx.lib.rom_buf_upload(self.h, offset, arr.ctypes.data, arr.size))
+        return self
+
+    def download(self, n=None, offset=0, shape=None) -> np.ndarray:
+        n = self.n - offset if n is None else int(n)
+        out = np.empty(n, dtype=np.float64)
+        check(self.ctx.lib.rom_buf_download(self.h, offset, out.ctypes.data, n))
+        return out.reshape(shape) if shape is not None else out
+
+    def fill(self, value=0.0, offset=0, n=None):
+        check(self.ctx.lib.rom_buf_fill(self.h, offset, self.n - offset if n is None else n, float(value)))
+        return self
+
+    def copy_from(self, src: "Buffer", n, dst_off=0, src_off=0):
+        check(self.ctx.lib.rom_buf_copy(self.h, dst_off, src.h, src_off, n))
+        return self
+
+    def gather_rows_from(self, src: "Buffer", rows, dim):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        check(self.ctx.lib.rom_buf_gather_rows(self.h, src.h, rows.ctypes.data, rows.size, dim))
+        return self
+
+    def free(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.ctx.lib.rom_buf_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def get_context(device: int | None = None) -> Context:
+    if device is None:
+        device = int(os.environ.get("ROMHC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]
+
+
+class Fem:
+    """Handle of one FE space (blocks_geometry, N) on the device."""
+
+    def __init__(self, ctx: Context, nrb: int, ncb: int, N: int):
+        self.ctx = ctx
+        h = _vp()
+        check(ctx.lib.rom_fem_create(ctx.h, nrb, ncb, N, C.byref(h)))
+        self.h = h
+        nr, nc, ng, nt = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        dim = C.c_int64(0)
+        check(ctx.lib.rom_fem_dims(h, C.byref(nr), C.byref(nc), C.byref(dim), C.byref(ng), C.byref(nt)))
+        self.nr, self.nc, self.dim, self.n_interface, self.n_tiles = nr.value, nc.value, dim.value, ng.value, nt.value
+        self.nrb, self.ncb, self.N, self.kblk = nrb, ncb, N, nrb * ncb
+
+    def load_vector(self) -> np.ndarray:
+        B = np.empty(self.dim)
+        check(self.ctx.lib.rom_fem_load_vector_host(self.h, B.ctypes.data))
+        return B
+
+    def solve_batch(self, a: Buffer, M: int, U: Buffer, row0: int = 0):
+        check(self.ctx.lib.rom_solve_batch(self.h, a.h, M, U.h, row0))
+
+    def solve_work(self):
+        v = [C.c_double(0) for _ in range(4)]
+        check(self.ctx.lib.rom_solve_work(self.h, *[C.byref(x) for x in v]))
+        return dict(flops_own=v[0].value, bytes_own=v[1].value, flops_banded=v[2].value, bytes_banded=v[3].value)
+
+    def assemble_batch(self, a: Buffer, M: int, diag: Buffer, east: Buffer, north: Buffer):
+        check(self.ctx.lib.rom_assemble_batch(self.h, a.h, M, diag.h, east.h, north.h))
+
+    def stencil_apply(self, X: Buffer, K: int, Y: Buffer, a_one=None, x_row0=0, y_row0=0):
+        if a_one is None:
+            check(self.ctx.lib.rom_stencil_apply(self.h, None, 1, X.h, x_row0, K, Y.h, y_row0))
+        else:
+            a_one = _host(a_one)
+            assert a_one.size == self.kblk
+            check(self.ctx.lib.rom_stencil_apply(self.h, a_one.ctypes.data, 0, X.h, x_row0, K, Y.h, y_row0))
+
+    def h10norm(self, U: Buffer, K: int, u_row0=0, V: Buffer | None = None, v_row0=0) -> np.ndarray:
+        out = np.empty(K)
+        check(self.ctx.lib.rom_h10norm(self.h, U.h, u_row0, V.h if V is not None else None, v_row0, K,
+                                       out.ctypes.data))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.ctx.lib.rom_fem_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

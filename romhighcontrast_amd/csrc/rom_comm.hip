@@ -1,0 +1,139 @@
+// RCCL all-gather of the snapshot block over xGMI.
+//
+// The reference has no communication backend (its only parallelism is a process-pool `map`,
+// src/lib/SolutionsManagers.py:51); the sweep shards contiguously over the GPUs of a node and the
+// (M/G, dim) fp64 shards are exchanged once with ncclAllGather before the basis stage.
+// librccl.so.1 is dlopen()ed on first use so that single-GPU runs carry no RCCL dependency.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "romhc_internal.h"
+
+namespace {
+
+// minimal slice of the RCCL ABI (rccl.h): opaque comm, 128-byte unique id, enums
+typedef struct { char internal[128]; } nccl_uid_t;
+typedef void* nccl_comm_t;
+enum { NCCL_FLOAT64 = 8 };            // ncclDouble
+enum { NCCL_SUM = 0, NCCL_MAX = 2 };  // ncclSum, ncclMax
+
+struct Rccl {
+  void* h = nullptr;
+  int (*GetUniqueId)(nccl_uid_t*) = nullptr;
+  int (*CommInitRank)(nccl_comm_t*, int, nccl_uid_t, int) = nullptr;
+  int (*CommDestroy)(nccl_comm_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.h) return ROM_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    rom_set_error("cannot dlopen librccl: %s", dlerror());
+    return ROM_ERR_COMM;
+  }
+#define SYM(field, name)                                               \
+  *(void**)(&g_rccl.field) = dlsym(h, name);                           \
+  if (!g_rccl.field) {                                                 \
+    rom_set_error("librccl lacks symbol %s", name);                    \
+    return ROM_ERR_COMM;                                               \
+  }
+  SYM(GetUniqueId, "ncclGetUniqueId");
+  SYM(CommInitRank, "ncclCommInitRank");
+  SYM(CommDestroy, "ncclCommDestroy");
+  SYM(AllGather, "ncclAllGather");
+  SYM(AllReduce, "ncclAllReduce");
+  SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  g_rccl.h = h;
+  return ROM_OK;
+}
+
+#define ROM_NCCL(call)                                                                   \
+  do {                                                                                   \
+    int _r = (call);                                                                     \
+    if (_r != 0) {                                                                       \
+      rom_set_error("%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?"); \
+      return ROM_ERR_COMM;                                                               \
+    }                                                                                    \
+  } while (0)
+
+}  // namespace
+
+extern "C" int rom_comm_unique_id(char* id_out, size_t cap) {
+  ROM_CHECK(id_out && cap >= sizeof(nccl_uid_t), "rom_comm_unique_id: need a %zu-byte buffer", sizeof(nccl_uid_t));
+  ROM_TRY(load_rccl());
+  nccl_uid_t id;
+  ROM_NCCL(g_rccl.GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return ROM_OK;
+}
+
+extern "C" int rom_comm_init(rom_ctx* ctx, const char* id, size_t id_len, int rank, int nranks) {
+  ROM_CHECK(ctx && id && id_len >= sizeof(nccl_uid_t), "rom_comm_init: bad arguments");
+  ROM_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "rom_comm_init: rank %d / %d", rank, nranks);
+  ROM_CHECK(!ctx->comm, "rom_comm_init: communicator already initialised");
+  ROM_TRY(load_rccl());
+  ROM_HIP(hipSetDevice(ctx->device));
+  nccl_uid_t uid;
+  memcpy(&uid, id, sizeof(uid));
+  nccl_comm_t comm = nullptr;
+  ROM_NCCL(g_rccl.CommInitRank(&comm, nranks, uid, rank));
+  ctx->comm = comm;
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  return ROM_OK;
+}
+
+extern "C" int rom_comm_destroy(rom_ctx* ctx) {
+  if (!ctx || !ctx->comm) return ROM_OK;
+  hipStreamSynchronize(ctx->stream);
+  g_rccl.CommDestroy((nccl_comm_t)ctx->comm);
+  ctx->comm = nullptr;
+  ctx->rank = 0;
+  ctx->nranks = 1;
+  return ROM_OK;
+}
+
+extern "C" int rom_comm_allgather(rom_ctx* ctx, rom_buf* send, size_t send_off, rom_buf* recv, size_t recv_off,
+                                  size_t count) {
+  ROM_CHECK(ctx && send && recv, "rom_comm_allgather: null argument");
+  ROM_CHECK(ctx->comm, "rom_comm_allgather: communicator not initialised (rom_comm_init)");
+  ROM_CHECK(send_off + count <= send->n, "rom_comm_allgather: send range out of bounds");
+  ROM_CHECK(recv_off + count * size_t(ctx->nranks) <= recv->n, "rom_comm_allgather: recv range out of bounds");
+  {
+    ROM_PROF(ctx, "rccl_allgather", 0, 8.0 * count * ctx->nranks);
+    ROM_NCCL(g_rccl.AllGather(send->p + send_off, recv->p + recv_off, count, NCCL_FLOAT64, (nccl_comm_t)ctx->comm,
+                              ctx->stream));
+  }
+  return ROM_OK;
+}
+
+extern "C" int rom_comm_allreduce_host(rom_ctx* ctx, double* vals, int n, int op) {
+  ROM_CHECK(ctx && vals && n >= 0 && n <= 1024, "rom_comm_allreduce_host: bad arguments");
+  ROM_CHECK(ctx->comm, "rom_comm_allreduce_host: communicator not initialised (rom_comm_init)");
+  if (n == 0) return ROM_OK;
+  double* d = nullptr;
+  ROM_HIP(hipMalloc(&d, n * sizeof(double)));
+  ROM_HIP(hipMemcpyAsync(d, vals, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int r = g_rccl.AllReduce(d, d, n, NCCL_FLOAT64, op == 1 ? NCCL_MAX : NCCL_SUM, (nccl_comm_t)ctx->comm, ctx->stream);
+  if (r != 0) {
+    hipFree(d);
+    rom_set_error("ncclAllReduce failed: %s", g_rccl.GetErrorString(r));
+    return ROM_ERR_COMM;
+  }
+  ROM_HIP(hipMemcpyAsync(vals, d, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  hipFree(d);
+  return ROM_OK;
+}

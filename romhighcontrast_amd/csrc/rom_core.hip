@@ -1,0 +1,276 @@
+// Context, device buffers, error strings, HIP-event stopwatch and per-kernel profiling.
+#include "romhc_internal.h"
+
+#include <cstring>
+
+static thread_local char g_err[1024] = "";
+
+void rom_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* rom_last_error(void) { return g_err; }
+extern "C" int rom_version(void) { return 100; }
+
+extern "C" int rom_device_count(int* n) {
+  ROM_CHECK(n, "rom_device_count: null output");
+  ROM_HIP(hipGetDeviceCount(n));
+  return ROM_OK;
+}
+
+extern "C" int rom_init(int device, rom_ctx** out) {
+  ROM_CHECK(out, "rom_init: null output");
+  int n = 0;
+  ROM_HIP(hipGetDeviceCount(&n));
+  ROM_CHECK(device >= 0 && device < n, "rom_init: device %d out of range (have %d)", device, n);
+  ROM_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  ROM_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    rom_set_error("rom_init: device %d is %s; libromhc is built for gfx950 (MI355X) only", device,
+                  prop.gcnArchName);
+    return ROM_ERR_INVALID;
+  }
+  rom_ctx* c = new rom_ctx();
+  c->device = device;
+  ROM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  ROM_HIP(hipEventCreate(&c->t0));
+  ROM_HIP(hipEventCreate(&c->t1));
+  ROM_HIP(hipMalloc(&c->d_status, sizeof(int)));
+  ROM_HIP(hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
+  *out = c;
+  return ROM_OK;
+}
+
+extern "C" int rom_shutdown(rom_ctx* c) {
+  if (!c) return ROM_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  rom_comm_destroy(c);
+  for (auto e : c->event_pool) hipEventDestroy(e);
+  for (auto& r : c->prof_recs) {
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  if (c->d_status) hipFree(c->d_status);
+  if (c->d_scratch) hipFree(c->d_scratch);
+  hipEventDestroy(c->t0);
+  hipEventDestroy(c->t1);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return ROM_OK;
+}
+
+extern "C" int rom_synchronize(rom_ctx* c) {
+  ROM_CHECK(c, "null context");
+  ROM_HIP(hipStreamSynchronize(c->stream));
+  return ROM_OK;
+}
+
+extern "C" int rom_set_workspace_limit(rom_ctx* c, size_t bytes) {
+  ROM_CHECK(c, "null context");
+  c->ws_limit = bytes;
+  return ROM_OK;
+}
+
+extern "C" int rom_device_name(rom_ctx* c, char* out, size_t cap) {
+  ROM_CHECK(c && out && cap > 0, "bad arguments");
+  hipDeviceProp_t prop;
+  ROM_HIP(hipGetDeviceProperties(&prop, c->device));
+  snprintf(out, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return ROM_OK;
+}
+
+int rom_ctx_scratch(rom_ctx* c, size_t n, double** out) {
+  if (c->scratch_doubles < n) {
+    ROM_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_scratch) ROM_HIP(hipFree(c->d_scratch));
+    c->d_scratch = nullptr;
+    c->scratch_doubles = 0;
+    ROM_HIP(hipMalloc(&c->d_scratch, n * sizeof(double)));
+    c->scratch_doubles = n;
+  }
+  *out = c->d_scratch;
+  return ROM_OK;
+}
+
+// ---- stopwatch ---------------------------------------------------------------------------------
+extern "C" int rom_timer_start(rom_ctx* c) {
+  ROM_CHECK(c, "null context");
+  ROM_HIP(hipEventRecord(c->t0, c->stream));
+  return ROM_OK;
+}
+
+extern "C" int rom_timer_stop(rom_ctx* c, double* ms) {
+  ROM_CHECK(c && ms, "bad arguments");
+  ROM_HIP(hipEventRecord(c->t1, c->stream));
+  ROM_HIP(hipEventSynchronize(c->t1));
+  float f = 0;
+  ROM_HIP(hipEventElapsedTime(&f, c->t0, c->t1));
+  *ms = f;
+  return ROM_OK;
+}
+
+// ---- per-kernel profiling ----------------------------------------------------------------------
+ProfScope::ProfScope(rom_ctx* c, const char* name, double flops, double bytes) : ctx(c) {
+  if (!c->profile) return;
+  int id = -1;
+  for (size_t i = 0; i < c->prof_names.size(); ++i)
+    if (c->prof_names[i] == name) id = int(i);
+  if (id < 0) {
+    id = int(c->prof_names.size());
+    c->prof_names.push_back(name);
+    c->prof_flops.push_back(0);
+    c->prof_bytes.push_back(0);
+  }
+  c->prof_flops[id] += flops;
+  c->prof_bytes[id] += bytes;
+  ProfRec r;
+  r.name_id = id;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  hipEventRecord(r.e0, c->stream);
+  c->prof_recs.push_back(r);
+  idx = int(c->prof_recs.size()) - 1;
+}
+
+ProfScope::~ProfScope() {
+  if (idx >= 0) hipEventRecord(ctx->prof_recs[idx].e1, ctx->stream);
+}
+
+extern "C" int rom_profile_enable(rom_ctx* c, int on) {
+  ROM_CHECK(c, "null context");
+  c->profile = on != 0;
+  return ROM_OK;
+}
+
+extern "C" int rom_profile_reset(rom_ctx* c) {
+  ROM_CHECK(c, "null context");
+  ROM_HIP(hipStreamSynchronize(c->stream));
+  for (auto& r : c->prof_recs) {
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  c->prof_recs.clear();
+  c->prof_names.clear();
+  c->prof_flops.clear();
+  c->prof_bytes.clear();
+  return ROM_OK;
+}
+
+extern "C" int rom_profile_count(rom_ctx* c, int* n) {
+  ROM_CHECK(c && n, "bad arguments");
+  *n = int(c->prof_names.size());
+  return ROM_OK;
+}
+
+extern "C" int rom_profile_query(rom_ctx* c, int idx, char* name, size_t cap, double* total_ms,
+                                 long* launches, double* flops, double* bytes) {
+  ROM_CHECK(c && idx >= 0 && idx < int(c->prof_names.size()), "rom_profile_query: bad index");
+  ROM_HIP(hipStreamSynchronize(c->stream));
+  double tot = 0;
+  long cnt = 0;
+  for (auto& r : c->prof_recs) {
+    if (r.name_id != idx) continue;
+    float f = 0;
+    ROM_HIP(hipEventElapsedTime(&f, r.e0, r.e1));
+    tot += f;
+    ++cnt;
+  }
+  if (name && cap) snprintf(name, cap, "%s", c->prof_names[idx].c_str());
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = cnt;
+  if (flops) *flops = c->prof_flops[idx];
+  if (bytes) *bytes = c->prof_bytes[idx];
+  return ROM_OK;
+}
+
+// ---- buffers -------------------------------------------------------------------------------------
+extern "C" int rom_buf_alloc(rom_ctx* c, size_t n, rom_buf** out) {
+  ROM_CHECK(c && out, "bad arguments");
+  ROM_HIP(hipSetDevice(c->device));
+  rom_buf* b = new rom_buf{c, nullptr, n};
+  hipError_t e = hipMalloc(&b->p, (n ? n : 1) * sizeof(double));
+  if (e != hipSuccess) {
+    delete b;
+    rom_set_error("rom_buf_alloc: hipMalloc of %zu bytes failed: %s", n * sizeof(double), hipGetErrorString(e));
+    return ROM_ERR_NOMEM;
+  }
+  *out = b;
+  return ROM_OK;
+}
+
+extern "C" int rom_buf_free(rom_buf* b) {
+  if (!b) return ROM_OK;
+  hipStreamSynchronize(b->ctx->stream);
+  hipFree(b->p);
+  delete b;
+  return ROM_OK;
+}
+
+extern "C" int rom_buf_size(rom_buf* b, size_t* n) {
+  ROM_CHECK(b && n, "bad arguments");
+  *n = b->n;
+  return ROM_OK;
+}
+
+extern "C" int rom_buf_upload(rom_buf* b, size_t off, const double* host, size_t n) {
+  ROM_CHECK(b && (host || n == 0), "bad arguments");
+  ROM_CHECK(off + n <= b->n, "rom_buf_upload: range [%zu,%zu) exceeds buffer of %zu", off, off + n, b->n);
+  if (n == 0) return ROM_OK;
+  ROM_HIP(hipMemcpyAsync(b->p + off, host, n * sizeof(double), hipMemcpyHostToDevice, b->ctx->stream));
+  ROM_HIP(hipStreamSynchronize(b->ctx->stream));  // host array may be reused by the caller
+  return ROM_OK;
+}
+
+extern "C" int rom_buf_download(rom_buf* b, size_t off, double* host, size_t n) {
+  ROM_CHECK(b && (host || n == 0), "bad arguments");
+  ROM_CHECK(off + n <= b->n, "rom_buf_download: range [%zu,%zu) exceeds buffer of %zu", off, off + n, b->n);
+  if (n == 0) return ROM_OK;
+  ROM_HIP(hipMemcpyAsync(host, b->p + off, n * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+  ROM_HIP(hipStreamSynchronize(b->ctx->stream));
+  return ROM_OK;
+}
+
+__global__ void k_fill(double* p, size_t n, double v) {
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  size_t stride = size_t(gridDim.x) * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+extern "C" int rom_buf_fill(rom_buf* b, size_t off, size_t n, double value) {
+  ROM_CHECK(b, "bad arguments");
+  ROM_CHECK(off + n <= b->n, "rom_buf_fill: range exceeds buffer");
+  if (n == 0) return ROM_OK;
+  if (value == 0.0) {
+    ROM_HIP(hipMemsetAsync(b->p + off, 0, n * sizeof(double), b->ctx->stream));
+    return ROM_OK;
+  }
+  int grid = int(std::min<size_t>((n + 255) / 256, 2048));
+  k_fill<<<grid, 256, 0, b->ctx->stream>>>(b->p + off, n, value);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+extern "C" int rom_buf_copy(rom_buf* dst, size_t dst_off, rom_buf* src, size_t src_off, size_t n) {
+  ROM_CHECK(dst && src, "bad arguments");
+  ROM_CHECK(dst_off + n <= dst->n && src_off + n <= src->n, "rom_buf_copy: range exceeds buffer");
+  if (n == 0) return ROM_OK;
+  ROM_HIP(hipMemcpyAsync(dst->p + dst_off, src->p + src_off, n * sizeof(double), hipMemcpyDeviceToDevice,
+                         dst->ctx->stream));
+  return ROM_OK;
+}
+
+extern "C" int rom_buf_gather_rows(rom_buf* dst, rom_buf* src, const int64_t* rows, int n_rows, size_t dim) {
+  ROM_CHECK(dst && src && (rows || n_rows == 0), "bad arguments");
+  ROM_CHECK(size_t(n_rows) * dim <= dst->n, "rom_buf_gather_rows: destination too small");
+  for (int i = 0; i < n_rows; ++i) {
+    ROM_CHECK(rows[i] >= 0 && size_t(rows[i] + 1) * dim <= src->n, "rom_buf_gather_rows: row %lld out of range",
+              (long long)rows[i]);
+    ROM_HIP(hipMemcpyAsync(dst->p + size_t(i) * dim, src->p + size_t(rows[i]) * dim, dim * sizeof(double),
+                           hipMemcpyDeviceToDevice, dst->ctx->stream));
+  }
+  return ROM_OK;
+}

@@ -1,0 +1,964 @@
+// FE space + batched parametric solve (the snapshot sweep).
+//
+// Replaces SolutionsManagerFEM.__init__ (src/lib/SolutionsManagers.py:146-219), galerkin (:17-40)
+// and generate_solutions (:64-68) of the reference.
+//
+// Algorithm (exact direct method, fp64): the coefficient is constant a_b on each unit block b, so
+// inside block b the operator is a_b * L with L the Dirichlet 5-point Laplacian of the block --
+// parameter independent.  Eliminating all block interiors leaves an SPD system on the interface
+// vertices (edges between blocks + cross points)
+//        S(a) u_G = g,      S(a) = A_GG(a) - sum_b a_b T_b,     g parameter independent,
+// with T_b the (dense) Dirichlet-to-Neumann blocks of the unit square, identical for all blocks
+// up to the side pairing (16 tables T[sr][sc]).  Per parameter the work is: assemble S(a) tile by
+// tile (never stored: each tile is built in registers when it is factored), a left-looking 64x64
+// tile Cholesky on MFMA with the forward substitution fused in, a backward substitution, and the
+// harmonic extension  u_I,b = (h^2/a_b) W + sum_sides H_s u_G|side   as one batched MFMA GEMM
+// that writes the snapshot rows straight into the caller's (M, dim) matrix.
+//
+// Setup tables come from the sine (DST-I) eigenbasis of the block:  H_0[(i,j),k] =
+// sum_m Q[j,m] rho_m(i) Q[k,m], rho_m(i) = sinh((N-i) phi_m)/sinh(N phi_m), cosh phi_m = 2-cos(pi m/N);
+// the other three sides are row permutations of H_0.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <set>
+
+#include "rom_mma.h"
+
+// ============================================================================================
+// device-side view of a rom_fem
+// ============================================================================================
+struct FemDev {
+  int nrb, ncb, N, n1, n1p, nr, nc, nGp, T, nslots, kblk;
+  long long dim;
+  const double* H0;
+  const double* Tm;
+  const double* W;
+  const double* g;
+  const TileDesc* desc;
+  const TileExtra* extra;
+  const int* kptr;
+  const int* kpair;
+  const int* colptr;
+  const int* colrow;
+  const int* colti;
+  const BlockSide* sides;
+  const int* vmap;
+  double* L;     // [Mc][nslots][64*64]
+  double* invL;  // [Mc][T][64*64]
+  double* y;     // [Mc][nGp]
+  int* status;
+};
+
+static FemDev make_dev(const rom_fem* f) {
+  FemDev d;
+  d.nrb = f->nrb; d.ncb = f->ncb; d.N = f->N; d.n1 = f->n1; d.n1p = f->n1p; d.nr = f->nr; d.nc = f->nc;
+  d.nGp = f->nGp; d.T = f->T; d.nslots = f->nslots; d.kblk = f->nrb * f->ncb; d.dim = f->dim;
+  d.H0 = f->d_H0; d.Tm = f->d_Tm; d.W = f->d_W; d.g = f->d_g; d.desc = f->d_desc; d.extra = f->d_extra;
+  d.kptr = f->d_kptr; d.kpair = f->d_kpair; d.colptr = f->d_colptr; d.colrow = f->d_colrow;
+  d.colti = f->d_colti; d.sides = f->d_sides; d.vmap = f->d_vmap; d.L = f->d_L; d.invL = f->d_invL;
+  d.y = f->d_y; d.status = f->ctx->d_status;
+  return d;
+}
+
+// ============================================================================================
+// setup kernels
+// ============================================================================================
+// A0[((i-1)*n1 + (j-1)) * n1p + m] = Q[j-1][m] * rho[m][i]   (rho stored [m][i], i = 0..N)
+__global__ void k_build_A0(double* A0, const double* Qp, const double* rho, int n1, int n1p, int N) {
+  size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  size_t total = size_t(n1) * n1 * n1p;
+  if (idx >= total) return;
+  int m = int(idx % n1p);
+  size_t ij = idx / n1p;
+  int j = int(ij % n1) + 1, i = int(ij / n1) + 1;
+  A0[idx] = (m < n1) ? Qp[size_t(j - 1) * n1p + m] * rho[size_t(m) * (N + 1) + i] : 0.0;
+}
+
+// row of H0 that holds the extension from side s evaluated at interior vertex (i,j), 1-based
+__host__ __device__ inline int h0_row(int s, int i, int j, int N, int n1) {
+  int ii, jj;
+  switch (s) {
+    case 0: ii = i; jj = j; break;
+    case 1: ii = N - i; jj = j; break;
+    case 2: ii = j; jj = i; break;
+    default: ii = N - j; jj = i; break;
+  }
+  return (ii - 1) * n1 + (jj - 1);
+}
+
+// Tm[sr*4+sc][t][k] = H_sc[adjacent interior vertex of node t+1 on side sr][k]
+__global__ void k_build_Tm(double* Tm, const double* H0, int n1, int n1p, int N) {
+  size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  size_t per = size_t(n1p) * n1p;
+  if (idx >= 16 * per) return;
+  int tm = int(idx / per);
+  int t = int((idx % per) / n1p), k = int(idx % n1p);
+  int sr = tm >> 2, sc = tm & 3;
+  double v = 0.0;
+  if (t < n1 && k < n1) {
+    int i, j;
+    switch (sr) {
+      case 0: i = 1; j = t + 1; break;
+      case 1: i = N - 1; j = t + 1; break;
+      case 2: i = t + 1; j = 1; break;
+      default: i = t + 1; j = N - 1; break;
+    }
+    v = H0[size_t(h0_row(sc, i, j, N, n1)) * n1p + k];
+  }
+  Tm[idx] = v;
+}
+
+// ============================================================================================
+// interface tile assembly  (A_GG(a) - sum_b a_b T_b, one entry)
+// ============================================================================================
+__device__ inline double s_entry(const TileDesc& d, const double* __restrict__ Tm, int n1p,
+                                 const double* __restrict__ am, int r, int c) {
+  double v = 0.0;
+  if (r < d.nvr && c < d.nvc) {
+    for (int t = 0; t < d.nterms; ++t) {
+      const TileTerm& tt = d.term[t];
+      v -= am[tt.blk] * Tm[(size_t(tt.tmat) * n1p + (tt.r0 + r)) * n1p + (tt.c0 + c)];
+    }
+    if (d.same_edge) {
+      int gr = d.lr0 + r, gc = d.lc0 + c;
+      double a0 = am[d.b0], a1 = am[d.b1];
+      if (gr == gc) {
+        // oracle order: k[r-1,c-1] + k[r-1,c] + k[r,c-1] + k[r,c]
+        v += d.hv == 0 ? ((a0 + a0) + a1) + a1 : ((a0 + a1) + a0) + a1;
+      } else if (gr - gc == 1 || gc - gr == 1) {
+        v += -(a1 + a0) / 2;
+      }
+    }
+  } else if (d.diag && r == c) {
+    v = 1.0;  // padding unknowns: identity
+  }
+  return v;
+}
+
+// C(LDS tile) = S_tile - acc ; then the sparse cross-point extras
+__device__ inline void tile_from_acc(double* Cb, const Acc& acc, const TileDesc& d, const FemDev& f,
+                                     const double* __restrict__ am, const WavePos& wp) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int r = acc_row(wp, i, g), c = acc_col(wp, j);
+        Cb[r * LDC + c] = s_entry(d, f.Tm, f.n1p, am, r, c) - acc.c[i][j][g];
+      }
+  __syncthreads();
+  for (int x = d.x0 + threadIdx.x; x < d.x1; x += blockDim.x) {
+    const TileExtra& e = f.extra[x];
+    double v = e.kind == 0 ? -(am[e.b[0]] + am[e.b[1]]) / 2
+                           : ((am[e.b[0]] + am[e.b[1]]) + am[e.b[2]]) + am[e.b[3]];
+    Cb[e.r * LDC + e.c] += v;
+  }
+  __syncthreads();
+}
+
+// ============================================================================================
+// factorisation kernels
+// ============================================================================================
+__global__ void k_init_rhs(FemDev f, int Mc) {
+  size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (idx >= size_t(Mc) * f.nGp) return;
+  f.y[idx] = f.g[idx % f.nGp];
+}
+
+// Diagonal tile j of every system: C = S_jj - sum_k L_jk L_jk^T ; L_jj = chol(C) ; invL_jj ;
+// y_j <- invL_jj y_j   (fused forward substitution)
+__global__ __launch_bounds__(256) void k_factor_diag(FemDev f, const double* __restrict__ a, int slot, int j) {
+  __shared__ __align__(16) double lds[STAGE_TOTAL + TILE_DOUBLES];
+  double* stage = lds;                 // STAGE_TOTAL (aliased by Ib later)
+  double* Cb = lds + STAGE_TOTAL;      // TILE_DOUBLES
+  double* Ib = lds;                    // inverse, aliases the staging area (TILE_DOUBLES <= STAGE_TOTAL)
+  __shared__ double sd[64];
+  __shared__ double gj[64];
+  const int m = blockIdx.x;
+  const WavePos wp;
+  const TileDesc& d = f.desc[slot];
+  const double* am = a + size_t(m) * f.kblk;
+  double* Lm = f.L + size_t(m) * f.nslots * 4096;
+
+  Acc acc;
+  acc_zero(acc);
+  const int srow = stage_row(), sseg = stage_seg();
+  for (int e = f.kptr[slot]; e < f.kptr[slot + 1]; ++e) {
+    const double* A = Lm + size_t(f.kpair[2 * e]) * 4096 + srow * 64 + sseg;
+    const double* B = Lm + size_t(f.kpair[2 * e + 1]) * 4096 + srow * 64 + sseg;
+    gemm_loop(
+        4, [&](int ch, double* v) { load4_aligned(A + ch * BK, v); },
+        [&](int ch, double* v) { load4_aligned(B + ch * BK, v); }, acc, stage, wp);
+  }
+  tile_from_acc(Cb, acc, d, f, am, wp);
+
+  // ---- LDL^T-style right-looking elimination in LDS, one barrier per column -----------------
+  const int t = threadIdx.x;
+  const int r = t >> 2, cg = t & 3;
+  for (int jj = 0; jj < 63; ++jj) {
+    double dj = Cb[jj * LDC + jj];
+    double invd = 1.0 / dj;
+    if (r > jj) {
+      double lr = Cb[r * LDC + jj] * invd;
+      for (int c = jj + 1 + cg; c <= r; c += 4) Cb[r * LDC + c] -= lr * Cb[c * LDC + jj];
+    }
+    __syncthreads();
+  }
+  if (t < 64) {
+    double dj = Cb[t * LDC + t];
+    if (!(dj > 0.0)) atomicOr(f.status, 1);
+    sd[t] = sqrt(dj);
+    gj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
+  }
+  __syncthreads();
+  for (int idx = t; idx < 4096; idx += 256) {
+    int rr = idx >> 6, cc = idx & 63;
+    double v = Cb[rr * LDC + cc];
+    v = rr > cc ? v / sd[cc] : (rr == cc ? sd[rr] : 0.0);
+    Cb[rr * LDC + cc] = v;
+    Ib[rr * LDC + cc] = 0.0;
+  }
+  __syncthreads();
+  // ---- inverse of the lower-triangular tile, 16x16 blocked ----------------------------------
+  if (t < 64) {
+    int bi = t >> 4, c = t;  // column c lives in diagonal block bi
+    int rend = bi * 16 + 16;
+    for (int rr = c; rr < rend; ++rr) {
+      double s = rr == c ? 1.0 : 0.0;
+      for (int k = c; k < rr; ++k) s -= Cb[rr * LDC + k] * Ib[k * LDC + c];
+      Ib[rr * LDC + c] = s / Cb[rr * LDC + rr];
+    }
+  }
+  __syncthreads();
+  {
+    const int rr = t >> 4, cc = t & 15;
+#pragma unroll
+    for (int bi = 1; bi < 4; ++bi) {
+      double z[3];
+#pragma unroll
+      for (int bj = 0; bj < bi; ++bj) {
+        double s = 0.0;
+        for (int k = bj * 16; k < bi * 16; ++k) s += Cb[(bi * 16 + rr) * LDC + k] * Ib[k * LDC + bj * 16 + cc];
+        z[bj] = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int bj = 0; bj < bi; ++bj) Ib[(bi * 16 + rr) * LDC + bj * 16 + cc] = z[bj];
+      __syncthreads();
+#pragma unroll
+      for (int bj = 0; bj < bi; ++bj) {
+        double s = 0.0;
+        for (int k = 0; k < 16; ++k) s += Ib[(bi * 16 + rr) * LDC + bi * 16 + k] * Ib[(bi * 16 + k) * LDC + bj * 16 + cc];
+        z[bj] = -s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int bj = 0; bj < bi; ++bj) Ib[(bi * 16 + rr) * LDC + bj * 16 + cc] = z[bj];
+      __syncthreads();
+    }
+  }
+  // ---- write L_jj, invL_jj ; y_j = invL_jj y_j ------------------------------------------------
+  double* Lout = Lm + size_t(slot) * 4096;
+  double* Iout = f.invL + (size_t(m) * f.T + j) * 4096;
+  for (int idx = t; idx < 4096; idx += 256) {
+    int rr = idx >> 6, cc = idx & 63;
+    Lout[idx] = Cb[rr * LDC + cc];
+    Iout[idx] = Ib[rr * LDC + cc];
+  }
+  if (t < 64) {
+    double s = 0.0;
+    for (int k = 0; k <= t; ++k) s += Ib[t * LDC + k] * gj[k];
+    f.y[size_t(m) * f.nGp + j * 64 + t] = s;
+  }
+}
+
+// Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;
+// y_i -= L_ij y_j
+__global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j) {
+  __shared__ __align__(16) double lds[STAGE_TOTAL + TILE_DOUBLES];
+  double* stage = lds;
+  double* Cb = lds + STAGE_TOTAL;
+  __shared__ double yj[64];
+  const int m = blockIdx.y;
+  const int ent = f.colptr[j] + blockIdx.x;
+  const int slot = f.colrow[ent];
+  const int ti = f.colti[ent];
+  const WavePos wp;
+  const TileDesc& d = f.desc[slot];
+  const double* am = a + size_t(m) * f.kblk;
+  double* Lm = f.L + size_t(m) * f.nslots * 4096;
+  const int t = threadIdx.x;
+
+  Acc acc;
+  acc_zero(acc);
+  const int srow = stage_row(), sseg = stage_seg();
+  for (int e = f.kptr[slot]; e < f.kptr[slot + 1]; ++e) {
+    const double* A = Lm + size_t(f.kpair[2 * e]) * 4096 + srow * 64 + sseg;
+    const double* B = Lm + size_t(f.kpair[2 * e + 1]) * 4096 + srow * 64 + sseg;
+    gemm_loop(
+        4, [&](int ch, double* v) { load4_aligned(A + ch * BK, v); },
+        [&](int ch, double* v) { load4_aligned(B + ch * BK, v); }, acc, stage, wp);
+  }
+  if (t < 64) yj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
+  tile_from_acc(Cb, acc, d, f, am, wp);
+
+  // X = C * invL_jj^T
+  acc_zero(acc);
+  const double* I = f.invL + (size_t(m) * f.T + j) * 4096 + srow * 64 + sseg;
+  gemm_loop_Atile(Cb, 4, [&](int ch, double* v) { load4_aligned(I + ch * BK, v); }, acc, stage, wp);
+
+  double* Lout = Lm + size_t(slot) * 4096;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int r = acc_row(wp, i, g), c = acc_col(wp, jb);
+        double v = acc.c[i][jb][g];
+        Lout[r * 64 + c] = v;
+        Cb[r * LDC + c] = v;
+      }
+  __syncthreads();
+  if (t < 64) {
+    double s = 0.0;
+    for (int k = 0; k < 64; ++k) s += Cb[t * LDC + k] * yj[k];
+    f.y[size_t(m) * f.nGp + ti * 64 + t] -= s;
+  }
+}
+
+// x = L^{-T} y, one workgroup per system, x kept in LDS, written back over y
+__global__ __launch_bounds__(256) void k_backsolve(FemDev f, const int* __restrict__ slot_of,
+                                                   const int* __restrict__ diag_slot_unused) {
+  extern __shared__ __align__(16) double xs[];  // nGp
+  __shared__ double red[4][64];
+  __shared__ double vs[64];
+  const int m = blockIdx.x;
+  const int t = threadIdx.x, c = t & 63, part = t >> 6;
+  const double* Lm = f.L + size_t(m) * f.nslots * 4096;
+  double* ym = f.y + size_t(m) * f.nGp;
+  for (int j = f.T - 1; j >= 0; --j) {
+    double s = 0.0;
+    for (int e = f.colptr[j]; e < f.colptr[j + 1]; ++e) {
+      const double* Lt = Lm + size_t(f.colrow[e]) * 4096;
+      const double* xi = xs + f.colti[e] * 64;
+#pragma unroll 4
+      for (int rr = part * 16; rr < part * 16 + 16; ++rr) s += Lt[rr * 64 + c] * xi[rr];
+    }
+    red[part][c] = s;
+    __syncthreads();
+    if (t < 64) vs[t] = ym[j * 64 + t] - (red[0][t] + red[1][t] + red[2][t] + red[3][t]);
+    __syncthreads();
+    const double* It = f.invL + (size_t(m) * f.T + j) * 4096;
+    s = 0.0;
+#pragma unroll 4
+    for (int rr = part * 16; rr < part * 16 + 16; ++rr) s += It[rr * 64 + c] * vs[rr];
+    red[part][c] = s;
+    __syncthreads();
+    if (t < 64) xs[j * 64 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    __syncthreads();
+  }
+  for (int v = t; v < f.nGp; v += 256) ym[v] = xs[v];
+}
+
+// ============================================================================================
+// harmonic extension + scatter: writes the snapshot rows
+// ============================================================================================
+// grid (ceil(n1^2/64), ceil(Mc/64), nblocks).  Tile rows = systems, tile cols = interior vertices.
+__global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restrict__ a, int Mc,
+                                                double* __restrict__ U, long long row0) {
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  double* stage = lds;
+  const WavePos wp;
+  const int b = blockIdx.z;
+  const int p = b / f.ncb, q = b % f.ncb;
+  const int n1 = f.n1, N = f.N;
+  const int nij = n1 * n1;
+  const BlockSide sd = f.sides[b];
+  const int srow = stage_row(), sseg = stage_seg();
+
+  const int mA = blockIdx.y * 64 + srow;
+  const double* Arow = mA < Mc ? f.y + size_t(mA) * f.nGp + sseg : nullptr;
+  const int ijB = blockIdx.x * 64 + srow;
+  int iB = 1, jB = 1;
+  if (ijB < nij) { iB = ijB / n1 + 1; jB = ijB % n1 + 1; }
+
+  Acc acc;
+  acc_zero(acc);
+  const int cps = f.n1p / BK;  // chunks per side
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int off = s == 0 ? sd.off[0] : s == 1 ? sd.off[1] : s == 2 ? sd.off[2] : sd.off[3];
+    if (off < 0) continue;  // side on the domain boundary (uniform branch)
+    const double* pA = Arow ? Arow + off : nullptr;
+    const double* pB = ijB < nij ? f.H0 + size_t(h0_row(s, iB, jB, N, n1)) * f.n1p + sseg : nullptr;
+    gemm_loop(
+        cps, [&](int ch, double* v) { load4_aligned(pA ? pA + ch * BK : nullptr, v); },
+        [&](int ch, double* v) { load4_aligned(pB ? pB + ch * BK : nullptr, v); }, acc, stage, wp);
+  }
+
+  const double h2 = 1.0 / (double(N) * double(N));
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int m = blockIdx.y * 64 + acc_row(wp, i, g);
+      if (m >= Mc) continue;
+      double sc = h2 / a[size_t(m) * f.kblk + b];
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        int ij = blockIdx.x * 64 + acc_col(wp, jb);
+        if (ij >= nij) continue;
+        int ii = ij / n1, jj = ij - ii * n1;
+        long long gidx = (long long)(p * N + ii) * f.nc + (q * N + jj);
+        U[(row0 + m) * f.dim + gidx] = acc.c[i][jb][g] + sc * f.W[ij];
+      }
+    }
+}
+
+__global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = blockIdx.y;
+  if (v >= f.nGp || m >= Mc) return;
+  int gi = f.vmap[v];
+  if (gi >= 0) U[(row0 + m) * f.dim + gi] = f.y[size_t(m) * f.nGp + v];
+}
+
+// stencil arrays for the API (einsum('pqij,pq->ij') in stencil form)
+__global__ void k_assemble_stencil(FemDev f, const double* __restrict__ a, int M, double* __restrict__ diag,
+                                   double* __restrict__ east, double* __restrict__ north) {
+  __shared__ double am[64];  // coefficients of this parameter staged in LDS
+  const int m = blockIdx.y;
+  for (int i = threadIdx.x; i < f.kblk; i += blockDim.x) am[i] = a[size_t(m) * f.kblk + i];
+  __syncthreads();
+  long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= f.dim) return;
+  int r = int(idx / f.nc) + 1, c = int(idx % f.nc) + 1;  // 1-based vertex coordinates
+  int N = f.N, ncb = f.ncb;
+  // kappa[line, col] = a[line / N][col / N]; the four cells around vertex (r, c)
+  double k00 = am[((r - 1) / N) * ncb + (c - 1) / N];
+  double k01 = am[((r - 1) / N) * ncb + c / N];
+  double k10 = am[(r / N) * ncb + (c - 1) / N];
+  double k11 = am[(r / N) * ncb + c / N];
+  diag[size_t(m) * f.dim + idx] = ((k00 + k01) + k10) + k11;
+  if (c < f.nc) east[size_t(m) * f.nr * (f.nc - 1) + size_t(r - 1) * (f.nc - 1) + (c - 1)] = -(k11 + k01) / 2;
+  if (r < f.nr) north[size_t(m) * (f.nr - 1) * f.nc + size_t(r - 1) * f.nc + (c - 1)] = -(k11 + k10) / 2;
+}
+
+// ============================================================================================
+// host: geometry, symbolic tile Cholesky, tables
+// ============================================================================================
+namespace {
+
+struct Edge {
+  int hv, p, q;  // hv 0: horizontal (r = pN, c in block column q); 1: vertical (c = qN, r in block row p)
+  int b0, b1;    // up/dn or lf/rt block indices
+};
+
+template <class Tp>
+int upload(Tp** dptr, const std::vector<Tp>& h) {
+  size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(Tp);
+  ROM_HIP(hipMalloc(dptr, bytes));
+  if (!h.empty()) ROM_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice));
+  return ROM_OK;
+}
+
+}  // namespace
+
+extern "C" int rom_fem_destroy(rom_fem* f) {
+  if (!f) return ROM_OK;
+  hipStreamSynchronize(f->ctx->stream);
+  void* ptrs[] = {f->d_H0, f->d_Tm, f->d_W, f->d_g, f->d_desc, f->d_extra, f->d_slot_of, f->d_kptr, f->d_kpair,
+                  f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L, f->d_invL, f->d_y};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  delete f;
+  return ROM_OK;
+}
+
+extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** out) {
+  ROM_CHECK(ctx && out, "rom_fem_create: null argument");
+  ROM_CHECK(nrb >= 1 && ncb >= 1 && N >= 2, "rom_fem_create: need nrb,ncb >= 1 and N >= 2 (got %d,%d,%d)", nrb, ncb, N);
+  ROM_CHECK(nrb * ncb <= 64, "rom_fem_create: at most 64 blocks supported (got %d)", nrb * ncb);
+  ROM_HIP(hipSetDevice(ctx->device));
+  rom_fem* f = new rom_fem();
+  f->ctx = ctx;
+  f->nrb = nrb; f->ncb = ncb; f->N = N;
+  const int n1 = N - 1;
+  f->n1 = n1;
+  f->tpe = (n1 + TB - 1) / TB;
+  f->n1p = f->tpe * TB;
+  f->nr = nrb * N - 1;
+  f->nc = ncb * N - 1;
+  f->dim = int64_t(f->nr) * f->nc;
+  const int n1p = f->n1p, tpe = f->tpe;
+
+  // ---- edges, crosses ------------------------------------------------------------------------
+  std::vector<Edge> edges;
+  std::map<std::pair<int, int>, int> hid, vid, xid;
+  for (int p = 1; p < nrb; ++p)
+    for (int q = 0; q < ncb; ++q) {
+      hid[{p, q}] = int(edges.size());
+      edges.push_back({0, p, q, (p - 1) * ncb + q, p * ncb + q});
+    }
+  for (int q = 1; q < ncb; ++q)
+    for (int p = 0; p < nrb; ++p) {
+      vid[{p, q}] = int(edges.size());
+      edges.push_back({1, p, q, p * ncb + (q - 1), p * ncb + q});
+    }
+  std::vector<std::pair<int, int>> crosses;
+  for (int p = 1; p < nrb; ++p)
+    for (int q = 1; q < ncb; ++q) {
+      xid[{p, q}] = int(crosses.size());
+      crosses.push_back({p, q});
+    }
+  const int E = int(edges.size());
+  const int ncross = int(crosses.size());
+  f->nG = E * n1 + ncross;
+  // block -> side -> edge id
+  std::vector<std::array<int, 4>> bside(nrb * ncb);
+  for (int p = 0; p < nrb; ++p)
+    for (int q = 0; q < ncb; ++q) {
+      auto& s = bside[p * ncb + q];
+      s[0] = p >= 1 ? hid[{p, q}] : -1;
+      s[1] = p + 1 < nrb ? hid[{p + 1, q}] : -1;
+      s[2] = q >= 1 ? vid[{p, q}] : -1;
+      s[3] = q + 1 < ncb ? vid[{p, q + 1}] : -1;
+    }
+  auto side_of = [&](int blk, int e) {
+    for (int s = 0; s < 4; ++s)
+      if (bside[blk][s] == e) return s;
+    return -1;
+  };
+
+  // ---- elimination order of the edges: greedy minimum degree on the edge graph ------------------
+  std::vector<std::set<int>> adj(E);
+  for (auto& s : bside)
+    for (int x = 0; x < 4; ++x)
+      for (int y = 0; y < 4; ++y)
+        if (x != y && s[x] >= 0 && s[y] >= 0) adj[s[x]].insert(s[y]);
+  // edges meeting at a cross point become coupled once the cross is ordered last: no extra edges now
+  std::vector<int> order;
+  {
+    std::vector<std::set<int>> g = adj;
+    std::vector<char> done(E, 0);
+    for (int step = 0; step < E; ++step) {
+      int best = -1;
+      size_t bd = 0;
+      for (int e = 0; e < E; ++e) {
+        if (done[e]) continue;
+        if (best < 0 || g[e].size() < bd) { best = e; bd = g[e].size(); }
+      }
+      done[best] = 1;
+      order.push_back(best);
+      std::vector<int> nb(g[best].begin(), g[best].end());
+      for (int x : nb) {
+        g[x].erase(best);
+        for (int y : nb)
+          if (x != y) g[x].insert(y);
+      }
+    }
+  }
+  std::vector<int> tile0(E);
+  for (int pos = 0; pos < E; ++pos) tile0[order[pos]] = pos * tpe;
+  const int xt0 = E * tpe;                         // first cross tile
+  const int nxt = (ncross + TB - 1) / TB;          // cross tiles
+  const int T = xt0 + nxt;
+  f->T = T;
+  f->nGp = T * TB;
+  // tile -> (edge id or -1 for cross, local tile index)
+  std::vector<int> tile_edge(T, -1), tile_loc(T, 0);
+  for (int e = 0; e < E; ++e)
+    for (int x = 0; x < tpe; ++x) { tile_edge[tile0[e] + x] = e; tile_loc[tile0[e] + x] = x; }
+  for (int x = 0; x < nxt; ++x) tile_loc[xt0 + x] = x;
+
+  // ---- cross <-> edge-end couplings ----------------------------------------------------------------
+  struct XCpl { int cross, edge, node; };  // node: 0-based local node on the edge
+  std::vector<XCpl> xc;
+  for (int e = 0; e < E; ++e) {
+    const Edge& ed = edges[e];
+    if (ed.hv == 0) {
+      if (ed.q >= 1) xc.push_back({xid[{ed.p, ed.q}], e, 0});
+      if (ed.q + 1 < ncb) xc.push_back({xid[{ed.p, ed.q + 1}], e, n1 - 1});
+    } else {
+      if (ed.p >= 1) xc.push_back({xid[{ed.p, ed.q}], e, 0});
+      if (ed.p + 1 < nrb) xc.push_back({xid[{ed.p + 1, ed.q}], e, n1 - 1});
+    }
+  }
+
+  // ---- tile mask + symbolic fill --------------------------------------------------------------------
+  std::vector<char> mask(size_t(T) * T, 0);
+  auto M_ = [&](int i, int j) -> char& { return mask[size_t(i) * T + j]; };
+  for (int e = 0; e < E; ++e)
+    for (int e2 = 0; e2 < E; ++e2)
+      if (e == e2 || adj[e].count(e2))
+        for (int x = 0; x < tpe; ++x)
+          for (int y = 0; y < tpe; ++y) M_(tile0[e] + x, tile0[e2] + y) = 1;
+  for (int x = 0; x < nxt; ++x) M_(xt0 + x, xt0 + x) = 1;
+  for (auto& c : xc) {
+    int ti = xt0 + c.cross / TB, tj = tile0[c.edge] + c.node / TB;
+    M_(ti, tj) = M_(tj, ti) = 1;
+  }
+  for (int k = 0; k < T; ++k)
+    for (int i = k + 1; i < T; ++i)
+      if (M_(i, k))
+        for (int j = k + 1; j <= i; ++j)
+          if (M_(j, k)) M_(i, j) = M_(j, i) = 1;
+
+  f->slot_of.assign(size_t(T) * T, -1);
+  std::vector<std::pair<int, int>> slots;
+  f->colptr.assign(T + 1, 0);
+  f->diag_slot.assign(T, -1);
+  for (int j = 0; j < T; ++j) {
+    f->diag_slot[j] = int(slots.size());
+    f->slot_of[size_t(j) * T + j] = int(slots.size());
+    slots.push_back({j, j});
+    for (int i = j + 1; i < T; ++i)
+      if (M_(i, j)) {
+        f->slot_of[size_t(i) * T + j] = int(slots.size());
+        f->colrow.push_back(int(slots.size()));
+        f->colti.push_back(i);
+        slots.push_back({i, j});
+      }
+    f->colptr[j + 1] = int(f->colrow.size());
+  }
+  f->nslots = int(slots.size());
+  f->kptr.assign(f->nslots + 1, 0);
+  double flops = 0;
+  for (int s = 0; s < f->nslots; ++s) {
+    int i = slots[s].first, j = slots[s].second;
+    for (int k = 0; k < j; ++k)
+      if (M_(i, k) && M_(j, k)) {
+        f->kpair.push_back(f->slot_of[size_t(i) * T + k]);
+        f->kpair.push_back(f->slot_of[size_t(j) * T + k]);
+        flops += 2.0 * TB * TB * TB;
+      }
+    f->kptr[s + 1] = int(f->kpair.size() / 2);
+    flops += (i == j) ? TB * double(TB) * TB / 3.0 : 2.0 * TB * TB * TB;  // potrf | trsm-as-gemm
+  }
+
+  // ---- tile descriptors + extras ------------------------------------------------------------------------
+  std::vector<TileExtra> extras;
+  f->desc.resize(f->nslots);
+  for (int s = 0; s < f->nslots; ++s) {
+    TileDesc d;
+    memset(&d, 0, sizeof(d));
+    d.ti = slots[s].first;
+    d.tj = slots[s].second;
+    d.diag = d.ti == d.tj;
+    int er = tile_edge[d.ti], ec = tile_edge[d.tj];
+    d.lr0 = tile_loc[d.ti] * TB;
+    d.lc0 = tile_loc[d.tj] * TB;
+    d.nvr = er >= 0 ? std::min(TB, n1 - d.lr0) : std::min(TB, ncross - d.lr0);
+    d.nvc = ec >= 0 ? std::min(TB, n1 - d.lc0) : std::min(TB, ncross - d.lc0);
+    if (er >= 0 && ec >= 0) {
+      // blocks adjacent to both edges
+      int cand[2] = {edges[er].b0, edges[er].b1};
+      for (int cb : cand) {
+        int sr = side_of(cb, er), sc = side_of(cb, ec);
+        if (sr >= 0 && sc >= 0) {
+          if (d.nterms >= 2) { rom_set_error("internal: more than 2 Schur terms per tile"); return ROM_ERR_INVALID; }
+          d.term[d.nterms++] = TileTerm{cb, sr * 4 + sc, d.lr0, d.lc0};
+        }
+      }
+      if (er == ec) {
+        d.same_edge = 1;
+        d.hv = edges[er].hv;
+        d.b0 = edges[er].b0;
+        d.b1 = edges[er].b1;
+      }
+    }
+    d.x0 = int(extras.size());
+    if (er < 0 && ec < 0 && d.diag) {
+      for (int x = 0; x < d.nvr; ++x) {
+        auto pq = crosses[d.lr0 + x];
+        int p = pq.first, q = pq.second;
+        TileExtra e{x, x, 1, {(p - 1) * ncb + (q - 1), (p - 1) * ncb + q, p * ncb + (q - 1), p * ncb + q}};
+        extras.push_back(e);
+      }
+    } else if (er < 0 && ec >= 0) {
+      for (auto& c : xc) {
+        if (c.edge != ec) continue;
+        if (c.cross / TB != tile_loc[d.ti] || c.node / TB != tile_loc[d.tj]) continue;
+        // coupling value uses the two blocks of the edge: -(k[r,c] + k[r-1,c])/2 resp. -(k[r,c]+k[r,c-1])/2
+        TileExtra e{c.cross % TB, c.node % TB, 0, {edges[ec].b1, edges[ec].b0, 0, 0}};
+        extras.push_back(e);
+      }
+    }
+    d.x1 = int(extras.size());
+    f->desc[s] = d;
+  }
+
+  // ---- block sides, vmap, interface rhs ---------------------------------------------------------------
+  f->sides.resize(nrb * ncb);
+  for (int b = 0; b < nrb * ncb; ++b)
+    for (int s = 0; s < 4; ++s) f->sides[b].off[s] = bside[b][s] >= 0 ? tile0[bside[b][s]] * TB : -1;
+  std::vector<int> vmap(std::max(f->nGp, 1), -1);
+  for (int e = 0; e < E; ++e) {
+    const Edge& ed = edges[e];
+    for (int t = 0; t < n1; ++t) {
+      int r, c;  // 1-based inner vertex coordinates
+      if (ed.hv == 0) { r = ed.p * N; c = ed.q * N + t + 1; }
+      else { r = ed.p * N + t + 1; c = ed.q * N; }
+      vmap[tile0[e] * TB + t] = (r - 1) * f->nc + (c - 1);
+    }
+  }
+  for (int x = 0; x < ncross; ++x) {
+    int r = crosses[x].first * N, c = crosses[x].second * N;
+    vmap[xt0 * TB + x] = (r - 1) * f->nc + (c - 1);
+  }
+
+  // ---- unit-block tables in long double ----------------------------------------------------------------
+  typedef long double ld;
+  const ld PI = acosl(-1.0L);
+  std::vector<ld> Q(size_t(n1) * n1), lam(n1);
+  for (int j = 1; j <= n1; ++j) {
+    lam[j - 1] = 2.0L - 2.0L * cosl(PI * j / N);
+    for (int m = 1; m <= n1; ++m) Q[size_t(j - 1) * n1 + (m - 1)] = sqrtl(2.0L / N) * sinl(PI * j * m / (ld)N);
+  }
+  std::vector<double> rho(size_t(n1) * (N + 1));
+  for (int m = 0; m < n1; ++m) {
+    ld phi = acoshl(1.0L + lam[m] / 2.0L);
+    ld den = -expm1l(-2.0L * N * phi);  // 1 - exp(-2 N phi)
+    for (int i = 0; i <= N; ++i) {
+      ld num = expl(-phi * i) * (-expm1l(-2.0L * (N - i) * phi));
+      rho[size_t(m) * (N + 1) + i] = double(num / den);
+    }
+  }
+  // W = L^{-1} 1 = Q (s s^T / (lam_l + lam_m)) Q
+  std::vector<ld> sv(n1, 0.0L), Z(size_t(n1) * n1), ZQ(size_t(n1) * n1);
+  for (int m = 0; m < n1; ++m)
+    for (int j = 0; j < n1; ++j) sv[m] += Q[size_t(j) * n1 + m];
+  for (int l = 0; l < n1; ++l)
+    for (int m = 0; m < n1; ++m) Z[size_t(l) * n1 + m] = sv[l] * sv[m] / (lam[l] + lam[m]);
+  for (int l = 0; l < n1; ++l)
+    for (int j = 0; j < n1; ++j) {
+      ld s = 0;
+      for (int m = 0; m < n1; ++m) s += Z[size_t(l) * n1 + m] * Q[size_t(j) * n1 + m];
+      ZQ[size_t(l) * n1 + j] = s;
+    }
+  std::vector<double> W(size_t(n1) * n1);
+  for (int i = 0; i < n1; ++i)
+    for (int j = 0; j < n1; ++j) {
+      ld s = 0;
+      for (int l = 0; l < n1; ++l) s += Q[size_t(i) * n1 + l] * ZQ[size_t(l) * n1 + j];
+      W[size_t(i) * n1 + j] = double(s);
+    }
+  const double h2 = 1.0 / (double(N) * double(N));
+  f->g_host.assign(std::max(f->nGp, 1), 0.0);
+  auto Wat = [&](int i, int j) { return W[size_t(i - 1) * n1 + (j - 1)]; };
+  for (int e = 0; e < E; ++e) {
+    const Edge& ed = edges[e];
+    for (int t = 1; t <= n1; ++t) {
+      double w = ed.hv == 0 ? Wat(N - 1, t) + Wat(1, t) : Wat(t, N - 1) + Wat(t, 1);
+      f->g_host[tile0[e] * TB + t - 1] = h2 * (1.0 + w);
+    }
+  }
+  for (int x = 0; x < ncross; ++x) f->g_host[xt0 * TB + x] = h2;
+
+  // ---- device tables -------------------------------------------------------------------------------------
+  std::vector<double> Qp(size_t(n1p) * n1p, 0.0);
+  for (int j = 0; j < n1; ++j)
+    for (int m = 0; m < n1; ++m) Qp[size_t(j) * n1p + m] = double(Q[size_t(j) * n1 + m]);
+  double *d_Qp = nullptr, *d_rho = nullptr, *d_A0 = nullptr;
+  ROM_TRY(upload(&d_Qp, Qp));
+  ROM_TRY(upload(&d_rho, rho));
+  const size_t hrows = size_t(n1) * n1;
+  ROM_HIP(hipMalloc(&d_A0, std::max<size_t>(hrows * n1p, 1) * sizeof(double)));
+  ROM_HIP(hipMalloc(&f->d_H0, std::max<size_t>(hrows * n1p, 1) * sizeof(double)));
+  ROM_HIP(hipMalloc(&f->d_Tm, size_t(16) * n1p * n1p * sizeof(double)));
+  {
+    size_t total = hrows * n1p;
+    k_build_A0<<<unsigned((total + 255) / 256), 256, 0, ctx->stream>>>(d_A0, d_Qp, d_rho, n1, n1p, N);
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(rom_launch_gemm_nt(ctx, int64_t(hrows), n1p, n1p, 1.0, d_A0, n1p, d_Qp, n1p, 0.0, f->d_H0, n1p,
+                               "setup_gemm_H0"));
+    size_t tt = size_t(16) * n1p * n1p;
+    k_build_Tm<<<unsigned((tt + 255) / 256), 256, 0, ctx->stream>>>(f->d_Tm, f->d_H0, n1, n1p, N);
+    ROM_HIP(hipGetLastError());
+    ROM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  hipFree(d_Qp);
+  hipFree(d_rho);
+  hipFree(d_A0);
+  ROM_TRY(upload(&f->d_W, W));
+  ROM_TRY(upload(&f->d_g, f->g_host));
+  ROM_TRY(upload(&f->d_desc, f->desc));
+  ROM_TRY(upload(&f->d_extra, extras));
+  ROM_TRY(upload(&f->d_slot_of, f->slot_of));
+  ROM_TRY(upload(&f->d_kptr, f->kptr));
+  ROM_TRY(upload(&f->d_kpair, f->kpair));
+  ROM_TRY(upload(&f->d_colptr, f->colptr));
+  ROM_TRY(upload(&f->d_colrow, f->colrow));
+  ROM_TRY(upload(&f->d_colti, f->colti));
+  ROM_TRY(upload(&f->d_sides, f->sides));
+  ROM_TRY(upload(&f->d_vmap, vmap));
+
+  // ---- work accounting of this algorithm, per snapshot solve ------------------------------------------------
+  double ext_flops = 0;
+  for (int b = 0; b < nrb * ncb; ++b) {
+    int ns = 0;
+    for (int s = 0; s < 4; ++s) ns += bside[b][s] >= 0;
+    ext_flops += 2.0 * double(n1) * n1 * ns * n1p;
+  }
+  double back_flops = 2.0 * 4096.0 * (f->nslots + T);
+  f->flops_solve = flops + ext_flops + back_flops;
+  // HBM bytes: factor tiles written once + read once by the back substitution, inverse tiles w+r,
+  // the snapshot row written once, the coefficients read.
+  f->bytes_solve = 8.0 * (2.0 * 4096.0 * f->nslots + 2.0 * 4096.0 * T + double(f->dim) + nrb * ncb);
+  *out = f;
+  return ROM_OK;
+}
+
+extern "C" int rom_fem_dims(rom_fem* f, int* nr, int* nc, int64_t* dim, int* n_interface, int* n_tiles) {
+  ROM_CHECK(f, "null fem");
+  if (nr) *nr = f->nr;
+  if (nc) *nc = f->nc;
+  if (dim) *dim = f->dim;
+  if (n_interface) *n_interface = f->nG;
+  if (n_tiles) *n_tiles = f->nslots;
+  return ROM_OK;
+}
+
+extern "C" int rom_fem_load_vector_host(rom_fem* f, double* B) {
+  ROM_CHECK(f && B, "bad arguments");
+  // (:177-185) every inner vertex collects area/6 + area/3 + area/3 + area/6 in this order
+  double area = (1.0 / f->N) * (1.0 / f->N);
+  double v = 0.0;
+  v += area / 6;
+  v += area / 3;
+  v += area / 3;
+  v += area / 6;
+  for (int64_t i = 0; i < f->dim; ++i) B[i] = v;
+  return ROM_OK;
+}
+
+extern "C" int rom_solve_work(rom_fem* f, double* flops_own, double* bytes_own, double* flops_banded,
+                              double* bytes_banded) {
+  ROM_CHECK(f, "null fem");
+  if (flops_own) *flops_own = f->flops_solve;
+  if (bytes_own) *bytes_own = f->bytes_solve;
+  double b = std::min(f->nr, f->nc), dim = double(f->dim);
+  double nnzL = dim * (b + 1) - b * (b + 1) / 2;
+  if (bytes_banded) *bytes_banded = 8.0 * (3 * nnzL + 5 * dim);
+  if (flops_banded) *flops_banded = dim * b * b + 4 * dim * b;
+  return ROM_OK;
+}
+
+extern "C" int rom_assemble_batch(rom_fem* f, rom_buf* a, int M, rom_buf* diag, rom_buf* east, rom_buf* north) {
+  ROM_CHECK(f && a && diag && east && north, "rom_assemble_batch: null argument");
+  ROM_CHECK(M >= 0, "rom_assemble_batch: negative M");
+  const int kblk = f->nrb * f->ncb;
+  ROM_CHECK(a->n >= size_t(M) * kblk, "rom_assemble_batch: `a` holds %zu doubles, need %zu", a->n, size_t(M) * kblk);
+  ROM_CHECK(diag->n >= size_t(M) * f->dim && east->n >= size_t(M) * f->nr * (f->nc - 1) &&
+                north->n >= size_t(M) * (f->nr - 1) * f->nc,
+            "rom_assemble_batch: output buffers too small");
+  if (M == 0) return ROM_OK;
+  FemDev d = make_dev(f);
+  dim3 grid(unsigned((f->dim + 255) / 256), M);
+  {
+    ROM_PROF(f->ctx, "assemble_stencil", 7.0 * f->dim * M, 24.0 * f->dim * M);
+    k_assemble_stencil<<<grid, 256, 0, f->ctx->stream>>>(d, a->p, M, diag->p, east->p, north->p);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+static int ensure_workspace(rom_fem* f, int Mc) {
+  if (f->ws_M >= Mc) return ROM_OK;
+  ROM_HIP(hipStreamSynchronize(f->ctx->stream));
+  if (f->d_L) hipFree(f->d_L);
+  if (f->d_invL) hipFree(f->d_invL);
+  if (f->d_y) hipFree(f->d_y);
+  f->d_L = f->d_invL = f->d_y = nullptr;
+  f->ws_M = 0;
+  ROM_HIP(hipMalloc(&f->d_L, std::max<size_t>(size_t(Mc) * f->nslots * 4096, 1) * sizeof(double)));
+  ROM_HIP(hipMalloc(&f->d_invL, std::max<size_t>(size_t(Mc) * f->T * 4096, 1) * sizeof(double)));
+  ROM_HIP(hipMalloc(&f->d_y, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
+  f->ws_M = Mc;
+  return ROM_OK;
+}
+
+extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0) {
+  ROM_CHECK(f && a && U, "rom_solve_batch: null argument");
+  ROM_CHECK(M >= 0 && row0 >= 0, "rom_solve_batch: negative M or row offset");
+  const int kblk = f->nrb * f->ncb;
+  ROM_CHECK(a->n >= size_t(M) * kblk, "rom_solve_batch: `a` holds %zu doubles, need %zu", a->n, size_t(M) * kblk);
+  ROM_CHECK(U->n >= size_t(row0 + M) * f->dim, "rom_solve_batch: U holds %zu doubles, need %zu", U->n,
+            size_t(row0 + M) * f->dim);
+  if (M == 0) return ROM_OK;
+  rom_ctx* ctx = f->ctx;
+  ROM_HIP(hipSetDevice(ctx->device));
+  // chunk the sweep so that the factor workspace respects the budget
+  size_t per_sys = (size_t(f->nslots) * 4096 + size_t(f->T) * 4096 + f->nGp) * sizeof(double);
+  int Mc_max = int(std::max<size_t>(1, std::min<size_t>(size_t(M), ctx->ws_limit / std::max<size_t>(per_sys, 1))));
+  if (f->ws_M > 0 && f->ws_M < Mc_max && f->ws_M >= 256) Mc_max = f->ws_M;  // reuse what we have
+  ROM_TRY(ensure_workspace(f, Mc_max));
+  hipStream_t st = ctx->stream;
+  ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), st));
+  const size_t lds_back = size_t(std::max(f->nGp, 1)) * sizeof(double);
+  ROM_CHECK(lds_back <= 60 * 1024, "rom_solve_batch: interface too large for the LDS-resident back substitution");
+  for (int m0 = 0; m0 < M; m0 += Mc_max) {
+    const int Mc = std::min(Mc_max, M - m0);
+    FemDev d = make_dev(f);
+    const double* am = a->p + size_t(m0) * kblk;
+    if (f->T > 0) {
+      {
+        ROM_PROF(ctx, "init_rhs", 0, 8.0 * Mc * f->nGp);
+        size_t tot = size_t(Mc) * f->nGp;
+        k_init_rhs<<<unsigned((tot + 255) / 256), 256, 0, st>>>(d, Mc);
+      }
+      for (int j = 0; j < f->T; ++j) {
+        {
+          int slot = f->diag_slot[j];
+          double nk = f->kptr[slot + 1] - f->kptr[slot];
+          ROM_PROF(ctx, "factor_diag", Mc * (nk * 2.0 * 262144 + 262144 / 3.0 + 262144 / 3.0),
+                   Mc * 8.0 * 4096 * (2 + 2 * nk));
+          k_factor_diag<<<Mc, 256, 0, st>>>(d, am, slot, j);
+        }
+        int nrows = f->colptr[j + 1] - f->colptr[j];
+        if (nrows > 0) {
+          double nk = 0;
+          for (int e = f->colptr[j]; e < f->colptr[j + 1]; ++e) nk += f->kptr[f->colrow[e] + 1] - f->kptr[f->colrow[e]];
+          ROM_PROF(ctx, "factor_panel", Mc * (nk + nrows) * 2.0 * 262144, Mc * 8.0 * 4096 * (2 * nk + 2 * nrows));
+          k_factor_panel<<<dim3(nrows, Mc), 256, 0, st>>>(d, am, j);
+        }
+      }
+      {
+        ROM_PROF(ctx, "backsolve", Mc * 2.0 * 4096 * (f->nslots + f->T), Mc * 8.0 * 4096 * (f->nslots + f->T));
+        k_backsolve<<<Mc, 256, lds_back, st>>>(d, f->d_slot_of, nullptr);
+      }
+    }
+    {
+      const int nij = f->n1 * f->n1;
+      if (nij > 0) {
+        dim3 grid((nij + 63) / 64, (Mc + 63) / 64, kblk);
+        double fl = 0;
+        for (int b = 0; b < kblk; ++b) {
+          int ns = 0;
+          for (int s = 0; s < 4; ++s) ns += f->sides[b].off[s] >= 0;
+          fl += 2.0 * nij * double(ns) * f->n1p;
+        }
+        ROM_PROF(ctx, "extend", fl * Mc, 8.0 * Mc * double(kblk) * nij);
+        k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U->p, (long long)(row0 + m0));
+      }
+      if (f->T > 0) {
+        ROM_PROF(ctx, "scatter_interface", 0, 16.0 * Mc * f->nG);
+        k_scatter_interface<<<dim3((f->nGp + 255) / 256, Mc), 256, 0, st>>>(d, Mc, U->p, (long long)(row0 + m0));
+      }
+    }
+    ROM_HIP(hipGetLastError());
+  }
+  int status = 0;
+  ROM_HIP(hipMemcpyAsync(&status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+  ROM_HIP(hipStreamSynchronize(st));
+  if (status != 0) {
+    rom_set_error("rom_solve_batch: interface matrix not positive definite (non-positive pivot); "
+                  "all block coefficients must be > 0");
+    return ROM_ERR_NOT_SPD;
+  }
+  return ROM_OK;
+}

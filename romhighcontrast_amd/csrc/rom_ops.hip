@@ -1,0 +1,461 @@
+// Dense fp64 MFMA contractions, stencil application, norms and the batched reduced solves.
+//
+// Reference counterparts: H10norm / l2norm (src/lib/SolutionsManagers.py:56-62), the
+// `C A_pq C^T`, `C A_1 U^T`, `c_i . basis` einsums of generate_fm_solutions (:93-106) and
+// project_solutions (:113-139), and the reduced `galerkin` solves (:104-105, :135-138).
+#include <algorithm>
+#include <cmath>
+
+#include "rom_mma.h"
+
+// ============================================================================================
+// generic NT GEMM:  C[m,n] = alpha * sum_k A[m,k] B[n,k] + beta C      (64x64 tiles, split-K)
+// ============================================================================================
+// bounds-checked load of 4 consecutive k of one row; ALIGNED => 16-B vector loads are legal
+template <bool ALIGNED>
+__device__ inline void load4_row(const double* __restrict__ row, long long k, long long kend, double v[4]) {
+  if (row == nullptr || k >= kend) {
+    v[0] = v[1] = v[2] = v[3] = 0.0;
+    return;
+  }
+  if (ALIGNED && k + 4 <= kend) {
+    load4_aligned(row + k, v);
+    return;
+  }
+#pragma unroll
+  for (int x = 0; x < 4; ++x) v[x] = (k + x < kend) ? row[k + x] : 0.0;
+}
+
+// grid (ceil(n/64), ceil(m/64), splits).  Each z-slice handles K range [z*kper, min(K,(z+1)*kper)).
+// splits == 1: writes alpha*acc + beta*C directly; else writes the raw partial tile to `part`
+// ([z][m][n], ld n) for the deterministic reduction kernel below.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_gemm_nt(long long m, long long n, long long K, long long kper,
+                                                 double alpha, const double* __restrict__ A, long long lda,
+                                                 const double* __restrict__ B, long long ldb, double beta,
+                                                 double* __restrict__ C, long long ldc, double* __restrict__ part) {
+  __shared__ __align__(16) double stage[STAGE_TOTAL];
+  const WavePos wp;
+  const long long r0 = blockIdx.y * 64LL, c0 = blockIdx.x * 64LL;
+  const long long kbeg = blockIdx.z * kper, kend = std::min<long long>(K, kbeg + kper);
+  const int srow = stage_row(), sseg = stage_seg();
+  const double* Ar = (r0 + srow < m) ? A + (r0 + srow) * lda : nullptr;
+  const double* Br = (c0 + srow < n) ? B + (c0 + srow) * ldb : nullptr;
+  Acc acc;
+  acc_zero(acc);
+  const int nch = int((kend - kbeg + BK - 1) / BK);
+  gemm_loop(
+      nch, [&](int ch, double* v) { load4_row<ALIGNED>(Ar, kbeg + ch * BK + sseg, kend, v); },
+      [&](int ch, double* v) { load4_row<ALIGNED>(Br, kbeg + ch * BK + sseg, kend, v); }, acc, stage, wp);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      long long r = r0 + acc_row(wp, i, g);
+      if (r >= m) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        long long c = c0 + acc_col(wp, j);
+        if (c >= n) continue;
+        double v = acc.c[i][j][g];
+        if (part) {
+          part[(blockIdx.z * m + r) * n + c] = v;
+        } else {
+          double* p = C + r * ldc + c;
+          *p = beta == 0.0 ? alpha * v : alpha * v + beta * *p;
+        }
+      }
+    }
+}
+
+__global__ void k_splitk_reduce(long long m, long long n, int splits, double alpha, const double* __restrict__ part,
+                                double beta, double* __restrict__ C, long long ldc) {
+  long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= m * n) return;
+  double s = 0.0;
+  for (int z = 0; z < splits; ++z) s += part[z * m * n + idx];
+  long long r = idx / n, c = idx % n;
+  double* p = C + r * ldc + c;
+  *p = beta == 0.0 ? alpha * s : alpha * s + beta * *p;
+}
+
+int rom_launch_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const char* prof_name) {
+  if (m <= 0 || n <= 0) return ROM_OK;
+  const long long tiles = ((m + 63) / 64) * ((n + 63) / 64);
+  int splits = 1;
+  if (k >= 1024 && tiles < 512) {
+    splits = int(std::min<long long>((768 + tiles - 1) / tiles, (k + 511) / 512));
+    splits = std::max(splits, 1);
+  }
+  long long kper = ((k + splits - 1) / splits + BK - 1) / BK * BK;
+  if (kper <= 0) kper = BK;
+  splits = int((k + kper - 1) / kper);
+  if (splits < 1) splits = 1;
+  double* part = nullptr;
+  if (splits > 1) ROM_TRY(rom_ctx_scratch(ctx, size_t(splits) * m * n, &part));
+  const bool aligned = (lda % 2 == 0) && (ldb % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (kper % 4 == 0);
+  dim3 grid(unsigned((n + 63) / 64), unsigned((m + 63) / 64), unsigned(splits));
+  {
+    ROM_PROF(ctx, prof_name, 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(m) * n));
+    if (aligned)
+      k_gemm_nt<true><<<grid, 256, 0, ctx->stream>>>(m, n, k, kper, alpha, A, lda, B, ldb, beta, C, ldc, part);
+    else
+      k_gemm_nt<false><<<grid, 256, 0, ctx->stream>>>(m, n, k, kper, alpha, A, lda, B, ldb, beta, C, ldc, part);
+  }
+  ROM_HIP(hipGetLastError());
+  if (splits > 1) {
+    ROM_PROF(ctx, "splitk_reduce", double(splits) * m * n, 8.0 * double(splits + 1) * m * n);
+    k_splitk_reduce<<<unsigned((m * n + 255) / 256), 256, 0, ctx->stream>>>(m, n, splits, alpha, part, beta, C, ldc);
+    ROM_HIP(hipGetLastError());
+  }
+  return ROM_OK;
+}
+
+extern "C" int rom_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, rom_buf* A, size_t a_off,
+                           int64_t lda, rom_buf* B, size_t b_off, int64_t ldb, double beta, rom_buf* C,
+                           size_t c_off, int64_t ldc) {
+  ROM_CHECK(ctx && A && B && C, "rom_gemm_nt: null argument");
+  ROM_CHECK(m >= 0 && n >= 0 && k >= 0 && lda >= k && ldb >= k && ldc >= n, "rom_gemm_nt: bad dimensions");
+  if (m == 0 || n == 0) return ROM_OK;
+  ROM_CHECK(a_off + size_t(m - 1) * lda + k <= A->n, "rom_gemm_nt: A out of range");
+  ROM_CHECK(b_off + size_t(n - 1) * ldb + k <= B->n, "rom_gemm_nt: B out of range");
+  ROM_CHECK(c_off + size_t(m - 1) * ldc + n <= C->n, "rom_gemm_nt: C out of range");
+  return rom_launch_gemm_nt(ctx, m, n, k, alpha, A->p + a_off, lda, B->p + b_off, ldb, beta, C->p + c_off, ldc,
+                            "gemm_nt");
+}
+
+// ============================================================================================
+// NN GEMM: C[m,n] = alpha * sum_k A[m,k] B[k,n] + beta C   (k small: the lift  c . basis)
+// ============================================================================================
+__global__ __launch_bounds__(256) void k_gemm_nn(long long m, long long n, long long K, double alpha,
+                                                 const double* __restrict__ A, long long lda,
+                                                 const double* __restrict__ B, long long ldb, double beta,
+                                                 double* __restrict__ C, long long ldc) {
+  __shared__ __align__(16) double stage[2 * STAGE_DOUBLES];
+  double* sA = stage;
+  double* sB = stage + STAGE_DOUBLES;
+  const WavePos wp;
+  const long long r0 = blockIdx.y * 64LL, c0 = blockIdx.x * 64LL;
+  const int t = threadIdx.x;
+  const int srow = stage_row(), sseg = stage_seg();
+  const double* Ar = (r0 + srow < m) ? A + (r0 + srow) * lda : nullptr;
+  const int bk = t >> 4, bc = (t & 15) * 4;  // B staging: row k0+bk, 4 consecutive columns
+  Acc acc;
+  acc_zero(acc);
+  for (long long k0 = 0; k0 < K; k0 += BK) {
+    double va[4], vb[4];
+    load4_row<false>(Ar, k0 + sseg, K, va);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      long long c = c0 + bc + x;
+      vb[x] = (k0 + bk < K && c < n) ? B[(k0 + bk) * ldb + c] : 0.0;
+    }
+    __syncthreads();  // previous chunk fully consumed
+    stage_store(sA, va);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) sB[(bc + x) * LDK + bk] = vb[x];
+    __syncthreads();
+    mma_chunk(sA, sB, acc, wp);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      long long r = r0 + acc_row(wp, i, g);
+      if (r >= m) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        long long c = c0 + acc_col(wp, j);
+        if (c >= n) continue;
+        double* p = C + r * ldc + c;
+        double v = acc.c[i][j][g];
+        *p = beta == 0.0 ? alpha * v : alpha * v + beta * *p;
+      }
+    }
+}
+
+extern "C" int rom_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, rom_buf* A, size_t a_off,
+                           int64_t lda, rom_buf* B, size_t b_off, int64_t ldb, double beta, rom_buf* C,
+                           size_t c_off, int64_t ldc) {
+  ROM_CHECK(ctx && A && B && C, "rom_gemm_nn: null argument");
+  ROM_CHECK(m >= 0 && n >= 0 && k >= 0 && lda >= k && ldb >= n && ldc >= n, "rom_gemm_nn: bad dimensions");
+  if (m == 0 || n == 0) return ROM_OK;
+  ROM_CHECK(a_off + size_t(m - 1) * lda + k <= A->n, "rom_gemm_nn: A out of range");
+  ROM_CHECK(k == 0 || b_off + size_t(k - 1) * ldb + n <= B->n, "rom_gemm_nn: B out of range");
+  ROM_CHECK(c_off + size_t(m - 1) * ldc + n <= C->n, "rom_gemm_nn: C out of range");
+  dim3 grid(unsigned((n + 63) / 64), unsigned((m + 63) / 64));
+  {
+    ROM_PROF(ctx, "gemm_nn", 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(m) * n));
+    k_gemm_nn<<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A->p + a_off, lda, B->p + b_off, ldb, beta,
+                                             C->p + c_off, ldc);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// ============================================================================================
+// stencil application and norms
+// ============================================================================================
+struct StencilGeom {
+  int nr, nc, N, ncb, kblk;
+  long long dim;
+};
+
+// (A(coef) x)(r,c) with x given as a functor over the flat inner-vertex index
+template <class XF>
+__device__ inline double stencil_at(const StencilGeom& g, const double* am, bool unit, long long idx, XF x) {
+  int r = int(idx / g.nc) + 1, c = int(idx % g.nc) + 1;
+  double k00 = 1.0, k01 = 1.0, k10 = 1.0, k11 = 1.0;
+  if (!unit) {
+    int N = g.N;
+    k00 = am[((r - 1) / N) * g.ncb + (c - 1) / N];
+    k01 = am[((r - 1) / N) * g.ncb + c / N];
+    k10 = am[(r / N) * g.ncb + (c - 1) / N];
+    k11 = am[(r / N) * g.ncb + c / N];
+  }
+  double y = (((k00 + k01) + k10) + k11) * x(idx);
+  if (c < g.nc) y += (-(k11 + k01) / 2) * x(idx + 1);
+  if (c > 1) y += (-(k10 + k00) / 2) * x(idx - 1);
+  if (r < g.nr) y += (-(k11 + k10) / 2) * x(idx + g.nc);
+  if (r > 1) y += (-(k01 + k00) / 2) * x(idx - g.nc);
+  return y;
+}
+
+__global__ void k_stencil_apply(StencilGeom g, const double* __restrict__ a_one, int unit,
+                                const double* __restrict__ X, double* __restrict__ Y) {
+  __shared__ double am[64];
+  if (!unit)
+    for (int i = threadIdx.x; i < g.kblk; i += blockDim.x) am[i] = a_one[i];
+  __syncthreads();
+  long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= g.dim) return;
+  const double* x = X + blockIdx.y * g.dim;
+  Y[blockIdx.y * g.dim + idx] = stencil_at(g, am, unit != 0, idx, [&](long long i) { return x[i]; });
+}
+
+__device__ inline double block_reduce_sum(double v) {
+  __shared__ double red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// partial[k][blk] = sum over this block's vertices of d * (A_1 d),  d = u - v (or u)
+__global__ __launch_bounds__(256) void k_h10_partial(StencilGeom g, const double* __restrict__ U,
+                                                     const double* __restrict__ V, double* __restrict__ partial,
+                                                     int nblk, int per_thread) {
+  const double* u = U + blockIdx.y * g.dim;
+  const double* v = V ? V + blockIdx.y * g.dim : nullptr;
+  double s = 0.0;
+  long long base = blockIdx.x * (long long)(256 * per_thread);
+  for (int it = 0; it < per_thread; ++it) {
+    long long idx = base + it * 256 + threadIdx.x;
+    if (idx < g.dim) {
+      if (v) {
+        auto xf = [&](long long i) { return u[i] - v[i]; };
+        s += xf(idx) * stencil_at(g, nullptr, true, idx, xf);
+      } else {
+        auto xf = [&](long long i) { return u[i]; };
+        s += xf(idx) * stencil_at(g, nullptr, true, idx, xf);
+      }
+    }
+  }
+  s = block_reduce_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.y * (long long)nblk + blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_sq_partial(long long dim, const double* __restrict__ U,
+                                                    double* __restrict__ partial, int nblk, int per_thread) {
+  const double* u = U + blockIdx.y * dim;
+  double s = 0.0;
+  long long base = blockIdx.x * (long long)(256 * per_thread);
+  for (int it = 0; it < per_thread; ++it) {
+    long long idx = base + it * 256 + threadIdx.x;
+    if (idx < dim) s += u[idx] * u[idx];
+  }
+  s = block_reduce_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.y * (long long)nblk + blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_finish_norm(const double* __restrict__ partial, int nblk,
+                                                     double* __restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partial[blockIdx.x * (long long)nblk + i];
+  s = block_reduce_sum(s);
+  if (threadIdx.x == 0) out[blockIdx.x] = sqrt(s);
+}
+
+static StencilGeom make_geom(int nrb, int ncb, int N) {
+  StencilGeom g;
+  g.N = N;
+  g.ncb = ncb;
+  g.kblk = nrb * ncb;
+  g.nr = nrb * N - 1;
+  g.nc = ncb * N - 1;
+  g.dim = (long long)g.nr * g.nc;
+  return g;
+}
+
+extern "C" int rom_stencil_apply(rom_fem* f, const double* a_one_host, int unit, rom_buf* X, int64_t x_row0,
+                                 int K, rom_buf* Y, int64_t y_row0) {
+  ROM_CHECK(f && X && Y, "rom_stencil_apply: null argument");
+  ROM_CHECK(unit || a_one_host, "rom_stencil_apply: coefficient required when unit == 0");
+  ROM_CHECK(K >= 0 && x_row0 >= 0 && y_row0 >= 0, "rom_stencil_apply: negative size");
+  ROM_CHECK(size_t(x_row0 + K) * f->dim <= X->n && size_t(y_row0 + K) * f->dim <= Y->n,
+            "rom_stencil_apply: rows out of range");
+  if (K == 0) return ROM_OK;
+  rom_ctx* ctx = f->ctx;
+  StencilGeom g = make_geom(f->nrb, f->ncb, f->N);
+  double* d_a = nullptr;
+  if (!unit) {
+    ROM_TRY(rom_ctx_scratch(ctx, 64, &d_a));
+    ROM_HIP(hipMemcpyAsync(d_a, a_one_host, g.kblk * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ROM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  dim3 grid(unsigned((g.dim + 255) / 256), K);
+  {
+    ROM_PROF(ctx, "stencil_apply", 14.0 * g.dim * K, 16.0 * g.dim * K);
+    k_stencil_apply<<<grid, 256, 0, ctx->stream>>>(g, d_a, unit, X->p + x_row0 * f->dim, Y->p + y_row0 * f->dim);
+  }
+  ROM_HIP(hipGetLastError());
+  if (!unit) ROM_HIP(hipStreamSynchronize(ctx->stream));  // scratch may be re-used by the next call
+  return ROM_OK;
+}
+
+extern "C" int rom_h10norm(rom_fem* f, rom_buf* U, int64_t u_row0, rom_buf* V, int64_t v_row0, int K,
+                           double* out_host) {
+  ROM_CHECK(f && U && (out_host || K == 0), "rom_h10norm: null argument");
+  ROM_CHECK(K >= 0 && u_row0 >= 0 && v_row0 >= 0, "rom_h10norm: negative size");
+  ROM_CHECK(size_t(u_row0 + K) * f->dim <= U->n, "rom_h10norm: U rows out of range");
+  ROM_CHECK(!V || size_t(v_row0 + K) * f->dim <= V->n, "rom_h10norm: V rows out of range");
+  if (K == 0) return ROM_OK;
+  rom_ctx* ctx = f->ctx;
+  StencilGeom g = make_geom(f->nrb, f->ncb, f->N);
+  const int per_thread = 8;
+  const int nblk = int((g.dim + 256 * per_thread - 1) / (256 * per_thread));
+  double* scratch = nullptr;
+  ROM_TRY(rom_ctx_scratch(ctx, size_t(K) * nblk + K, &scratch));
+  double* d_out = scratch + size_t(K) * nblk;
+  {
+    ROM_PROF(ctx, "h10norm", 16.0 * g.dim * K, (V ? 16.0 : 8.0) * g.dim * K);
+    k_h10_partial<<<dim3(nblk, K), 256, 0, ctx->stream>>>(g, U->p + u_row0 * f->dim,
+                                                         V ? V->p + v_row0 * f->dim : nullptr, scratch, nblk,
+                                                         per_thread);
+    k_finish_norm<<<K, 256, 0, ctx->stream>>>(scratch, nblk, d_out);
+  }
+  ROM_HIP(hipGetLastError());
+  ROM_HIP(hipMemcpyAsync(out_host, d_out, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  return ROM_OK;
+}
+
+extern "C" int rom_l2norm(rom_ctx* ctx, rom_buf* U, int64_t row0, int K, int64_t dim, double* out_host) {
+  ROM_CHECK(ctx && U && (out_host || K == 0), "rom_l2norm: null argument");
+  ROM_CHECK(K >= 0 && row0 >= 0 && dim >= 0, "rom_l2norm: negative size");
+  ROM_CHECK(size_t(row0 + K) * dim <= U->n, "rom_l2norm: rows out of range");
+  if (K == 0) return ROM_OK;
+  const int per_thread = 8;
+  const int nblk = int(std::max<int64_t>(1, (dim + 256 * per_thread - 1) / (256 * per_thread)));
+  double* scratch = nullptr;
+  ROM_TRY(rom_ctx_scratch(ctx, size_t(K) * nblk + K, &scratch));
+  double* d_out = scratch + size_t(K) * nblk;
+  {
+    ROM_PROF(ctx, "l2norm", 2.0 * dim * K, 8.0 * dim * K);
+    k_sq_partial<<<dim3(nblk, K), 256, 0, ctx->stream>>>(dim, U->p + row0 * dim, scratch, nblk, per_thread);
+    k_finish_norm<<<K, 256, 0, ctx->stream>>>(scratch, nblk, d_out);
+  }
+  ROM_HIP(hipGetLastError());
+  ROM_HIP(hipMemcpyAsync(out_host, d_out, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  return ROM_OK;
+}
+
+// ============================================================================================
+// batched reduced SPD solves (n <= 88): one workgroup per system, matrix resident in LDS
+// ============================================================================================
+__global__ __launch_bounds__(256) void k_reduced_solve(int n, int kb, const double* __restrict__ Ahat,
+                                                       const double* __restrict__ w, const double* __restrict__ rhs,
+                                                       int rhs_per_system, double* __restrict__ cout, int* status) {
+  extern __shared__ __align__(16) double sm[];  // n*(n+1) matrix + n rhs + n diag
+  const int ld = n + 1;
+  double* Am = sm;
+  double* b = sm + size_t(n) * ld;
+  double* sd = b + n;
+  const int m = blockIdx.x, t = threadIdx.x;
+  // A = sum_b w[m,b] Ahat[b]   (the reference's einsum('pqij,pq->ij') on the reduced tensor)
+  for (int idx = t; idx < n * n; idx += 256) {
+    int r = idx / n, c = idx % n;
+    double s = 0.0;
+    for (int q = 0; q < kb; ++q) s += w[size_t(m) * kb + q] * Ahat[(size_t(q) * n + r) * n + c];
+    Am[r * ld + c] = s;
+  }
+  for (int i = t; i < n; i += 256) b[i] = rhs_per_system ? rhs[size_t(m) * n + i] : rhs[i];
+  __syncthreads();
+  // right-looking elimination (LDL^T form), lower triangle
+  for (int j = 0; j < n - 1; ++j) {
+    double invd = 1.0 / Am[j * ld + j];
+    for (int idx = t; idx < (n - j - 1) * (n - j - 1); idx += 256) {
+      int r = j + 1 + idx / (n - j - 1), c = j + 1 + idx % (n - j - 1);
+      if (c <= r) Am[r * ld + c] -= Am[r * ld + j] * invd * Am[c * ld + j];
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < n; i += 256) {
+    double d = Am[i * ld + i];
+    if (!(d > 0.0)) atomicOr(status, 1);
+    sd[i] = sqrt(d);
+  }
+  __syncthreads();
+  // one wave finishes: L = Am / sd ; forward + backward substitution (n small)
+  if (t < 64) {
+    // forward: y_r = (b_r - sum_{k<r} L_rk y_k) / L_rr, column sweep so lanes work on rows r > k
+    for (int k = 0; k < n; ++k) {
+      double yk = b[k] / sd[k];
+      __builtin_amdgcn_wave_barrier();
+      if (t == 0) b[k] = yk;
+      for (int r = k + 1 + t; r < n; r += 64) b[r] -= (Am[r * ld + k] / sd[k]) * yk;
+      __builtin_amdgcn_wave_barrier();
+    }
+    // backward: x_k = (y_k - sum_{r>k} L_rk x_r) / L_kk
+    for (int k = n - 1; k >= 0; --k) {
+      double xk = b[k] / sd[k];
+      __builtin_amdgcn_wave_barrier();
+      if (t == 0) b[k] = xk;
+      for (int c = t; c < k; c += 64) b[c] -= (Am[k * ld + c] / sd[c]) * xk;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += 256) cout[size_t(m) * n + i] = b[i];
+}
+
+extern "C" int rom_reduced_solve_batch(rom_ctx* ctx, int n, int kb, int M, rom_buf* Ahat, rom_buf* w, rom_buf* rhs,
+                                       int rhs_per_system, rom_buf* c_out) {
+  ROM_CHECK(ctx && Ahat && w && rhs && c_out, "rom_reduced_solve_batch: null argument");
+  ROM_CHECK(n >= 1 && n <= 88, "rom_reduced_solve_batch: reduced dimension %d outside [1, 88]", n);
+  ROM_CHECK(kb >= 1 && M >= 0, "rom_reduced_solve_batch: bad sizes");
+  ROM_CHECK(Ahat->n >= size_t(kb) * n * n && w->n >= size_t(M) * kb && c_out->n >= size_t(M) * n &&
+                rhs->n >= (rhs_per_system ? size_t(M) * n : size_t(n)),
+            "rom_reduced_solve_batch: buffer too small");
+  if (M == 0) return ROM_OK;
+  ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+  size_t lds = (size_t(n) * (n + 1) + 2 * n) * sizeof(double);
+  {
+    ROM_PROF(ctx, "reduced_solve", M * (double(n) * n * n / 3 + 2.0 * kb * n * n), 8.0 * M * (kb + 2.0 * n));
+    k_reduced_solve<<<M, 256, lds, ctx->stream>>>(n, kb, Ahat->p, w->p, rhs->p, rhs_per_system, c_out->p,
+                                                  ctx->d_status);
+  }
+  ROM_HIP(hipGetLastError());
+  int status = 0;
+  ROM_HIP(hipMemcpyAsync(&status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  if (status) {
+    rom_set_error("rom_reduced_solve_batch: reduced matrix not positive definite");
+    return ROM_ERR_NOT_SPD;
+  }
+  return ROM_OK;
+}
