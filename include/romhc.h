@@ -129,6 +129,17 @@ int rom_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, rom
 int rom_reduced_solve_batch(rom_ctx* ctx, int n, int kb, int M, rom_buf* Ahat, rom_buf* w, rom_buf* rhs,
                             int rhs_per_system, rom_buf* c_out);
 
+/* ---- helpers of the basis builders ------------------------------------------------------ */
+int rom_buf_scale(rom_buf* b, size_t offset, size_t n, double alpha);
+/* X[row0+m, :] -= mean over m (column means, kept in `mean`, dim doubles): the centring step of
+ * sklearn PCA.fit called at src/lib/ReducedBasis.py:196 */
+int rom_center_rows(rom_ctx* ctx, rom_buf* X, int64_t row0, int M, int64_t dim, rom_buf* mean);
+/* evaluate_solutions (src/lib/SolutionsManagers.py:221-244): P1 interpolation of K FE vectors at
+ * npts points.  ix/iy = cell index of each point (searchsorted(points_c/points_r) - 1), tx/ty its
+ * local coordinates in the cell; out_host is (K, npts). */
+int rom_evaluate_points(rom_fem* fem, rom_buf* U, int64_t row0, int K, int npts, const int* ix_host,
+                        const int* iy_host, const double* tx_host, const double* ty_host, double* out_host);
+
 /* ---- multi-GPU: RCCL all-gather of the snapshot block --------------------- */
 /* id_out: 128 bytes (ncclUniqueId).  librccl is dlopen()ed on first use. */
 int rom_comm_unique_id(char* id_out, size_t cap);

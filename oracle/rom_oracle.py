@@ -299,17 +299,17 @@ def get_starting_basis(solutions2train, a2train, add_inf_solutions=True):
 def pca_components(X: np.ndarray, n: int):
     """Deterministic equivalent of ``PCA(n_components=n).fit(X).components_`` (:196).
 
-    Mean-centred thin SVD; rows = right singular vectors with scikit-learn's ``svd_flip``
-    sign convention (u-based: the largest-|.| entry of each *left* vector is positive).
-    scikit-learn may pick a randomized solver at large sizes, so parity is
-    asserted on the subspace / singular values, not on signed vectors.
+    Mean-centred thin SVD; rows = right singular vectors with scikit-learn >= 1.5's ``svd_flip``
+    convention (``u_based_decision=False``: the largest-|.| entry of every component row is
+    positive).  scikit-learn may pick a randomized solver at large sizes, so at
+    those sizes parity is asserted on the subspace / singular values, not on signed vectors.
     Returns (components (n,dim), singular_values (n,)).
     """
     X = np.asarray(X, dtype=np.float64)
     Xc = X - X.mean(axis=0)
-    U, S, Vt = np.linalg.svd(Xc, full_matrices=False)
-    max_abs_rows = np.argmax(np.abs(U), axis=0)
-    signs = np.sign(U[max_abs_rows, range(U.shape[1])])
+    _, S, Vt = np.linalg.svd(Xc, full_matrices=False)
+    piv = np.argmax(np.abs(Vt), axis=1)
+    signs = np.sign(Vt[np.arange(Vt.shape[0]), piv])
     signs[signs == 0] = 1.0
     Vt = Vt * signs[:, None]
     return Vt[:n], S[:n]

@@ -67,6 +67,9 @@ PROTOTYPES = {
     "rom_gemm_nn": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_double, _vp, C.c_size_t, C.c_int64,
                               _vp, C.c_size_t, C.c_int64, C.c_double, _vp, C.c_size_t, C.c_int64]),
     "rom_reduced_solve_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
+    "rom_buf_scale": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_double]),
+    "rom_center_rows": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
+    "rom_evaluate_points": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "rom_comm_unique_id": (C.c_int, [C.c_char_p, C.c_size_t]),
     "rom_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),
     "rom_comm_destroy": (C.c_int, [_vp]),
@@ -189,6 +192,9 @@ class Context:
         check(self.lib.rom_reduced_solve_batch(self.h, n, kb, M, Ahat.h, w.h, rhs.h, 1 if rhs_per_system else 0,
                                                c_out.h))
 
+    def center_rows(self, X: "Buffer", M, dim, mean: "Buffer", row0=0):
+        check(self.lib.rom_center_rows(self.h, X.h, row0, M, dim, mean.h))
+
     def l2norm(self, U: "Buffer", row0, K, dim) -> np.ndarray:
         out = np.empty(K)
         check(self.lib.rom_l2norm(self.h, U.h, row0, K, dim, out.ctypes.data))
@@ -247,6 +253,10 @@ class Buffer:
     def gather_rows_from(self, src: "Buffer", rows, dim):
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         check(self.ctx.lib.rom_buf_gather_rows(self.h, src.h, rows.ctypes.data, rows.size, dim))
+        return self
+
+    def scale(self, alpha, offset=0, n=None):
+        check(self.ctx.lib.rom_buf_scale(self.h, offset, self.n - offset if n is None else n, float(alpha)))
         return self
 
     def free(self):
@@ -314,6 +324,15 @@ class Fem:
         out = np.empty(K)
         check(self.ctx.lib.rom_h10norm(self.h, U.h, u_row0, V.h if V is not None else None, v_row0, K,
                                        out.ctypes.data))
+        return out
+
+    def evaluate_points(self, U: Buffer, K: int, ix, iy, tx, ty, row0=0) -> np.ndarray:
+        ix = np.ascontiguousarray(ix, dtype=np.int32)
+        iy = np.ascontiguousarray(iy, dtype=np.int32)
+        tx, ty = _host(tx), _host(ty)
+        out = np.empty((K, ix.size))
+        check(self.ctx.lib.rom_evaluate_points(self.h, U.h, row0, K, ix.size, ix.ctypes.data, iy.ctypes.data,
+                                               tx.ctypes.data, ty.ctypes.data, out.ctypes.data))
         return out
 
     def __del__(self):

@@ -459,3 +459,107 @@ extern "C" int rom_reduced_solve_batch(rom_ctx* ctx, int n, int kb, int M, rom_b
   }
   return ROM_OK;
 }
+
+// ============================================================================================
+// small helpers for the basis builders: scaling, mean-centring, P1 point evaluation
+// ============================================================================================
+__global__ void k_scale(double* p, size_t n, double alpha) {
+  size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  size_t stride = size_t(gridDim.x) * blockDim.x;
+  for (; i < n; i += stride) p[i] *= alpha;
+}
+
+extern "C" int rom_buf_scale(rom_buf* b, size_t off, size_t n, double alpha) {
+  ROM_CHECK(b, "rom_buf_scale: null buffer");
+  ROM_CHECK(off + n <= b->n, "rom_buf_scale: range exceeds buffer");
+  if (n == 0) return ROM_OK;
+  int grid = int(std::min<size_t>((n + 255) / 256, 4096));
+  k_scale<<<grid, 256, 0, b->ctx->stream>>>(b->p + off, n, alpha);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// column means of the (M, dim) snapshot block, subtracted in place (PCA centring,
+// sklearn PCA.fit called at src/lib/ReducedBasis.py:196); mean[dim] is kept for the caller.
+__global__ void k_center_rows(double* __restrict__ X, int M, long long dim, double* __restrict__ mean) {
+  long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (j >= dim) return;
+  double s = 0.0;
+  for (int m = 0; m < M; ++m) s += X[m * dim + j];
+  s /= double(M);
+  mean[j] = s;
+  for (int m = 0; m < M; ++m) X[m * dim + j] -= s;
+}
+
+extern "C" int rom_center_rows(rom_ctx* ctx, rom_buf* X, int64_t row0, int M, int64_t dim, rom_buf* mean) {
+  ROM_CHECK(ctx && X && mean, "rom_center_rows: null argument");
+  ROM_CHECK(M >= 1 && dim >= 1 && row0 >= 0, "rom_center_rows: bad sizes");
+  ROM_CHECK(size_t(row0 + M) * dim <= X->n && size_t(dim) <= mean->n, "rom_center_rows: buffers too small");
+  {
+    ROM_PROF(ctx, "center_rows", 2.0 * M * dim, 24.0 * M * dim);
+    k_center_rows<<<unsigned((dim + 255) / 256), 256, 0, ctx->stream>>>(X->p + row0 * dim, M, dim, mean->p);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// evaluate_solutions (src/lib/SolutionsManagers.py:221-244): P1 interpolation on the SW-NE split
+// cells.  Cell indices / local coordinates are computed by the host shim (searchsorted on the two
+// 1-D grids); the kernel gathers the three vertex values per (solution, point).
+__global__ void k_eval_points(int nr, int nc, long long dim, const double* __restrict__ U, int K, int npts,
+                              const int* __restrict__ ix, const int* __restrict__ iy,
+                              const double* __restrict__ tx, const double* __restrict__ ty,
+                              double* __restrict__ out) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int k = blockIdx.y;
+  if (p >= npts || k >= K) return;
+  const double* u = U + k * dim;
+  // vertex grid with Dirichlet ring: V[y][x], y = 0..nr+1, x = 0..nc+1 ; inner vertex (y,x) -> u[(y-1)*nc + x-1]
+  auto val = [&](int y, int x) -> double {
+    return (y >= 1 && y <= nr && x >= 1 && x <= nc) ? u[(long long)(y - 1) * nc + (x - 1)] : 0.0;
+  };
+  int x0 = ix[p], y0 = iy[p];
+  double qx = tx[p], qy = ty[p];
+  double v;
+  if (qx + qy < 1)
+    v = (1 - qx - qy) * val(y0, x0) + qx * val(y0, x0 + 1) + qy * val(y0 + 1, x0);
+  else
+    v = (qx + qy - 1) * val(y0 + 1, x0 + 1) + (1 - qx) * val(y0 + 1, x0) + (1 - qy) * val(y0, x0 + 1);
+  out[(size_t)k * npts + p] = v;
+}
+
+extern "C" int rom_evaluate_points(rom_fem* f, rom_buf* U, int64_t row0, int K, int npts, const int* ix_host,
+                                   const int* iy_host, const double* tx_host, const double* ty_host,
+                                   double* out_host) {
+  ROM_CHECK(f && U && (npts == 0 || (ix_host && iy_host && tx_host && ty_host)) && (out_host || K * npts == 0),
+            "rom_evaluate_points: null argument");
+  ROM_CHECK(K >= 0 && npts >= 0 && row0 >= 0, "rom_evaluate_points: negative size");
+  ROM_CHECK(size_t(row0 + K) * f->dim <= U->n, "rom_evaluate_points: rows out of range");
+  if (K == 0 || npts == 0) return ROM_OK;
+  for (int p = 0; p < npts; ++p)
+    ROM_CHECK(ix_host[p] >= 0 && ix_host[p] <= f->nc && iy_host[p] >= 0 && iy_host[p] <= f->nr,
+              "rom_evaluate_points: point %d outside the domain", p);
+  rom_ctx* ctx = f->ctx;
+  int *d_i = nullptr;
+  double* d_t = nullptr;
+  double* d_out = nullptr;
+  ROM_HIP(hipMalloc(&d_i, 2 * size_t(npts) * sizeof(int)));
+  ROM_HIP(hipMalloc(&d_t, 2 * size_t(npts) * sizeof(double)));
+  ROM_HIP(hipMalloc(&d_out, size_t(K) * npts * sizeof(double)));
+  ROM_HIP(hipMemcpyAsync(d_i, ix_host, npts * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  ROM_HIP(hipMemcpyAsync(d_i + npts, iy_host, npts * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  ROM_HIP(hipMemcpyAsync(d_t, tx_host, npts * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ROM_HIP(hipMemcpyAsync(d_t + npts, ty_host, npts * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  {
+    ROM_PROF(ctx, "eval_points", 8.0 * K * npts, 32.0 * K * npts);
+    k_eval_points<<<dim3((npts + 255) / 256, K), 256, 0, ctx->stream>>>(f->nr, f->nc, f->dim, U->p + row0 * f->dim,
+                                                                       K, npts, d_i, d_i + npts, d_t, d_t + npts, d_out);
+  }
+  ROM_HIP(hipGetLastError());
+  ROM_HIP(hipMemcpyAsync(out_host, d_out, size_t(K) * npts * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  hipFree(d_i);
+  hipFree(d_t);
+  hipFree(d_out);
+  return ROM_OK;
+}

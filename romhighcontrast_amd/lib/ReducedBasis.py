@@ -1,0 +1,300 @@
+"""Host-side mirror of the reference's ``src/lib/ReducedBasis.py`` driving the HIP kernels.
+
+Same public names (constants, helper functions, ``BaseReducedBasis``, ``ReducedBasisGreedy``,
+``ReducedBasisRandom``, ``ReducedBasisPCA``) and the same ``build(n, sm, solutions2train, a2train,
+solutions2train_h1norm, **kwargs)`` contract; citations are reference file:line.
+
+The arithmetic runs on the GPU: Euclidean orthonormalisation is a re-orthogonalised Gram-Schmidt
+(two passes of MFMA GEMMs per vector), the greedy sweep keeps the training set, the approximations
+and the residual norms in HBM, and the PCA is an MFMA Gram matrix + a small eigenproblem.
+Orthonormal bases are defined up to the sign of each vector (NumPy's Householder QR at :19 may
+return negative diagonals in R); every consumer in the reference is sign-invariant.
+"""
+from __future__ import annotations
+
+from logging import warning
+from typing import List
+
+import numpy as np
+
+from .. import _ffi
+from .Estimators import EstimatorInv, EstimatorLinear
+from .SolutionsManagers import DeviceArray, SolutionsManager, _as_device
+
+INFINIT_A = 1e10  # (:11)
+
+GREEDY_FOR_H10 = r"$H^1_0$"  # (:101)
+GREEDY_FOR_GALERKIN = "galerkin"  # (:102)
+
+
+def get_high_contrast_coefficient(a):
+    """(:14-15) largest block coefficient of each parameter."""
+    return np.array([np.max(coefs, axis=(-1, -2)) for coefs in a])
+
+
+def _orthonormalize_device(ctx: _ffi.Context, X: DeviceArray) -> DeviceArray:
+    """Rows of X -> Euclidean-orthonormal rows spanning the same nested subspaces (CGS2)."""
+    n, dim = X.rows, X.dim
+    Q = ctx.alloc(max(n * dim, 1))
+    if n == 0:
+        return DeviceArray(Q, 0, dim)
+    Q.copy_from(X.buf, n * dim)
+    h = ctx.alloc(max(n, 1))
+    for j in range(n):
+        off = j * dim
+        if j > 0:
+            for _ in range(2):  # "twice is enough"
+                ctx.gemm_nt(j, 1, dim, Q, 0, dim, Q, off, dim, h, 0, 1)  # h = Q[:j] v
+                ctx.gemm_nn(1, dim, j, h, 0, j, Q, 0, dim, Q, off, dim, alpha=-1.0, beta=1.0)  # v -= h^T Q[:j]
+        nrm = float(ctx.l2norm(Q, j, 1, dim)[0])
+        if nrm > 1e-300:
+            Q.scale(1.0 / nrm, offset=off, n=dim)
+        else:
+            Q.fill(0.0, offset=off, n=dim)
+    return DeviceArray(Q, n, dim)
+
+
+def orthonormalize_base(rb):
+    """(:18-21) Euclidean orthonormalisation of the basis rows (thin QR of ``rb.T``)."""
+    if isinstance(rb, DeviceArray):
+        return _orthonormalize_device(_ffi.get_context(), rb)
+    rb = np.asarray(rb, dtype=np.float64)
+    if rb.size == 0:
+        return rb.reshape(0, rb.shape[-1] if rb.ndim == 2 else 0)
+    ctx = _ffi.get_context()
+    return _orthonormalize_device(ctx, _as_device(ctx, rb, rb.shape[-1])).numpy()
+
+
+def sort_orthogonalize_base(a_selected, rb):
+    """(:24-29): order by ``argsort(1/a)``; like the reference the row permutation is applied
+    twice before the orthonormalisation."""
+    a_selected = np.asarray(a_selected, dtype=np.float64)
+    order = np.argsort(1 / a_selected)
+    rb = np.asarray(rb)[order, :]
+    return a_selected[order], orthonormalize_base(rb[order, :])
+
+
+class BaseReducedBasis:
+    """(:32-98)."""
+
+    def __init__(self):
+        self.basis = None
+        self.a = None
+        self.inverse_parameter_estimator = None
+        self.linear_parameter_estimator = None
+
+    def build(self, **kwargs):
+        raise Exception("Not implemented.")
+
+    def set(self, basis, a):
+        self.basis = basis
+        self.a = a
+        self.inverse_parameter_estimator = EstimatorInv(a)
+        self.linear_parameter_estimator = EstimatorLinear(a)
+
+    @property
+    def dim(self):
+        return np.shape(self.basis)[0]
+
+    @property
+    def ambient_space_dim(self):
+        return np.shape(self.basis)[1]
+
+    def __str__(self):
+        return self.__class__.__name__
+
+    def forward_modeling(self, sm: SolutionsManager, a: np.ndarray):
+        return sm.generate_fm_solutions(a=a, coefficients_rom=self.basis)
+
+    def projection(self, sm: SolutionsManager, true_solutions: np.ndarray):
+        return sm.project_solutions(true_solutions, self.basis)
+
+    def state_estimation(self, sm: SolutionsManager, measurement_points: np.ndarray, measurements: np.ndarray,
+                         return_coefs=False):
+        """(:65-70) least squares on point evaluations of the basis (tiny m x n problem, host)."""
+        rb_evaluations_in_points = sm.evaluate_solutions(measurement_points, self.basis)
+        c = np.linalg.lstsq(rb_evaluations_in_points.T, measurements.T, rcond=-1)[0]
+        solution_estimations = c.T @ np.array(self.basis)
+        return (c, solution_estimations) if return_coefs else solution_estimations
+
+    def parameter_estimation_inverse(self, c):
+        return self.inverse_parameter_estimator.estimate_parameter(c_values=c)
+
+    def parameter_estimation_linear(self, c):
+        return self.linear_parameter_estimator.estimate_parameter(c_values=c)
+
+    def __getitem__(self, item):
+        rb = BaseReducedBasis()
+        rb.set(basis=self.basis[item], a=self.a[item])
+        return rb
+
+    def orthonormalize(self):
+        """(:94-98)."""
+        _, self.basis = sort_orthogonalize_base(
+            get_high_contrast_coefficient(self.a),
+            np.reshape(self.basis, (-1, self.ambient_space_dim))
+        )
+
+
+class ReducedBasisGreedy(BaseReducedBasis):
+    """Strong greedy in relative H^1_0 error (:105-139)."""
+
+    def __init__(self, greedy_for=GREEDY_FOR_GALERKIN):
+        self.greedy_for = greedy_for
+        self.name = "Greedy " + self.greedy_for
+        self.linestyle = "solid" if greedy_for == GREEDY_FOR_H10 else "dashed"
+        super().__init__()
+
+    def build(self, n: int, sm: SolutionsManager, solutions2train, a2train: List[np.ndarray] = (()),
+              solutions2train_h1norm=1, **kwargs):
+        if self.greedy_for not in (GREEDY_FOR_H10, GREEDY_FOR_GALERKIN):
+            raise Exception(f"Not implemented greedy for {self.greedy_for}, "
+                            f"should be one of [{GREEDY_FOR_H10}, {GREEDY_FOR_GALERKIN}]")
+        ctx = sm._ctx
+        dim = sm.vspace_dim
+        a2train = np.asarray(a2train)
+        high_contrast_a = get_high_contrast_coefficient(a2train)
+        U = _as_device(ctx, solutions2train, dim)  # training set stays in HBM for the whole build
+        picks: List[int] = []
+        self.max_errors = []
+        for _ in range(n):
+            # orthonormal basis of the current picks, sorted by contrast (:135-136)
+            if picks:
+                contrast = np.ravel(high_contrast_a[picks])
+                order = np.argsort(1 / contrast)
+                rows = np.asarray(picks)[order][order]  # the reference permutes twice (:27-28)
+                sel = ctx.alloc(len(picks) * dim).gather_rows_from(U.buf, rows, dim)
+                C_orth = _orthonormalize_device(ctx, DeviceArray(sel, len(picks), dim))
+            else:
+                C_orth = np.empty((0, 0))
+            if self.greedy_for == GREEDY_FOR_H10:
+                approx = sm.project_solutions_device(U, C_orth)  # (:122)
+            else:
+                approx = sm.generate_fm_solutions_device(a2train, C_orth)  # (:124)
+            rel = sm.H10norm_diff(approx, U) / solutions2train_h1norm  # (:129)
+            ix = int(np.argmax(rel))
+            self.max_errors.append(float(rel[ix]))
+            picks.append(ix)
+        self.picks = list(picks)
+        if isinstance(solutions2train, DeviceArray):
+            basis = ctx.alloc(max(len(picks) * dim, 1)).gather_rows_from(U.buf, np.asarray(picks), dim)
+            basis = DeviceArray(basis, len(picks), dim).numpy()
+        else:
+            basis = np.asarray(solutions2train)[picks].reshape(len(picks), -1)
+        super().set(basis=basis, a=[a2train[i] for i in picks])  # raw snapshots in pick order (:138)
+        return self
+
+
+def get_inf_solutions_starting_basis(solutions2train, a2train, only_one_block=True):
+    """(:142-150) split off the snapshots that have blocks exactly equal to INFINIT_A."""
+    a2train = np.asarray(a2train)
+    solutions2train = np.asarray(solutions2train)
+    num_hc_blocks = np.sum(a2train == INFINIT_A, axis=(-1, -2))
+    chosen = (num_hc_blocks == 1) if only_one_block else (num_hc_blocks != 0)
+    chosen_ix, free_ix = np.flatnonzero(chosen), np.flatnonzero(~chosen)
+    return solutions2train[chosen_ix], a2train[chosen_ix], solutions2train[free_ix], a2train[free_ix]
+
+
+def get_starting_basis(solutions2train, a2train, add_inf_solutions=True):
+    """(:153-164)."""
+    basis, a, solutions2train, a2train = get_inf_solutions_starting_basis(solutions2train, a2train,
+                                                                          only_one_block=False)
+    if not add_inf_solutions:
+        basis = np.empty((0, np.shape(solutions2train)[1]))
+        a = np.empty((0,) + np.shape(a2train)[1:])
+    return basis, a, solutions2train, a2train
+
+
+class ReducedBasisRandom(BaseReducedBasis):
+    """(:167-180) host indexing only."""
+
+    def __init__(self, add_inf_solutions=True):
+        self.add_inf_solutions = add_inf_solutions
+        self.name = "Random" + (r" $\infty$" if add_inf_solutions else "")
+        super().__init__()
+
+    def build(self, n: int, sm: SolutionsManager, solutions2train, a2train: List[np.ndarray] = (()),
+              solutions2train_h1norm=1, seed=42, **kwargs):
+        basis, a, solutions2train, a2train = get_starting_basis(solutions2train, a2train, self.add_inf_solutions)
+        np.random.seed(seed)
+        chosen_ix = np.random.choice(len(solutions2train), size=n, replace=False)
+        super().set(basis=np.vstack((basis, solutions2train[chosen_ix]))[:n],
+                    a=np.vstack((a, a2train[chosen_ix]))[:n])
+        return self
+
+
+def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=2):
+    """Leading ``n`` right singular vectors / singular values of the (M, dim) snapshot block.
+
+    MFMA Gram matrix ``G = Xc Xc^T`` -> symmetric eigenproblem of the small M x M matrix -> lift
+    ``V = S^-1 W^T Xc``.  The Gram matrix squares the condition number (modes below ~1e-8 sigma_1
+    drown in fp64 roundoff), so the modes found are deflated from the block and the procedure is
+    repeated on the remainder (``passes`` times), each pass resolving ~7 more orders of magnitude.
+    Rows follow scikit-learn's ``svd_flip(u_based_decision=False)`` sign convention (the PCA call at
+    src/lib/ReducedBasis.py:196).  X is overwritten (centred / deflated).
+    """
+    M, dim = X.rows, X.dim
+    n = min(n, M, dim)
+    if center:
+        ctx.center_rows(X.buf, M, dim, ctx.alloc(dim))
+    V = ctx.alloc(max(n * dim, 1))
+    sig = np.zeros(n)
+    found = 0
+    for p in range(passes):
+        if found >= n:
+            break
+        G = ctx.alloc(M * M)
+        ctx.gemm_nt(M, M, dim, X.buf, 0, dim, X.buf, 0, dim, G, 0, M)
+        Gh = G.download(M * M, shape=(M, M))
+        Gh = 0.5 * (Gh + Gh.T)
+        lam, W = np.linalg.eigh(Gh)  # small M x M host eigenproblem
+        lam, W = lam[::-1], W[:, ::-1]
+        lam = np.maximum(lam, 0.0)
+        # modes of this pass: those well above the Gram roundoff floor of the current block
+        floor = lam[0] * 1e-13 if lam[0] > 0 else 0.0
+        last_pass = p == passes - 1
+        take = 0
+        while found + take < n and take < M and (lam[take] > floor or last_pass):
+            take += 1
+        if take == 0:
+            break
+        s = np.sqrt(lam[:take])
+        sig[found:found + take] = s
+        Wt = np.ascontiguousarray((W[:, :take] / np.where(s > 0, s, 1.0)).T)  # (take, M)
+        ctx.gemm_nn(take, dim, M, ctx.upload(Wt), 0, M, X.buf, 0, dim, V, found * dim, dim)
+        # re-orthonormalise the new modes against all earlier ones (keeps V orthonormal to ~eps)
+        Vall = _orthonormalize_device(ctx, DeviceArray(V, found + take, dim))
+        V.copy_from(Vall.buf, (found + take) * dim)
+        found += take
+        if found < n and not last_pass:
+            # deflate: X <- X - (X V^T) V
+            Y = ctx.alloc(M * found)
+            ctx.gemm_nt(M, found, dim, X.buf, 0, dim, V, 0, dim, Y, 0, found)
+            ctx.gemm_nn(M, dim, found, Y, 0, found, V, 0, dim, X.buf, 0, dim, alpha=-1.0, beta=1.0)
+    comps = V.download(n * dim, shape=(n, dim)) if n else np.zeros((0, dim))
+    piv = np.argmax(np.abs(comps), axis=1)
+    signs = np.sign(comps[np.arange(n), piv])
+    signs[signs == 0] = 1.0
+    return comps * signs[:, None], sig
+
+
+class ReducedBasisPCA(BaseReducedBasis):
+    """(:183-200) mean-centred PCA of the training snapshots (INFINIT_A ones peeled off first)."""
+
+    def __init__(self, add_inf_solutions=True):
+        self.add_inf_solutions = add_inf_solutions
+        self.name = "PCA" + (r" $\infty$" if add_inf_solutions else "")
+        super().__init__()
+
+    def build(self, n: int, sm: SolutionsManager, solutions2train, a2train: List[np.ndarray] = (()),
+              solutions2train_h1norm=1, add_inf_solutions=True, seed=42, **kwargs):
+        if isinstance(solutions2train, DeviceArray):
+            solutions2train = solutions2train.numpy()
+        basis, a, solutions2train, a2train = get_starting_basis(solutions2train, a2train, self.add_inf_solutions)
+        ctx = sm._ctx
+        X = _as_device(ctx, np.array(solutions2train, dtype=np.float64), sm.vspace_dim)  # private copy
+        comps, sigma = pod_modes(ctx, X, n, center=True)
+        self.singular_values_ = sigma
+        super().set(basis=np.vstack((basis, comps))[:n], a=np.vstack((a, a2train))[:n])
+        warning("PCA method has not been adapted for inverse parameter estimation, the a coefficients are not correct.")
+        return self

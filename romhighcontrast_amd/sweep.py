@@ -1,0 +1,109 @@
+"""Sharding of the parameter sweep over the GPUs of one node.
+
+The reference's only parallelism is ``map`` over parameters through a process pool
+(src/lib/SolutionsManagers.py:51,64-68).  Here rank g owns the contiguous rows
+[g*Mp, min(M,(g+1)*Mp)), Mp = ceil(M/G); the shards are exchanged with ONE all-gather (RCCL over
+xGMI on the GPU path) before the basis stage.  Because only the trailing shard(s) can be short, the
+gathered (G*Mp, dim) block holds the M valid rows contiguously at the front.
+"""
+from __future__ import annotations
+
+import os
+import tempfile
+import time
+
+import numpy as np
+
+
+def shard_rows(M: int, world: int) -> int:
+    """Rows per rank (padded): ceil(M / world)."""
+    return (int(M) + world - 1) // world if M > 0 else 0
+
+
+def shard_bounds(M: int, world: int, rank: int):
+    """Half-open row range owned by `rank`."""
+    mp = shard_rows(M, world)
+    lo = min(M, rank * mp)
+    return lo, min(M, lo + mp)
+
+
+def sharded_sweep(a_all, world: int, rank: int, solve_local, allgather):
+    """Run the sweep sharded: ``solve_local(a_shard, rows_padded)`` returns this rank's padded
+    (Mp, dim) block, ``allgather(block)`` returns the (world*Mp, dim) concatenation in rank order.
+    Returns (gathered block, M): rows [0, M) are the snapshots in the order of ``a_all``."""
+    a_all = np.asarray(a_all)
+    M = a_all.shape[0]
+    mp = shard_rows(M, world)
+    lo, hi = shard_bounds(M, world, rank)
+    local = solve_local(a_all[lo:hi], mp)
+    return allgather(local), M
+
+
+# ---- rendezvous for the RCCL unique id (one node, processes started by torch.distributed.run) ----
+def rendezvous_path() -> str:
+    tag = "_".join([os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
+                    os.environ.get("TORCHELASTIC_RUN_ID", "none"), str(os.getppid())])
+    return os.path.join(tempfile.gettempdir(), f"romhc_rdzv_{tag}.bin")
+
+
+def exchange_unique_id(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
+    """Rank 0 creates the id and publishes it atomically through a file unique to this launch
+    (MASTER_ADDR/PORT + run id + parent pid); the other ranks poll for it."""
+    path = rendezvous_path()
+    if rank == 0:
+        uid = make_id()
+        tmp = path + f".{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while time.time() - t0 < timeout_s:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) >= 128:
+                return uid[:128]
+        except FileNotFoundError:
+            pass
+        time.sleep(0.02)
+    raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s}s")
+
+
+def cleanup_rendezvous(rank: int):
+    if rank == 0:
+        try:
+            os.remove(rendezvous_path())
+        except OSError:
+            pass
+
+
+class RcclSweep:
+    """GPU realisation: local shard solved by libromhc, exchanged with ncclAllGather."""
+
+    def __init__(self, sm, rank: int, world: int):
+        self.sm, self.rank, self.world = sm, rank, world
+        self.ctx = sm._ctx
+
+    def generate_solutions_device(self, a_all):
+        from .lib.SolutionsManagers import DeviceArray
+        dim, ctx = self.sm.vspace_dim, self.ctx
+
+        def solve_local(a_shard, mp):
+            buf = ctx.alloc(max(mp * dim, 1))
+            if len(a_shard) < mp:
+                buf.fill(0.0)
+            if len(a_shard):
+                a = np.ascontiguousarray(np.asarray(a_shard, dtype=np.float64).reshape(len(a_shard), -1))
+                self.sm._fem.solve_batch(ctx.upload(a), len(a_shard), buf)
+            return DeviceArray(buf, mp, dim)
+
+        def allgather(local):
+            if self.world == 1:
+                return local
+            full = ctx.alloc(max(self.world * local.rows * dim, 1))
+            ctx.allgather(local.buf, 0, full, 0, local.rows * dim)
+            return DeviceArray(full, self.world * local.rows, dim)
+
+        full, M = sharded_sweep(a_all, self.world, self.rank, solve_local, allgather)
+        return DeviceArray(full.buf, M, dim)

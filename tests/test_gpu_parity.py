@@ -1,0 +1,288 @@
+"""Parity of the HIP path (through the reference-shaped Python API -> ctypes -> C-ABI) against the
+committed golden fixtures (reference outputs) and the pinned CPU oracle.  Needs an MI355X.
+
+Tolerances (relative H^1_0 norm of the difference unless stated):
+  * snapshots: 1e-11 (observed 1e-15 .. 4e-13; the substructured direct solve and LAPACK/SuperLU
+    are both backward stable, kappa(A) <= 1e9 on these inputs);
+  * rows with an interior ("floating") block at INFINIT_A = 1e10: kappa(A) ~ 3e11 and the plateau level
+    of that block is only determined to ~contrast*eps; the reference's own two direct solvers
+    (fixtures hold both) disagree by 8.5e-6 (3x3) / 2.6e-7 (4x4) there.  Bound: FLOATING_TOL = 5e-5
+    (~6x the reference's largest self-disagreement); every other row keeps 1e-11;
+  * reduced-basis relative errors: |err_gpu - err_ref| <= 1e-10 (BASELINE.json target).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import rom_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+SNAP_TOL = 1e-11
+FLOATING_TOL = 5e-5
+
+
+@pytest.fixture(scope="module")
+def api():
+    from src.lib import SolutionsManagers as SM
+    from src.lib import ReducedBasis as RB
+    return SM, RB
+
+
+def relh10(g, U, Uref):
+    return ro.H10norm(g, np.asarray(U) - Uref) / ro.H10norm(g, Uref)
+
+
+def test_native_library_is_the_one_running(api):
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    assert "gfx950" in ctx.device_name()
+    assert open("/proc/self/maps").read().count("libromhc.so") > 0
+
+
+def test_g1_snapshots_norms_eval(api):
+    SM, _ = api
+    z = load_golden("g1_basic.npz")
+    sm = SM.SolutionsManagerFEM(tuple(z["blocks"]), int(z["N"]))
+    g = ro.Geometry(tuple(z["blocks"]), int(z["N"]))
+    assert sm.vspace_dim == 361 and str(sm) == "SolutionsManagerFEM"
+    assert np.array_equal(sm.B_total, z["B_total"])
+    assert np.array_equal(sm.points_c, z["points_c"]) and np.array_equal(sm.points_r, z["points_r"])
+    U = sm.generate_solutions(z["a"])
+    assert U.shape == z["U"].shape
+    assert relh10(g, U, z["U"]).max() < SNAP_TOL
+    # integer-typed parameters are accepted (InverseProblemPipeline.ipynb cell 17)
+    Ui = sm.generate_solutions(np.array([[[1, 2], [3, 4]]]))
+    assert relh10(g, Ui, z["U"][2:3]).max() < SNAP_TOL
+    np.testing.assert_allclose(sm.H10norm(z["U"]), z["H10"], rtol=1e-13)
+    np.testing.assert_allclose(sm.l2norm(z["U"]), z["l2"], rtol=1e-13)
+    np.testing.assert_allclose(SM.SolutionsManager.l2norm(z["U"]), z["l2"], rtol=1e-13)
+    np.testing.assert_allclose(sm.evaluate_solutions(z["points"], z["U"]), z["evals"], rtol=1e-12, atol=1e-15)
+    d, e, n = sm.stencil_arrays(z["a"][2:3])
+    assert np.array_equal(d[0], z["diag"]) and np.array_equal(e[0], z["east"]) and np.array_equal(n[0], z["north"])
+    # the lazily materialised dense tensor equals the reference's
+    A = np.einsum("pqij,pq->ij", sm.A_preassembled, z["a"][2])
+    assert np.array_equal(A, ro.assemble_dense(g, z["a"][2]))
+    assert np.count_nonzero(sm.A_preassembled4h1_norm) == 1729
+
+
+def test_g2_config_c1(api):
+    SM, _ = api
+    z = load_golden("g2_c1.npz")
+    g = ro.Geometry(tuple(z["blocks"]), int(z["N"]))
+    for method in ("lsq", "lsqsparse"):
+        sm = SM.SolutionsManagerFEM(tuple(z["blocks"]), int(z["N"]), method=method)
+        U = sm.generate_solutions(z["a"])
+        assert relh10(g, U, z["U_lsq"]).max() < SNAP_TOL
+        assert relh10(g, U, z["U_lsqsparse"]).max() < SNAP_TOL
+    np.testing.assert_allclose(sm.H10norm(U), z["H10"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["r23", "r32"])
+def test_g3_rectangular(api, name):
+    SM, _ = api
+    z = load_golden("g3_rect.npz")
+    blocks, N = tuple(z[f"{name}_blocks"]), int(z[f"{name}_N"])
+    sm = SM.SolutionsManagerFEM(blocks, N)
+    g = ro.Geometry(blocks, N)
+    assert relh10(g, sm.generate_solutions(z[f"{name}_a"]), z[f"{name}_U"]).max() < SNAP_TOL
+    np.testing.assert_allclose(sm.H10norm(z[f"{name}_U"]), z[f"{name}_H10"], rtol=1e-13)
+    d, e, n = sm.stencil_arrays(z[f"{name}_a"][:1])
+    assert np.array_equal(d[0], z[f"{name}_diag"]) and np.array_equal(n[0], z[f"{name}_north"])
+
+
+@pytest.mark.parametrize("name", ["b22", "b33", "b44"])
+def test_g4_high_contrast(api, name):
+    SM, _ = api
+    z = load_golden("g4_contrast.npz")
+    blocks, N = tuple(z[f"{name}_blocks"]), int(z[f"{name}_N"])
+    sm = SM.SolutionsManagerFEM(blocks, N)
+    g = ro.Geometry(blocks, N)
+    U = sm.generate_solutions(z[f"{name}_a"])
+    err = relh10(g, U, z[f"{name}_U"])
+    self_gap = relh10(g, z[f"{name}_U_lsqsparse"], z[f"{name}_U"])
+    assert self_gap[:7].max() < 1e-13  # the reference agrees with itself except on the floating-block row
+    bound = np.where(self_gap > 1e-9, FLOATING_TOL, SNAP_TOL)
+    assert np.all(err <= bound), (err, bound)
+
+
+def test_g5_projectors(api):
+    SM, _ = api
+    z = load_golden("g5_projectors.npz")
+    sm = SM.SolutionsManagerFEM(tuple(z["blocks"]), int(z["N"]))
+    scale = np.abs(z["U"]).max()
+    for tag in ("0", "1", "5", "10", "snap"):
+        C = z["C" + tag] if tag != "snap" else z["Csnap"]
+        pk, fk = ("proj" + tag, "fm" + tag) if tag != "snap" else ("proj_snap", "fm_snap")
+        np.testing.assert_allclose(sm.project_solutions(z["U"], C), z[pk], atol=1e-11 * scale)
+        np.testing.assert_allclose(sm.generate_fm_solutions(z["a"], C), z[fk], atol=1e-11 * scale)
+    # empty inputs
+    assert sm.project_solutions(z["U"], np.empty((0, 0))).shape == z["U"].shape
+    assert sm.generate_solutions(np.empty((0, 2, 2))).shape == (0, sm.vspace_dim)
+
+
+def test_orthonormalize_base_matches_numpy_qr_up_to_sign(api):
+    _, RB = api
+    z = load_golden("g5_projectors.npz")
+    Q = RB.orthonormalize_base(z["U"][:4])
+    ref = z["Csnap"]  # np.linalg.qr in the reference
+    signs = np.sign(np.sum(Q * ref, axis=1))
+    np.testing.assert_allclose(Q * signs[:, None], ref, atol=1e-11)
+    np.testing.assert_allclose(Q @ Q.T, np.eye(4), atol=1e-14)
+
+
+@pytest.mark.parametrize("tag,mode_name", [("h10", "GREEDY_FOR_H10"), ("gal", "GREEDY_FOR_GALERKIN")])
+def test_g6_greedy(api, tag, mode_name):
+    SM, RB = api
+    z = load_golden("g6_greedy.npz")
+    sm = SM.SolutionsManagerFEM(tuple(z["blocks"]), int(z["N"]))
+    n = int(z["n"])
+    h1 = sm.H10norm(z["U"])
+    np.testing.assert_allclose(h1, z["h1"], rtol=1e-13)
+    rb = RB.ReducedBasisGreedy(greedy_for=getattr(RB, mode_name)).build(
+        n=n, sm=sm, solutions2train=z["U"], a2train=z["a"], solutions2train_h1norm=h1)
+    assert rb.picks[0] == 0 and rb.max_errors[0] == 1.0
+    assert rb.picks == list(z[f"{tag}_picks"])  # max errors are >> roundoff for all 6 picks
+    assert np.array_equal(rb.basis, z["U"][rb.picks])
+    assert rb.name == "Greedy " + getattr(RB, mode_name)
+    for m in range(1, n + 1):
+        sub = rb[:m]
+        sub.orthonormalize()
+        ep = sm.H10norm(sub.projection(sm, z["U"]) - z["U"]) / h1
+        ef = sm.H10norm(sub.forward_modeling(sm, z["a"]) - z["U"]) / h1
+        assert np.max(np.abs(ep - z[f"{tag}_errs_proj"][m - 1])) < 1e-10  # BASELINE: within 1e-10 of reference
+        assert np.max(np.abs(ef - z[f"{tag}_errs_fm"][m - 1])) < 1e-10
+    rb.orthonormalize()
+    ref = z[f"{tag}_basis"]
+    signs = np.sign(np.sum(rb.basis * ref, axis=1))
+    np.testing.assert_allclose(rb.basis * signs[:, None], ref, atol=1e-9)
+    with pytest.raises(Exception, match="Not implemented greedy for"):
+        RB.ReducedBasisGreedy(greedy_for="x").build(n=1, sm=sm, solutions2train=z["U"], a2train=z["a"])
+
+
+def test_g7_pca_random(api):
+    SM, RB = api
+    z = load_golden("g7_pca_random.npz")
+    sm = SM.SolutionsManagerFEM(tuple(z["blocks"]), int(z["N"]))
+    n = int(z["n"])
+    for flag in (1, 0):
+        rb = RB.ReducedBasisPCA(add_inf_solutions=bool(flag)).build(n=n, sm=sm, solutions2train=z["U"], a2train=z["a"])
+        ref = z[f"pca_basis_{flag}"]
+        assert rb.basis.shape == ref.shape
+        np.testing.assert_allclose(rb.basis, ref, atol=2e-9)  # signed modes (sigma_5/sigma_1 ~ 1e-4 here)
+        np.testing.assert_allclose(np.array(rb.a), z[f"pca_a_{flag}"])
+        np.testing.assert_allclose(rb.singular_values_[:n - (2 if flag else 0)],
+                                   z["sigma"][:n - (2 if flag else 0)], rtol=1e-9)
+        rr = RB.ReducedBasisRandom(add_inf_solutions=bool(flag)).build(n=n, sm=sm, solutions2train=z["U"], a2train=z["a"])
+        assert np.array_equal(rr.basis, z[f"rnd_basis_{flag}"]) and np.array_equal(np.array(rr.a), z[f"rnd_a_{flag}"])
+
+
+def test_g9_n32(api):
+    SM, _ = api
+    z = load_golden("g9_n32.npz")
+    sm = SM.SolutionsManagerFEM(tuple(z["blocks"]), int(z["N"]))
+    U = sm.generate_solutions(z["a"])
+    np.testing.assert_allclose(sm.H10norm(U), z["H10"], rtol=1e-12)
+    np.testing.assert_allclose(sm.l2norm(U), z["l2"], rtol=1e-12)
+    np.testing.assert_allclose(U.sum(axis=1), z["sums"], rtol=1e-11)
+    np.testing.assert_allclose(U[:, z["probe"]], z["U_probe"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("blocks,N", [((1, 1), 8), ((1, 3), 7), ((2, 2), 2), ((2, 2), 3), ((2, 2), 65), ((2, 2), 70),
+                                      ((3, 3), 40), ((5, 2), 9), ((2, 2), 129)])
+def test_ragged_geometries_vs_oracle(api, blocks, N):
+    """Tile padding edge cases: edges shorter / longer than one 64-tile, one-node edges, strips."""
+    SM, _ = api
+    sm = SM.SolutionsManagerFEM(blocks, N)
+    g = ro.Geometry(blocks, N)
+    a = 10.0 ** np.random.default_rng(N).uniform(0, 3, size=(3,) + blocks)
+    U = sm.generate_solutions(a)
+    assert relh10(g, U, ro.generate_solutions(g, a)).max() < SNAP_TOL
+
+
+def test_error_behaviour(api):
+    SM, _ = api
+    from scipy.linalg import LinAlgError
+    sm = SM.SolutionsManagerFEM((2, 2), 4, method="ridge")
+    with pytest.raises(Exception, match="Method ridge Not implemented."):
+        sm.generate_solutions(np.ones((1, 2, 2)))
+    sm = SM.SolutionsManagerFEM((2, 2), 4)
+    with pytest.raises(LinAlgError):  # scipy posv raises LinAlgError on a non-SPD matrix
+        sm.generate_solutions(np.array([[[1.0, -1.0], [1.0, 1.0]]]))
+    with pytest.raises(Exception, match="Not implemented."):
+        sm.generate_riesz([[0.0, 0.0]], norm="h10")
+    assert sm.generate_riesz([[0.1, 0.2], [0.3, -0.4]], norm="l2").shape == (2, sm.vspace_dim)  # (m, N) as the reference docstring says
+    np.testing.assert_allclose(SM.galerkin(np.ones((1, 1)), np.array([1.0, 2.0]), np.array([[[[2.0, 0.0], [0.0, 4.0]]]])),
+                               [0.5, 0.5])
+
+
+def test_full_size_c2_properties(api):
+    """BASELINE config C2 ((2,2)/N=128, 1024-parameter sweep): size-independent checks on the device."""
+    SM, _ = api
+    from romhighcontrast_amd import _ffi
+    sm = SM.SolutionsManagerFEM((2, 2), 128)
+    ctx, fem, dim = sm._ctx, sm._fem, sm.vspace_dim
+    assert dim == 65025
+    M = 1024
+    a = 10.0 ** np.random.default_rng(20240807).uniform(0, 2, size=(M, 2, 2))
+    Ud = sm.generate_solutions_device(a)
+    # residual: A(a_m) u_m - B = 0 for sampled rows, through the independent stencil kernel
+    Y = ctx.alloc(dim)
+    for m in (0, 1, 511, 1023):
+        row = _ffi.Buffer(ctx, dim).copy_from(Ud.buf, dim, 0, m * dim)
+        fem.stencil_apply(row, 1, Y, a_one=a[m].ravel())
+        r = Y.download(dim) - sm.B_total
+        u = row.download(dim)
+        # ||r||_inf relative to ||diag(A) u||_inf
+        assert np.abs(r).max() < 1e-11 * np.abs(u).max() * 4 * a[m].max()
+    # linearity in 1/a: u(2a) = u(a)/2 exactly up to roundoff
+    U2 = sm.generate_solutions_device(2.0 * a[:8]).numpy()
+    U1 = Ud.numpy()[:8] if False else np.stack([Ud.buf.download(dim, offset=i * dim) for i in range(8)])
+    assert np.max(np.abs(2.0 * U2 - U1)) < 1e-12 * np.abs(U1).max()
+    # symmetry: swapping the two block columns mirrors the solution left-right
+    am = a[:4][:, :, ::-1]
+    Um = sm.generate_solutions(am).reshape(4, 255, 255)[:, :, ::-1].reshape(4, -1)
+    assert np.max(np.abs(Um - U1[:4])) < 1e-11 * np.abs(U1).max()
+    # three rows against the SuperLU oracle
+    g = ro.Geometry((2, 2), 128)
+    idx = [0, 511, 1023]
+    Uo = ro.generate_solutions(g, a[idx])
+    Ug = np.stack([Ud.buf.download(dim, offset=i * dim) for i in idx])
+    assert relh10(g, Ug, Uo).max() < SNAP_TOL
+    # norms on the device agree with the oracle's on the same vectors
+    np.testing.assert_allclose(sm.H10norm(Ud)[idx], ro.H10norm(g, Ug), rtol=1e-12)
+
+
+def test_rccl_single_rank_allgather(api):
+    """The RCCL plumbing with a 1-rank communicator (a box has one GPU): id, init, all-gather, reduce."""
+    from romhighcontrast_amd import _ffi, sweep
+    SM, _ = api
+    ctx = _ffi.get_context()
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, 0, 1)
+    try:
+        x = np.arange(1000, dtype=np.float64)
+        src, dst = ctx.upload(x), ctx.alloc(1000)
+        ctx.allgather(src, 0, dst, 0, 1000)
+        assert np.array_equal(dst.download(), x)
+        assert ctx.allreduce_host([3.5, -1.0], "max").tolist() == [3.5, -1.0]
+        sm = SM.SolutionsManagerFEM((2, 2), 8)
+        a = 10.0 ** np.random.default_rng(3).uniform(0, 2, size=(5, 2, 2))
+        U = sweep.RcclSweep(sm, 0, 1).generate_solutions_device(a)
+        assert np.array_equal(U.numpy(), sm.generate_solutions(a))
+    finally:
+        ctx.comm_destroy()
+
+
+def test_pickle_roundtrip_of_basis_and_manager(api):
+    import pickle
+    SM, RB = api
+    sm = SM.SolutionsManagerFEM((2, 2), 6)
+    a = 10.0 ** np.random.default_rng(5).uniform(0, 2, size=(6, 2, 2))
+    U = sm.generate_solutions(a)
+    rb = RB.ReducedBasisGreedy(RB.GREEDY_FOR_H10).build(3, sm, U, a, sm.H10norm(U))
+    rb2 = pickle.loads(pickle.dumps(rb))
+    sm2 = pickle.loads(pickle.dumps(sm))
+    assert np.array_equal(rb2.basis, rb.basis)
+    assert np.array_equal(sm2.generate_solutions(a[:2]), U[:2])
