@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- snapshot-sweep throughput of the HIP hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: rom_solve_batch of the BASELINE config C2
+workload (2x2 blocks, N=128 -> 256x256 cells, dim 65 025, 1024-parameter sweep, seeded
+10**U(0,2) coefficients) with the parameters already resident in HBM and the (M, dim) fp64
+snapshot block left in HBM.  With N > 1 (one process per GPU, started by torch.distributed.run)
+every rank solves its own 1024-parameter shard (weak scaling: N=8 is config C3, 8192 parameters)
+and the shards are exchanged with one RCCL all-gather per step, inside the timed region.
+
+The timed region is bracketed by a barrier + stream synchronisation on both sides (RCCL all-reduce
+for N > 1), the reported time is the max over ranks, and rank 0 prints ONE JSON line.
+
+Host side is plain Python + ctypes (no torch): the rendezvous for the RCCL unique id goes through
+a launch-scoped file (romhighcontrast_amd/sweep.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X spec fp64 matrix peak; sustained microbench: 47.1
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(blocks, N, a, budget_s=15.0):
+    """The oracle's restatement of the reference's method='lsqsparse' path (stencil -> CSC ->
+    scipy.sparse.linalg.spsolve, src/lib/SolutionsManagers.py:31) on one host core (the reference
+    default num_cores=1), over a bounded sample of the same sweep."""
+    from oracle import rom_oracle as ro
+    g = ro.Geometry(blocks, N)
+    B = ro.load_vector(g)
+    t0 = time.perf_counter()
+    n = 0
+    while n < len(a) and (time.perf_counter() - t0 < budget_s or n < 4):
+        ro.solve_one(g, a[n], B, "lsqsparse")
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} of the {len(a)} C2 parameters, oracle stencil->CSC->scipy spsolve (SuperLU), "
+                      f"{dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--M", type=int, default=1024, help="parameters per GPU per step")
+    ap.add_argument("--N", type=int, default=128, help="cells per block per dimension")
+    ap.add_argument("--blocks", type=int, nargs=2, default=[2, 2])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pod", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    from romhighcontrast_amd import _ffi, sweep
+    from romhighcontrast_amd.lib.SolutionsManagers import DeviceArray, SolutionsManagerFEM
+    from romhighcontrast_amd.lib.ReducedBasis import pod_modes
+
+    ctx = _ffi.get_context(local_rank)
+    blocks, N, M = tuple(args.blocks), args.N, args.M
+    sm = SolutionsManagerFEM(blocks, N, device=local_rank)
+    fem, dim = sm._fem, sm.vspace_dim
+
+    if world > 1:
+        uid = sweep.exchange_unique_id(rank, ctx.comm_unique_id)
+        ctx.comm_init(uid, rank, world)
+
+    def barrier():
+        ctx.synchronize()
+        if world > 1:
+            ctx.allreduce_host([0.0], "sum")
+
+    # synthetic sweep of SURVEY.md 8(d): seeded, all blocks free, contrast <= 1e2; rank r owns rows
+    # [r*M, (r+1)*M) of the (world*M)-parameter sweep
+    rng = np.random.default_rng(20240807)
+    a_all = 10.0 ** rng.uniform(0, 2, size=(world * M,) + blocks)
+    a_loc = a_all[rank * M:(rank + 1) * M]
+    a_dev = ctx.upload(a_loc.reshape(M, -1))
+    U_loc = ctx.alloc(M * dim)
+    U_all = ctx.alloc(world * M * dim) if world > 1 else U_loc
+
+    def step():
+        fem.solve_batch(a_dev, M, U_loc)
+        if world > 1:
+            ctx.allgather(U_loc, 0, U_all, 0, M * dim)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_reset()
+    ctx.profile(True)  # per-kernel HIP events on the launch stream, over the timed region
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        step()
+    ev_ms = ctx.timer_stop()
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    ctx.profile(False)
+    if world > 1:
+        wall = float(ctx.allreduce_host([wall], "max")[0])
+    barrier()
+
+    if rank != 0:
+        if world > 1:
+            ctx.comm_destroy()
+        return
+
+    prof = ctx.profile_report()
+    work = fem.solve_work()
+    solves = world * M * args.steps
+    value = solves / wall
+    kernels = {}
+    for name, v in prof.items():
+        if v["launches"] == 0:
+            continue
+        avg_ms = v["total_ms"] / v["launches"]
+        kernels[name] = {"launches_per_step": v["launches"] / args.steps, "avg_ms": round(avg_ms, 5),
+                         "ms_per_step": round(v["total_ms"] / args.steps, 4),
+                         "tflops": round(v["flops"] / v["total_ms"] * 1e-9, 3) if v["total_ms"] > 0 else 0.0,
+                         "gbs": round(v["bytes"] / v["total_ms"] * 1e-6, 1) if v["total_ms"] > 0 else 0.0}
+    dom = max((k for k in prof if k != "rccl_allgather"), key=lambda k: prof[k]["total_ms"])
+    d = prof[dom]
+    achieved = d["flops"] / d["total_ms"] * 1e-9  # algorithmic flops of the launches / their event time
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP64_MATRIX_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP64_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(d["total_ms"] / d["launches"], 5),
+                "flops_per_launch": d["flops"] / d["launches"],
+                "peak_measured_sustained": 47.1,
+                "note": "fp64 MFMA (v_mfma_f64_16x16x4_f64); peak = spec fp64 matrix rate; a bare MFMA loop "
+                        "sustains 47.1 TFLOP/s on this part (tools/mfma_f64_peak.hip)"}
+    out = {
+        "metric": "snapshot_solves_per_sec", "value": round(value, 1), "unit": "solves/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C{2 if world == 1 else 3}: {blocks[0]}x{blocks[1]} blocks, N={N} "
+                               f"({blocks[0] * N}x{blocks[1] * N} cells, dim {dim}), {M}-parameter sweep per GPU "
+                               f"({world * M} total), a=10**U(0,2) seed 20240807"
+                               + (", RCCL all-gather of the snapshot block each step" if world > 1 else ""),
+                   "blocks_geometry": list(blocks), "N": N, "dim": dim, "M_per_gpu": M, "M_total": world * M,
+                   "parallelism": f"sweep sharded over {world} GPU(s)"},
+        "event_ms_per_step": round(ev_ms / args.steps, 4),
+        "algorithm": {"flops_per_solve": work["flops_own"], "hbm_bytes_per_solve": work["bytes_own"],
+                      "canonical_banded_flops_per_solve": work["flops_banded"],
+                      "canonical_banded_bytes_per_solve": work["bytes_banded"],
+                      "canonical_banded_equiv_gbs": round(value * work["bytes_banded"] * 1e-9, 1)},
+        "roofline": roofline, "kernels": kernels,
+    }
+
+    if world == 1 and not args.no_pod:
+        # secondary figure of the metric: POD-SVD GF/s on the snapshot block just produced
+        X = ctx.alloc(M * dim).copy_from(U_loc, M * dim)
+        r = 50
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        comps, sig = pod_modes(ctx, DeviceArray(X, M, dim), r, center=True, passes=1)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        f_pod = 2.0 * M * M * dim + 2.0 * r * M * dim + 10.0 * M ** 3
+        out["pod"] = {"gflops": round(f_pod / dt * 1e-9, 1), "seconds": round(dt, 4), "M": M, "dim": dim, "modes": r,
+                      "F_pod": f_pod, "note": "Gram (MFMA) + M x M eigh (host LAPACK) + lift (MFMA), one pass"}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(blocks, N, a_loc)
+    if world > 1:
+        ctx.comm_destroy()
+        sweep.cleanup_rendezvous(rank)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
