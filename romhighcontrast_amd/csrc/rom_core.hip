@@ -1,6 +1,8 @@
 // Context, device buffers, error strings, HIP-event stopwatch and per-kernel profiling.
 #include "romhc_internal.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 static thread_local char g_err[1024] = "";
@@ -37,6 +39,12 @@ extern "C" int rom_init(int device, rom_ctx** out) {
   rom_ctx* c = new rom_ctx();
   c->device = device;
   ROM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int i = 0; i < 3; ++i) {
+    ROM_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+    ROM_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+  }
+  ROM_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  if (const char* e = getenv("ROMHC_STREAMS")) c->n_streams = std::max(1, std::min(4, atoi(e)));
   ROM_HIP(hipEventCreate(&c->t0));
   ROM_HIP(hipEventCreate(&c->t1));
   ROM_HIP(hipMalloc(&c->d_status, sizeof(int)));
@@ -59,6 +67,11 @@ extern "C" int rom_shutdown(rom_ctx* c) {
   if (c->d_scratch) hipFree(c->d_scratch);
   hipEventDestroy(c->t0);
   hipEventDestroy(c->t1);
+  for (int i = 0; i < 3; ++i) {
+    if (c->aux[i]) hipStreamDestroy(c->aux[i]);
+    if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
+  }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
   hipStreamDestroy(c->stream);
   delete c;
   return ROM_OK;
@@ -131,13 +144,14 @@ ProfScope::ProfScope(rom_ctx* c, const char* name, double flops, double bytes) :
   ProfRec r;
   r.name_id = id;
   if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
-  hipEventRecord(r.e0, c->stream);
+  r.st = c->prof_stream ? c->prof_stream : c->stream;
+  hipEventRecord(r.e0, r.st);
   c->prof_recs.push_back(r);
   idx = int(c->prof_recs.size()) - 1;
 }
 
 ProfScope::~ProfScope() {
-  if (idx >= 0) hipEventRecord(ctx->prof_recs[idx].e1, ctx->stream);
+  if (idx >= 0) hipEventRecord(ctx->prof_recs[idx].e1, ctx->prof_recs[idx].st);
 }
 
 extern "C" int rom_profile_enable(rom_ctx* c, int on) {

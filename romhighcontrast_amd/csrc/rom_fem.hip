@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 
@@ -131,24 +132,36 @@ __device__ inline double s_entry(const TileDesc& d, const double* __restrict__ T
         v += -(a1 + a0) / 2;
       }
     }
-  } else if (d.diag && r == c) {
+  } else if (d.diag && r == c && r >= d.ndr) {
     v = 1.0;  // padding unknowns: identity
   }
   return v;
 }
 
+// this thread's 16 entries of the assembled interface tile, in accumulator order
+struct STile {
+  double v[2][2][4];
+};
+
+__device__ inline void s_tile_load(STile& st, const TileDesc& d, const FemDev& f, const double* __restrict__ am,
+                                   const WavePos& wp) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) st.v[i][j][g] = s_entry(d, f.Tm, f.n1p, am, acc_row(wp, i, g), acc_col(wp, j));
+}
+
 // C(LDS tile) = S_tile - acc ; then the sparse cross-point extras
-__device__ inline void tile_from_acc(double* Cb, const Acc& acc, const TileDesc& d, const FemDev& f,
+__device__ inline void tile_from_acc(double* Cb, const Acc& acc, const STile& st, const TileDesc& d, const FemDev& f,
                                      const double* __restrict__ am, const WavePos& wp) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        int r = acc_row(wp, i, g), c = acc_col(wp, j);
-        Cb[r * LDC + c] = s_entry(d, f.Tm, f.n1p, am, r, c) - acc.c[i][j][g];
-      }
+      for (int g = 0; g < 4; ++g) Cb[acc_row(wp, i, g) * LDC + acc_col(wp, j)] = st.v[i][j][g] - acc.c[i][j][g];
   __syncthreads();
   for (int x = d.x0 + threadIdx.x; x < d.x1; x += blockDim.x) {
     const TileExtra& e = f.extra[x];
@@ -157,6 +170,29 @@ __device__ inline void tile_from_acc(double* Cb, const Acc& acc, const TileDesc&
     Cb[e.r * LDC + e.c] += v;
   }
   __syncthreads();
+}
+
+// LDS carve-up of the factor kernels: B staging (2 buffers) | union { A staging (2 buffers), C tile }
+constexpr int FACT_LDS_DOUBLES = 2 * STAGE_DOUBLES + TILE_DOUBLES;  // 6528 doubles = 52,224 B -> 3 WG / CU
+constexpr int KP_MAX = 64;                                            // k-pairs cached in LDS per pass
+
+// acc += sum over the k-list of `slot` of L[slotA] * L[slotB]^T, one merged pipelined loop
+template <class FP>
+__device__ inline void accumulate_klist(const FemDev& f, int slot, const double* Lm, int* kp, FP active, Acc& acc,
+                                        double* stA, double* stB, const WavePos& wp) {
+  const int e0 = f.kptr[slot], e1 = f.kptr[slot + 1];
+  const int srow = stage_row(), sseg = stage_seg();
+  for (int eb = e0; eb < e1; eb += KP_MAX) {
+    const int np = min(KP_MAX, e1 - eb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * np; i += blockDim.x) kp[i] = f.kpair[2 * eb + i];
+    __syncthreads();
+    const double* base = Lm + srow * 64 + sseg;
+    gemm_loop2(
+        4 * np, [&](int ch, double* v) { load4_aligned(base + size_t(kp[2 * (ch >> 2)]) * 4096 + (ch & 3) * BK, v); },
+        [&](int ch, double* v) { load4_aligned(base + size_t(kp[2 * (ch >> 2) + 1]) * 4096 + (ch & 3) * BK, v); },
+        active, acc, stA, stB, wp);
+  }
 }
 
 // ============================================================================================
@@ -168,120 +204,137 @@ __global__ void k_init_rhs(FemDev f, int Mc) {
   f.y[idx] = f.g[idx % f.nGp];
 }
 
-// Diagonal tile j of every system: C = S_jj - sum_k L_jk L_jk^T ; L_jj = chol(C) ; invL_jj ;
-// y_j <- invL_jj y_j   (fused forward substitution)
-__global__ __launch_bounds__(256) void k_factor_diag(FemDev f, const double* __restrict__ a, int slot, int j) {
-  __shared__ __align__(16) double lds[STAGE_TOTAL + TILE_DOUBLES];
-  double* stage = lds;                 // STAGE_TOTAL (aliased by Ib later)
-  double* Cb = lds + STAGE_TOTAL;      // TILE_DOUBLES
-  double* Ib = lds;                    // inverse, aliases the staging area (TILE_DOUBLES <= STAGE_TOTAL)
-  __shared__ double sd[64];
-  __shared__ double gj[64];
+// Diagonal tile j, step 1 of 3 (MFMA): C = S_jj - sum_k L_jk L_jk^T, written to the tile's L slot.
+// Only the lower triangle is consumed by the factorisation: the wave owning the upper-right
+// quadrant skips its MFMAs.
+__global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __restrict__ a, int slot) {
+  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];
+  __shared__ int kp[2 * KP_MAX];
+  double* stB = lds;
+  double* stA = lds + 2 * STAGE_DOUBLES;
+  double* Cb = lds + 2 * STAGE_DOUBLES;  // aliases the A staging area (used after the k-loop only)
   const int m = blockIdx.x;
   const WavePos wp;
   const TileDesc& d = f.desc[slot];
   const double* am = a + size_t(m) * f.kblk;
   double* Lm = f.L + size_t(m) * f.nslots * 4096;
-
+  STile st;
+  s_tile_load(st, d, f, am, wp);  // table reads fly under the MFMAs below
   Acc acc;
   acc_zero(acc);
-  const int srow = stage_row(), sseg = stage_seg();
-  for (int e = f.kptr[slot]; e < f.kptr[slot + 1]; ++e) {
-    const double* A = Lm + size_t(f.kpair[2 * e]) * 4096 + srow * 64 + sseg;
-    const double* B = Lm + size_t(f.kpair[2 * e + 1]) * 4096 + srow * 64 + sseg;
-    gemm_loop(
-        4, [&](int ch, double* v) { load4_aligned(A + ch * BK, v); },
-        [&](int ch, double* v) { load4_aligned(B + ch * BK, v); }, acc, stage, wp);
-  }
-  tile_from_acc(Cb, acc, d, f, am, wp);
-
-  // ---- LDL^T-style right-looking elimination in LDS, one barrier per column -----------------
-  const int t = threadIdx.x;
-  const int r = t >> 2, cg = t & 3;
-  for (int jj = 0; jj < 63; ++jj) {
-    double dj = Cb[jj * LDC + jj];
-    double invd = 1.0 / dj;
-    if (r > jj) {
-      double lr = Cb[r * LDC + jj] * invd;
-      for (int c = jj + 1 + cg; c <= r; c += 4) Cb[r * LDC + c] -= lr * Cb[c * LDC + jj];
-    }
-    __syncthreads();
-  }
-  if (t < 64) {
-    double dj = Cb[t * LDC + t];
-    if (!(dj > 0.0)) atomicOr(f.status, 1);
-    sd[t] = sqrt(dj);
-    gj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
-  }
-  __syncthreads();
-  for (int idx = t; idx < 4096; idx += 256) {
-    int rr = idx >> 6, cc = idx & 63;
-    double v = Cb[rr * LDC + cc];
-    v = rr > cc ? v / sd[cc] : (rr == cc ? sd[rr] : 0.0);
-    Cb[rr * LDC + cc] = v;
-    Ib[rr * LDC + cc] = 0.0;
-  }
-  __syncthreads();
-  // ---- inverse of the lower-triangular tile, 16x16 blocked ----------------------------------
-  if (t < 64) {
-    int bi = t >> 4, c = t;  // column c lives in diagonal block bi
-    int rend = bi * 16 + 16;
-    for (int rr = c; rr < rend; ++rr) {
-      double s = rr == c ? 1.0 : 0.0;
-      for (int k = c; k < rr; ++k) s -= Cb[rr * LDC + k] * Ib[k * LDC + c];
-      Ib[rr * LDC + c] = s / Cb[rr * LDC + rr];
-    }
-  }
-  __syncthreads();
-  {
-    const int rr = t >> 4, cc = t & 15;
-#pragma unroll
-    for (int bi = 1; bi < 4; ++bi) {
-      double z[3];
-#pragma unroll
-      for (int bj = 0; bj < bi; ++bj) {
-        double s = 0.0;
-        for (int k = bj * 16; k < bi * 16; ++k) s += Cb[(bi * 16 + rr) * LDC + k] * Ib[k * LDC + bj * 16 + cc];
-        z[bj] = s;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int bj = 0; bj < bi; ++bj) Ib[(bi * 16 + rr) * LDC + bj * 16 + cc] = z[bj];
-      __syncthreads();
-#pragma unroll
-      for (int bj = 0; bj < bi; ++bj) {
-        double s = 0.0;
-        for (int k = 0; k < 16; ++k) s += Ib[(bi * 16 + rr) * LDC + bi * 16 + k] * Ib[(bi * 16 + k) * LDC + bj * 16 + cc];
-        z[bj] = -s;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int bj = 0; bj < bi; ++bj) Ib[(bi * 16 + rr) * LDC + bj * 16 + cc] = z[bj];
-      __syncthreads();
-    }
-  }
-  // ---- write L_jj, invL_jj ; y_j = invL_jj y_j ------------------------------------------------
+  const bool lower = !(wp.wr == 0 && wp.wc == 1);
+  accumulate_klist(f, slot, Lm, kp, [&](int) { return lower; }, acc, stA, stB, wp);
+  tile_from_acc(Cb, acc, st, d, f, am, wp);
   double* Lout = Lm + size_t(slot) * 4096;
-  double* Iout = f.invL + (size_t(m) * f.T + j) * 4096;
-  for (int idx = t; idx < 4096; idx += 256) {
-    int rr = idx >> 6, cc = idx & 63;
-    Lout[idx] = Cb[rr * LDC + cc];
-    Iout[idx] = Ib[rr * LDC + cc];
+  for (int idx = threadIdx.x; idx < 4096; idx += 256) Lout[idx] = Cb[(idx >> 6) * LDC + (idx & 63)];
+}
+
+// 1/sqrt(d) for a positive normal d: hardware seed (v_rsq_f64, ~2^-26 relative error) + two Newton
+// steps -> within 1-2 ulp; a fraction of the dependent-instruction chain of 1.0 / sqrt(d).
+__device__ inline double rsqrt_newton(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double hd = 0.5 * d;
+  y = y * fma(-hd * y, y, 1.5);
+  y = y * fma(-hd * y, y, 1.5);
+  return y;
+}
+
+__device__ inline double readlane_f64(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Diagonal tile j, step 2 of 3: in-register Cholesky, ONE WAVE per system (all systems of the batch
+// resident at once, one wave per SIMD).  Lane r keeps row r of the 64x64 tile in registers; the
+// elimination is fully unrolled (static register indices), column j of L is broadcast through LDS
+// each step; no barriers.  (Steps 2 and 3 are separate kernels because hipcc's register allocation
+// collapses into scratch when the two fully unrolled phases share one function.)
+__global__ __launch_bounds__(64) void k_diag_potrf(FemDev f, int slot) {
+  __shared__ __align__(16) double Ls[64 * LDC];
+  __shared__ __align__(16) double lv[2][64];
+  const int m = blockIdx.x, lane = threadIdx.x;
+  double* Lt = f.L + (size_t(m) * f.nslots + slot) * 4096;
+  for (int i = 0; i < 64; ++i) Ls[i * LDC + lane] = Lt[i * 64 + lane];
+  __syncthreads();
+  double a[64];
+#pragma unroll
+  for (int c = 0; c < 64; c += 2) {
+    double2 v = *reinterpret_cast<const double2*>(&Ls[lane * LDC + c]);
+    a[c] = v.x;
+    a[c + 1] = v.y;
   }
-  if (t < 64) {
-    double s = 0.0;
-    for (int k = 0; k <= t; ++k) s += Ib[t * LDC + k] * gj[k];
-    f.y[size_t(m) * f.nGp + j * 64 + t] = s;
+  bool bad = false;
+#pragma unroll
+  for (int jj = 0; jj < 64; ++jj) {
+    const double dj = readlane_f64(a[jj], jj);
+    bad = bad || !(dj > 0.0);
+    const double rs = rsqrt_newton(dj);
+    const double l = a[jj] * rs;  // L[lane][jj] for lane >= jj
+    a[jj] = l;
+    if (jj < 63) {
+      double* bv = lv[jj & 1];
+      bv[lane] = l;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < 64; ++c)
+        if (c > jj) a[c] -= l * bv[c];  // constant trip count so that both loops unroll fully
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (bad && lane == 0) atomicOr(f.status, 1);
+  __syncthreads();
+  // L (lower, zero above the diagonal) back through LDS, coalesced to HBM
+#pragma unroll
+  for (int c = 0; c < 64; ++c) Ls[lane * LDC + c] = c <= lane ? a[c] : 0.0;
+  __syncthreads();
+  for (int i = 0; i < 64; ++i) Lt[i * 64 + lane] = Ls[i * LDC + lane];
+}
+
+// Diagonal tile j, step 3 of 3 (one wave per system): y_j <- L_jj^-1 y_j by column-oriented
+// substitution, and X = L_jj^-1 with lane c owning column c of X in registers:
+// X[r][c] = (delta_rc - sum_{k<r} L[r][k] X[k][c]) / L[r][r]; L is read from LDS with wave-uniform
+// addresses (broadcast), every row of X is stored coalesced.
+__global__ __launch_bounds__(64) void k_diag_inverse(FemDev f, int slot, int j) {
+  __shared__ __align__(16) double Ls[64 * LDC];
+  __shared__ double rinv[64];
+  const int m = blockIdx.x, lane = threadIdx.x;
+  const double* Lt = f.L + (size_t(m) * f.nslots + slot) * 4096;
+  for (int i = 0; i < 64; ++i) Ls[i * LDC + lane] = Lt[i * 64 + lane];
+  __syncthreads();
+  rinv[lane] = 1.0 / Ls[lane * LDC + lane];
+  __syncthreads();
+  double g = f.y[size_t(m) * f.nGp + j * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    const double yk = readlane_f64(g, k) * rinv[k];
+    if (lane == k) g = yk;
+    else if (lane > k) g -= Ls[lane * LDC + k] * yk;
+  }
+  f.y[size_t(m) * f.nGp + j * 64 + lane] = g;
+  double* It = f.invL + (size_t(m) * f.T + j) * 4096;
+  double x[64];
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    double s = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k)
+      if (k < r) s -= Ls[r * LDC + k] * x[k];
+    x[r] = s * rinv[r];
+    It[r * 64 + lane] = x[r];
   }
 }
 
 // Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;
-// y_i -= L_ij y_j
+// y_i -= L_ij y_j.  invL_jj is lower triangular: the waves owning output columns 0..31 only need
+// k < 32 of the second product.
 __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j) {
-  __shared__ __align__(16) double lds[STAGE_TOTAL + TILE_DOUBLES];
-  double* stage = lds;
-  double* Cb = lds + STAGE_TOTAL;
+  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];
+  __shared__ int kp[2 * KP_MAX];
   __shared__ double yj[64];
+  double* stB = lds;
+  double* stA = lds + 2 * STAGE_DOUBLES;
+  double* Cb = lds + 2 * STAGE_DOUBLES;
   const int m = blockIdx.y;
   const int ent = f.colptr[j] + blockIdx.x;
   const int slot = f.colrow[ent];
@@ -291,24 +344,20 @@ __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __
   const double* am = a + size_t(m) * f.kblk;
   double* Lm = f.L + size_t(m) * f.nslots * 4096;
   const int t = threadIdx.x;
-
+  STile st;
+  s_tile_load(st, d, f, am, wp);
+  if (t < 64) yj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
   Acc acc;
   acc_zero(acc);
-  const int srow = stage_row(), sseg = stage_seg();
-  for (int e = f.kptr[slot]; e < f.kptr[slot + 1]; ++e) {
-    const double* A = Lm + size_t(f.kpair[2 * e]) * 4096 + srow * 64 + sseg;
-    const double* B = Lm + size_t(f.kpair[2 * e + 1]) * 4096 + srow * 64 + sseg;
-    gemm_loop(
-        4, [&](int ch, double* v) { load4_aligned(A + ch * BK, v); },
-        [&](int ch, double* v) { load4_aligned(B + ch * BK, v); }, acc, stage, wp);
-  }
-  if (t < 64) yj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
-  tile_from_acc(Cb, acc, d, f, am, wp);
+  accumulate_klist(f, slot, Lm, kp, [](int) { return true; }, acc, stA, stB, wp);
+  tile_from_acc(Cb, acc, st, d, f, am, wp);
 
   // X = C * invL_jj^T
   acc_zero(acc);
-  const double* I = f.invL + (size_t(m) * f.T + j) * 4096 + srow * 64 + sseg;
-  gemm_loop_Atile(Cb, 4, [&](int ch, double* v) { load4_aligned(I + ch * BK, v); }, acc, stage, wp);
+  const double* I = f.invL + (size_t(m) * f.T + j) * 4096 + stage_row() * 64 + stage_seg();
+  const int kmax = (wp.wc + 1) * 32;  // invL[c][k] = 0 for k > c
+  gemm_loop_Atile(Cb, 4, [&](int ch, double* v) { load4_aligned(I + ch * BK, v); },
+                  [&](int ch) { return ch * BK < kmax; }, acc, stB, wp);
 
   double* Lout = Lm + size_t(slot) * 4096;
 #pragma unroll
@@ -562,18 +611,8 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       }
     }
   }
-  std::vector<int> tile0(E);
-  for (int pos = 0; pos < E; ++pos) tile0[order[pos]] = pos * tpe;
-  const int xt0 = E * tpe;                         // first cross tile
-  const int nxt = (ncross + TB - 1) / TB;          // cross tiles
-  const int T = xt0 + nxt;
-  f->T = T;
-  f->nGp = T * TB;
-  // tile -> (edge id or -1 for cross, local tile index)
-  std::vector<int> tile_edge(T, -1), tile_loc(T, 0);
-  for (int e = 0; e < E; ++e)
-    for (int x = 0; x < tpe; ++x) { tile_edge[tile0[e] + x] = e; tile_loc[tile0[e] + x] = x; }
-  for (int x = 0; x < nxt; ++x) tile_loc[xt0 + x] = x;
+  std::vector<int> tile0(E), epos(E);
+  for (int pos = 0; pos < E; ++pos) { tile0[order[pos]] = pos * tpe; epos[order[pos]] = pos; }
 
   // ---- cross <-> edge-end couplings ----------------------------------------------------------------
   struct XCpl { int cross, edge, node; };  // node: 0-based local node on the edge
@@ -589,6 +628,37 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     }
   }
 
+  // ---- placement of the cross points: into the padding slots behind an adjacent edge (the one
+  //      eliminated last), so that they do not cost tiles of their own; overflow goes to extra
+  //      tiles at the end of the ordering ------------------------------------------------------------
+  const int free_per_edge = n1p - n1;
+  std::vector<int> used(E, 0), xpos(ncross, -1), overflow;
+  for (int x = 0; x < ncross; ++x) {
+    int best = -1;
+    for (auto& c : xc)
+      if (c.cross == x && used[c.edge] < free_per_edge && (best < 0 || epos[c.edge] > epos[best])) best = c.edge;
+    if (best >= 0) xpos[x] = tile0[best] * TB + n1 + used[best]++;
+    else overflow.push_back(x);
+  }
+  const int xt0 = E * tpe;                                   // first overflow tile
+  const int nxt = (int(overflow.size()) + TB - 1) / TB;      // overflow tiles
+  for (size_t o = 0; o < overflow.size(); ++o) xpos[overflow[o]] = xt0 * TB + int(o);
+  const int T = xt0 + nxt;
+  f->T = T;
+  f->nGp = T * TB;
+  // tile -> (edge id or -1 for an overflow tile, local tile index, number of defined rows)
+  std::vector<int> tile_edge(T, -1), tile_loc(T, 0), tile_ndr(T, 0);
+  for (int e = 0; e < E; ++e)
+    for (int x = 0; x < tpe; ++x) {
+      tile_edge[tile0[e] + x] = e;
+      tile_loc[tile0[e] + x] = x;
+      tile_ndr[tile0[e] + x] = std::max(0, std::min(TB, n1 + used[e] - x * TB));
+    }
+  for (int x = 0; x < nxt; ++x) {
+    tile_loc[xt0 + x] = x;
+    tile_ndr[xt0 + x] = std::min(TB, int(overflow.size()) - x * TB);
+  }
+
   // ---- tile mask + symbolic fill --------------------------------------------------------------------
   std::vector<char> mask(size_t(T) * T, 0);
   auto M_ = [&](int i, int j) -> char& { return mask[size_t(i) * T + j]; };
@@ -597,9 +667,9 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       if (e == e2 || adj[e].count(e2))
         for (int x = 0; x < tpe; ++x)
           for (int y = 0; y < tpe; ++y) M_(tile0[e] + x, tile0[e2] + y) = 1;
-  for (int x = 0; x < nxt; ++x) M_(xt0 + x, xt0 + x) = 1;
+  for (int x = 0; x < ncross; ++x) M_(xpos[x] / TB, xpos[x] / TB) = 1;
   for (auto& c : xc) {
-    int ti = xt0 + c.cross / TB, tj = tile0[c.edge] + c.node / TB;
+    int ti = xpos[c.cross] / TB, tj = tile0[c.edge] + c.node / TB;
     M_(ti, tj) = M_(tj, ti) = 1;
   }
   for (int k = 0; k < T; ++k)
@@ -652,8 +722,9 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     int er = tile_edge[d.ti], ec = tile_edge[d.tj];
     d.lr0 = tile_loc[d.ti] * TB;
     d.lc0 = tile_loc[d.tj] * TB;
-    d.nvr = er >= 0 ? std::min(TB, n1 - d.lr0) : std::min(TB, ncross - d.lr0);
-    d.nvc = ec >= 0 ? std::min(TB, n1 - d.lc0) : std::min(TB, ncross - d.lc0);
+    d.nvr = er >= 0 ? std::max(0, std::min(TB, n1 - d.lr0)) : 0;  // edge nodes in the tile rows / cols
+    d.nvc = ec >= 0 ? std::max(0, std::min(TB, n1 - d.lc0)) : 0;
+    d.ndr = tile_ndr[d.ti];                                        // + cross slots: rows that are unknowns
     if (er >= 0 && ec >= 0) {
       // blocks adjacent to both edges
       int cand[2] = {edges[er].b0, edges[er].b1};
@@ -672,20 +743,25 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       }
     }
     d.x0 = int(extras.size());
-    if (er < 0 && ec < 0 && d.diag) {
-      for (int x = 0; x < d.nvr; ++x) {
-        auto pq = crosses[d.lr0 + x];
-        int p = pq.first, q = pq.second;
-        TileExtra e{x, x, 1, {(p - 1) * ncb + (q - 1), (p - 1) * ncb + q, p * ncb + (q - 1), p * ncb + q}};
-        extras.push_back(e);
+    // entries that involve cross points (placed by interface position)
+    for (int x = 0; x < ncross; ++x) {
+      if (d.diag && xpos[x] / TB == d.ti) {
+        int p = crosses[x].first, q = crosses[x].second, l = xpos[x] % TB;
+        extras.push_back(TileExtra{l, l, 1, {(p - 1) * ncb + (q - 1), (p - 1) * ncb + q, p * ncb + (q - 1), p * ncb + q}});
       }
-    } else if (er < 0 && ec >= 0) {
-      for (auto& c : xc) {
-        if (c.edge != ec) continue;
-        if (c.cross / TB != tile_loc[d.ti] || c.node / TB != tile_loc[d.tj]) continue;
-        // coupling value uses the two blocks of the edge: -(k[r,c] + k[r-1,c])/2 resp. -(k[r,c]+k[r,c-1])/2
-        TileExtra e{c.cross % TB, c.node % TB, 0, {edges[ec].b1, edges[ec].b0, 0, 0}};
-        extras.push_back(e);
+    }
+    for (auto& c : xc) {
+      int pa = xpos[c.cross], pb = tile0[c.edge] * TB + c.node;
+      // coupling value uses the two blocks of the edge: -(k[r,c] + k[r-1,c])/2 resp. -(k[r,c]+k[r,c-1])/2
+      const int ta = pa / TB, tb = pb / TB;
+      const TileExtra rc{pa % TB, pb % TB, 0, {edges[c.edge].b1, edges[c.edge].b0, 0, 0}};
+      const TileExtra cr{pb % TB, pa % TB, 0, {edges[c.edge].b1, edges[c.edge].b0, 0, 0}};
+      if (ta == tb) {
+        if (d.diag && d.ti == ta) { extras.push_back(rc); extras.push_back(cr); }
+      } else if (d.ti == ta && d.tj == tb) {
+        extras.push_back(rc);
+      } else if (d.ti == tb && d.tj == ta) {
+        extras.push_back(cr);
       }
     }
     d.x1 = int(extras.size());
@@ -708,7 +784,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
   for (int x = 0; x < ncross; ++x) {
     int r = crosses[x].first * N, c = crosses[x].second * N;
-    vmap[xt0 * TB + x] = (r - 1) * f->nc + (c - 1);
+    vmap[xpos[x]] = (r - 1) * f->nc + (c - 1);
   }
 
   // ---- unit-block tables in long double ----------------------------------------------------------------
@@ -757,7 +833,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       f->g_host[tile0[e] * TB + t - 1] = h2 * (1.0 + w);
     }
   }
-  for (int x = 0; x < ncross; ++x) f->g_host[xt0 * TB + x] = h2;
+  for (int x = 0; x < ncross; ++x) f->g_host[xpos[x]] = h2;
 
   // ---- device tables -------------------------------------------------------------------------------------
   std::vector<double> Qp(size_t(n1p) * n1p, 0.0);
@@ -882,6 +958,73 @@ static int ensure_workspace(rom_fem* f, int Mc) {
   return ROM_OK;
 }
 
+// enqueue every kernel of one sub-batch (Mc systems, workspace pointers already offset) on `st`
+static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, double* U, long long row,
+                         hipStream_t st, size_t lds_back) {
+  rom_ctx* ctx = f->ctx;
+  const int kblk = f->nrb * f->ncb;
+  static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-column kernel names
+  char nm[4][48];
+  if (f->T > 0) {
+    {
+      ROM_PROF(ctx, "init_rhs", 0, 8.0 * Mc * f->nGp);
+      size_t tot = size_t(Mc) * f->nGp;
+      k_init_rhs<<<unsigned((tot + 255) / 256), 256, 0, st>>>(d, Mc);
+    }
+    for (int j = 0; j < f->T; ++j) {
+      {
+        int slot = f->diag_slot[j];
+        double nk = f->kptr[slot + 1] - f->kptr[slot];
+        const char* base[4] = {"diag_update", "diag_potrf", "diag_inverse", "factor_panel"};
+        for (int q = 0; q < 4; ++q) detail ? snprintf(nm[q], 48, "%s_j%02d", base[q], j) : snprintf(nm[q], 48, "%s", base[q]);
+        {
+          ROM_PROF(ctx, nm[0], Mc * nk * 2.0 * 262144, Mc * 8.0 * 4096 * (1 + 2 * nk));
+          k_diag_update<<<Mc, 256, 0, st>>>(d, am, slot);
+        }
+        {
+          ROM_PROF(ctx, nm[1], Mc * (262144 / 3.0), Mc * 8.0 * 4096 * 2);
+          k_diag_potrf<<<Mc, 64, 0, st>>>(d, slot);
+        }
+        {
+          ROM_PROF(ctx, nm[2], Mc * (262144 / 3.0 + 4096.0), Mc * 8.0 * 4096 * 2);
+          k_diag_inverse<<<Mc, 64, 0, st>>>(d, slot, j);
+        }
+      }
+      int nrows = f->colptr[j + 1] - f->colptr[j];
+      if (nrows > 0) {
+        double nk = 0;
+        for (int e = f->colptr[j]; e < f->colptr[j + 1]; ++e) nk += f->kptr[f->colrow[e] + 1] - f->kptr[f->colrow[e]];
+        ROM_PROF(ctx, nm[3], Mc * (nk + nrows) * 2.0 * 262144, Mc * 8.0 * 4096 * (2 * nk + 2 * nrows));
+        k_factor_panel<<<dim3(nrows, Mc), 256, 0, st>>>(d, am, j);
+      }
+    }
+    {
+      ROM_PROF(ctx, "backsolve", Mc * 2.0 * 4096 * (f->nslots + f->T), Mc * 8.0 * 4096 * (f->nslots + f->T));
+      k_backsolve<<<Mc, 256, lds_back, st>>>(d, f->d_slot_of, nullptr);
+    }
+  }
+  {
+    const int nij = f->n1 * f->n1;
+    if (nij > 0) {
+      dim3 grid((nij + 63) / 64, (Mc + 63) / 64, kblk);
+      double fl = 0;
+      for (int b = 0; b < kblk; ++b) {
+        int ns = 0;
+        for (int s = 0; s < 4; ++s) ns += f->sides[b].off[s] >= 0;
+        fl += 2.0 * nij * double(ns) * f->n1p;
+      }
+      ROM_PROF(ctx, "extend", fl * Mc, 8.0 * Mc * double(kblk) * nij);
+      k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row);
+    }
+    if (f->T > 0) {
+      ROM_PROF(ctx, "scatter_interface", 0, 16.0 * Mc * f->nG);
+      k_scatter_interface<<<dim3((f->nGp + 255) / 256, Mc), 256, 0, st>>>(d, Mc, U, row);
+    }
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
 extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0) {
   ROM_CHECK(f && a && U, "rom_solve_batch: null argument");
   ROM_CHECK(M >= 0 && row0 >= 0, "rom_solve_batch: negative M or row offset");
@@ -897,61 +1040,44 @@ extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_
   int Mc_max = int(std::max<size_t>(1, std::min<size_t>(size_t(M), ctx->ws_limit / std::max<size_t>(per_sys, 1))));
   if (f->ws_M > 0 && f->ws_M < Mc_max && f->ws_M >= 256) Mc_max = f->ws_M;  // reuse what we have
   ROM_TRY(ensure_workspace(f, Mc_max));
-  hipStream_t st = ctx->stream;
-  ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), st));
+  ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
   const size_t lds_back = size_t(std::max(f->nGp, 1)) * sizeof(double);
   ROM_CHECK(lds_back <= 60 * 1024, "rom_solve_batch: interface too large for the LDS-resident back substitution");
+  // Sub-batches run on separate HIP streams: the wave-per-system diagonal kernels are latency bound
+  // (one wave per SIMD), the MFMA kernels of another sub-batch fill the chip meanwhile.
+  const int nsub = std::max(1, std::min(ctx->n_streams, (M + 255) / 256));
+  ROM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+  for (int s = 1; s < nsub; ++s) ROM_HIP(hipStreamWaitEvent(ctx->aux[s - 1], ctx->ev_fork, 0));
   for (int m0 = 0; m0 < M; m0 += Mc_max) {
-    const int Mc = std::min(Mc_max, M - m0);
-    FemDev d = make_dev(f);
-    const double* am = a->p + size_t(m0) * kblk;
-    if (f->T > 0) {
-      {
-        ROM_PROF(ctx, "init_rhs", 0, 8.0 * Mc * f->nGp);
-        size_t tot = size_t(Mc) * f->nGp;
-        k_init_rhs<<<unsigned((tot + 255) / 256), 256, 0, st>>>(d, Mc);
-      }
-      for (int j = 0; j < f->T; ++j) {
-        {
-          int slot = f->diag_slot[j];
-          double nk = f->kptr[slot + 1] - f->kptr[slot];
-          ROM_PROF(ctx, "factor_diag", Mc * (nk * 2.0 * 262144 + 262144 / 3.0 + 262144 / 3.0),
-                   Mc * 8.0 * 4096 * (2 + 2 * nk));
-          k_factor_diag<<<Mc, 256, 0, st>>>(d, am, slot, j);
-        }
-        int nrows = f->colptr[j + 1] - f->colptr[j];
-        if (nrows > 0) {
-          double nk = 0;
-          for (int e = f->colptr[j]; e < f->colptr[j + 1]; ++e) nk += f->kptr[f->colrow[e] + 1] - f->kptr[f->colrow[e]];
-          ROM_PROF(ctx, "factor_panel", Mc * (nk + nrows) * 2.0 * 262144, Mc * 8.0 * 4096 * (2 * nk + 2 * nrows));
-          k_factor_panel<<<dim3(nrows, Mc), 256, 0, st>>>(d, am, j);
-        }
-      }
-      {
-        ROM_PROF(ctx, "backsolve", Mc * 2.0 * 4096 * (f->nslots + f->T), Mc * 8.0 * 4096 * (f->nslots + f->T));
-        k_backsolve<<<Mc, 256, lds_back, st>>>(d, f->d_slot_of, nullptr);
-      }
+    const int Mchunk = std::min(Mc_max, M - m0);
+    const int per = ((Mchunk + nsub - 1) / nsub + 63) / 64 * 64;
+    for (int s = 0; s < nsub; ++s) {
+      const int off = s * per;
+      if (off >= Mchunk) break;
+      const int Mc = std::min(per, Mchunk - off);
+      hipStream_t st = s == 0 ? ctx->stream : ctx->aux[s - 1];
+      ctx->prof_stream = st;
+      FemDev d = make_dev(f);
+      d.L += size_t(off) * f->nslots * 4096;
+      d.invL += size_t(off) * f->T * 4096;
+      d.y += size_t(off) * f->nGp;
+      ROM_TRY(enqueue_solve(f, d, a->p + size_t(m0 + off) * kblk, Mc, U->p, (long long)(row0 + m0 + off), st, lds_back));
     }
-    {
-      const int nij = f->n1 * f->n1;
-      if (nij > 0) {
-        dim3 grid((nij + 63) / 64, (Mc + 63) / 64, kblk);
-        double fl = 0;
-        for (int b = 0; b < kblk; ++b) {
-          int ns = 0;
-          for (int s = 0; s < 4; ++s) ns += f->sides[b].off[s] >= 0;
-          fl += 2.0 * nij * double(ns) * f->n1p;
-        }
-        ROM_PROF(ctx, "extend", fl * Mc, 8.0 * Mc * double(kblk) * nij);
-        k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U->p, (long long)(row0 + m0));
+    ctx->prof_stream = nullptr;
+    if (m0 + Mc_max < M) {  // the workspace is reused by the next chunk: join first
+      for (int s = 1; s < nsub; ++s) {
+        ROM_HIP(hipEventRecord(ctx->ev_join[s - 1], ctx->aux[s - 1]));
+        ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[s - 1], 0));
       }
-      if (f->T > 0) {
-        ROM_PROF(ctx, "scatter_interface", 0, 16.0 * Mc * f->nG);
-        k_scatter_interface<<<dim3((f->nGp + 255) / 256, Mc), 256, 0, st>>>(d, Mc, U->p, (long long)(row0 + m0));
-      }
+      ROM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+      for (int s = 1; s < nsub; ++s) ROM_HIP(hipStreamWaitEvent(ctx->aux[s - 1], ctx->ev_fork, 0));
     }
-    ROM_HIP(hipGetLastError());
   }
+  for (int s = 1; s < nsub; ++s) {
+    ROM_HIP(hipEventRecord(ctx->ev_join[s - 1], ctx->aux[s - 1]));
+    ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[s - 1], 0));
+  }
+  hipStream_t st = ctx->stream;
   int status = 0;
   ROM_HIP(hipMemcpyAsync(&status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
   ROM_HIP(hipStreamSynchronize(st));

@@ -106,17 +106,20 @@ __device__ inline void load4_aligned(const double* __restrict__ p, double v[4]) 
 }
 
 // Generic pipelined loop over `nchunks` K-chunks.  loadA(ch, v) / loadB(ch, v) fetch this thread's
-// 4 doubles of chunk ch.  `stage` points at STAGE_TOTAL doubles of LDS.  Ends with a barrier, so
-// the staging area may be reused by the caller right after.
-template <class FA, class FB>
-__device__ inline void gemm_loop(int nchunks, FA loadA, FB loadB, Acc& acc, double* stage, const WavePos& wp) {
+// 4 doubles of chunk ch.  stA / stB each point at 2*STAGE_DOUBLES doubles of LDS (two buffers).
+// `active(ch)` is a wave-uniform predicate: a wave whose quadrant does not need chunk ch skips the
+// MFMAs (it still takes part in staging and barriers).  Ends with a barrier, so the staging area
+// may be reused by the caller right after.
+template <class FA, class FB, class FP>
+__device__ inline void gemm_loop2(int nchunks, FA loadA, FB loadB, FP active, Acc& acc, double* stA, double* stB,
+                                  const WavePos& wp) {
   if (nchunks <= 0) return;
   double va[4], vb[4];
   loadA(0, va);
   loadB(0, vb);
   for (int ch = 0; ch < nchunks; ++ch) {
-    double* sA = stage + (ch & 1) * 2 * STAGE_DOUBLES;
-    double* sB = sA + STAGE_DOUBLES;
+    double* sA = stA + (ch & 1) * STAGE_DOUBLES;
+    double* sB = stB + (ch & 1) * STAGE_DOUBLES;
     stage_store(sA, va);
     stage_store(sB, vb);
     __syncthreads();
@@ -124,25 +127,30 @@ __device__ inline void gemm_loop(int nchunks, FA loadA, FB loadB, Acc& acc, doub
       loadA(ch + 1, va);
       loadB(ch + 1, vb);
     }
-    mma_chunk(sA, sB, acc, wp);
+    if (active(ch)) mma_chunk(sA, sB, acc, wp);
     // the buffer written next iteration is the other one; the barrier of that iteration orders
     // its readers (iteration ch-1 ... already passed the barrier of iteration ch) -> no 2nd barrier
   }
   __syncthreads();
 }
 
-// Variant: A operand is a resident [64][LDC] LDS tile (K = 64), B streamed.
-template <class FB>
-__device__ inline void gemm_loop_Atile(const double* tileA, int nchunks, FB loadB, Acc& acc, double* stage,
+template <class FA, class FB>
+__device__ inline void gemm_loop(int nchunks, FA loadA, FB loadB, Acc& acc, double* stage, const WavePos& wp) {
+  gemm_loop2(nchunks, loadA, loadB, [](int) { return true; }, acc, stage, stage + 2 * STAGE_DOUBLES, wp);
+}
+
+// Variant: A operand is a resident [64][LDC] LDS tile (K = 64), B streamed through stB (2 buffers).
+template <class FB, class FP>
+__device__ inline void gemm_loop_Atile(const double* tileA, int nchunks, FB loadB, FP active, Acc& acc, double* stB,
                                        const WavePos& wp) {
   double vb[4];
   loadB(0, vb);
   for (int ch = 0; ch < nchunks; ++ch) {
-    double* sB = stage + (ch & 1) * 2 * STAGE_DOUBLES + STAGE_DOUBLES;
+    double* sB = stB + (ch & 1) * STAGE_DOUBLES;
     stage_store(sB, vb);
     __syncthreads();
     if (ch + 1 < nchunks) loadB(ch + 1, vb);
-    mma_chunk_Atile(tileA, ch * BK, sB, acc, wp);
+    if (active(ch)) mma_chunk_Atile(tileA, ch * BK, sB, acc, wp);
   }
   __syncthreads();
 }

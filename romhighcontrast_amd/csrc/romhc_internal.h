@@ -46,11 +46,16 @@ constexpr int LDC = 66;  // LDS row stride of a full [64][64] tile
 struct ProfRec {
   hipEvent_t e0, e1;
   int name_id;
+  hipStream_t st;
 };
 
 struct rom_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // sub-batch streams of rom_solve_batch
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  int n_streams = 1;  // ROMHC_STREAMS=2..4 splits a sweep into concurrent sub-batches (no gain measured at M=1024)
+  hipStream_t prof_stream = nullptr;  // stream the next ROM_PROF bracket records on (null: `stream`)
   size_t ws_limit = size_t(24) << 30;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   // profiling
@@ -101,7 +106,8 @@ struct TileDesc {
   int hv;            // 0 horizontal edge (blocks up/down), 1 vertical (left/right)
   int b0, b1;        // the two blocks of that edge: (up, dn) or (lf, rt)
   int lr0, lc0;      // local node index (on the edge) of tile row 0 / col 0
-  int nvr, nvc;      // number of real (non padding) rows / cols in the tile
+  int nvr, nvc;      // number of edge nodes among the tile rows / cols
+  int ndr;           // rows [0, ndr) are unknowns (edge nodes + cross slots); beyond: identity padding
   int x0, x1;        // range in the extras list
   int diag;          // 1 if ti == tj
 };
