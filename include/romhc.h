@@ -117,6 +117,10 @@ int rom_l2norm(rom_ctx* ctx, rom_buf* U, int64_t row0, int K, int64_t dim, doubl
 int rom_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, rom_buf* A, size_t a_off,
                 int64_t lda, rom_buf* B, size_t b_off, int64_t ldb, double beta, rom_buf* C, size_t c_off,
                 int64_t ldc);
+/* G[m,m] = A A^T (row-major A[m,k]): the snapshot Gram matrix of the POD; only the lower tiles are
+ * computed on MFMA, the strict upper triangle is mirrored */
+int rom_gram(rom_ctx* ctx, int64_t m, int64_t k, rom_buf* A, size_t a_off, int64_t lda, rom_buf* C, size_t c_off,
+             int64_t ldc);
 /* C[m,n] = alpha * sum_k A[m,k] B[k,n] + beta*C   (row-major, "NN": lift c_i . basis, :106/:139) */
 int rom_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, rom_buf* A, size_t a_off,
                 int64_t lda, rom_buf* B, size_t b_off, int64_t ldb, double beta, rom_buf* C, size_t c_off,

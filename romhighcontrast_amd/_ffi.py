@@ -64,6 +64,7 @@ PROTOTYPES = {
     "rom_l2norm": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
     "rom_gemm_nt": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_double, _vp, C.c_size_t, C.c_int64,
                               _vp, C.c_size_t, C.c_int64, C.c_double, _vp, C.c_size_t, C.c_int64]),
+    "rom_gram": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, C.c_size_t, C.c_int64, _vp, C.c_size_t, C.c_int64]),
     "rom_gemm_nn": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_double, _vp, C.c_size_t, C.c_int64,
                               _vp, C.c_size_t, C.c_int64, C.c_double, _vp, C.c_size_t, C.c_int64]),
     "rom_reduced_solve_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
@@ -184,6 +185,9 @@ class Context:
     # -- dense ops ---------------------------------------------------------------------------
     def gemm_nt(self, m, n, k, A, a_off, lda, B, b_off, ldb, Cb, c_off, ldc, alpha=1.0, beta=0.0):
         check(self.lib.rom_gemm_nt(self.h, m, n, k, alpha, A.h, a_off, lda, B.h, b_off, ldb, beta, Cb.h, c_off, ldc))
+
+    def gram(self, m, k, A, a_off, lda, Cb, c_off, ldc):
+        check(self.lib.rom_gram(self.h, m, k, A.h, a_off, lda, Cb.h, c_off, ldc))
 
     def gemm_nn(self, m, n, k, A, a_off, lda, B, b_off, ldb, Cb, c_off, ldc, alpha=1.0, beta=0.0):
         check(self.lib.rom_gemm_nn(self.h, m, n, k, alpha, A.h, a_off, lda, B.h, b_off, ldb, beta, Cb.h, c_off, ldc))

@@ -328,15 +328,30 @@ __global__ __launch_bounds__(64) void k_diag_inverse(FemDev f, int slot, int j) 
 // Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;
 // y_i -= L_ij y_j.  invL_jj is lower triangular: the waves owning output columns 0..31 only need
 // k < 32 of the second product.
-__global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j) {
+__global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc) {
   __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];
   __shared__ int kp[2 * KP_MAX];
   __shared__ double yj[64];
   double* stB = lds;
   double* stA = lds + 2 * STAGE_DOUBLES;
   double* Cb = lds + 2 * STAGE_DOUBLES;
-  const int m = blockIdx.y;
-  const int ent = f.colptr[j] + blockIdx.x;
+  // XCD-aware mapping: block ids are dealt round-robin to the 8 XCDs (each with its own L2); all row
+  // tiles of one system are given ids of the same residue mod 8 so that the L_jk / invL_jj tiles they
+  // share are served by one L2.  (Placement only affects speed, never correctness.)
+  const int nrows = f.colptr[j + 1] - f.colptr[j];
+  int m, row;
+  {
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int full = (Mc >> 3) << 3;  // systems covered by complete groups of 8
+    m = xcd + 8 * (idx / nrows);
+    row = idx % nrows;
+    if (m >= full) {  // ragged tail (Mc % 8 systems): plain order
+      const int tb = b - full * nrows;
+      m = full + tb / nrows;
+      row = tb % nrows;
+    }
+  }
+  const int ent = f.colptr[j] + row;
   const int slot = f.colrow[ent];
   const int ti = f.colti[ent];
   const WavePos wp;
@@ -995,7 +1010,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         double nk = 0;
         for (int e = f->colptr[j]; e < f->colptr[j + 1]; ++e) nk += f->kptr[f->colrow[e] + 1] - f->kptr[f->colrow[e]];
         ROM_PROF(ctx, nm[3], Mc * (nk + nrows) * 2.0 * 262144, Mc * 8.0 * 4096 * (2 * nk + 2 * nrows));
-        k_factor_panel<<<dim3(nrows, Mc), 256, 0, st>>>(d, am, j);
+        k_factor_panel<<<nrows * Mc, 256, 0, st>>>(d, am, j, Mc);
       }
     }
     {

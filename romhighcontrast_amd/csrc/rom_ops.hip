@@ -33,10 +33,21 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_gemm_nt(long long m, long long n, long long K, long long kper,
                                                  double alpha, const double* __restrict__ A, long long lda,
                                                  const double* __restrict__ B, long long ldb, double beta,
-                                                 double* __restrict__ C, long long ldc, double* __restrict__ part) {
+                                                 double* __restrict__ C, long long ldc, double* __restrict__ part,
+                                                 int lower_only) {
   __shared__ __align__(16) double stage[STAGE_TOTAL];
+  // Gram (lower_only): 1-D grid over the tiles on/below the diagonal, so that consecutive block ids
+  // (dealt round-robin to the 8 XCDs) all carry work; the strict upper triangle comes from the mirror pass
+  long long ty = blockIdx.y, tx = blockIdx.x;
+  if (lower_only) {
+    const long long t = blockIdx.x;
+    ty = (long long)((sqrt(8.0 * double(t) + 1.0) - 1.0) * 0.5);
+    while (ty * (ty + 1) / 2 > t) --ty;
+    while ((ty + 1) * (ty + 2) / 2 <= t) ++ty;
+    tx = t - ty * (ty + 1) / 2;
+  }
   const WavePos wp;
-  const long long r0 = blockIdx.y * 64LL, c0 = blockIdx.x * 64LL;
+  const long long r0 = ty * 64LL, c0 = tx * 64LL;
   const long long kbeg = blockIdx.z * kper, kend = std::min<long long>(K, kbeg + kper);
   const int srow = stage_row(), sseg = stage_seg();
   const double* Ar = (r0 + srow < m) ? A + (r0 + srow) * lda : nullptr;
@@ -68,10 +79,18 @@ __global__ __launch_bounds__(256) void k_gemm_nt(long long m, long long n, long 
     }
 }
 
+__global__ void k_mirror_lower(long long n, double* __restrict__ C, long long ldc) {
+  long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= n * n) return;
+  long long r = idx / n, c = idx % n;
+  if (c > r) C[r * ldc + c] = C[c * ldc + r];
+}
+
 __global__ void k_splitk_reduce(long long m, long long n, int splits, double alpha, const double* __restrict__ part,
-                                double beta, double* __restrict__ C, long long ldc) {
+                                double beta, double* __restrict__ C, long long ldc, int lower_only) {
   long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (idx >= m * n) return;
+  if (lower_only && (idx % n) / 64 > (idx / n) / 64) return;
   double s = 0.0;
   for (int z = 0; z < splits; ++z) s += part[z * m * n + idx];
   long long r = idx / n, c = idx % n;
@@ -81,8 +100,17 @@ __global__ void k_splitk_reduce(long long m, long long n, int splits, double alp
 
 int rom_launch_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const char* prof_name) {
+  return rom_launch_gemm_nt_ex(ctx, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, prof_name, 0);
+}
+
+// lower_only != 0: the product is symmetric (A == B); only tiles on/below the diagonal are computed
+// and the strict upper triangle is filled by a mirror pass (half the MFMA work of the Gram matrix).
+int rom_launch_gemm_nt_ex(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
+                          const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const char* prof_name,
+                          int lower_only) {
   if (m <= 0 || n <= 0) return ROM_OK;
-  const long long tiles = ((m + 63) / 64) * ((n + 63) / 64);
+  const long long nt = (m + 63) / 64;
+  const long long tiles = lower_only ? nt * (nt + 1) / 2 : nt * ((n + 63) / 64);  // tiles that do work
   int splits = 1;
   if (k >= 1024 && tiles < 512) {
     splits = int(std::min<long long>((768 + tiles - 1) / tiles, (k + 511) / 512));
@@ -97,17 +125,25 @@ int rom_launch_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alp
   const bool aligned = (lda % 2 == 0) && (ldb % 2 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0) &&
                        (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (kper % 4 == 0);
   dim3 grid(unsigned((n + 63) / 64), unsigned((m + 63) / 64), unsigned(splits));
+  if (lower_only) grid = dim3(unsigned(tiles), 1, unsigned(splits));
   {
-    ROM_PROF(ctx, prof_name, 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(m) * n));
+    ROM_PROF(ctx, prof_name, (lower_only ? 1.0 : 2.0) * m * n * k + (lower_only ? 64.0 * n * k : 0.0),
+             8.0 * (double(m) * k + double(n) * k + double(m) * n));
     if (aligned)
-      k_gemm_nt<true><<<grid, 256, 0, ctx->stream>>>(m, n, k, kper, alpha, A, lda, B, ldb, beta, C, ldc, part);
+      k_gemm_nt<true><<<grid, 256, 0, ctx->stream>>>(m, n, k, kper, alpha, A, lda, B, ldb, beta, C, ldc, part, lower_only);
     else
-      k_gemm_nt<false><<<grid, 256, 0, ctx->stream>>>(m, n, k, kper, alpha, A, lda, B, ldb, beta, C, ldc, part);
+      k_gemm_nt<false><<<grid, 256, 0, ctx->stream>>>(m, n, k, kper, alpha, A, lda, B, ldb, beta, C, ldc, part, lower_only);
   }
   ROM_HIP(hipGetLastError());
   if (splits > 1) {
     ROM_PROF(ctx, "splitk_reduce", double(splits) * m * n, 8.0 * double(splits + 1) * m * n);
-    k_splitk_reduce<<<unsigned((m * n + 255) / 256), 256, 0, ctx->stream>>>(m, n, splits, alpha, part, beta, C, ldc);
+    k_splitk_reduce<<<unsigned((m * n + 255) / 256), 256, 0, ctx->stream>>>(m, n, splits, alpha, part, beta, C, ldc,
+                                                                           lower_only);
+    ROM_HIP(hipGetLastError());
+  }
+  if (lower_only) {
+    ROM_PROF(ctx, "mirror_lower", 0, 8.0 * n * n);
+    k_mirror_lower<<<unsigned((n * n + 255) / 256), 256, 0, ctx->stream>>>(n, C, ldc);
     ROM_HIP(hipGetLastError());
   }
   return ROM_OK;
@@ -124,6 +160,17 @@ extern "C" int rom_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double
   ROM_CHECK(c_off + size_t(m - 1) * ldc + n <= C->n, "rom_gemm_nt: C out of range");
   return rom_launch_gemm_nt(ctx, m, n, k, alpha, A->p + a_off, lda, B->p + b_off, ldb, beta, C->p + c_off, ldc,
                             "gemm_nt");
+}
+
+extern "C" int rom_gram(rom_ctx* ctx, int64_t m, int64_t k, rom_buf* A, size_t a_off, int64_t lda, rom_buf* C,
+                        size_t c_off, int64_t ldc) {
+  ROM_CHECK(ctx && A && C, "rom_gram: null argument");
+  ROM_CHECK(m >= 0 && k >= 0 && lda >= k && ldc >= m, "rom_gram: bad dimensions");
+  if (m == 0) return ROM_OK;
+  ROM_CHECK(a_off + size_t(m - 1) * lda + k <= A->n, "rom_gram: A out of range");
+  ROM_CHECK(c_off + size_t(m - 1) * ldc + m <= C->n, "rom_gram: C out of range");
+  return rom_launch_gemm_nt_ex(ctx, m, m, k, 1.0, A->p + a_off, lda, A->p + a_off, lda, 0.0, C->p + c_off, ldc, "gram",
+                               1);
 }
 
 // ============================================================================================

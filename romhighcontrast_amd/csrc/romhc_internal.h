@@ -164,3 +164,6 @@ struct rom_fem {
 int rom_launch_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                        int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
                        const char* prof_name);
+int rom_launch_gemm_nt_ex(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
+                          int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+                          const char* prof_name, int lower_only);

@@ -54,6 +54,25 @@ def _orthonormalize_device(ctx: _ffi.Context, X: DeviceArray) -> DeviceArray:
     return DeviceArray(Q, n, dim)
 
 
+def _cholqr2_device(ctx: _ffi.Context, X: DeviceArray) -> DeviceArray:
+    """Orthonormalise rows that are already well conditioned (kappa << 1e7): CholeskyQR2.
+    Two rounds of {b x b Gram on MFMA, Cholesky of that tiny matrix on the host, X <- R^-T X as a GEMM}.
+    Used for power-iteration bases and lifted POD modes; ill-conditioned snapshot bases go through
+    the re-orthogonalised Gram-Schmidt above."""
+    b, dim = X.rows, X.dim
+    cur = X.buf
+    for _ in range(2):
+        Gb = ctx.alloc(b * b)
+        ctx.gram(b, dim, cur, 0, dim, Gb, 0, b)
+        Gh = Gb.download(b * b, shape=(b, b))
+        R = np.linalg.cholesky(0.5 * (Gh + Gh.T))          # Gh = R R^T (lower)
+        Rinv = np.linalg.inv(R)                              # rows_new = R^-1 rows
+        nxt = ctx.alloc(b * dim)
+        ctx.gemm_nn(b, dim, b, ctx.upload(np.ascontiguousarray(Rinv)), 0, b, cur, 0, dim, nxt, 0, dim)
+        cur = nxt
+    return DeviceArray(cur, b, dim)
+
+
 def orthonormalize_base(rb):
     """(:18-21) Euclidean orthonormalisation of the basis rows (thin QR of ``rb.T``)."""
     if isinstance(rb, DeviceArray):
@@ -223,14 +242,71 @@ class ReducedBasisRandom(BaseReducedBasis):
         return self
 
 
+def _top_eigenpairs_device(ctx: _ffi.Context, G: _ffi.Buffer, M: int, nev: int, oversample=12, tol=2e-14,
+                           max_iter=80, seed=0):
+    """Leading ``nev`` eigenpairs of the symmetric PSD matrix G (M x M, device) by orthogonal
+    (subspace) iteration with Rayleigh-Ritz acceleration.  Every M-sized operation is an MFMA GEMM
+    on the device (``Z = Y G``, ``H = Z Y^T``, the rotations, the residuals, the re-orthogonalised
+    Gram-Schmidt); the host only sees (nev+p) x (nev+p) projected matrices and nev+p norms.
+    Stops when every wanted residual ``||G y_i - theta_i y_i||`` is below ``tol * theta_0`` or has
+    stopped decreasing (fp64 floor).
+    Returns (theta (nev,), W DeviceArray (nev, M) with orthonormal rows = eigenvectors).
+    """
+    b = int(min(M, nev + oversample))
+    rng = np.random.default_rng(seed)
+    Y = _cholqr2_device(ctx, DeviceArray(ctx.upload(rng.standard_normal((b, M))), b, M))  # Gaussian rows: kappa ~ 1
+    Z, H = ctx.alloc(b * M), ctx.alloc(b * b)
+    Zr, Yr = ctx.alloc(b * M), ctx.alloc(b * M)
+    best, stall = np.inf, 0
+    for it in range(max_iter):
+        ctx.gemm_nt(b, M, M, Y.buf, 0, M, G, 0, M, Z, 0, M)          # Z = Y G   (G symmetric)
+        ctx.gemm_nt(b, b, M, Z, 0, M, Y.buf, 0, M, H, 0, b)          # H = Y G Y^T
+        Hh = H.download(b * b, shape=(b, b))
+        theta, S = np.linalg.eigh(0.5 * (Hh + Hh.T))                  # (b x b) projected problem
+        theta, S = theta[::-1], S[:, ::-1]
+        St = ctx.upload(np.ascontiguousarray(S.T))
+        ctx.gemm_nn(b, M, b, St, 0, b, Y.buf, 0, M, Yr, 0, M)         # Ritz vectors  S^T Y
+        if b == M:                                                    # full space: exact after one Ritz step
+            return theta[:nev], DeviceArray(Yr, nev, M)
+        ctx.gemm_nn(b, M, b, St, 0, b, Z, 0, M, Zr, 0, M)             # G applied to them: S^T (Y G)
+        # residuals  Zr - diag(theta) Yr, row norms on the device
+        Res = ctx.alloc(b * M).copy_from(Zr, b * M)
+        ctx.gemm_nn(b, M, b, ctx.upload(np.diag(-theta)), 0, b, Yr, 0, M, Res, 0, M, alpha=1.0, beta=1.0)
+        res = ctx.l2norm(Res, 0, nev, M)
+        # pairs whose eigenvalue sits at the fp64 noise floor of G (theta_i < 1e-13 theta_0) cannot be
+        # resolved from the Gram matrix at all (pod_modes deflates and retries for those)
+        resolvable = theta[:nev] > 1e-13 * abs(theta[0])
+        worst = float(res[resolvable].max()) / max(abs(theta[0]), 1e-300) if resolvable.any() else 0.0
+        _top_eigenpairs_device.last_iterations = it + 1
+        if worst < 0.7 * best:
+            best, stall = worst, 0
+        else:
+            stall += 1
+        if worst <= tol or stall >= 3 or it == max_iter - 1:
+            return theta[:nev], DeviceArray(Yr, nev, M)
+        # next basis: the rotated power step G y_i / theta_i for the resolvable pairs (nearly orthonormal
+        # rows), the Ritz vector y_i itself where theta_i sits at the noise floor; then CholeskyQR2
+        ok = theta > 1e-13 * abs(theta[0])
+        Zs = ctx.alloc(b * M)
+        ctx.gemm_nn(b, M, b, ctx.upload(np.diag(np.where(ok, 1.0 / np.where(ok, theta, 1.0), 0.0))), 0, b, Zr, 0, M,
+                    Zs, 0, M)
+        ctx.gemm_nn(b, M, b, ctx.upload(np.diag(np.where(ok, 0.0, 1.0))), 0, b, Yr, 0, M, Zs, 0, M, alpha=1.0, beta=1.0)
+        try:
+            Y = _cholqr2_device(ctx, DeviceArray(Zs, b, M))
+        except np.linalg.LinAlgError:                                # rank-deficient noise directions
+            Y = _orthonormalize_device(ctx, DeviceArray(Zs, b, M))
+    raise AssertionError("unreachable")
+
+
 def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=2):
     """Leading ``n`` right singular vectors / singular values of the (M, dim) snapshot block.
 
-    MFMA Gram matrix ``G = Xc Xc^T`` -> symmetric eigenproblem of the small M x M matrix -> lift
-    ``V = S^-1 W^T Xc``.  The Gram matrix squares the condition number (modes below ~1e-8 sigma_1
-    drown in fp64 roundoff), so the modes found are deflated from the block and the procedure is
-    repeated on the remainder (``passes`` times), each pass resolving ~7 more orders of magnitude.
-    Rows follow scikit-learn's ``svd_flip(u_based_decision=False)`` sign convention (the PCA call at
+    MFMA Gram matrix ``G = Xc Xc^T`` (lower tiles + mirror) -> leading eigenpairs of the M x M
+    matrix by subspace iteration on the device -> lift ``V = S^-1 W^T Xc``.  The Gram matrix squares
+    the condition number (modes below ~1e-8 sigma_1 drown in fp64 roundoff), so the modes found are
+    deflated from the block and the procedure is repeated on the remainder (``passes`` times), each
+    pass resolving ~7 more orders of magnitude.  Rows follow scikit-learn's
+    ``svd_flip(u_based_decision=False)`` sign convention (the PCA call at
     src/lib/ReducedBasis.py:196).  X is overwritten (centred / deflated).
     """
     M, dim = X.rows, X.dim
@@ -244,26 +320,27 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=2):
         if found >= n:
             break
         G = ctx.alloc(M * M)
-        ctx.gemm_nt(M, M, dim, X.buf, 0, dim, X.buf, 0, dim, G, 0, M)
-        Gh = G.download(M * M, shape=(M, M))
-        Gh = 0.5 * (Gh + Gh.T)
-        lam, W = np.linalg.eigh(Gh)  # small M x M host eigenproblem
-        lam, W = lam[::-1], W[:, ::-1]
+        ctx.gram(M, dim, X.buf, 0, dim, G, 0, M)
+        lam, W = _top_eigenpairs_device(ctx, G, M, n - found)
         lam = np.maximum(lam, 0.0)
         # modes of this pass: those well above the Gram roundoff floor of the current block
         floor = lam[0] * 1e-13 if lam[0] > 0 else 0.0
         last_pass = p == passes - 1
         take = 0
-        while found + take < n and take < M and (lam[take] > floor or last_pass):
+        while found + take < n and take < len(lam) and (lam[take] > floor or last_pass):
             take += 1
         if take == 0:
             break
         s = np.sqrt(lam[:take])
         sig[found:found + take] = s
-        Wt = np.ascontiguousarray((W[:, :take] / np.where(s > 0, s, 1.0)).T)  # (take, M)
-        ctx.gemm_nn(take, dim, M, ctx.upload(Wt), 0, M, X.buf, 0, dim, V, found * dim, dim)
+        for i in range(take):
+            W.buf.scale(1.0 / s[i] if s[i] > 0 else 0.0, offset=i * M, n=M)
+        ctx.gemm_nn(take, dim, M, W.buf, 0, M, X.buf, 0, dim, V, found * dim, dim)   # V = S^-1 W^T Xc
         # re-orthonormalise the new modes against all earlier ones (keeps V orthonormal to ~eps)
-        Vall = _orthonormalize_device(ctx, DeviceArray(V, found + take, dim))
+        try:
+            Vall = _cholqr2_device(ctx, DeviceArray(V, found + take, dim))
+        except np.linalg.LinAlgError:
+            Vall = _orthonormalize_device(ctx, DeviceArray(V, found + take, dim))
         V.copy_from(Vall.buf, (found + take) * dim)
         found += take
         if found < n and not last_pass:

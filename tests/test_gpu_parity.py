@@ -177,6 +177,28 @@ def test_g7_pca_random(api):
         assert np.array_equal(rr.basis, z[f"rnd_basis_{flag}"]) and np.array_equal(np.array(rr.a), z[f"rnd_a_{flag}"])
 
 
+def test_pod_subspace_iteration_vs_oracle(api):
+    """POD with M > n + oversampling, so that the device subspace iteration (not the one-step full-space
+    Ritz solve) produces the modes; compared with the oracle's LAPACK SVD."""
+    SM, RB = api
+    sm = SolutionsManagerFEM_cached(SM, (2, 2), 8)
+    M, n = 96, 6
+    a = 10.0 ** np.random.default_rng(11).uniform(0, 2, size=(M, 2, 2))
+    U = sm.generate_solutions(a)
+    rb = RB.ReducedBasisPCA(add_inf_solutions=False).build(n=n, sm=sm, solutions2train=U, a2train=a)
+    comps, sigma = ro.pca_components(U, n)
+    np.testing.assert_allclose(rb.singular_values_, sigma, rtol=1e-9)
+    np.testing.assert_allclose(rb.basis, comps, atol=1e-8)   # sigma_6 / sigma_1 ~ 1e-4: gaps are small
+    np.testing.assert_allclose(rb.basis @ rb.basis.T, np.eye(n), atol=1e-13)
+    # subspace (projector) agreement, the sign- and rotation-free statement
+    P1, P2 = rb.basis.T @ rb.basis, comps.T @ comps
+    assert np.abs(P1 - P2).max() < 1e-9
+
+
+def SolutionsManagerFEM_cached(SM, blocks, N):
+    return SM.SolutionsManagerFEM(blocks, N)
+
+
 def test_g9_n32(api):
     SM, _ = api
     z = load_golden("g9_n32.npz")
