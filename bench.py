@@ -159,6 +159,18 @@ def main():
                 "peak_measured_sustained": 47.1,
                 "note": "fp64 MFMA (v_mfma_f64_16x16x4_f64); peak = spec fp64 matrix rate; a bare MFMA loop "
                         "sustains 47.1 TFLOP/s on this part (tools/mfma_f64_peak.hip)"}
+    # PMC-measured memory-side traffic of the dominant kernel, if a summary of separate
+    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command is committed
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    kname = {"factor_panel": "k_factor_panel", "diag_update": "k_diag_update", "extend": "k_extend",
+             "diag_potrf": "k_diag_potrf", "diag_inverse": "k_diag_inverse", "backsolve": "k_backsolve"}.get(dom)
+    if os.path.exists(pmc_path) and (blocks, N, M) == ((2, 2), 128, 1024):
+        pmc = json.load(open(pmc_path))["kernels"].get(kname)
+        if pmc:
+            roofline["traffic"] = pmc["traffic_bytes_per_launch"]
+            roofline["traffic_note"] = ("bytes per launch from profiles/r01_pmc_traffic.json: rocprofv3 --pmc "
+                                        "FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes; includes "
+                                        "Infinity-Cache hits")
     out = {
         "metric": "snapshot_solves_per_sec", "value": round(value, 1), "unit": "solves/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
