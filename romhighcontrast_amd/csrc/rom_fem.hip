@@ -31,8 +31,12 @@
 // device-side view of a rom_fem
 // ============================================================================================
 struct FemDev {
-  int nrb, ncb, N, n1, n1p, nr, nc, nGp, T, nslots, kblk;
+  int nrb, ncb, N, n1, n1p, nr, nc, nGp, nGa, T, nslots, kblk, npre, nrhs;
   long long dim;
+  const double* R;
+  const double* vec;
+  const RhsTerm* rhs;
+  const PreEdge* pre;
   const double* H0;
   const double* Tm;
   const double* W;
@@ -55,7 +59,8 @@ struct FemDev {
 static FemDev make_dev(const rom_fem* f) {
   FemDev d;
   d.nrb = f->nrb; d.ncb = f->ncb; d.N = f->N; d.n1 = f->n1; d.n1p = f->n1p; d.nr = f->nr; d.nc = f->nc;
-  d.nGp = f->nGp; d.T = f->T; d.nslots = f->nslots; d.kblk = f->nrb * f->ncb; d.dim = f->dim;
+  d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.R = f->d_R; d.vec = f->d_vec;
+  d.rhs = f->d_rhs; d.pre = f->d_pre; d.T = f->T; d.nslots = f->nslots; d.kblk = f->nrb * f->ncb; d.dim = f->dim;
   d.H0 = f->d_H0; d.Tm = f->d_Tm; d.W = f->d_W; d.g = f->d_g; d.desc = f->d_desc; d.extra = f->d_extra;
   d.kptr = f->d_kptr; d.kpair = f->d_kpair; d.colptr = f->d_colptr; d.colrow = f->d_colrow;
   d.colti = f->d_colti; d.sides = f->d_sides; d.vmap = f->d_vmap; d.L = f->d_L; d.invL = f->d_invL;
@@ -114,9 +119,18 @@ __global__ void k_build_Tm(double* Tm, const double* H0, int n1, int n1p, int N)
 // ============================================================================================
 // interface tile assembly  (A_GG(a) - sum_b a_b T_b, one entry)
 // ============================================================================================
-__device__ inline double s_entry(const TileDesc& d, const double* __restrict__ Tm, int n1p,
-                                 const double* __restrict__ am, int r, int c) {
+__device__ inline double s_entry(const TileDesc& d, const double* __restrict__ Tm, const double* __restrict__ R,
+                                 int n1p, const double* __restrict__ am, int r, int c) {
   double v = 0.0;
+  if (r < d.ndr && c < d.ndc) {
+    for (int t = 0; t < d.npre; ++t) {
+      const PreTerm& pt = d.pre[t];
+      const double se = am[pt.e0] + am[pt.e1];
+      const double cr = r < d.nvr ? (pt.brow >= 0 ? am[pt.brow] : 0.0) : se / 2;
+      const double cc = c < d.nvc ? (pt.bcol >= 0 ? am[pt.bcol] : 0.0) : se / 2;
+      v -= cr * cc / se * R[(size_t(pt.table) * n1p + (pt.r0 + r)) * n1p + (pt.c0 + c)];
+    }
+  }
   if (r < d.nvr && c < d.nvc) {
     for (int t = 0; t < d.nterms; ++t) {
       const TileTerm& tt = d.term[t];
@@ -150,7 +164,7 @@ __device__ inline void s_tile_load(STile& st, const TileDesc& d, const FemDev& f
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) st.v[i][j][g] = s_entry(d, f.Tm, f.n1p, am, acc_row(wp, i, g), acc_col(wp, j));
+      for (int g = 0; g < 4; ++g) st.v[i][j][g] = s_entry(d, f.Tm, f.R, f.n1p, am, acc_row(wp, i, g), acc_col(wp, j));
 }
 
 // C(LDS tile) = S_tile - acc ; then the sparse cross-point extras
@@ -202,6 +216,82 @@ __global__ void k_init_rhs(FemDev f, int Mc) {
   size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
   if (idx >= size_t(Mc) * f.nGp) return;
   f.y[idx] = f.g[idx % f.nGp];
+}
+
+// rhs of the condensed system: g_f + sum_e diag(c_f) X_fe K^-1 g_e / s_e   (grid: 64 threads x (tile rows, Mc))
+__global__ void k_rhs_pre(FemDev f, const double* __restrict__ a, int ntile_rows) {
+  const int m = blockIdx.y, tile = blockIdx.x, r = threadIdx.x;
+  const double* am = a + size_t(m) * f.kblk;
+  double acc = 0.0;
+  for (int t = 0; t < f.nrhs; ++t) {
+    const RhsTerm& rt = f.rhs[t];
+    if (rt.tile != tile || r >= rt.ndr) continue;
+    const double se = am[rt.e0] + am[rt.e1];
+    const double cr = r < rt.nvr ? (rt.brow >= 0 ? am[rt.brow] : 0.0) : se / 2;
+    acc += cr / se * f.vec[rt.qoff + rt.lr0 + r];
+  }
+  f.y[size_t(m) * f.nGp + tile * 64 + r] += acc;
+}
+
+// Back substitution of the pre-eliminated edges: x_e = (w_e + sum_f B_fe (c_f . x_f)) / s_e as one batched
+// MFMA GEMM: tile rows = systems, tile cols = nodes of e, K = positions on the neighbours.
+// grid (n1p/64, ceil(Mc/64), npre)
+__global__ __launch_bounds__(256) void k_back_pre(FemDev f, const double* __restrict__ a, int Mc) {
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  const WavePos wp;
+  const PreEdge& pe = f.pre[blockIdx.z];
+  const int srow = stage_row(), sseg = stage_seg();
+  const int mA = blockIdx.y * 64 + srow;
+  const int iB = blockIdx.x * 64 + srow;  // node of e handled by this thread's B row
+  const double* am = mA < Mc ? a + size_t(mA) * f.kblk : nullptr;
+  const double seA = am ? am[pe.e0] + am[pe.e1] : 0.0;
+  Acc acc;
+  acc_zero(acc);
+  const int cps = f.n1p / BK;
+  for (int q = 0; q < pe.nnb; ++q) {
+    const PreNb nb = pe.nb[q];
+    const double* pA = am ? f.y + size_t(mA) * f.nGp + nb.fpos + sseg : nullptr;
+    const double* pB = f.R + (size_t(nb.bt) * f.n1p + iB) * f.n1p + sseg;
+    const double cedge = (am && nb.blk >= 0) ? am[nb.blk] : 0.0;
+    gemm_loop(
+        cps,
+        [&](int ch, double* v) {
+          load4_aligned(pA ? pA + ch * BK : nullptr, v);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const int k = ch * BK + sseg + x;
+            v[x] *= k < f.n1 ? cedge : (k < f.n1 + nb.nused ? seA / 2 : 0.0);
+          }
+        },
+        [&](int ch, double* v) { load4_aligned(pB + ch * BK, v); }, acc, lds, wp);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m = blockIdx.y * 64 + acc_row(wp, i, g);
+      if (m >= Mc) continue;
+      const double* amr = a + size_t(m) * f.kblk;
+      const double inv = 1.0 / (amr[pe.e0] + amr[pe.e1]);
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const int node = blockIdx.x * 64 + acc_col(wp, jb);
+        f.y[size_t(m) * f.nGp + pe.pos + node] = node < f.n1 ? (f.vec[pe.woff + node] + acc.c[i][jb][g]) * inv : 0.0;
+      }
+    }
+}
+
+// X_fe (n1p x n1p): rows = positions on the active edge f (edge nodes, then cross slots), cols = nodes of e
+__global__ void k_build_X(double* X, const double* Tm, int n1, int n1p, int tmat, int nx, const int* xrow,
+                          const int* xcol) {
+  size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  if (idx >= size_t(n1p) * n1p) return;
+  int r = int(idx / n1p), c = int(idx % n1p);
+  double v = 0.0;
+  if (tmat >= 0 && r < n1 && c < n1) v = Tm[(size_t(tmat) * n1p + r) * n1p + c];
+  for (int x = 0; x < nx; ++x)
+    if (r == xrow[x] && c == xcol[x]) v = 1.0;
+  X[idx] = v;
 }
 
 // Diagonal tile j, step 1 of 3 (MFMA): C = S_jj - sum_k L_jk L_jk^T, written to the tile's L slot.
@@ -397,7 +487,7 @@ __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __
 // x = L^{-T} y, one workgroup per system, x kept in LDS, written back over y
 __global__ __launch_bounds__(256) void k_backsolve(FemDev f, const int* __restrict__ slot_of,
                                                    const int* __restrict__ diag_slot_unused) {
-  extern __shared__ __align__(16) double xs[];  // nGp
+  extern __shared__ __align__(16) double xs[];  // nGa
   __shared__ double red[4][64];
   __shared__ double vs[64];
   const int m = blockIdx.x;
@@ -425,7 +515,7 @@ __global__ __launch_bounds__(256) void k_backsolve(FemDev f, const int* __restri
     if (t < 64) xs[j * 64 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
     __syncthreads();
   }
-  for (int v = t; v < f.nGp; v += 256) ym[v] = xs[v];
+  for (int v = t; v < f.nGa; v += 256) ym[v] = xs[v];
 }
 
 // ============================================================================================
@@ -536,7 +626,8 @@ extern "C" int rom_fem_destroy(rom_fem* f) {
   if (!f) return ROM_OK;
   hipStreamSynchronize(f->ctx->stream);
   void* ptrs[] = {f->d_H0, f->d_Tm, f->d_W, f->d_g, f->d_desc, f->d_extra, f->d_slot_of, f->d_kptr, f->d_kpair,
-                  f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L, f->d_invL, f->d_y};
+                  f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L, f->d_invL, f->d_y, f->d_R, f->d_vec,
+                  f->d_rhs, f->d_pre};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete f;
@@ -598,37 +689,6 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     return -1;
   };
 
-  // ---- elimination order of the edges: greedy minimum degree on the edge graph ------------------
-  std::vector<std::set<int>> adj(E);
-  for (auto& s : bside)
-    for (int x = 0; x < 4; ++x)
-      for (int y = 0; y < 4; ++y)
-        if (x != y && s[x] >= 0 && s[y] >= 0) adj[s[x]].insert(s[y]);
-  // edges meeting at a cross point become coupled once the cross is ordered last: no extra edges now
-  std::vector<int> order;
-  {
-    std::vector<std::set<int>> g = adj;
-    std::vector<char> done(E, 0);
-    for (int step = 0; step < E; ++step) {
-      int best = -1;
-      size_t bd = 0;
-      for (int e = 0; e < E; ++e) {
-        if (done[e]) continue;
-        if (best < 0 || g[e].size() < bd) { best = e; bd = g[e].size(); }
-      }
-      done[best] = 1;
-      order.push_back(best);
-      std::vector<int> nb(g[best].begin(), g[best].end());
-      for (int x : nb) {
-        g[x].erase(best);
-        for (int y : nb)
-          if (x != y) g[x].insert(y);
-      }
-    }
-  }
-  std::vector<int> tile0(E), epos(E);
-  for (int pos = 0; pos < E; ++pos) { tile0[order[pos]] = pos * tpe; epos[order[pos]] = pos; }
-
   // ---- cross <-> edge-end couplings ----------------------------------------------------------------
   struct XCpl { int cross, edge, node; };  // node: 0-based local node on the edge
   std::vector<XCpl> xc;
@@ -642,50 +702,161 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       if (ed.p + 1 < nrb) xc.push_back({xid[{ed.p + 1, ed.q}], e, n1 - 1});
     }
   }
-
-  // ---- placement of the cross points: into the padding slots behind an adjacent edge (the one
-  //      eliminated last), so that they do not cost tiles of their own; overflow goes to extra
-  //      tiles at the end of the ordering ------------------------------------------------------------
+  // block adjacency of the edges
+  std::vector<std::set<int>> adj(E);
+  for (auto& s : bside)
+    for (int x = 0; x < 4; ++x)
+      for (int y = 0; y < 4; ++y)
+        if (x != y && s[x] >= 0 && s[y] >= 0) adj[s[x]].insert(s[y]);
+  auto shared_block = [&](int e1, int e2) {  // the one block two distinct edges can share, or -1
+    for (int b1 : {edges[e1].b0, edges[e1].b1})
+      for (int b2 : {edges[e2].b0, edges[e2].b1})
+        if (b1 == b2) return b1;
+    return -1;
+  };
   const int free_per_edge = n1p - n1;
-  std::vector<int> used(E, 0), xpos(ncross, -1), overflow;
-  for (int x = 0; x < ncross; ++x) {
-    int best = -1;
-    for (auto& c : xc)
-      if (c.cross == x && used[c.edge] < free_per_edge && (best < 0 || epos[c.edge] > epos[best])) best = c.edge;
-    if (best >= 0) xpos[x] = tile0[best] * TB + n1 + used[best]++;
-    else overflow.push_back(x);
+
+  // Everything below depends on which edges are eliminated in closed form (`pre`); if the cross points
+  // cannot all be hosted in padding slots of active edges the set is dropped and the layout redone.
+  std::vector<char> is_pre(E, 0);
+  if (free_per_edge >= 1 && !getenv("ROMHC_NO_PREELIM")) {
+    // maximal set of edges no two of which touch the same block (greedy): their self-interaction is
+    // (a_b0 + a_b1) K with K parameter independent and they do not couple to each other
+    std::vector<char> busy(nrb * ncb, 0);
+    for (int e = 0; e < E; ++e)
+      if (!busy[edges[e].b0] && !busy[edges[e].b1]) { is_pre[e] = 1; busy[edges[e].b0] = busy[edges[e].b1] = 1; }
   }
-  const int xt0 = E * tpe;                                   // first overflow tile
-  const int nxt = (int(overflow.size()) + TB - 1) / TB;      // overflow tiles
+  std::vector<int> order, tile0, epos, used, xpos, overflow, pre_list, ppos;
+  int nact = 0, xt0 = 0, nxt = 0, T = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    pre_list.clear();
+    for (int e = 0; e < E; ++e)
+      if (is_pre[e]) pre_list.push_back(e);
+    // ordering graph of the active edges: shared block, or common neighbour of an eliminated edge
+    std::vector<std::set<int>> g(E);
+    for (int e = 0; e < E; ++e)
+      if (!is_pre[e])
+        for (int x : adj[e])
+          if (!is_pre[x]) g[e].insert(x);
+    for (int e : pre_list)
+      for (int x : adj[e])
+        for (int y : adj[e])
+          if (x != y && !is_pre[x] && !is_pre[y]) g[x].insert(y);
+    order.clear();
+    std::vector<char> done(E, 0);
+    nact = E - int(pre_list.size());
+    for (int step = 0; step < nact; ++step) {  // greedy minimum degree
+      int best = -1;
+      size_t bd = 0;
+      for (int e = 0; e < E; ++e) {
+        if (done[e] || is_pre[e]) continue;
+        if (best < 0 || g[e].size() < bd) { best = e; bd = g[e].size(); }
+      }
+      done[best] = 1;
+      order.push_back(best);
+      std::vector<int> nb(g[best].begin(), g[best].end());
+      for (int x : nb) {
+        g[x].erase(best);
+        for (int y : nb)
+          if (x != y) g[x].insert(y);
+      }
+    }
+    tile0.assign(E, -1);
+    epos.assign(E, -1);
+    for (int pos = 0; pos < nact; ++pos) { tile0[order[pos]] = pos * tpe; epos[order[pos]] = pos; }
+    // cross points go into the padding slots behind an adjacent active edge (the one eliminated last)
+    used.assign(E, 0);
+    xpos.assign(ncross, -1);
+    overflow.clear();
+    for (int x = 0; x < ncross; ++x) {
+      int best = -1;
+      for (auto& c : xc)
+        if (c.cross == x && !is_pre[c.edge] && used[c.edge] < free_per_edge &&
+            (best < 0 || epos[c.edge] > epos[best]))
+          best = c.edge;
+      if (best >= 0) xpos[x] = tile0[best] * TB + n1 + used[best]++;
+      else overflow.push_back(x);
+    }
+    if (!overflow.empty() && !pre_list.empty()) {  // keep the closed-form elimination simple: no overflow tiles
+      std::fill(is_pre.begin(), is_pre.end(), 0);
+      continue;
+    }
+    break;
+  }
+  xt0 = nact * tpe;                                    // first overflow tile
+  nxt = (int(overflow.size()) + TB - 1) / TB;          // overflow tiles
   for (size_t o = 0; o < overflow.size(); ++o) xpos[overflow[o]] = xt0 * TB + int(o);
-  const int T = xt0 + nxt;
+  T = xt0 + nxt;
+  const int npre = int(pre_list.size());
   f->T = T;
-  f->nGp = T * TB;
+  f->nGa = T * TB;
+  f->npre = npre;
+  f->nGp = f->nGa + npre * n1p;
+  ppos.assign(E, -1);  // position of an edge's n1p block in the interface vectors
+  for (int e = 0; e < E; ++e)
+    if (!is_pre[e]) ppos[e] = tile0[e] * TB;
+  for (int i = 0; i < npre; ++i) ppos[pre_list[i]] = f->nGa + i * n1p;
   // tile -> (edge id or -1 for an overflow tile, local tile index, number of defined rows)
   std::vector<int> tile_edge(T, -1), tile_loc(T, 0), tile_ndr(T, 0);
-  for (int e = 0; e < E; ++e)
+  for (int e = 0; e < E; ++e) {
+    if (is_pre[e]) continue;
     for (int x = 0; x < tpe; ++x) {
       tile_edge[tile0[e] + x] = e;
       tile_loc[tile0[e] + x] = x;
       tile_ndr[tile0[e] + x] = std::max(0, std::min(TB, n1 + used[e] - x * TB));
     }
+  }
   for (int x = 0; x < nxt; ++x) {
     tile_loc[xt0 + x] = x;
     tile_ndr[xt0 + x] = std::min(TB, int(overflow.size()) - x * TB);
   }
+
+  // ---- neighbours of every eliminated edge: active edges sharing a block, or hosting a cross point
+  //      that touches one of its ends -------------------------------------------------------------------
+  struct Nb { int f; int blk; std::vector<std::pair<int, int>> xs; };  // xs: (row on f, end node on e)
+  std::vector<std::vector<Nb>> nbs(npre);
+  for (int i = 0; i < npre; ++i) {
+    const int e = pre_list[i];
+    std::map<int, Nb> m;
+    for (int x : adj[e])
+      if (!is_pre[x]) m[x] = Nb{x, shared_block(e, x), {}};
+    for (auto& c : xc) {
+      if (c.edge != e) continue;
+      const int host = tile_edge[xpos[c.cross] / TB];
+      if (!m.count(host)) m[host] = Nb{host, -1, {}};
+      m[host].xs.push_back({xpos[c.cross] - tile0[host] * TB, c.node});
+    }
+    for (auto& kv : m) nbs[i].push_back(kv.second);
+    if (nbs[i].size() > 8) { rom_set_error("internal: more than 8 neighbours of an eliminated edge"); return ROM_ERR_INVALID; }
+  }
+  auto nb_tiles = [&](const Nb& nb) {  // tiles of the neighbour that actually couple to e
+    std::set<int> t;
+    if (nb.blk >= 0)
+      for (int x = 0; x < tpe; ++x) t.insert(tile0[nb.f] + x);
+    for (auto& xr : nb.xs) t.insert(tile0[nb.f] + xr.first / TB);
+    return t;
+  };
 
   // ---- tile mask + symbolic fill --------------------------------------------------------------------
   std::vector<char> mask(size_t(T) * T, 0);
   auto M_ = [&](int i, int j) -> char& { return mask[size_t(i) * T + j]; };
   for (int e = 0; e < E; ++e)
     for (int e2 = 0; e2 < E; ++e2)
-      if (e == e2 || adj[e].count(e2))
+      if (!is_pre[e] && !is_pre[e2] && (e == e2 || adj[e].count(e2)))
         for (int x = 0; x < tpe; ++x)
           for (int y = 0; y < tpe; ++y) M_(tile0[e] + x, tile0[e2] + y) = 1;
   for (int x = 0; x < ncross; ++x) M_(xpos[x] / TB, xpos[x] / TB) = 1;
   for (auto& c : xc) {
+    if (is_pre[c.edge]) continue;
     int ti = xpos[c.cross] / TB, tj = tile0[c.edge] + c.node / TB;
     M_(ti, tj) = M_(tj, ti) = 1;
+  }
+  for (int i = 0; i < npre; ++i) {  // fill created by the closed-form elimination
+    std::set<int> ts;
+    for (auto& nb : nbs[i])
+      for (int t : nb_tiles(nb)) ts.insert(t);
+    for (int x : ts)
+      for (int y : ts) M_(x, y) = 1;
   }
   for (int k = 0; k < T; ++k)
     for (int i = k + 1; i < T; ++i)
@@ -725,6 +896,15 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     flops += (i == j) ? TB * double(TB) * TB / 3.0 : 2.0 * TB * TB * TB;  // potrf | trsm-as-gemm
   }
 
+  // ---- tables of the eliminated edges: which R = X_f K^-1 X_f'^T are needed -----------------------------
+  // table ids: R tables first (one per (pre edge, f, f') actually used by a tile), then the B^T tables
+  std::map<std::array<int, 3>, int> rid;  // (pre index, f, f') -> table id
+  auto nb_index = [&](int i, int fedge) {
+    for (size_t q = 0; q < nbs[i].size(); ++q)
+      if (nbs[i][q].f == fedge) return int(q);
+    return -1;
+  };
+
   // ---- tile descriptors + extras ------------------------------------------------------------------------
   std::vector<TileExtra> extras;
   f->desc.resize(f->nslots);
@@ -740,6 +920,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     d.nvr = er >= 0 ? std::max(0, std::min(TB, n1 - d.lr0)) : 0;  // edge nodes in the tile rows / cols
     d.nvc = ec >= 0 ? std::max(0, std::min(TB, n1 - d.lc0)) : 0;
     d.ndr = tile_ndr[d.ti];                                        // + cross slots: rows that are unknowns
+    d.ndc = tile_ndr[d.tj];
     if (er >= 0 && ec >= 0) {
       // blocks adjacent to both edges
       int cand[2] = {edges[er].b0, edges[er].b1};
@@ -756,6 +937,17 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         d.b0 = edges[er].b0;
         d.b1 = edges[er].b1;
       }
+      // closed-form contributions of the eliminated edges that see both er and ec
+      for (int i = 0; i < npre; ++i) {
+        int qr = nb_index(i, er), qc = nb_index(i, ec);
+        if (qr < 0 || qc < 0) continue;
+        if (!nb_tiles(nbs[i][qr]).count(d.ti) || !nb_tiles(nbs[i][qc]).count(d.tj)) continue;
+        std::array<int, 3> key{i, er, ec};
+        if (!rid.count(key)) { int id = int(rid.size()); rid[key] = id; }
+        if (d.npre >= 4) { rom_set_error("internal: more than 4 pre-elimination terms per tile"); return ROM_ERR_INVALID; }
+        const Edge& pe = edges[pre_list[i]];
+        d.pre[d.npre++] = PreTerm{rid[key], d.lr0, d.lc0, nbs[i][qr].blk, nbs[i][qc].blk, pe.b0, pe.b1};
+      }
     }
     d.x0 = int(extras.size());
     // entries that involve cross points (placed by interface position)
@@ -766,6 +958,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       }
     }
     for (auto& c : xc) {
+      if (is_pre[c.edge]) continue;  // folded into the R tables
       int pa = xpos[c.cross], pb = tile0[c.edge] * TB + c.node;
       // coupling value uses the two blocks of the edge: -(k[r,c] + k[r-1,c])/2 resp. -(k[r,c]+k[r,c-1])/2
       const int ta = pa / TB, tb = pb / TB;
@@ -783,10 +976,10 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     f->desc[s] = d;
   }
 
-  // ---- block sides, vmap, interface rhs ---------------------------------------------------------------
+  // ---- block sides, vmap ------------------------------------------------------------------------------------
   f->sides.resize(nrb * ncb);
   for (int b = 0; b < nrb * ncb; ++b)
-    for (int s = 0; s < 4; ++s) f->sides[b].off[s] = bside[b][s] >= 0 ? tile0[bside[b][s]] * TB : -1;
+    for (int s = 0; s < 4; ++s) f->sides[b].off[s] = bside[b][s] >= 0 ? ppos[bside[b][s]] : -1;
   std::vector<int> vmap(std::max(f->nGp, 1), -1);
   for (int e = 0; e < E; ++e) {
     const Edge& ed = edges[e];
@@ -794,7 +987,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       int r, c;  // 1-based inner vertex coordinates
       if (ed.hv == 0) { r = ed.p * N; c = ed.q * N + t + 1; }
       else { r = ed.p * N + t + 1; c = ed.q * N; }
-      vmap[tile0[e] * TB + t] = (r - 1) * f->nc + (c - 1);
+      vmap[ppos[e] + t] = (r - 1) * f->nc + (c - 1);
     }
   }
   for (int x = 0; x < ncross; ++x) {
@@ -845,7 +1038,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     const Edge& ed = edges[e];
     for (int t = 1; t <= n1; ++t) {
       double w = ed.hv == 0 ? Wat(N - 1, t) + Wat(1, t) : Wat(t, N - 1) + Wat(t, 1);
-      f->g_host[tile0[e] * TB + t - 1] = h2 * (1.0 + w);
+      f->g_host[ppos[e] + t - 1] = h2 * (1.0 + w);
     }
   }
   for (int x = 0; x < ncross; ++x) f->g_host[xpos[x]] = h2;
@@ -872,11 +1065,115 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     ROM_HIP(hipGetLastError());
     ROM_HIP(hipStreamSynchronize(ctx->stream));
   }
-  hipFree(d_Qp);
   hipFree(d_rho);
   hipFree(d_A0);
   ROM_TRY(upload(&f->d_W, W));
   ROM_TRY(upload(&f->d_g, f->g_host));
+
+  // ---- closed-form elimination tables ------------------------------------------------------------------------
+  // K = tridiag(-1/2, 2, -1/2) - T_same = Q diag(1 + lam_m/2 - rho_m(1)) Q   =>   K^-1 = Q diag(1/kappa_m) Q
+  std::vector<RhsTerm> rhs_terms;
+  std::vector<PreEdge> pre_edges(npre);
+  double pre_flops = 0;
+  if (npre > 0) {
+    std::vector<double> Kinv(size_t(n1p) * n1p, 0.0);
+    {
+      std::vector<ld> QD(size_t(n1) * n1);
+      for (int j = 0; j < n1; ++j)
+        for (int m = 0; m < n1; ++m) {
+          ld kappa = 1.0L + lam[m] / 2.0L - (ld)rho[size_t(m) * (N + 1) + 1];
+          QD[size_t(j) * n1 + m] = Q[size_t(j) * n1 + m] / kappa;
+        }
+      for (int i = 0; i < n1; ++i)
+        for (int j = 0; j <= i; ++j) {
+          ld sacc = 0;
+          for (int m = 0; m < n1; ++m) sacc += QD[size_t(i) * n1 + m] * Q[size_t(j) * n1 + m];
+          Kinv[size_t(i) * n1p + j] = Kinv[size_t(j) * n1p + i] = double(sacc);
+        }
+    }
+    double* d_Kinv = nullptr;
+    ROM_TRY(upload(&d_Kinv, Kinv));
+    const size_t tsz = size_t(n1p) * n1p;
+    // per (pre edge, neighbour): X_fe, B_fe = X_fe K^-1 ; tables kept: B^T (back substitution), R (tiles)
+    int nbt = 0;
+    for (int i = 0; i < npre; ++i) nbt += int(nbs[i].size());
+    const int nR = int(rid.size());
+    ROM_HIP(hipMalloc(&f->d_R, std::max<size_t>(size_t(nR + nbt) * tsz, 1) * sizeof(double)));
+    int nvec = 0;
+    for (int i = 0; i < npre; ++i) nvec += 1 + int(nbs[i].size());
+    ROM_HIP(hipMalloc(&f->d_vec, std::max<size_t>(size_t(nvec) * n1p, 1) * sizeof(double)));
+    ROM_HIP(hipMemsetAsync(f->d_vec, 0, size_t(nvec) * n1p * sizeof(double), ctx->stream));
+    double *d_X = nullptr, *d_B = nullptr;
+    int maxnb = 0;
+    for (int i = 0; i < npre; ++i) maxnb = std::max(maxnb, int(nbs[i].size()));
+    ROM_HIP(hipMalloc(&d_X, size_t(maxnb) * tsz * sizeof(double)));
+    ROM_HIP(hipMalloc(&d_B, size_t(maxnb) * tsz * sizeof(double)));
+    int* d_xrc = nullptr;
+    ROM_HIP(hipMalloc(&d_xrc, 64 * sizeof(int)));
+    int bt_next = nR, vec_next = 0;
+    for (int i = 0; i < npre; ++i) {
+      const int e = pre_list[i];
+      const Edge& pe = edges[e];
+      PreEdge& P = pre_edges[i];
+      memset(&P, 0, sizeof(P));
+      P.pos = ppos[e];
+      P.e0 = pe.b0;
+      P.e1 = pe.b1;
+      P.nnb = int(nbs[i].size());
+      // w_e = K^-1 g_e
+      P.woff = (vec_next++) * n1p;
+      ROM_TRY(rom_launch_gemm_nt(ctx, n1p, 1, n1p, 1.0, d_Kinv, n1p, f->d_g + ppos[e], n1p, 0.0, f->d_vec + P.woff, 1,
+                                 "setup_gemm"));
+      for (int q = 0; q < P.nnb; ++q) {
+        const Nb& nb = nbs[i][q];
+        int tmat = -1;
+        if (nb.blk >= 0) tmat = side_of(nb.blk, nb.f) * 4 + side_of(nb.blk, e);
+        std::vector<int> xrc;
+        for (auto& xr : nb.xs) xrc.push_back(xr.first);
+        for (auto& xr : nb.xs) xrc.push_back(xr.second);
+        if (xrc.size() > 64) { rom_set_error("internal: too many cross points on one edge"); return ROM_ERR_INVALID; }
+        if (!xrc.empty()) ROM_HIP(hipMemcpy(d_xrc, xrc.data(), xrc.size() * sizeof(int), hipMemcpyHostToDevice));
+        double* Xq = d_X + size_t(q) * tsz;
+        double* Bq = d_B + size_t(q) * tsz;
+        k_build_X<<<unsigned((tsz + 255) / 256), 256, 0, ctx->stream>>>(Xq, f->d_Tm, n1, n1p, tmat, int(nb.xs.size()),
+                                                                      d_xrc, d_xrc + nb.xs.size());
+        ROM_HIP(hipGetLastError());
+        ROM_HIP(hipStreamSynchronize(ctx->stream));  // d_xrc is reused
+        // B_fe = X_fe K^-1 (K^-1 symmetric)
+        ROM_TRY(rom_launch_gemm_nt(ctx, n1p, n1p, n1p, 1.0, Xq, n1p, d_Kinv, n1p, 0.0, Bq, n1p, "setup_gemm"));
+        // B^T table for the back substitution: (K^-1 X_fe^T)[node of e][position on f]
+        const int bt = bt_next++;
+        ROM_TRY(rom_launch_gemm_nt(ctx, n1p, n1p, n1p, 1.0, d_Kinv, n1p, Xq, n1p, 0.0, f->d_R + size_t(bt) * tsz, n1p,
+                                   "setup_gemm"));
+        P.nb[q] = PreNb{ppos[nb.f], nb.blk, used[nb.f], bt};
+        // q_{e,f} = B_fe g_e : rhs correction of the active unknowns on f
+        const int qoff = (vec_next++) * n1p;
+        ROM_TRY(rom_launch_gemm_nt(ctx, n1p, 1, n1p, 1.0, Bq, n1p, f->d_g + ppos[e], n1p, 0.0, f->d_vec + qoff, 1,
+                                   "setup_gemm"));
+        for (int t : nb_tiles(nb)) {
+          const int lr0 = tile_loc[t] * TB;
+          rhs_terms.push_back(RhsTerm{t, lr0, std::max(0, std::min(TB, n1 - lr0)), tile_ndr[t], qoff, nb.blk, pe.b0, pe.b1});
+        }
+        pre_flops += 2.0 * n1p * double(n1p);  // back substitution GEMM share of this neighbour
+      }
+      // R tables of this edge
+      for (auto& kv : rid) {
+        if (kv.first[0] != i) continue;
+        const int qr = nb_index(i, kv.first[1]), qc = nb_index(i, kv.first[2]);
+        ROM_TRY(rom_launch_gemm_nt(ctx, n1p, n1p, n1p, 1.0, d_B + size_t(qr) * tsz, n1p, d_X + size_t(qc) * tsz, n1p, 0.0,
+                                   f->d_R + size_t(kv.second) * tsz, n1p, "setup_gemm"));
+      }
+      ROM_HIP(hipStreamSynchronize(ctx->stream));  // d_X / d_B are reused by the next edge
+    }
+    hipFree(d_X);
+    hipFree(d_B);
+    hipFree(d_xrc);
+    hipFree(d_Kinv);
+  }
+  hipFree(d_Qp);
+  f->nrhs = int(rhs_terms.size());
+  ROM_TRY(upload(&f->d_rhs, rhs_terms));
+  ROM_TRY(upload(&f->d_pre, pre_edges));
   ROM_TRY(upload(&f->d_desc, f->desc));
   ROM_TRY(upload(&f->d_extra, extras));
   ROM_TRY(upload(&f->d_slot_of, f->slot_of));
@@ -896,7 +1193,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     ext_flops += 2.0 * double(n1) * n1 * ns * n1p;
   }
   double back_flops = 2.0 * 4096.0 * (f->nslots + T);
-  f->flops_solve = flops + ext_flops + back_flops;
+  f->flops_solve = flops + ext_flops + back_flops + pre_flops;
   // HBM bytes: factor tiles written once + read once by the back substitution, inverse tiles w+r,
   // the snapshot row written once, the coefficients read.
   f->bytes_solve = 8.0 * (2.0 * 4096.0 * f->nslots + 2.0 * 4096.0 * T + double(f->dim) + nrb * ncb);
@@ -980,11 +1277,12 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   const int kblk = f->nrb * f->ncb;
   static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-column kernel names
   char nm[4][48];
-  if (f->T > 0) {
+  if (f->nGp > 0) {
     {
       ROM_PROF(ctx, "init_rhs", 0, 8.0 * Mc * f->nGp);
       size_t tot = size_t(Mc) * f->nGp;
       k_init_rhs<<<unsigned((tot + 255) / 256), 256, 0, st>>>(d, Mc);
+      if (f->nrhs > 0) k_rhs_pre<<<dim3(f->T, Mc), 64, 0, st>>>(d, am, f->T);
     }
     for (int j = 0; j < f->T; ++j) {
       {
@@ -1013,9 +1311,13 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         k_factor_panel<<<nrows * Mc, 256, 0, st>>>(d, am, j, Mc);
       }
     }
-    {
+    if (f->T > 0) {
       ROM_PROF(ctx, "backsolve", Mc * 2.0 * 4096 * (f->nslots + f->T), Mc * 8.0 * 4096 * (f->nslots + f->T));
       k_backsolve<<<Mc, 256, lds_back, st>>>(d, f->d_slot_of, nullptr);
+    }
+    if (f->npre > 0) {
+      ROM_PROF(ctx, "back_pre", Mc * 2.0 * f->n1p * double(f->n1p) * 3.0 * f->npre, 8.0 * Mc * f->n1p * 4.0 * f->npre);
+      k_back_pre<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->npre), 256, 0, st>>>(d, am, Mc);
     }
   }
   {
@@ -1031,7 +1333,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
       ROM_PROF(ctx, "extend", fl * Mc, 8.0 * Mc * double(kblk) * nij);
       k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row);
     }
-    if (f->T > 0) {
+    if (f->nGp > 0) {
       ROM_PROF(ctx, "scatter_interface", 0, 16.0 * Mc * f->nG);
       k_scatter_interface<<<dim3((f->nGp + 255) / 256, Mc), 256, 0, st>>>(d, Mc, U, row);
     }
@@ -1056,7 +1358,7 @@ extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_
   if (f->ws_M > 0 && f->ws_M < Mc_max && f->ws_M >= 256) Mc_max = f->ws_M;  // reuse what we have
   ROM_TRY(ensure_workspace(f, Mc_max));
   ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
-  const size_t lds_back = size_t(std::max(f->nGp, 1)) * sizeof(double);
+  const size_t lds_back = size_t(std::max(f->nGa, 1)) * sizeof(double);
   ROM_CHECK(lds_back <= 60 * 1024, "rom_solve_batch: interface too large for the LDS-resident back substitution");
   // Sub-batches run on separate HIP streams: the wave-per-system diagonal kernels are latency bound
   // (one wave per SIMD), the MFMA kernels of another sub-batch fill the chip meanwhile.

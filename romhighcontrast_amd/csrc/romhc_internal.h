@@ -98,10 +98,23 @@ struct TileTerm {
   int c0;    // col offset inside the table
 };
 
+// Contribution of one pre-eliminated edge e (closed-form elimination, D_e = (a_e0 + a_e1) K) to a tile:
+//   - c_row c_col / (a_e0 + a_e1) * R[table][r0 + r][c0 + c],   c = a[blk] on edge-node rows/cols,
+//   (a_e0 + a_e1)/2 on cross-point slots (R = X_f K^-1 X_f'^T, parameter independent).
+struct PreTerm {
+  int table;       // index of the R table (n1p x n1p doubles each)
+  int r0, c0;      // offset of the tile inside the table
+  int brow, bcol;  // blocks scaling edge-node rows / cols (-1: the edge shares no block with e)
+  int e0, e1;      // the two blocks of the eliminated edge
+};
+
 struct TileDesc {
   int ti, tj;        // tile coordinates in the (permuted) interface ordering, ti >= tj
   int nterms;        // 0..2 Schur terms  - a[blk] * T[tmat][r0+r][c0+c]
   TileTerm term[2];
+  int npre;          // 0..4 pre-eliminated-edge terms
+  PreTerm pre[4];
+  int ndc;           // cols [0, ndc) are unknowns (as ndr for rows)
   int same_edge;     // 1: rows and cols lie on the same edge -> tridiagonal A_GammaGamma part
   int hv;            // 0 horizontal edge (blocks up/down), 1 vertical (left/right)
   int b0, b1;        // the two blocks of that edge: (up, dn) or (lf, rt)
@@ -122,13 +135,38 @@ struct BlockSide {  // per block, per side: where its interface values live (or 
   int off[4];
 };
 
+// rhs correction of one tile of active unknowns by one pre-eliminated edge:
+//   y[tile*64 + r] += c_row / (a_e0 + a_e1) * q[qoff + lr0 + r]
+struct RhsTerm {
+  int tile, lr0, nvr, ndr;  // tile row, its local offset on the edge, edge-node rows, defined rows
+  int qoff;                 // offset of the q vector (n1p doubles) in the vector table
+  int brow, e0, e1;
+};
+
+// back substitution of one pre-eliminated edge:  x_e = (w_e + sum_f B_fe (c_f . x_f)) / (a_e0 + a_e1)
+struct PreNb {
+  int fpos;    // position of the neighbour's n1p block in the interface vector
+  int blk;     // block scaling its edge nodes (-1: none)
+  int nused;   // cross-point slots behind the edge nodes (scaled by (a_e0+a_e1)/2)
+  int bt;      // index of the B^T table (n1p x n1p): row = node of e, col = position on the neighbour
+};
+struct PreEdge {
+  int pos;     // position of e's n1p block in the interface vector
+  int e0, e1;
+  int woff;    // offset of w_e = K^-1 g_e in the vector table
+  int nnb;
+  PreNb nb[8];
+};
+
 struct rom_fem {
   rom_ctx* ctx;
   int nrb, ncb, N, n1, n1p, tpe;  // n1 = N-1, n1p = padded to TB multiple, tpe tiles per edge
   int nr, nc;
   int64_t dim;
   int nG;      // real interface unknowns
-  int nGp;     // padded = T*TB
+  int nGp;     // stride of the interface vectors = T*TB + (pre-eliminated edges)*n1p
+  int nGa;     // active (factorised) part = T*TB
+  int npre;    // edges eliminated in closed form
   int T;       // tiles per dimension
   int nslots;  // nonzero lower tiles
   // device tables
@@ -144,6 +182,11 @@ struct rom_fem {
   int* d_colptr = nullptr;   // T+1 : rows below the diagonal in column j
   int* d_colrow = nullptr;   // slots of those tiles (and their tile row in d_colti)
   int* d_colti = nullptr;
+  double* d_R = nullptr;       // R / B^T tables of the pre-eliminated edges (n1p*n1p each)
+  double* d_vec = nullptr;     // q / w vectors of the pre-eliminated edges (n1p each)
+  RhsTerm* d_rhs = nullptr;
+  PreEdge* d_pre = nullptr;
+  int nrhs = 0;
   BlockSide* d_sides = nullptr;  // nrb*ncb
   int* d_vmap = nullptr;         // nG real interface unknowns: padded position -> global dof (or -1), size nGp
   // host copies
