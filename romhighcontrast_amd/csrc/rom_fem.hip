@@ -119,63 +119,115 @@ __global__ void k_build_Tm(double* Tm, const double* H0, int n1, int n1p, int N)
 // ============================================================================================
 // interface tile assembly  (A_GG(a) - sum_b a_b T_b, one entry)
 // ============================================================================================
-__device__ inline double s_entry(const TileDesc& d, const double* __restrict__ Tm, const double* __restrict__ R,
-                                 int n1p, const double* __restrict__ am, int r, int c) {
-  double v = 0.0;
-  if (r < d.ndr && c < d.ndc) {
-    for (int t = 0; t < d.npre; ++t) {
-      const PreTerm& pt = d.pre[t];
-      const double se = am[pt.e0] + am[pt.e1];
-      const double cr = r < d.nvr ? (pt.brow >= 0 ? am[pt.brow] : 0.0) : se / 2;
-      const double cc = c < d.nvc ? (pt.bcol >= 0 ? am[pt.bcol] : 0.0) : se / 2;
-      v -= cr * cc / se * R[(size_t(pt.table) * n1p + (pt.r0 + r)) * n1p + (pt.c0 + c)];
-    }
-  }
-  if (r < d.nvr && c < d.nvc) {
-    for (int t = 0; t < d.nterms; ++t) {
-      const TileTerm& tt = d.term[t];
-      v -= am[tt.blk] * Tm[(size_t(tt.tmat) * n1p + (tt.r0 + r)) * n1p + (tt.c0 + c)];
-    }
-    if (d.same_edge) {
-      int gr = d.lr0 + r, gc = d.lc0 + c;
-      double a0 = am[d.b0], a1 = am[d.b1];
-      if (gr == gc) {
-        // oracle order: k[r-1,c-1] + k[r-1,c] + k[r,c-1] + k[r,c]
-        v += d.hv == 0 ? ((a0 + a0) + a1) + a1 : ((a0 + a1) + a0) + a1;
-      } else if (gr - gc == 1 || gc - gr == 1) {
-        v += -(a1 + a0) / 2;
-      }
-    }
-  } else if (d.diag && r == c && r >= d.ndr) {
-    v = 1.0;  // padding unknowns: identity
-  }
-  return v;
-}
-
-// this thread's 16 entries of the assembled interface tile, in accumulator order
-struct STile {
-  double v[2][2][4];
+// Per-system scalar coefficients of one tile (uniform over the workgroup, computed once per thread):
+// the tile is a linear combination of parameter-independent tables with these weights.
+struct TileCoef {
+  double cT[2];                             // - a_b                              (Schur terms)
+  double cEE[4], cEX[4], cXE[4], cXX[4];    // pre-eliminated edge terms by (row kind, col kind), negated
+  double dg, off;                           // tridiagonal A_GammaGamma part of a same-edge tile
 };
 
-__device__ inline void s_tile_load(STile& st, const TileDesc& d, const FemDev& f, const double* __restrict__ am,
-                                   const WavePos& wp) {
+__device__ inline void tile_coefs(TileCoef& tc, const TileDesc& d, const double* __restrict__ am) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int t = 0; t < 2; ++t) tc.cT[t] = t < d.nterms ? -am[d.term[t].blk] : 0.0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+  for (int t = 0; t < 4; ++t) {
+    tc.cEE[t] = tc.cEX[t] = tc.cXE[t] = tc.cXX[t] = 0.0;
+    if (t < d.npre) {
+      const PreTerm& pt = d.pre[t];
+      const double se = am[pt.e0] + am[pt.e1];
+      const double ar = pt.brow >= 0 ? am[pt.brow] : 0.0, ac = pt.bcol >= 0 ? am[pt.bcol] : 0.0;
+      tc.cEE[t] = -(ar * ac / se);  // c_row c_col / s_e with c = a_b on edge nodes, s_e / 2 on cross slots
+      tc.cEX[t] = -(ar / 2);
+      tc.cXE[t] = -(ac / 2);
+      tc.cXX[t] = -(se / 4);
+    }
+  }
+  tc.dg = tc.off = 0.0;
+  if (d.same_edge) {
+    const double a0 = am[d.b0], a1 = am[d.b1];
+    // oracle order: k[r-1,c-1] + k[r-1,c] + k[r,c-1] + k[r,c]
+    tc.dg = d.hv == 0 ? ((a0 + a0) + a1) + a1 : ((a0 + a1) + a0) + a1;
+    tc.off = -(a1 + a0) / 2;
+  }
+}
+
+// This thread's share of the assembled interface tile: row (t >> 2), 16 consecutive columns starting
+// at (t & 3) * 16.  In this layout every table is read with 16-byte loads, 128 contiguous bytes per
+// thread and table; the values wait in registers while the MFMA k-loop runs.
+struct STile {
+  double v[16];
+};
+
+__device__ inline void s_tile_load(STile& st, const TileDesc& d, const FemDev& f, const double* __restrict__ am) {
+  TileCoef tc;
+  tile_coefs(tc, d, am);
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) st.v[i][j][g] = s_entry(d, f.Tm, f.R, f.n1p, am, acc_row(wp, i, g), acc_col(wp, j));
+  for (int x = 0; x < 16; ++x) st.v[x] = 0.0;
+  const bool re = r < d.nvr;
+  if (r < d.ndr) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < d.npre) {
+        const PreTerm& pt = d.pre[t];
+        const double2* src = reinterpret_cast<const double2*>(f.R + (size_t(pt.table) * f.n1p + (pt.r0 + r)) * f.n1p +
+                                                              (pt.c0 + c0));
+        const double ce_coef = re ? tc.cEE[t] : tc.cXE[t], cx_coef = re ? tc.cEX[t] : tc.cXX[t];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          const double2 w = src[x];
+          const int c = c0 + 2 * x;
+          st.v[2 * x] += (c < d.nvc ? ce_coef : (c < d.ndc ? cx_coef : 0.0)) * w.x;
+          st.v[2 * x + 1] += (c + 1 < d.nvc ? ce_coef : (c + 1 < d.ndc ? cx_coef : 0.0)) * w.y;
+        }
+      }
+  }
+  if (re) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (t < d.nterms) {
+        const TileTerm& tt = d.term[t];
+        const double2* src = reinterpret_cast<const double2*>(f.Tm + (size_t(tt.tmat) * f.n1p + (tt.r0 + r)) * f.n1p +
+                                                              (tt.c0 + c0));
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          const double2 w = src[x];  // the tables are zero beyond the edge nodes: no column mask needed
+          st.v[2 * x] += tc.cT[t] * w.x;
+          st.v[2 * x + 1] += tc.cT[t] * w.y;
+        }
+      }
+    if (d.same_edge) {
+      const int gr = d.lr0 + r;
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int c = c0 + x, gc = d.lc0 + c;
+        if (c < d.nvc) st.v[x] += gr == gc ? tc.dg : ((gr - gc == 1 || gc - gr == 1) ? tc.off : 0.0);
+      }
+    }
+  }
+  if (d.diag && r >= d.ndr) {
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+      if (c0 + x == r) st.v[x] = 1.0;  // padding unknowns: identity
+  }
 }
 
 // C(LDS tile) = S_tile - acc ; then the sparse cross-point extras
 __device__ inline void tile_from_acc(double* Cb, const Acc& acc, const STile& st, const TileDesc& d, const FemDev& f,
                                      const double* __restrict__ am, const WavePos& wp) {
+  {
+    double2* dst = reinterpret_cast<double2*>(Cb + (threadIdx.x >> 2) * LDC + (threadIdx.x & 3) * 16);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) dst[x] = double2{st.v[2 * x], st.v[2 * x + 1]};
+  }
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) Cb[acc_row(wp, i, g) * LDC + acc_col(wp, j)] = st.v[i][j][g] - acc.c[i][j][g];
+      for (int g = 0; g < 4; ++g) Cb[acc_row(wp, i, g) * LDC + acc_col(wp, j)] -= acc.c[i][j][g];
   __syncthreads();
   for (int x = d.x0 + threadIdx.x; x < d.x1; x += blockDim.x) {
     const TileExtra& e = f.extra[x];
@@ -309,7 +361,7 @@ __global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __r
   const double* am = a + size_t(m) * f.kblk;
   double* Lm = f.L + size_t(m) * f.nslots * 4096;
   STile st;
-  s_tile_load(st, d, f, am, wp);  // table reads fly under the MFMAs below
+  s_tile_load(st, d, f, am);  // table reads fly under the MFMAs below
   Acc acc;
   acc_zero(acc);
   const bool lower = !(wp.wr == 0 && wp.wc == 1);
@@ -450,7 +502,7 @@ __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __
   double* Lm = f.L + size_t(m) * f.nslots * 4096;
   const int t = threadIdx.x;
   STile st;
-  s_tile_load(st, d, f, am, wp);
+  s_tile_load(st, d, f, am);
   if (t < 64) yj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
   Acc acc;
   acc_zero(acc);
