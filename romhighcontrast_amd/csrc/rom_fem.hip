@@ -37,7 +37,11 @@ struct FemDev {
   const double* vec;
   const RhsTerm* rhs;
   const PreEdge* pre;
-  const double* H0;
+  const double* A0;    // (n1*n1) x n1p : Q[j,mode] rho_mode(i), harmonic extension in the sine basis
+  const double* Qp;    // n1p x n1p sine matrix (zero padded)
+  const int* kmax;     // [N+1] modes (multiple of 16) that matter at distance d from a side
+  const int* epos;     // position of every edge's n1p block in the interface vectors
+  double* yhat;        // [Mc][nGp] sine coefficients of the interface values
   const double* Tm;
   const double* W;
   const double* g;
@@ -61,7 +65,7 @@ static FemDev make_dev(const rom_fem* f) {
   d.nrb = f->nrb; d.ncb = f->ncb; d.N = f->N; d.n1 = f->n1; d.n1p = f->n1p; d.nr = f->nr; d.nc = f->nc;
   d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.R = f->d_R; d.vec = f->d_vec;
   d.rhs = f->d_rhs; d.pre = f->d_pre; d.T = f->T; d.nslots = f->nslots; d.kblk = f->nrb * f->ncb; d.dim = f->dim;
-  d.H0 = f->d_H0; d.Tm = f->d_Tm; d.W = f->d_W; d.g = f->d_g; d.desc = f->d_desc; d.extra = f->d_extra;
+  d.A0 = f->d_A0; d.Qp = f->d_Qp; d.kmax = f->d_kmax; d.epos = f->d_epos; d.yhat = f->d_yhat; d.Tm = f->d_Tm; d.W = f->d_W; d.g = f->d_g; d.desc = f->d_desc; d.extra = f->d_extra;
   d.kptr = f->d_kptr; d.kpair = f->d_kpair; d.colptr = f->d_colptr; d.colrow = f->d_colrow;
   d.colti = f->d_colti; d.sides = f->d_sides; d.vmap = f->d_vmap; d.L = f->d_L; d.invL = f->d_invL;
   d.y = f->d_y; d.status = f->ctx->d_status;
@@ -573,7 +577,42 @@ __global__ __launch_bounds__(256) void k_backsolve(FemDev f, const int* __restri
 // ============================================================================================
 // harmonic extension + scatter: writes the snapshot rows
 // ============================================================================================
-// grid (ceil(n1^2/64), ceil(Mc/64), nblocks).  Tile rows = systems, tile cols = interior vertices.
+// Sine transform of the interface values, edge by edge:  yhat[m, pos_e + mode] = sum_k y[m, pos_e + k] Q[k, mode]
+// (Q symmetric).  grid (n1p/64, ceil(Mc/64), n_edges); tile rows = systems, tile cols = modes.
+__global__ __launch_bounds__(256) void k_edge_transform(FemDev f, int Mc) {
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  const WavePos wp;
+  const int pos = f.epos[blockIdx.z];
+  const int srow = stage_row(), sseg = stage_seg();
+  const int mA = blockIdx.y * 64 + srow;
+  const double* pA = mA < Mc ? f.y + size_t(mA) * f.nGp + pos + sseg : nullptr;
+  const double* pB = f.Qp + size_t(blockIdx.x * 64 + srow) * f.n1p + sseg;
+  Acc acc;
+  acc_zero(acc);
+  gemm_loop(
+      f.n1p / BK, [&](int ch, double* v) { load4_aligned(pA ? pA + ch * BK : nullptr, v); },
+      [&](int ch, double* v) { load4_aligned(pB + ch * BK, v); }, acc, lds, wp);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m = blockIdx.y * 64 + acc_row(wp, i, g);
+      if (m >= Mc) continue;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+        f.yhat[size_t(m) * f.nGp + pos + blockIdx.x * 64 + acc_col(wp, jb)] = acc.c[i][jb][g];
+    }
+}
+
+// Harmonic extension in the sine basis of each side:
+//   U_I,b[m,(i,j)] = (h^2/a_b) W[i,j] + sum_{sides s} sum_mode yhat_s[m, mode] * A0[pi_s(i,j)][mode],
+//   A0[(i',j'), mode] = Q[j', mode] rho_mode(i'),   rho_mode(i') ~ exp(-i' phi_mode).
+// Far from a side only the low modes survive in fp64: kmax[d] (multiple of 16) is the number of modes with
+// rho_mode(d) above 1e-24, so a tile whose vertices are at distance >= d from side s stops its K loop
+// there (terms below 1e-24 of the leading ones cannot change an fp64 sum).
+// Tile columns = a 4 x 16 patch of interior vertices (so that the distance to all four sides is bounded
+// below per tile and rows are still written in 128-byte segments); tile rows = systems.
+// grid (patches, ceil(Mc/64), nblocks)
 __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restrict__ a, int Mc,
                                                 double* __restrict__ U, long long row0) {
   __shared__ __align__(16) double lds[STAGE_TOTAL];
@@ -582,27 +621,30 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
   const int b = blockIdx.z;
   const int p = b / f.ncb, q = b % f.ncb;
   const int n1 = f.n1, N = f.N;
-  const int nij = n1 * n1;
   const BlockSide sd = f.sides[b];
   const int srow = stage_row(), sseg = stage_seg();
+  const int npj = (n1 + 15) / 16;                     // patches per patch row
+  const int pi = blockIdx.x / npj, pj = blockIdx.x % npj;
+  const int i0 = 4 * pi + 1, j0 = 16 * pj + 1;        // first vertex of the patch (1-based)
+  const int i1 = min(i0 + 3, n1), j1 = min(j0 + 15, n1);
 
   const int mA = blockIdx.y * 64 + srow;
-  const double* Arow = mA < Mc ? f.y + size_t(mA) * f.nGp + sseg : nullptr;
-  const int ijB = blockIdx.x * 64 + srow;
-  int iB = 1, jB = 1;
-  if (ijB < nij) { iB = ijB / n1 + 1; jB = ijB % n1 + 1; }
+  const double* Arow = mA < Mc ? f.yhat + size_t(mA) * f.nGp + sseg : nullptr;
+  const int iB = i0 + (srow >> 4), jB = j0 + (srow & 15);  // vertex of this thread's B row
+  const bool vB = iB <= n1 && jB <= n1;
 
   Acc acc;
   acc_zero(acc);
-  const int cps = f.n1p / BK;  // chunks per side
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int off = s == 0 ? sd.off[0] : s == 1 ? sd.off[1] : s == 2 ? sd.off[2] : sd.off[3];
     if (off < 0) continue;  // side on the domain boundary (uniform branch)
+    const int dist = s == 0 ? i0 : s == 1 ? N - i1 : s == 2 ? j0 : N - j1;  // closest vertex of the patch
+    const int nch = f.kmax[dist] / BK;
     const double* pA = Arow ? Arow + off : nullptr;
-    const double* pB = ijB < nij ? f.H0 + size_t(h0_row(s, iB, jB, N, n1)) * f.n1p + sseg : nullptr;
+    const double* pB = vB ? f.A0 + size_t(h0_row(s, iB, jB, N, n1)) * f.n1p + sseg : nullptr;
     gemm_loop(
-        cps, [&](int ch, double* v) { load4_aligned(pA ? pA + ch * BK : nullptr, v); },
+        nch, [&](int ch, double* v) { load4_aligned(pA ? pA + ch * BK : nullptr, v); },
         [&](int ch, double* v) { load4_aligned(pB ? pB + ch * BK : nullptr, v); }, acc, stage, wp);
   }
 
@@ -616,11 +658,11 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
       double sc = h2 / a[size_t(m) * f.kblk + b];
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
-        int ij = blockIdx.x * 64 + acc_col(wp, jb);
-        if (ij >= nij) continue;
-        int ii = ij / n1, jj = ij - ii * n1;
+        const int cidx = acc_col(wp, jb);
+        const int ii = i0 + (cidx >> 4) - 1, jj = j0 + (cidx & 15) - 1;  // 0-based interior indices
+        if (ii >= n1 || jj >= n1) continue;
         long long gidx = (long long)(p * N + ii) * f.nc + (q * N + jj);
-        U[(row0 + m) * f.dim + gidx] = acc.c[i][jb][g] + sc * f.W[ij];
+        U[(row0 + m) * f.dim + gidx] = acc.c[i][jb][g] + sc * f.W[ii * n1 + jj];
       }
     }
 }
@@ -677,7 +719,7 @@ int upload(Tp** dptr, const std::vector<Tp>& h) {
 extern "C" int rom_fem_destroy(rom_fem* f) {
   if (!f) return ROM_OK;
   hipStreamSynchronize(f->ctx->stream);
-  void* ptrs[] = {f->d_H0, f->d_Tm, f->d_W, f->d_g, f->d_desc, f->d_extra, f->d_slot_of, f->d_kptr, f->d_kpair,
+  void* ptrs[] = {f->d_A0, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_Tm, f->d_W, f->d_g, f->d_desc, f->d_extra, f->d_slot_of, f->d_kptr, f->d_kpair,
                   f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L, f->d_invL, f->d_y, f->d_R, f->d_vec,
                   f->d_rhs, f->d_pre};
   for (void* p : ptrs)
@@ -1099,26 +1141,55 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   std::vector<double> Qp(size_t(n1p) * n1p, 0.0);
   for (int j = 0; j < n1; ++j)
     for (int m = 0; m < n1; ++m) Qp[size_t(j) * n1p + m] = double(Q[size_t(j) * n1 + m]);
-  double *d_Qp = nullptr, *d_rho = nullptr, *d_A0 = nullptr;
+  double *d_Qp = nullptr, *d_rho = nullptr, *d_A0 = nullptr, *d_H0 = nullptr;
   ROM_TRY(upload(&d_Qp, Qp));
   ROM_TRY(upload(&d_rho, rho));
   const size_t hrows = size_t(n1) * n1;
   ROM_HIP(hipMalloc(&d_A0, std::max<size_t>(hrows * n1p, 1) * sizeof(double)));
-  ROM_HIP(hipMalloc(&f->d_H0, std::max<size_t>(hrows * n1p, 1) * sizeof(double)));
+  ROM_HIP(hipMalloc(&d_H0, std::max<size_t>(hrows * n1p, 1) * sizeof(double)));
   ROM_HIP(hipMalloc(&f->d_Tm, size_t(16) * n1p * n1p * sizeof(double)));
   {
     size_t total = hrows * n1p;
     k_build_A0<<<unsigned((total + 255) / 256), 256, 0, ctx->stream>>>(d_A0, d_Qp, d_rho, n1, n1p, N);
     ROM_HIP(hipGetLastError());
-    ROM_TRY(rom_launch_gemm_nt(ctx, int64_t(hrows), n1p, n1p, 1.0, d_A0, n1p, d_Qp, n1p, 0.0, f->d_H0, n1p,
+    ROM_TRY(rom_launch_gemm_nt(ctx, int64_t(hrows), n1p, n1p, 1.0, d_A0, n1p, d_Qp, n1p, 0.0, d_H0, n1p,
                                "setup_gemm_H0"));
     size_t tt = size_t(16) * n1p * n1p;
-    k_build_Tm<<<unsigned((tt + 255) / 256), 256, 0, ctx->stream>>>(f->d_Tm, f->d_H0, n1, n1p, N);
+    k_build_Tm<<<unsigned((tt + 255) / 256), 256, 0, ctx->stream>>>(f->d_Tm, d_H0, n1, n1p, N);
     ROM_HIP(hipGetLastError());
     ROM_HIP(hipStreamSynchronize(ctx->stream));
   }
   hipFree(d_rho);
-  hipFree(d_A0);
+  hipFree(d_H0);  // only needed for the Dirichlet-to-Neumann tables; the extension runs in the sine basis (A0)
+  f->d_A0 = d_A0;
+  {
+    // kmax[d]: modes with rho_mode(d) >= 1e-24, rounded up to the K chunk
+    std::vector<int> kmax(N + 1, n1p);
+    for (int dd = 1; dd <= N; ++dd) {
+      int last = -1;
+      for (int m = 0; m < n1; ++m)
+        if (rho[size_t(m) * (N + 1) + std::min(dd, N)] >= 1e-24) last = m;
+      kmax[dd] = std::min(n1p, std::max(BK, (last + 1 + BK - 1) / BK * BK));
+    }
+    kmax[0] = n1p;
+    ROM_TRY(upload(&f->d_kmax, kmax));
+    std::vector<int> eposv(std::max(E, 1), 0);
+    for (int e = 0; e < E; ++e) eposv[e] = ppos[e];
+    ROM_TRY(upload(&f->d_epos, eposv));
+    f->n_edges = E;
+    // flops of the truncated extension, per system (for the work accounting)
+    double fl = 0;
+    const int npj = (n1 + 15) / 16, npi = (n1 + 3) / 4;
+    for (int b = 0; b < nrb * ncb; ++b)
+      for (int pi = 0; pi < npi; ++pi)
+        for (int pj = 0; pj < npj; ++pj) {
+          int i0 = 4 * pi + 1, j0 = 16 * pj + 1, i1 = std::min(i0 + 3, n1), j1 = std::min(j0 + 15, n1);
+          int dist[4] = {i0, N - i1, j0, N - j1};
+          for (int sdx = 0; sdx < 4; ++sdx)
+            if (bside[b][sdx] >= 0) fl += 2.0 * 64 * kmax[dist[sdx]];
+        }
+    f->ext_flops = fl + 2.0 * E * double(n1p) * n1p;
+  }
   ROM_TRY(upload(&f->d_W, W));
   ROM_TRY(upload(&f->d_g, f->g_host));
 
@@ -1222,7 +1293,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     hipFree(d_xrc);
     hipFree(d_Kinv);
   }
-  hipFree(d_Qp);
+  f->d_Qp = d_Qp;
   f->nrhs = int(rhs_terms.size());
   ROM_TRY(upload(&f->d_rhs, rhs_terms));
   ROM_TRY(upload(&f->d_pre, pre_edges));
@@ -1238,12 +1309,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   ROM_TRY(upload(&f->d_vmap, vmap));
 
   // ---- work accounting of this algorithm, per snapshot solve ------------------------------------------------
-  double ext_flops = 0;
-  for (int b = 0; b < nrb * ncb; ++b) {
-    int ns = 0;
-    for (int s = 0; s < 4; ++s) ns += bside[b][s] >= 0;
-    ext_flops += 2.0 * double(n1) * n1 * ns * n1p;
-  }
+  const double ext_flops = f->ext_flops;
   double back_flops = 2.0 * 4096.0 * (f->nslots + T);
   f->flops_solve = flops + ext_flops + back_flops + pre_flops;
   // HBM bytes: factor tiles written once + read once by the back substitution, inverse tiles w+r,
@@ -1313,11 +1379,13 @@ static int ensure_workspace(rom_fem* f, int Mc) {
   if (f->d_L) hipFree(f->d_L);
   if (f->d_invL) hipFree(f->d_invL);
   if (f->d_y) hipFree(f->d_y);
-  f->d_L = f->d_invL = f->d_y = nullptr;
+  if (f->d_yhat) hipFree(f->d_yhat);
+  f->d_L = f->d_invL = f->d_y = f->d_yhat = nullptr;
   f->ws_M = 0;
   ROM_HIP(hipMalloc(&f->d_L, std::max<size_t>(size_t(Mc) * f->nslots * 4096, 1) * sizeof(double)));
   ROM_HIP(hipMalloc(&f->d_invL, std::max<size_t>(size_t(Mc) * f->T * 4096, 1) * sizeof(double)));
   ROM_HIP(hipMalloc(&f->d_y, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
+  ROM_HIP(hipMalloc(&f->d_yhat, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
   f->ws_M = Mc;
   return ROM_OK;
 }
@@ -1375,14 +1443,13 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   {
     const int nij = f->n1 * f->n1;
     if (nij > 0) {
-      dim3 grid((nij + 63) / 64, (Mc + 63) / 64, kblk);
-      double fl = 0;
-      for (int b = 0; b < kblk; ++b) {
-        int ns = 0;
-        for (int s = 0; s < 4; ++s) ns += f->sides[b].off[s] >= 0;
-        fl += 2.0 * nij * double(ns) * f->n1p;
+      if (f->n_edges > 0) {
+        ROM_PROF(ctx, "edge_transform", Mc * 2.0 * f->n_edges * double(f->n1p) * f->n1p, 16.0 * Mc * f->n_edges * f->n1p);
+        k_edge_transform<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->n_edges), 256, 0, st>>>(d, Mc);
       }
-      ROM_PROF(ctx, "extend", fl * Mc, 8.0 * Mc * double(kblk) * nij);
+      const int npatch = ((f->n1 + 3) / 4) * ((f->n1 + 15) / 16);
+      dim3 grid(npatch, (Mc + 63) / 64, kblk);
+      ROM_PROF(ctx, "extend", (f->ext_flops - 2.0 * f->n_edges * double(f->n1p) * f->n1p) * Mc, 8.0 * Mc * double(kblk) * nij);
       k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row);
     }
     if (f->nGp > 0) {
@@ -1405,7 +1472,7 @@ extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_
   rom_ctx* ctx = f->ctx;
   ROM_HIP(hipSetDevice(ctx->device));
   // chunk the sweep so that the factor workspace respects the budget
-  size_t per_sys = (size_t(f->nslots) * 4096 + size_t(f->T) * 4096 + f->nGp) * sizeof(double);
+  size_t per_sys = (size_t(f->nslots) * 4096 + size_t(f->T) * 4096 + 2 * size_t(f->nGp)) * sizeof(double);
   int Mc_max = int(std::max<size_t>(1, std::min<size_t>(size_t(M), ctx->ws_limit / std::max<size_t>(per_sys, 1))));
   if (f->ws_M > 0 && f->ws_M < Mc_max && f->ws_M >= 256) Mc_max = f->ws_M;  // reuse what we have
   ROM_TRY(ensure_workspace(f, Mc_max));
@@ -1430,6 +1497,7 @@ extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_
       d.L += size_t(off) * f->nslots * 4096;
       d.invL += size_t(off) * f->T * 4096;
       d.y += size_t(off) * f->nGp;
+      d.yhat += size_t(off) * f->nGp;
       ROM_TRY(enqueue_solve(f, d, a->p + size_t(m0 + off) * kblk, Mc, U->p, (long long)(row0 + m0 + off), st, lds_back));
     }
     ctx->prof_stream = nullptr;

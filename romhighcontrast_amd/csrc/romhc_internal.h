@@ -170,7 +170,13 @@ struct rom_fem {
   int T;       // tiles per dimension
   int nslots;  // nonzero lower tiles
   // device tables
-  double* d_H0 = nullptr;    // (n1*n1) x n1p harmonic extension from side i=0
+  double* d_A0 = nullptr;    // (n1*n1) x n1p : Q[j,mode] rho_mode(i) (harmonic extension from side i=0, sine basis)
+  double* d_Qp = nullptr;    // n1p x n1p sine matrix
+  int* d_kmax = nullptr;     // [N+1]
+  int* d_epos = nullptr;     // [n_edges]
+  int n_edges = 0;
+  double ext_flops = 0;
+  double* d_yhat = nullptr;  // [ws_M][nGp]
   double* d_Tm = nullptr;    // 16 x n1p x n1p
   double* d_W = nullptr;     // n1*n1 : L^{-1} 1
   double* d_g = nullptr;     // nGp : parameter independent interface rhs
