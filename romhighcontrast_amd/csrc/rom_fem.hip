@@ -462,11 +462,16 @@ __global__ __launch_bounds__(64) void k_diag_inverse(FemDev f, int slot, int j) 
   double x[64];
 #pragma unroll
   for (int r = 0; r < 64; ++r) {
-    double s = (r == lane) ? 1.0 : 0.0;
+    // four independent partial sums: the dot product is otherwise one dependent FMA chain of length r
+    double s0 = (r == lane) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 64; ++k)
-      if (k < r) s -= Ls[r * LDC + k] * x[k];
-    x[r] = s * rinv[r];
+    for (int k = 0; k < 64; k += 4) {
+      if (k < r) s0 -= Ls[r * LDC + k] * x[k];
+      if (k + 1 < r) s1 -= Ls[r * LDC + k + 1] * x[k + 1];
+      if (k + 2 < r) s2 -= Ls[r * LDC + k + 2] * x[k + 2];
+      if (k + 3 < r) s3 -= Ls[r * LDC + k + 3] * x[k + 3];
+    }
+    x[r] = ((s0 + s1) + (s2 + s3)) * rinv[r];
     It[r * 64 + lane] = x[r];
   }
 }
