@@ -222,6 +222,34 @@ def test_ragged_geometries_vs_oracle(api, blocks, N):
     assert relh10(g, U, ro.generate_solutions(g, a)).max() < SNAP_TOL
 
 
+def test_workspace_chunking_and_streams(api):
+    """A small factor-workspace budget forces the sweep through several chunks (and the multi-stream
+    sub-batch path); results must be bit-identical to the single-chunk run."""
+    SM, _ = api
+    sm = SM.SolutionsManagerFEM((2, 2), 20)
+    a = 10.0 ** np.random.default_rng(2).uniform(0, 3, size=(300, 2, 2))
+    ref = sm.generate_solutions(a)
+    ctx = sm._ctx
+    per_sys = 40 * 4096 * 8  # generous estimate of the factor bytes of one system at this size
+    ctx.set_workspace_limit(70 * per_sys)
+    try:
+        sm2 = SM.SolutionsManagerFEM((2, 2), 20)
+        assert np.array_equal(sm2.generate_solutions(a), ref)
+    finally:
+        ctx.set_workspace_limit(24 << 30)
+
+
+@pytest.mark.parametrize("blocks,N", [((1, 2), 6), ((2, 1), 9), ((1, 4), 5), ((3, 3), 20), ((4, 4), 6), ((2, 2), 64)])
+def test_closed_form_edge_elimination_geometries(api, blocks, N):
+    """Geometries that exercise the closed-form elimination: every edge eliminated ((1,2)), chains,
+    cross points whose hosting edge is not a block neighbour of the eliminated edge (3x3, 4x4)."""
+    SM, _ = api
+    sm = SM.SolutionsManagerFEM(blocks, N)
+    g = ro.Geometry(blocks, N)
+    a = 10.0 ** np.random.default_rng(N + blocks[0]).uniform(0, 4, size=(4,) + blocks)
+    assert relh10(g, sm.generate_solutions(a), ro.generate_solutions(g, a)).max() < SNAP_TOL
+
+
 def test_error_behaviour(api):
     SM, _ = api
     from scipy.linalg import LinAlgError
