@@ -8,7 +8,9 @@ workload (2x2 blocks, N=128 -> 256x256 cells, dim 65 025, 1024-parameter sweep, 
 10**U(0,2) coefficients) with the parameters already resident in HBM and the (M, dim) fp64
 snapshot block left in HBM.  With N > 1 (one process per GPU, started by torch.distributed.run)
 every rank solves its own 1024-parameter shard (weak scaling: N=8 is config C3, 8192 parameters)
-and the shards are exchanged with one RCCL all-gather per step, inside the timed region.
+and the shards are exchanged with one RCCL all-gather per step, inside the timed region; the
+all-gather of step k runs on a communication stream and overlaps the solves of step k+1 (double
+buffered), the region ends when the last all-gather has landed.
 
 The timed region is bracketed by a barrier + stream synchronisation on both sides (RCCL all-reduce
 for N > 1), the reported time is the max over ranks, and rank 0 prints ONE JSON line.
@@ -17,6 +19,7 @@ Host side is plain Python + ctypes (no torch): the rendezvous for the RCCL uniqu
 a launch-scoped file (romhighcontrast_amd/sweep.py).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -49,6 +52,20 @@ def cpu_baseline(blocks, N, a, budget_s=15.0):
                       f"{dt:.1f} s on 1 of {os.cpu_count()} host cores"}
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner on the C-level stdout at init; keep stdout for the one JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +76,8 @@ def main():
     ap.add_argument("--blocks", type=int, nargs=2, default=[2, 2])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pod", action="store_true")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="rehearsal: run the N>1 code path (RCCL communicator, overlapped all-gather) with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,13 +100,16 @@ def main():
     sm = SolutionsManagerFEM(blocks, N, device=dev)
     fem, dim = sm._fem, sm.vspace_dim
 
-    if world > 1:
-        uid = sweep.exchange_unique_id(rank, ctx.comm_unique_id)
-        ctx.comm_init(uid, rank, world)
+    comm = world > 1 or args.force_comm
+    if comm:
+        with stdout_to_stderr():
+            uid = sweep.exchange_unique_id(rank, ctx.comm_unique_id)
+            ctx.comm_init(uid, rank, world)
+            ctx.allreduce_host([0.0], "sum")  # first collective: connection set-up, banner
 
     def barrier():
         ctx.synchronize()
-        if world > 1:
+        if comm:
             ctx.allreduce_host([0.0], "sum")
 
     # synthetic sweep of SURVEY.md 8(d): seeded, all blocks free, contrast <= 1e2; rank r owns rows
@@ -97,24 +119,38 @@ def main():
     a_loc = a_all[rank * M:(rank + 1) * M]
     a_dev = ctx.upload(a_loc.reshape(M, -1))
     U_loc = ctx.alloc(M * dim)
-    U_all = ctx.alloc(world * M * dim) if world > 1 else U_loc
+    # N > 1: two local shards and two gathered blocks so that the RCCL all-gather of step k (on the
+    # communication stream) overlaps the solves of step k+1 (on the compute stream)
+    U_pair = [U_loc, ctx.alloc(M * dim)] if comm else [U_loc]
+    U_all = [ctx.alloc(world * M * dim) for _ in range(2)] if comm else [U_loc]
+    step_no = [0]
 
     def step():
-        fem.solve_batch(a_dev, M, U_loc)
-        if world > 1:
-            ctx.allgather(U_loc, 0, U_all, 0, M * dim)
+        k = step_no[0] & 1 if comm else 0
+        step_no[0] += 1
+        if comm:
+            ctx.comm_wait_slot(k)  # the all-gather that last read this shard buffer must have finished
+        fem.solve_batch(a_dev, M, U_pair[k])
+        if comm:
+            ctx.allgather_async(U_pair[k], 0, U_all[k], 0, M * dim, slot=k)
+
+    def drain():
+        if comm:
+            ctx.comm_wait(True)
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
         step()
+    drain()  # the timed region ends when the last all-gather has landed
     ev_ms = ctx.timer_stop()
     ctx.synchronize()
     wall = time.perf_counter() - t0
-    if world > 1:
+    if comm:
         wall = float(ctx.allreduce_host([wall], "max")[0])
     barrier()
 
@@ -126,13 +162,19 @@ def main():
     tp = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     ctx.synchronize()
     wall_prof = time.perf_counter() - tp
     ctx.profile(False)
     barrier()
 
+    if comm:  # the gathered block must equal the local shard in this rank's slot
+        last = (step_no[0] - 1) & 1
+        probe = [0, (M // 2) * dim + 17, M * dim - 1]
+        for off in probe:
+            assert U_all[last].download(1, offset=rank * M * dim + off)[0] == U_pair[last].download(1, offset=off)[0]
     if rank != 0:
-        if world > 1:
+        if comm:
             ctx.comm_destroy()
         return
 
@@ -213,7 +255,7 @@ def main():
                               "+ 10 M^3 (SURVEY 8d) over the wall time incl. the download of the r modes"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blocks, N, a_loc)
-    if world > 1:
+    if comm:
         ctx.comm_destroy()
         sweep.cleanup_rendezvous(rank)
     print(json.dumps(out))

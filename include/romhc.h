@@ -152,6 +152,14 @@ int rom_comm_destroy(rom_ctx* ctx);
 /* recv[(r*count) ...] = send of rank r; count doubles per rank */
 int rom_comm_allgather(rom_ctx* ctx, rom_buf* send, size_t send_off, rom_buf* recv, size_t recv_off,
                        size_t count);
+/* same collective on the context's communication stream, ordered after the work enqueued so far on the
+ * compute stream but not blocking it (the next sweep step overlaps the exchange); rom_comm_wait makes the
+ * compute stream (and the host if host_sync != 0) wait for the outstanding collectives */
+int rom_comm_allgather_async(rom_ctx* ctx, rom_buf* send, size_t send_off, rom_buf* recv, size_t recv_off,
+                             size_t count, int slot /* 0|1: double-buffer slot of the send buffer */);
+int rom_comm_wait(rom_ctx* ctx, int host_sync);
+/* compute stream waits for the collective last issued with `slot` (before its send buffer is rewritten) */
+int rom_comm_wait_slot(rom_ctx* ctx, int slot);
 /* in-place max / sum all-reduce of n host doubles staged through the device (control plane:
  * barrier + max-over-ranks timing of bench.py) */
 int rom_comm_allreduce_host(rom_ctx* ctx, double* vals, int n, int op /*0=sum,1=max*/);

@@ -75,6 +75,9 @@ PROTOTYPES = {
     "rom_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),
     "rom_comm_destroy": (C.c_int, [_vp]),
     "rom_comm_allgather": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t]),
+    "rom_comm_allgather_async": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_int]),
+    "rom_comm_wait_slot": (C.c_int, [_vp, C.c_int]),
+    "rom_comm_wait": (C.c_int, [_vp, C.c_int]),
     "rom_comm_allreduce_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
 }
 
@@ -218,6 +221,15 @@ class Context:
 
     def allgather(self, send: "Buffer", send_off, recv: "Buffer", recv_off, count):
         check(self.lib.rom_comm_allgather(self.h, send.h, send_off, recv.h, recv_off, count))
+
+    def allgather_async(self, send: "Buffer", send_off, recv: "Buffer", recv_off, count, slot=0):
+        check(self.lib.rom_comm_allgather_async(self.h, send.h, send_off, recv.h, recv_off, count, slot))
+
+    def comm_wait_slot(self, slot):
+        check(self.lib.rom_comm_wait_slot(self.h, slot))
+
+    def comm_wait(self, host_sync=True):
+        check(self.lib.rom_comm_wait(self.h, 1 if host_sync else 0))
 
     def allreduce_host(self, vals, op="sum") -> np.ndarray:
         v = _host(np.atleast_1d(vals)).copy()

@@ -98,6 +98,18 @@ extern "C" int rom_comm_init(rom_ctx* ctx, const char* id, size_t id_len, int ra
 extern "C" int rom_comm_destroy(rom_ctx* ctx) {
   if (!ctx || !ctx->comm) return ROM_OK;
   hipStreamSynchronize(ctx->stream);
+  if (ctx->comm_stream) {
+    hipStreamSynchronize(ctx->comm_stream);
+    hipStreamDestroy(ctx->comm_stream);
+    hipEventDestroy(ctx->ev_comm);
+    for (int i = 0; i < 2; ++i) {
+      hipEventDestroy(ctx->ev_slot[i]);
+      ctx->ev_slot[i] = nullptr;
+      ctx->slot_used[i] = false;
+    }
+    ctx->comm_stream = nullptr;
+    ctx->ev_comm = nullptr;
+  }
   g_rccl.CommDestroy((nccl_comm_t)ctx->comm);
   ctx->comm = nullptr;
   ctx->rank = 0;
@@ -116,6 +128,49 @@ extern "C" int rom_comm_allgather(rom_ctx* ctx, rom_buf* send, size_t send_off, 
     ROM_NCCL(g_rccl.AllGather(send->p + send_off, recv->p + recv_off, count, NCCL_FLOAT64, (nccl_comm_t)ctx->comm,
                               ctx->stream));
   }
+  return ROM_OK;
+}
+
+// Overlapped form: the collective runs on the context's communication stream, ordered after everything
+// enqueued so far on the compute stream; the compute stream is NOT blocked, so the next sweep step can
+// run while the shards travel over xGMI.  rom_comm_wait() makes the compute stream (and the host, if
+// `host_sync`) wait for all outstanding collectives.
+extern "C" int rom_comm_allgather_async(rom_ctx* ctx, rom_buf* send, size_t send_off, rom_buf* recv, size_t recv_off,
+                                        size_t count, int slot) {
+  ROM_CHECK(slot >= 0 && slot < 2, "rom_comm_allgather_async: slot must be 0 or 1");
+  ROM_CHECK(ctx && send && recv, "rom_comm_allgather_async: null argument");
+  ROM_CHECK(ctx->comm, "rom_comm_allgather_async: communicator not initialised (rom_comm_init)");
+  ROM_CHECK(send_off + count <= send->n, "rom_comm_allgather_async: send range out of bounds");
+  ROM_CHECK(recv_off + count * size_t(ctx->nranks) <= recv->n, "rom_comm_allgather_async: recv range out of bounds");
+  if (!ctx->comm_stream) {
+    ROM_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    ROM_HIP(hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) ROM_HIP(hipEventCreateWithFlags(&ctx->ev_slot[i], hipEventDisableTiming));
+  }
+  ROM_HIP(hipEventRecord(ctx->ev_comm, ctx->stream));
+  ROM_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm, 0));
+  ROM_NCCL(g_rccl.AllGather(send->p + send_off, recv->p + recv_off, count, NCCL_FLOAT64, (nccl_comm_t)ctx->comm,
+                            ctx->comm_stream));
+  ROM_HIP(hipEventRecord(ctx->ev_slot[slot], ctx->comm_stream));
+  ctx->slot_used[slot] = true;
+  return ROM_OK;
+}
+
+// compute stream waits until the collective last issued with this slot has finished (its send buffer
+// may then be overwritten by the next sweep step)
+extern "C" int rom_comm_wait_slot(rom_ctx* ctx, int slot) {
+  ROM_CHECK(ctx && slot >= 0 && slot < 2, "rom_comm_wait_slot: bad arguments");
+  if (!ctx->comm_stream || !ctx->slot_used[slot]) return ROM_OK;
+  ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_slot[slot], 0));
+  return ROM_OK;
+}
+
+extern "C" int rom_comm_wait(rom_ctx* ctx, int host_sync) {
+  ROM_CHECK(ctx, "rom_comm_wait: null context");
+  if (!ctx->comm_stream) return ROM_OK;
+  ROM_HIP(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
+  ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_comm, 0));
+  if (host_sync) ROM_HIP(hipStreamSynchronize(ctx->comm_stream));
   return ROM_OK;
 }
 

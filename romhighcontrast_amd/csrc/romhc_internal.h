@@ -71,6 +71,9 @@ struct rom_ctx {
   // RCCL
   void* comm = nullptr;
   int rank = 0, nranks = 1;
+  hipStream_t comm_stream = nullptr;  // collectives overlapped with compute (rom_comm_allgather_async)
+  hipEvent_t ev_comm = nullptr, ev_slot[2] = {nullptr, nullptr};
+  bool slot_used[2] = {false, false};
 };
 
 struct rom_buf {

@@ -317,6 +317,14 @@ def test_rccl_single_rank_allgather(api):
         ctx.allgather(src, 0, dst, 0, 1000)
         assert np.array_equal(dst.download(), x)
         assert ctx.allreduce_host([3.5, -1.0], "max").tolist() == [3.5, -1.0]
+        # overlapped form on the communication stream, both double-buffer slots
+        dst2 = ctx.alloc(1000)
+        for slot in (0, 1, 0):
+            ctx.comm_wait_slot(slot)
+            src.upload(x + slot)
+            ctx.allgather_async(src, 0, dst2, 0, 1000, slot=slot)
+            ctx.comm_wait(True)
+            assert np.array_equal(dst2.download(), x + slot)
         sm = SM.SolutionsManagerFEM((2, 2), 8)
         a = 10.0 ** np.random.default_rng(3).uniform(0, 2, size=(5, 2, 2))
         U = sweep.RcclSweep(sm, 0, 1).generate_solutions_device(a)
