@@ -354,11 +354,13 @@ __global__ void k_build_X(double* X, const double* Tm, int n1, int n1p, int tmat
 // Only the lower triangle is consumed by the factorisation: the wave owning the upper-right
 // quadrant skips its MFMAs.
 __global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __restrict__ a, int slot) {
-  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];
+  // 36.9 KB: four workgroups per CU, i.e. all 1024 systems of a C2 step resident in one round
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
   __shared__ int kp[2 * KP_MAX];
   double* stB = lds;
   double* stA = lds + 2 * STAGE_DOUBLES;
-  double* Cb = lds + 2 * STAGE_DOUBLES;  // aliases the A staging area (used after the k-loop only)
+  double* Cb = lds;  // the C tile aliases the whole staging area (used after the k-loop only)
+  static_assert(TILE_DOUBLES <= STAGE_TOTAL, "C tile must fit in the staging area");
   const int m = blockIdx.x;
   const WavePos wp;
   const TileDesc& d = f.desc[slot];
@@ -546,8 +548,7 @@ __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __
 }
 
 // x = L^{-T} y, one workgroup per system, x kept in LDS, written back over y
-__global__ __launch_bounds__(256) void k_backsolve(FemDev f, const int* __restrict__ slot_of,
-                                                   const int* __restrict__ diag_slot_unused) {
+__global__ __launch_bounds__(256) void k_backsolve(FemDev f) {
   extern __shared__ __align__(16) double xs[];  // nGa
   __shared__ double red[4][64];
   __shared__ double vs[64];
@@ -1438,7 +1439,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
     }
     if (f->T > 0) {
       ROM_PROF(ctx, "backsolve", Mc * 2.0 * 4096 * (f->nslots + f->T), Mc * 8.0 * 4096 * (f->nslots + f->T));
-      k_backsolve<<<Mc, 256, lds_back, st>>>(d, f->d_slot_of, nullptr);
+      k_backsolve<<<Mc, 256, lds_back, st>>>(d);
     }
     if (f->npre > 0) {
       ROM_PROF(ctx, "back_pre", Mc * 2.0 * f->n1p * double(f->n1p) * 3.0 * f->npre, 8.0 * Mc * f->n1p * 4.0 * f->npre);
