@@ -63,6 +63,9 @@ extern "C" int rom_shutdown(rom_ctx* c) {
     hipEventDestroy(r.e0);
     hipEventDestroy(r.e1);
   }
+  for (auto& kv : c->free_blocks)
+    for (double* p : kv.second) hipFree(p);
+  c->free_blocks.clear();
   if (c->d_status) hipFree(c->d_status);
   if (c->d_scratch) hipFree(c->d_scratch);
   hipEventDestroy(c->t0);
@@ -202,15 +205,42 @@ extern "C" int rom_profile_query(rom_ctx* c, int idx, char* name, size_t cap, do
 }
 
 // ---- buffers -------------------------------------------------------------------------------------
+// Device buffers come from a small caching allocator: the host-side drivers (greedy, POD) create and
+// drop many temporaries per iteration, and hipMalloc / hipFree are slow and synchronise the device.
+// A freed block goes back to a per-size free list and is handed to the next request of the same
+// rounded size; because every kernel of the library is enqueued on the context's in-order stream, a
+// recycled block cannot be overwritten before earlier work that used it has finished.
+static size_t round_bytes(size_t bytes) {
+  if (bytes < 4096) return 4096;
+  if (bytes < (size_t(1) << 20)) return (bytes + 4095) / 4096 * 4096;
+  return (bytes + (size_t(1) << 20) - 1) >> 20 << 20;  // 1 MiB granules above 1 MiB
+}
+
 extern "C" int rom_buf_alloc(rom_ctx* c, size_t n, rom_buf** out) {
   ROM_CHECK(c && out, "bad arguments");
   ROM_HIP(hipSetDevice(c->device));
+  const size_t bytes = round_bytes((n ? n : 1) * sizeof(double));
   rom_buf* b = new rom_buf{c, nullptr, n};
-  hipError_t e = hipMalloc(&b->p, (n ? n : 1) * sizeof(double));
-  if (e != hipSuccess) {
-    delete b;
-    rom_set_error("rom_buf_alloc: hipMalloc of %zu bytes failed: %s", n * sizeof(double), hipGetErrorString(e));
-    return ROM_ERR_NOMEM;
+  auto it = c->free_blocks.find(bytes);
+  if (it != c->free_blocks.end() && !it->second.empty()) {
+    b->p = it->second.back();
+    it->second.pop_back();
+    c->cached_bytes -= bytes;
+  } else {
+    hipError_t e = hipMalloc(&b->p, bytes);
+    if (e != hipSuccess && c->cached_bytes > 0) {  // give the cache back and retry once
+      hipStreamSynchronize(c->stream);
+      for (auto& kv : c->free_blocks)
+        for (double* p : kv.second) hipFree(p);
+      c->free_blocks.clear();
+      c->cached_bytes = 0;
+      e = hipMalloc(&b->p, bytes);
+    }
+    if (e != hipSuccess) {
+      delete b;
+      rom_set_error("rom_buf_alloc: hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+      return ROM_ERR_NOMEM;
+    }
   }
   *out = b;
   return ROM_OK;
@@ -218,8 +248,15 @@ extern "C" int rom_buf_alloc(rom_ctx* c, size_t n, rom_buf** out) {
 
 extern "C" int rom_buf_free(rom_buf* b) {
   if (!b) return ROM_OK;
-  hipStreamSynchronize(b->ctx->stream);
-  hipFree(b->p);
+  rom_ctx* c = b->ctx;
+  const size_t bytes = round_bytes((b->n ? b->n : 1) * sizeof(double));
+  if (c->cached_bytes + bytes <= c->cache_limit) {
+    c->free_blocks[bytes].push_back(b->p);
+    c->cached_bytes += bytes;
+  } else {
+    hipStreamSynchronize(c->stream);
+    hipFree(b->p);
+  }
   delete b;
   return ROM_OK;
 }

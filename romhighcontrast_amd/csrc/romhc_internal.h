@@ -64,6 +64,9 @@ struct rom_ctx {
   std::vector<double> prof_flops, prof_bytes;
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> event_pool;
+  // caching allocator of rom_buf blocks (rounded size -> free device pointers)
+  std::map<size_t, std::vector<double*>> free_blocks;
+  size_t cached_bytes = 0, cache_limit = size_t(64) << 30;
   // device status word (not-SPD flag) + scratch for reductions
   int* d_status = nullptr;
   double* d_scratch = nullptr;
