@@ -94,7 +94,12 @@ def main():
 
     # one process per GPU: device = LOCAL_RANK (ROMHC_FORCE_DEVICE only for rehearsing the launch
     # path on a box with fewer GPUs than ranks)
-    dev = int(os.environ.get("ROMHC_FORCE_DEVICE", local_rank))
+    import ctypes
+    ndev = ctypes.c_int(0)
+    _ffi.check(_ffi.load_library().rom_device_count(ctypes.byref(ndev)))
+    # normally every GPU of the node is visible and LOCAL_RANK picks one; if the launcher pinned one
+    # GPU per process (HIP_VISIBLE_DEVICES) only device 0 exists
+    dev = int(os.environ.get("ROMHC_FORCE_DEVICE", local_rank % max(ndev.value, 1)))
     ctx = _ffi.get_context(dev)
     blocks, N, M = tuple(args.blocks), args.N, args.M
     sm = SolutionsManagerFEM(blocks, N, device=dev)
