@@ -243,7 +243,7 @@ class ReducedBasisRandom(BaseReducedBasis):
 
 
 def _top_eigenpairs_device(ctx: _ffi.Context, G: _ffi.Buffer, M: int, nev: int, oversample=12, tol=2e-14,
-                           max_iter=80, seed=0):
+                           max_iter=30, seed=0):
     """Leading ``nev`` eigenpairs of the symmetric PSD matrix G (M x M, device) by orthogonal
     (subspace) iteration with Rayleigh-Ritz acceleration.  Every M-sized operation is an MFMA GEMM
     on the device (``Z = Y G``, ``H = Z Y^T``, the rotations, the residuals, the re-orthogonalised
@@ -278,6 +278,7 @@ def _top_eigenpairs_device(ctx: _ffi.Context, G: _ffi.Buffer, M: int, nev: int, 
         resolvable = theta[:nev] > 1e-13 * abs(theta[0])
         worst = float(res[resolvable].max()) / max(abs(theta[0]), 1e-300) if resolvable.any() else 0.0
         _top_eigenpairs_device.last_iterations = it + 1
+        _top_eigenpairs_device.total_iterations = getattr(_top_eigenpairs_device, 'total_iterations', 0) + 1
         if worst < 0.7 * best:
             best, stall = worst, 0
         else:
@@ -323,11 +324,12 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=2):
         ctx.gram(M, dim, X.buf, 0, dim, G, 0, M)
         lam, W = _top_eigenpairs_device(ctx, G, M, n - found)
         lam = np.maximum(lam, 0.0)
-        # modes of this pass: those well above the Gram roundoff floor of the current block
+        # modes of this pass: those above the Gram roundoff floor of the current (deflated) block; what is
+        # below it after the last pass is fp64 noise of the snapshot set and is returned as zero rows
         floor = lam[0] * 1e-13 if lam[0] > 0 else 0.0
         last_pass = p == passes - 1
         take = 0
-        while found + take < n and take < len(lam) and (lam[take] > floor or last_pass):
+        while found + take < n and take < len(lam) and lam[take] > floor:
             take += 1
         if take == 0:
             break
