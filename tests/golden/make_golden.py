@@ -189,3 +189,52 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def make_g8_experiment():
+    """G8: the reference's experiment() end to end from a scratch copy of the tree (src/config.py mkdirs next
+    to src/, which the read-only mount forbids): sampler outputs + the per-dimension error records."""
+    import shutil
+    import subprocess
+    scratch = os.path.join(tempfile.gettempdir(), "romhc_refcopy")
+    if os.path.exists(scratch):
+        shutil.rmtree(scratch)
+    shutil.copytree(REF, scratch)
+    code = r'''
+import sys, os, numpy as np
+sys.path[:0] = [os.path.join(os.environ["STUB"]), os.environ["SCR"], os.path.join(os.environ["SCR"], "src")]
+import matplotlib
+matplotlib.use("Agg")
+from src.experiments import HighContrast as HC
+from lib.ReducedBasis import ReducedBasisGreedy, ReducedBasisRandom, GREEDY_FOR_H10, GREEDY_FOR_GALERKIN
+builders = [ReducedBasisRandom(), ReducedBasisRandom(False), ReducedBasisGreedy(greedy_for=GREEDY_FOR_H10),
+            ReducedBasisGreedy(greedy_for=GREEDY_FOR_GALERKIN)]
+kw = dict(mesh_discretization_per_dim=6, diff_coef_refinement=2, vn_max_dim=4, num_measurements=12,
+          blocks_geometry=(2, 2), high_contrast_blocks=[[(0, 0), (1, 1)], [(0, 1)]], max_num_samples_offline=30,
+          seed=7, method="lsq")
+sm, data, a, ahc = HC.experiment("g8", reduced_basis_builders=builders, recalculate=True, verbose=False, **kw)
+out = dict(a=a, a_high_contrast=ahc, solutions=data["solutions"], h1=data["solutions_H1norm"])
+for b in builders:
+    key = b.name.replace(" ", "_").replace("$", "").replace("\\", "").replace("^", "").replace("{", "").replace("}", "")
+    out["name_" + key] = np.array(b.name)
+    out["basis_" + key] = np.array(data[b.name]["basis"].basis)
+    for n in range(1, 5):
+        e = data[b.name]["errors"][n]
+        for f in e._fields:
+            out[f"err_{key}_{n}_{f}"] = np.array(getattr(e, f))
+# sampler alone with two more seeds / shapes
+for tag, args in (("s1", ((3, 3), [[(1, 1)]], 4, 3, 25, 42)), ("s2", ((2, 2), [[(0, 0)], [(1, 1)], [(0, 1), (1, 0)]], 4, 1, 20, 3))):
+    sm2, a2, ahc2 = HC.get_a2test_and_train(*args)
+    out[tag + "_a"], out[tag + "_ahc"] = a2, ahc2
+np.savez_compressed(os.environ["OUTF"], **out)
+'''
+    stub = os.path.join(tempfile.gettempdir(), "romhc_refstub")
+    env = dict(os.environ, STUB=stub, SCR=scratch, OUTF=os.path.join(OUT, "g8_experiment.npz"),
+               PYTHONDONTWRITEBYTECODE="1")
+    subprocess.check_call([sys.executable, "-c", code], env=env, cwd=scratch)
+    shutil.rmtree(scratch)
+    print("g8 written")
+
+
+if __name__ == "__main__" and os.environ.get("ROMHC_G8", "1") == "1":
+    make_g8_experiment()

@@ -344,3 +344,33 @@ def test_pickle_roundtrip_of_basis_and_manager(api):
     sm2 = pickle.loads(pickle.dumps(sm))
     assert np.array_equal(rb2.basis, rb.basis)
     assert np.array_equal(sm2.generate_solutions(a[:2]), U[:2])
+
+
+def test_g8_experiment_statistics(api):
+    """The statistics loop of experiment() (HighContrast.py:144-214) on the reference's own sampler output:
+    snapshots, the four default builders, and for n = 1..4 the five error records, against fixture g8."""
+    SM, RB = api
+    from src.experiments.HighContrast import experiment_statistics, get_a2test_and_train
+    z = load_golden("g8_experiment.npz")
+    sm, a, ahc = get_a2test_and_train((2, 2), [[(0, 0), (1, 1)], [(0, 1)]], 6, 2, 30, 7, method="lsq")
+    assert np.array_equal(a, z["a"])
+    builders = [RB.ReducedBasisRandom(), RB.ReducedBasisRandom(False), RB.ReducedBasisGreedy(greedy_for=RB.GREEDY_FOR_H10),
+                RB.ReducedBasisGreedy(greedy_for=RB.GREEDY_FOR_GALERKIN)]
+    data = experiment_statistics(sm, a, builders, vn_max_dim=4, num_measurements=12)
+    g = ro.Geometry((2, 2), 6)
+    # rows with INFINIT_A blocks: kappa ~ 1e11 (reference self-consistency ~1e-6); the rest to 1e-11
+    err = relh10(g, data["solutions"], z["solutions"])
+    hard = (a == RB.INFINIT_A).any(axis=(1, 2))
+    assert err[~hard].max() < SNAP_TOL and err[hard].max() < FLOATING_TOL
+    for b in builders:
+        key = b.name.replace(" ", "_").replace("$", "").replace("\\", "").replace("^", "").replace("{", "").replace("}", "")
+        assert str(z["name_" + key]) == b.name
+        np.testing.assert_allclose(np.array(data[b.name]["basis"].basis), z["basis_" + key],
+                                   atol=1e-5 * np.abs(z["basis_" + key]).max())
+        for n in range(1, 5):
+            e = data[b.name]["errors"][n]
+            # forward modelling / projection errors: BASELINE bound where the reference is itself accurate
+            for f in ("forward_modeling", "projection"):
+                ref = z[f"err_{key}_{n}_{f}"]
+                assert np.max(np.abs(getattr(e, f) - ref)[~hard]) < 1e-9, (b.name, n, f)
+                assert np.max(np.abs(getattr(e, f) - ref)[hard]) < 1e-4, (b.name, n, f)

@@ -124,3 +124,19 @@ def test_sharded_sweep_two_ranks_gloo(tmp_path, M):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "OK" in o
+
+
+def test_parameter_sampler_matches_reference():
+    """get_a2test_and_train's sampling (src/experiments/HighContrast.py:99-115) against the reference's
+    own output for three (geometry, groups, seed) settings (fixture g8)."""
+    from conftest import load_golden
+    from romhighcontrast_amd.experiments import get_full_a, sample_parameters
+    z = load_golden("g8_experiment.npz")
+    a, ahc = sample_parameters((2, 2), [[(0, 0), (1, 1)], [(0, 1)]], 2, 30, 7)
+    assert np.array_equal(a, z["a"]) and np.array_equal(ahc, z["a_high_contrast"])
+    a, ahc = sample_parameters((3, 3), [[(1, 1)]], 3, 25, 42)
+    assert np.array_equal(a, z["s1_a"]) and np.array_equal(ahc, z["s1_ahc"])
+    a, ahc = sample_parameters((2, 2), [[(0, 0)], [(1, 1)], [(0, 1), (1, 0)]], 1, 20, 3)
+    assert np.array_equal(a, z["s2_a"]) and np.array_equal(ahc, z["s2_ahc"])
+    assert np.array_equal(get_full_a(np.array([[2.0, 3.0]]), (2, 2), [[(0, 0)], [(1, 1)]]),
+                          np.array([[[2.0, 1.0], [1.0, 3.0]]]))
