@@ -51,6 +51,22 @@ def calculate_relative_error(sm: SolutionsManager, solutions, approximate_soluti
     return sm.H10norm(approximate_solutions - solutions) / sm.H10norm(solutions)
 
 
+def get_data(experiment_path):
+    """(:93-96) load the experiment cache ``<experiment_path>/data.compressed`` (joblib) or start empty."""
+    import os
+    import joblib
+    data_path = f"{experiment_path}/data.compressed"
+    data = joblib.load(data_path) if os.path.exists(data_path) else dict()
+    return data, data_path
+
+
+def save_data(data, data_path):
+    """The reference's only persistence format (:150,170,214): one joblib dump of the ``data`` dict.
+    Basis objects pickle as plain NumPy arrays + parameters (device handles are rebuilt on load)."""
+    import joblib
+    joblib.dump(data, data_path)
+
+
 def get_a2test_and_train(blocks_geometry, high_contrast_blocks, mesh_discretization_per_dim, diff_coef_refinement,
                          max_num_samples_offline, seed, num_cores=1, method="lsq"):
     """(:99-115) tensor grid in 1/a per coefficient group (uniform in 1/a between 1/INFINIT_A and 1),
@@ -78,7 +94,7 @@ def sample_parameters(blocks_geometry, high_contrast_blocks, diff_coef_refinemen
 
 
 def experiment_statistics(sm, a, reduced_basis_builders, vn_max_dim=20, num_measurements=50, vn_max_dim2do_stats=None,
-                          verbose=False, data=None):
+                          verbose=False, data=None, data_path=None):
     """Snapshots, bases and the per-dimension error / time records of ``experiment()`` (:144-214),
     returned as the same ``data`` dictionary (keys ``solutions``, ``solutions_H1norm``,
     ``time2calculate_*`` and, per builder name, ``basis`` / ``time2build`` / ``errors`` / ``times``).
@@ -120,4 +136,6 @@ def experiment_statistics(sm, a, reduced_basis_builders, vn_max_dim=20, num_meas
                 parameter_estimation_inverse=np.abs(1 - np.array(rb.parameter_estimation_inverse(c)) / a),
                 parameter_estimation_linear=np.abs(1 - np.array(rb.parameter_estimation_linear(c)) / a))
             rec["times"][n] = TypeOfProblems(fm_time, pj_time, se_time, inv_time, lin_time)
+    if data_path is not None:
+        save_data(data, data_path)
     return data

@@ -8,7 +8,8 @@ if _root not in _sys.path:
     _sys.path.insert(0, _root)
 
 from romhighcontrast_amd.experiments import (MachinePrecision, TypeOfProblems, calculate_relative_error,  # noqa: E402,F401
-                                             calculate_time, experiment_statistics, get_a2test_and_train, get_full_a)
+                                             calculate_time, experiment_statistics, get_a2test_and_train, get_data,
+                                             get_full_a, save_data)
 from romhighcontrast_amd.lib.ReducedBasis import (GREEDY_FOR_GALERKIN, GREEDY_FOR_H10, INFINIT_A,  # noqa: E402,F401
                                                   ReducedBasisGreedy, ReducedBasisRandom)
 from romhighcontrast_amd.lib.SolutionsManagers import SolutionsManager, SolutionsManagerFEM  # noqa: E402,F401

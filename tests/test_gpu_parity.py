@@ -356,7 +356,15 @@ def test_g8_experiment_statistics(api):
     assert np.array_equal(a, z["a"])
     builders = [RB.ReducedBasisRandom(), RB.ReducedBasisRandom(False), RB.ReducedBasisGreedy(greedy_for=RB.GREEDY_FOR_H10),
                 RB.ReducedBasisGreedy(greedy_for=RB.GREEDY_FOR_GALERKIN)]
-    data = experiment_statistics(sm, a, builders, vn_max_dim=4, num_measurements=12)
+    import tempfile
+    from src.experiments.HighContrast import get_data
+    with tempfile.TemporaryDirectory() as tmp:
+        data0, data_path = get_data(tmp)
+        assert data0 == {}
+        data = experiment_statistics(sm, a, builders, vn_max_dim=4, num_measurements=12, data_path=data_path)
+        loaded, _ = get_data(tmp)  # joblib round trip of the reference's cache layout
+        assert np.array_equal(loaded["solutions"], data["solutions"])
+        assert np.array_equal(loaded[builders[2].name]["basis"].basis, data[builders[2].name]["basis"].basis)
     g = ro.Geometry((2, 2), 6)
     # rows with INFINIT_A blocks: kappa ~ 1e11 (reference self-consistency ~1e-6); the rest to 1e-11
     err = relh10(g, data["solutions"], z["solutions"])
