@@ -303,6 +303,42 @@ def test_full_size_c2_properties(api):
     np.testing.assert_allclose(sm.H10norm(Ud)[idx], ro.H10norm(g, Ug), rtol=1e-12)
 
 
+def test_full_size_c4_properties(api):
+    """BASELINE config C4 geometry ((3,3)/N=171: 512 x 512 unknowns, contrast up to 1e8): residual through the
+    independent stencil kernel, one row against SuperLU, norms, and a short greedy on the device block."""
+    SM, RB = api
+    from romhighcontrast_amd import _ffi
+    sm = SM.SolutionsManagerFEM((3, 3), 171)
+    ctx, fem, dim = sm._ctx, sm._fem, sm.vspace_dim
+    assert dim == 262144
+    M = 48
+    rng = np.random.default_rng(20240807)
+    a = np.ones((M, 3, 3))
+    for jb in range(9):
+        a[1 + jb].flat[jb] = 1e8          # the "limit solutions" the reference seeds its training sets with
+    a[10] = 1e8
+    a[11:] = 10.0 ** rng.uniform(0, 8, size=(M - 11, 3, 3))
+    Ud = sm.generate_solutions_device(a)
+    Y = ctx.alloc(dim)
+    for m in (0, 3, 10, M - 1):
+        row = _ffi.Buffer(ctx, dim).copy_from(Ud.buf, dim, 0, m * dim)
+        fem.stencil_apply(row, 1, Y, a_one=a[m].ravel())
+        res = Y.download(dim) - sm.B_total
+        u = row.download(dim)
+        assert np.abs(res).max() < 1e-11 * np.abs(u).max() * 4 * a[m].max()
+    g = ro.Geometry((3, 3), 171)
+    m = M - 1
+    uo = ro.solve_one(g, a[m], ro.load_vector(g), "lsqsparse")
+    ug = Ud.buf.download(dim, offset=m * dim)
+    assert relh10(g, ug[None], uo[None]).max() < SNAP_TOL
+    h1 = sm.H10norm(Ud)
+    np.testing.assert_allclose(h1[m], ro.H10norm(g, ug[None])[0], rtol=1e-12)
+    rb = RB.ReducedBasisGreedy(RB.GREEDY_FOR_H10).build(6, sm, Ud, a, h1)
+    assert rb.picks[0] == 0 and rb.max_errors[0] == 1.0
+    assert all(e2 <= e1 * (1 + 1e-12) for e1, e2 in zip(rb.max_errors, rb.max_errors[1:]))  # greedy errors decrease
+    assert rb.basis.shape == (6, dim)
+
+
 def test_rccl_single_rank_allgather(api):
     """The RCCL plumbing with a 1-rank communicator (a box has one GPU): id, init, all-gather, reduce."""
     from romhighcontrast_amd import _ffi, sweep
