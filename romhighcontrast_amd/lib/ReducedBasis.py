@@ -94,7 +94,8 @@ def sort_orthogonalize_base(a_selected, rb):
 
 
 class BaseReducedBasis:
-    """(:32-98)."""
+    """Container of a reduced basis (rows of ``basis``) and the parameters it came from, with the online
+    operations of the reference (:32-98).  Pure host object: picklable, no device state."""
 
     def __init__(self):
         self.basis = None
@@ -103,14 +104,15 @@ class BaseReducedBasis:
         self.linear_parameter_estimator = None
 
     def build(self, **kwargs):
-        raise Exception("Not implemented.")
+        raise Exception("Not implemented.")  # (:39-40)
 
     def set(self, basis, a):
-        self.basis = basis
-        self.a = a
+        """(:42-46) install a basis and the two parameter estimators built on its parameters."""
+        self.basis, self.a = basis, a
         self.inverse_parameter_estimator = EstimatorInv(a)
         self.linear_parameter_estimator = EstimatorLinear(a)
 
+    # -- sizes -----------------------------------------------------------------------------------------
     @property
     def dim(self):
         return np.shape(self.basis)[0]
@@ -120,39 +122,44 @@ class BaseReducedBasis:
         return np.shape(self.basis)[1]
 
     def __str__(self):
-        return self.__class__.__name__
+        return type(self).__name__
 
+    def __getitem__(self, item):
+        """(:88-92) sub-basis with the same slicing applied to vectors and parameters."""
+        sub = BaseReducedBasis()
+        sub.set(basis=self.basis[item], a=self.a[item])
+        return sub
+
+    # -- online stage: thin wrappers over the solutions manager (GPU) ---------------------------------------
     def forward_modeling(self, sm: SolutionsManager, a: np.ndarray):
+        """(:59-60) Galerkin reduced-order solutions for the parameters ``a``."""
         return sm.generate_fm_solutions(a=a, coefficients_rom=self.basis)
 
     def projection(self, sm: SolutionsManager, true_solutions: np.ndarray):
+        """(:62-63) H^1_0-orthogonal projections of ``true_solutions``."""
         return sm.project_solutions(true_solutions, self.basis)
 
     def state_estimation(self, sm: SolutionsManager, measurement_points: np.ndarray, measurements: np.ndarray,
                          return_coefs=False):
-        """(:65-70) least squares on point evaluations of the basis (tiny m x n problem, host)."""
-        rb_evaluations_in_points = sm.evaluate_solutions(measurement_points, self.basis)
-        c = np.linalg.lstsq(rb_evaluations_in_points.T, measurements.T, rcond=-1)[0]
-        solution_estimations = c.T @ np.array(self.basis)
-        return (c, solution_estimations) if return_coefs else solution_estimations
+        """(:65-70) fit the basis coefficients to point measurements: the basis is evaluated at the
+        measurement points on the device, the (points x n) least-squares problem is solved on the host."""
+        E = sm.evaluate_solutions(measurement_points, self.basis)          # (n, points)
+        c, *_ = np.linalg.lstsq(E.T, measurements.T, rcond=-1)              # (n, n_measured_states)
+        estimates = c.T @ np.array(self.basis)
+        return (c, estimates) if return_coefs else estimates
 
     def parameter_estimation_inverse(self, c):
+        """(:72-78) harmonic-mean style estimate from the state-estimation coefficients."""
         return self.inverse_parameter_estimator.estimate_parameter(c_values=c)
 
     def parameter_estimation_linear(self, c):
+        """(:80-86) linear estimate from the state-estimation coefficients."""
         return self.linear_parameter_estimator.estimate_parameter(c_values=c)
 
-    def __getitem__(self, item):
-        rb = BaseReducedBasis()
-        rb.set(basis=self.basis[item], a=self.a[item])
-        return rb
-
     def orthonormalize(self):
-        """(:94-98)."""
-        _, self.basis = sort_orthogonalize_base(
-            get_high_contrast_coefficient(self.a),
-            np.reshape(self.basis, (-1, self.ambient_space_dim))
-        )
+        """(:94-98) replace the basis by its contrast-sorted Euclidean-orthonormal version."""
+        vectors = np.reshape(self.basis, (-1, self.ambient_space_dim))
+        self.basis = sort_orthogonalize_base(get_high_contrast_coefficient(self.a), vectors)[1]
 
 
 class ReducedBasisGreedy(BaseReducedBasis):
@@ -205,27 +212,24 @@ class ReducedBasisGreedy(BaseReducedBasis):
 
 
 def get_inf_solutions_starting_basis(solutions2train, a2train, only_one_block=True):
-    """(:142-150) split off the snapshots that have blocks exactly equal to INFINIT_A."""
-    a2train = np.asarray(a2train)
-    solutions2train = np.asarray(solutions2train)
-    num_hc_blocks = np.sum(a2train == INFINIT_A, axis=(-1, -2))
-    chosen = (num_hc_blocks == 1) if only_one_block else (num_hc_blocks != 0)
-    chosen_ix, free_ix = np.flatnonzero(chosen), np.flatnonzero(~chosen)
-    return solutions2train[chosen_ix], a2train[chosen_ix], solutions2train[free_ix], a2train[free_ix]
+    """(:142-150) peel off the snapshots that have blocks exactly at INFINIT_A (exactly one such block, or
+    any number, per the flag).  Returns (chosen solutions, chosen a, remaining solutions, remaining a)."""
+    a2train, solutions2train = np.asarray(a2train), np.asarray(solutions2train)
+    n_inf = (a2train == INFINIT_A).reshape(len(a2train), -1).sum(axis=1)
+    chosen = (n_inf == 1) if only_one_block else (n_inf > 0)
+    return solutions2train[chosen], a2train[chosen], solutions2train[~chosen], a2train[~chosen]
 
 
 def get_starting_basis(solutions2train, a2train, add_inf_solutions=True):
-    """(:153-164)."""
-    basis, a, solutions2train, a2train = get_inf_solutions_starting_basis(solutions2train, a2train,
-                                                                          only_one_block=False)
+    """(:153-164) the INFINIT_A snapshots always leave the pool; they lead the basis only on request."""
+    lead, lead_a, pool, pool_a = get_inf_solutions_starting_basis(solutions2train, a2train, only_one_block=False)
     if not add_inf_solutions:
-        basis = np.empty((0, np.shape(solutions2train)[1]))
-        a = np.empty((0,) + np.shape(a2train)[1:])
-    return basis, a, solutions2train, a2train
+        lead, lead_a = np.empty((0, pool.shape[1])), np.empty((0,) + pool_a.shape[1:])
+    return lead, lead_a, pool, pool_a
 
 
 class ReducedBasisRandom(BaseReducedBasis):
-    """(:167-180) host indexing only."""
+    """(:167-180) seeded random snapshots behind the optional INFINIT_A lead -- host indexing only."""
 
     def __init__(self, add_inf_solutions=True):
         self.add_inf_solutions = add_inf_solutions
@@ -234,11 +238,10 @@ class ReducedBasisRandom(BaseReducedBasis):
 
     def build(self, n: int, sm: SolutionsManager, solutions2train, a2train: List[np.ndarray] = (()),
               solutions2train_h1norm=1, seed=42, **kwargs):
-        basis, a, solutions2train, a2train = get_starting_basis(solutions2train, a2train, self.add_inf_solutions)
+        lead, lead_a, pool, pool_a = get_starting_basis(solutions2train, a2train, self.add_inf_solutions)
         np.random.seed(seed)
-        chosen_ix = np.random.choice(len(solutions2train), size=n, replace=False)
-        super().set(basis=np.vstack((basis, solutions2train[chosen_ix]))[:n],
-                    a=np.vstack((a, a2train[chosen_ix]))[:n])
+        picked = np.random.choice(len(pool), size=n, replace=False)
+        self.set(basis=np.vstack((lead, pool[picked]))[:n], a=np.vstack((lead_a, pool_a[picked]))[:n])
         return self
 
 
