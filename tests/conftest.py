@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the shared library is a build artefact (git-ignored): build it when a fresh checkout has none
+    lib = os.path.join(ROOT, "romhighcontrast_amd", "csrc", "libromhc.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def load_golden(name):
