@@ -134,6 +134,37 @@ __device__ inline void gemm_loop2(int nchunks, FA loadA, FB loadB, FP active, Ac
   __syncthreads();
 }
 
+// Staging map for rows that are only 8-byte aligned (odd leading dimension, e.g. snapshot rows of odd
+// length): lane -> k (t & 15), so that one wave-instruction reads four rows x 128 contiguous bytes;
+// thread t handles rows (t >> 4) + 16 x, x = 0..3, of the 64-row chunk.
+__device__ inline int kmajor_k() { return threadIdx.x & 15; }
+__device__ inline int kmajor_row(int x) { return (threadIdx.x >> 4) + 16 * x; }
+__device__ inline void stage_store_kmajor(double* s, const double v[4]) {
+#pragma unroll
+  for (int x = 0; x < 4; ++x) s[kmajor_row(x) * LDK + kmajor_k()] = v[x];
+}
+
+template <class FA, class FB>
+__device__ inline void gemm_loop_kmajor(int nchunks, FA loadA, FB loadB, Acc& acc, double* stage, const WavePos& wp) {
+  if (nchunks <= 0) return;
+  double va[4], vb[4];
+  loadA(0, va);
+  loadB(0, vb);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    double* sA = stage + (ch & 1) * STAGE_DOUBLES;
+    double* sB = stage + 2 * STAGE_DOUBLES + (ch & 1) * STAGE_DOUBLES;
+    stage_store_kmajor(sA, va);
+    stage_store_kmajor(sB, vb);
+    __syncthreads();
+    if (ch + 1 < nchunks) {
+      loadA(ch + 1, va);
+      loadB(ch + 1, vb);
+    }
+    mma_chunk(sA, sB, acc, wp);
+  }
+  __syncthreads();
+}
+
 template <class FA, class FB>
 __device__ inline void gemm_loop(int nchunks, FA loadA, FB loadB, Acc& acc, double* stage, const WavePos& wp) {
   gemm_loop2(nchunks, loadA, loadB, [](int) { return true; }, acc, stage, stage + 2 * STAGE_DOUBLES, wp);

@@ -49,15 +49,39 @@ __global__ __launch_bounds__(256) void k_gemm_nt(long long m, long long n, long 
   const WavePos wp;
   const long long r0 = ty * 64LL, c0 = tx * 64LL;
   const long long kbeg = blockIdx.z * kper, kend = std::min<long long>(K, kbeg + kper);
-  const int srow = stage_row(), sseg = stage_seg();
-  const double* Ar = (r0 + srow < m) ? A + (r0 + srow) * lda : nullptr;
-  const double* Br = (c0 + srow < n) ? B + (c0 + srow) * ldb : nullptr;
   Acc acc;
   acc_zero(acc);
   const int nch = int((kend - kbeg + BK - 1) / BK);
-  gemm_loop(
-      nch, [&](int ch, double* v) { load4_row<ALIGNED>(Ar, kbeg + ch * BK + sseg, kend, v); },
-      [&](int ch, double* v) { load4_row<ALIGNED>(Br, kbeg + ch * BK + sseg, kend, v); }, acc, stage, wp);
+  if (ALIGNED) {  // rows 16-byte aligned: each thread streams 32 contiguous bytes of one row
+    const int srow = stage_row(), sseg = stage_seg();
+    const double* Ar = (r0 + srow < m) ? A + (r0 + srow) * lda : nullptr;
+    const double* Br = (c0 + srow < n) ? B + (c0 + srow) * ldb : nullptr;
+    gemm_loop(
+        nch, [&](int ch, double* v) { load4_row<ALIGNED>(Ar, kbeg + ch * BK + sseg, kend, v); },
+        [&](int ch, double* v) { load4_row<ALIGNED>(Br, kbeg + ch * BK + sseg, kend, v); }, acc, stage, wp);
+  } else {  // odd leading dimension: lane -> k, a wave-instruction covers 4 rows x 128 contiguous bytes
+    const long long kk = kmajor_k();
+    const double* Ar[4];
+    const double* Br[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      Ar[x] = (r0 + kmajor_row(x) < m) ? A + (r0 + kmajor_row(x)) * lda : nullptr;
+      Br[x] = (c0 + kmajor_row(x) < n) ? B + (c0 + kmajor_row(x)) * ldb : nullptr;
+    }
+    gemm_loop_kmajor(
+        nch,
+        [&](int ch, double* v) {
+          const long long k = kbeg + ch * BK + kk;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) v[x] = (Ar[x] && k < kend) ? Ar[x][k] : 0.0;
+        },
+        [&](int ch, double* v) {
+          const long long k = kbeg + ch * BK + kk;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) v[x] = (Br[x] && k < kend) ? Br[x][k] : 0.0;
+        },
+        acc, stage, wp);
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -162,6 +186,138 @@ extern "C" int rom_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double
                             "gemm_nt");
 }
 
+// ============================================================================================
+// Gram matrix with 128 x 128 workgroup tiles (each wave a 64 x 64 quadrant = 4 x 4 MFMA accumulators):
+// twice the arithmetic intensity of the 64 x 64 engine (16 flop per operand byte), which is what the
+// snapshot Gram needs once the block no longer fits in the Infinity Cache (C5: 34 GB).
+// 1-D grid over the lower tiles (XCD-balanced) x split-K; partial tiles go to `part`, reduced + mirrored after.
+// ============================================================================================
+constexpr int G128_STAGE = 128 * LDK;  // one operand chunk [128][BK]
+
+__global__ __launch_bounds__(256) void k_gram128(long long m, long long K, long long kper, const double* __restrict__ A,
+                                                 long long lda, double* __restrict__ part) {
+  __shared__ __align__(16) double lds[4 * G128_STAGE];  // {A,B} x 2 buffers = 73,728 B
+  const long long t = blockIdx.x;
+  long long ty = (long long)((sqrt(8.0 * double(t) + 1.0) - 1.0) * 0.5);
+  while (ty * (ty + 1) / 2 > t) --ty;
+  while ((ty + 1) * (ty + 2) / 2 <= t) ++ty;
+  const long long tx = t - ty * (ty + 1) / 2;
+  const long long r0 = ty * 128, c0 = tx * 128;
+  const long long kbeg = blockIdx.z * kper, kend = std::min<long long>(K, kbeg + kper);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
+  // staging: lane -> k (t & 15), thread t handles rows (t >> 4) + 16 x, x = 0..7: one wave-instruction
+  // reads 4 rows x 128 contiguous bytes whatever the alignment of the (odd-length) snapshot rows
+  const int sk = threadIdx.x & 15, sr0 = threadIdx.x >> 4;
+  const double* Ar[8];
+  const double* Br[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) {
+    Ar[x] = (r0 + sr0 + 16 * x < m) ? A + (r0 + sr0 + 16 * x) * lda : nullptr;
+    Br[x] = (c0 + sr0 + 16 * x < m) ? A + (c0 + sr0 + 16 * x) * lda : nullptr;
+  }
+  d4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+  auto load8 = [&](const double* const* rows, long long k0, double* v) {
+    const long long k = k0 + sk;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) v[x] = (rows[x] && k < kend) ? rows[x][k] : 0.0;
+  };
+  auto store8 = [&](double* sbuf, const double* v) {
+#pragma unroll
+    for (int x = 0; x < 8; ++x) sbuf[(sr0 + 16 * x) * LDK + sk] = v[x];
+  };
+  const int nch = int((kend - kbeg + BK - 1) / BK);
+  double va[8], vb[8];
+  if (nch > 0) {
+    load8(Ar, kbeg, va);
+    load8(Br, kbeg, vb);
+  }
+  const int fr = lane & 15, kq = lane >> 4;
+  for (int ch = 0; ch < nch; ++ch) {
+    double* sA = lds + (ch & 1) * 2 * G128_STAGE;
+    double* sB = sA + G128_STAGE;
+    store8(sA, va);
+    store8(sB, vb);
+    __syncthreads();
+    if (ch + 1 < nch) {
+      load8(Ar, kbeg + (ch + 1) * BK, va);
+      load8(Br, kbeg + (ch + 1) * BK, vb);
+    }
+    const double* pa = sA + (wr * 64 + fr) * LDK + kq;
+    const double* pb = sB + (wc * 64 + fr) * LDK + kq;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = pa[i * 16 * LDK + kk];
+        bf[i] = pb[i * 16 * LDK + kk];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // raw partial tile: part[z][m][m]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const long long r = r0 + wr * 64 + i * 16 + (lane >> 4) + 4 * g;
+      if (r >= m) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long c = c0 + wc * 64 + j * 16 + (lane & 15);
+        if (c < m) part[(blockIdx.z * m + r) * m + c] = acc[i][j][g];
+      }
+    }
+}
+
+// C = sum_z part[z] on the lower 128-tiles, mirrored into the strict upper triangle
+__global__ void k_gram128_finish(long long m, int splits, const double* __restrict__ part, double* __restrict__ C,
+                                 long long ldc) {
+  long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= m * m) return;
+  long long r = idx / m, c = idx % m;
+  if (c > r) return;  // the upper triangle is written by the mirror image below the diagonal
+  double s = 0.0;
+  for (int z = 0; z < splits; ++z) s += part[z * m * m + idx];
+  C[r * ldc + c] = s;
+  if (c != r) C[c * ldc + r] = s;
+}
+
+static int launch_gram128(rom_ctx* ctx, int64_t m, int64_t k, const double* A, int64_t lda, double* C, int64_t ldc) {
+  const long long nt = (m + 127) / 128, tiles = nt * (nt + 1) / 2;
+  // split K so that the grid fills whole rounds of the 512 resident workgroups (2 per CU) with little tail
+  const long long smax = std::max<long long>(1, std::min<long long>(64, (k + 2047) / 2048));
+  int splits = 1;
+  double best = 1e30;
+  for (long long sp = 1; sp <= smax; ++sp) {
+    const double rounds = std::ceil(double(tiles * sp) / 512.0);
+    const double cost = rounds / double(sp) + 0.002 * sp;  // time ~ rounds * (K / sp); mild penalty on partial traffic
+    if (cost < best) { best = cost; splits = int(sp); }
+  }
+  long long kper = ((k + splits - 1) / splits + BK - 1) / BK * BK;
+  splits = int((k + kper - 1) / kper);
+  double* part = nullptr;
+  ROM_TRY(rom_ctx_scratch(ctx, size_t(splits) * m * m, &part));
+  {
+    ROM_PROF(ctx, "gram128", double(tiles) * 2.0 * 128 * 128 * k, 8.0 * (2.0 * tiles * 128 * double(k) + double(m) * m));
+    k_gram128<<<dim3(unsigned(tiles), 1, unsigned(splits)), 256, 0, ctx->stream>>>(m, k, kper, A, lda, part);
+  }
+  ROM_HIP(hipGetLastError());
+  {
+    ROM_PROF(ctx, "gram128_finish", double(splits) * m * m, 8.0 * double(splits + 1) * m * m);
+    k_gram128_finish<<<unsigned((m * m + 255) / 256), 256, 0, ctx->stream>>>(m, splits, part, C, ldc);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
 extern "C" int rom_gram(rom_ctx* ctx, int64_t m, int64_t k, rom_buf* A, size_t a_off, int64_t lda, rom_buf* C,
                         size_t c_off, int64_t ldc) {
   ROM_CHECK(ctx && A && C, "rom_gram: null argument");
@@ -169,6 +325,7 @@ extern "C" int rom_gram(rom_ctx* ctx, int64_t m, int64_t k, rom_buf* A, size_t a
   if (m == 0) return ROM_OK;
   ROM_CHECK(a_off + size_t(m - 1) * lda + k <= A->n, "rom_gram: A out of range");
   ROM_CHECK(c_off + size_t(m - 1) * ldc + m <= C->n, "rom_gram: C out of range");
+  if (m >= 512 && k >= 4096) return launch_gram128(ctx, m, k, A->p + a_off, lda, C->p + c_off, ldc);
   return rom_launch_gemm_nt_ex(ctx, m, m, k, 1.0, A->p + a_off, lda, A->p + a_off, lda, 0.0, C->p + c_off, ldc, "gram",
                                1);
 }

@@ -16,7 +16,7 @@ if which == "c4":
     a[10] = 1e8
     a[11:] = 10.0 ** rng.uniform(0, 8, size=(M - 11, 3, 3))
 else:
-    blocks, N, M = (4, 4), 256, 64
+    blocks, N, M = (4, 4), 256, int(os.environ.get("M", "64"))
     a = 10.0 ** np.random.default_rng(20240807).uniform(0, 3, size=(M, 4, 4))
 t0 = time.time()
 fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)

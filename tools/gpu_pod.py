@@ -21,6 +21,8 @@ print(f"gram (lower+mirror) {t*1e3:.2f} ms -> {M*(M+64)*dim/t*1e-12:.2f} TFLOP/s
 G2 = ctx.alloc(M * M)
 _, t = T(lambda: ctx.gemm_nt(M, M, dim, X, 0, dim, X, 0, dim, G2, 0, M)); _, t = T(lambda: ctx.gemm_nt(M, M, dim, X, 0, dim, X, 0, dim, G2, 0, M))
 print(f"gemm_nt full {t*1e3:.2f} ms -> {2*M*M*dim/t*1e-12:.2f} TFLOP/s")
+g1 = G.download(M * M, shape=(M, M)); g2 = G2.download(M * M, shape=(M, M))
+print("gram vs gemm_nt max rel diff", np.abs(g1 - g2).max() / np.abs(g2).max(), "symmetric:", bool((g1 == g1.T).all()))
 (lam, W), t = T(lambda: RB._top_eigenpairs_device(ctx, G, M, r)); print(f"eigs {t*1e3:.2f} ms, {RB._top_eigenpairs_device.last_iterations} iterations")
 Gh = G.download(M * M, shape=(M, M)); t0 = time.perf_counter(); lr = np.linalg.eigvalsh(Gh)[::-1]; print(f"host eigvalsh {1e3*(time.perf_counter()-t0):.1f} ms; resolvable {int((lr[:r] > 1e-13*lr[0]).sum())}, their max rel err {np.max((np.abs(lam-lr[:r])/lr[:r])[lr[:r] > 1e-13*lr[0]]):.2e}")
 V = ctx.alloc(r * dim)
