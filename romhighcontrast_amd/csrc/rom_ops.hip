@@ -345,7 +345,9 @@ __global__ __launch_bounds__(256) void k_gemm_nn(long long m, long long n, long 
   const int t = threadIdx.x;
   const int srow = stage_row(), sseg = stage_seg();
   const double* Ar = (r0 + srow < m) ? A + (r0 + srow) * lda : nullptr;
-  const int bk = t >> 4, bc = (t & 15) * 4;  // B staging: row k0+bk, 4 consecutive columns
+  // B staging: lane -> column (t & 63), thread t handles k rows (t >> 6) + 4 x: every wave-instruction
+  // reads 512 contiguous bytes of one row of B
+  const int bc = t & 63, bk0 = t >> 6;
   Acc acc;
   acc_zero(acc);
   for (long long k0 = 0; k0 < K; k0 += BK) {
@@ -353,13 +355,13 @@ __global__ __launch_bounds__(256) void k_gemm_nn(long long m, long long n, long 
     load4_row<false>(Ar, k0 + sseg, K, va);
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      long long c = c0 + bc + x;
-      vb[x] = (k0 + bk < K && c < n) ? B[(k0 + bk) * ldb + c] : 0.0;
+      const long long kk = k0 + bk0 + 4 * x, c = c0 + bc;
+      vb[x] = (kk < K && c < n) ? B[kk * ldb + c] : 0.0;
     }
     __syncthreads();  // previous chunk fully consumed
     stage_store(sA, va);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) sB[(bc + x) * LDK + bk] = vb[x];
+    for (int x = 0; x < 4; ++x) sB[bc * LDK + bk0 + 4 * x] = vb[x];
     __syncthreads();
     mma_chunk(sA, sB, acc, wp);
   }
