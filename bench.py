@@ -69,8 +69,8 @@ def stdout_to_stderr():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--M", type=int, default=1024, help="parameters per GPU per step")
     ap.add_argument("--N", type=int, default=128, help="cells per block per dimension")
     ap.add_argument("--blocks", type=int, nargs=2, default=[2, 2])
