@@ -40,9 +40,19 @@ def sharded_sweep(a_all, world: int, rank: int, solve_local, allgather):
 
 
 # ---- rendezvous for the RCCL unique id (one node, processes started by torch.distributed.run) ----
+def _launcher_start_time() -> str:
+    """Start time (clock ticks since boot) of the parent process = the launcher that spawned all ranks;
+    together with its pid this identifies one launch even if pids and ports get reused."""
+    try:
+        with open(f"/proc/{os.getppid()}/stat") as f:
+            return f.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        return "0"
+
+
 def rendezvous_path() -> str:
     tag = "_".join([os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
-                    os.environ.get("TORCHELASTIC_RUN_ID", "none"), str(os.getppid())])
+                    os.environ.get("TORCHELASTIC_RUN_ID", "none"), str(os.getppid()), _launcher_start_time()])
     return os.path.join(tempfile.gettempdir(), f"romhc_rdzv_{tag}.bin")
 
 
