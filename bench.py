@@ -30,7 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X spec fp64 matrix peak; sustained microbench: 47.1
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X spec fp64 matrix peak; the instruction itself sustains 48.8
 HBM_PEAK_GBS = 8000.0
 
 
@@ -203,9 +203,10 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / FP64_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_ms": round(d["total_ms"] / d["launches"], 5),
                 "flops_per_launch": d["flops"] / d["launches"],
-                "peak_measured_sustained": 47.1,
-                "note": "fp64 MFMA (v_mfma_f64_16x16x4_f64); peak = spec fp64 matrix rate; a bare MFMA loop "
-                        "sustains 47.1 TFLOP/s on this part (tools/mfma_f64_peak.hip)"}
+                "peak_measured_sustained": 48.8,
+                "note": "fp64 MFMA (v_mfma_f64_16x16x4_f64); peak = spec fp64 matrix rate; the instruction issues "
+                        "every ~100 cycles per SIMD at 2.35-2.4 GHz, i.e. 48.8 TFLOP/s with 8 waves/SIMD x 8 "
+                        "independent accumulators (tools/mfma_f64_peak2.hip, profiles/r01_mfma_f64_peak_microbench_v2.txt)"}
     # PMC-measured memory-side traffic of the dominant kernel, if a summary of separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command is committed
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
