@@ -32,9 +32,10 @@ void run(double* d, unsigned long long* dc, int wg_per_cu) {
   unsigned long long c[2]; hipMemcpy(c, dc, 16, hipMemcpyDeviceToHost);
   double fl = 256.0 * wg_per_cu * 4 * iters * NACC * 2048.0;
   double ghz = double(c[0]) / double(c[1]) * 0.1;  // memrealtime ticks at 100 MHz
-  double cyc_per_mfma_simd = double(c[0]) / (double(iters) * NACC * wg_per_cu);
-  printf("acc/wave %2d, waves/SIMD %d: %6.2f TFLOP/s, in-kernel clock %.2f GHz, %.1f cycles per MFMA per SIMD\n", NACC,
-         wg_per_cu, fl / ms * 1e-9, ghz, cyc_per_mfma_simd);
+  double tf = fl / ms * 1e-9;
+  double interval = 2048.0 * 1024.0 * ghz * 1e9 / (tf * 1e12);  // chip rate -> issue interval per SIMD at that clock
+  printf("acc/wave %2d, waves/SIMD %d: %6.2f TFLOP/s, in-kernel clock %.2f GHz -> one MFMA per %.0f cycles per SIMD\n", NACC,
+         wg_per_cu, tf, ghz, interval);
 }
 int main() {
   double* d; unsigned long long* dc;
