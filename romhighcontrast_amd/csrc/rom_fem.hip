@@ -9,11 +9,21 @@
 // vertices (edges between blocks + cross points)
 //        S(a) u_G = g,      S(a) = A_GG(a) - sum_b a_b T_b,     g parameter independent,
 // with T_b the (dense) Dirichlet-to-Neumann blocks of the unit square, identical for all blocks
-// up to the side pairing (16 tables T[sr][sc]).  Per parameter the work is: assemble S(a) tile by
-// tile (never stored: each tile is built in registers when it is factored), a left-looking 64x64
-// tile Cholesky on MFMA with the forward substitution fused in, a backward substitution, and the
-// harmonic extension  u_I,b = (h^2/a_b) W + sum_sides H_s u_G|side   as one batched MFMA GEMM
-// that writes the snapshot rows straight into the caller's (M, dim) matrix.
+// up to the side pairing (16 tables T[sr][sc]).  Two further reductions are parameter independent
+// up to scalar weights and therefore tabulated once per FE space:
+//   (1) an independent set of edges (no two on the same block) has the self block (a_p + a_q) K with K
+//       fixed, so it is eliminated in closed form (tables X K^-1 X^T);
+//   (2) on every remaining ("active") edge f all couplings to the rest of the interface act through a
+//       numerically low-rank range W_f (the smooth traces of the neighbouring sides + the end nodes
+//       that touch cross points), so u_f = P_f z_f + p0_f / s_f with z_f = W_f^T u_f of dimension
+//       rank(W_f) ~ 30 at N = 128, and the system that is actually factorised couples only the z_f
+//       and the cross points.
+// Per parameter the work is: assemble the reduced system tile by tile (never stored: each tile is
+// built in registers when it is factored), a left-looking 64x64 tile Cholesky on MFMA with the
+// forward substitution fused in, a backward substitution, the expansion z -> edge values, the back
+// substitution of the closed-form edges, and the harmonic extension
+//        u_I,b = (h^2/a_b) W + sum_sides H_s u_G|side
+// as one batched MFMA GEMM that writes the snapshot rows straight into the caller's (M, dim) matrix.
 //
 // Setup tables come from the sine (DST-I) eigenbasis of the block:  H_0[(i,j),k] =
 // sum_m Q[j,m] rho_m(i) Q[k,m], rho_m(i) = sinh((N-i) phi_m)/sinh(N phi_m), cosh phi_m = 2-cos(pi m/N);
@@ -23,30 +33,35 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <set>
 
+#include "rom_hostla.h"
 #include "rom_mma.h"
 
 // ============================================================================================
 // device-side view of a rom_fem
 // ============================================================================================
 struct FemDev {
-  int nrb, ncb, N, n1, n1p, nr, nc, nGp, nGa, T, nslots, kblk, npre, nrhs;
+  int nrb, ncb, N, n1, n1p, nr, nc, nGp, nGa, T, nslots, kblk, npre, nrhs, nexp, ncross, xb0;
   long long dim;
-  const double* R;
+  const double* pool;  // 64x64 tables of the tile terms
+  const GenTerm* terms;
+  const double* Bt;    // back substitution tables of the closed-form edges
+  const double* P;     // expansion tables of the active edges
   const double* vec;
   const RhsTerm* rhs;
   const PreEdge* pre;
+  const ExpEdge* exp;
+  const int* xred;
   const double* A0;    // (n1*n1) x n1p : Q[j,mode] rho_mode(i), harmonic extension in the sine basis
   const double* Qp;    // n1p x n1p sine matrix (zero padded)
   const int* kmax;     // [N+1] modes (multiple of 16) that matter at distance d from a side
-  const int* epos;     // position of every edge's n1p block in the interface vectors
+  const int* epos;     // position of every edge's nodal n1p block in the interface vectors
   double* yhat;        // [Mc][nGp] sine coefficients of the interface values
-  const double* Tm;
   const double* W;
   const double* g;
   const TileDesc* desc;
-  const TileExtra* extra;
   const int* kptr;
   const int* kpair;
   const int* colptr;
@@ -56,16 +71,19 @@ struct FemDev {
   const int* vmap;
   double* L;     // [Mc][nslots][64*64]
   double* invL;  // [Mc][T][64*64]
-  double* y;     // [Mc][nGp]
+  double* y;     // [Mc][nGp]: reduced unknowns | nodal edge blocks | cross block
   int* status;
 };
 
 static FemDev make_dev(const rom_fem* f) {
   FemDev d;
   d.nrb = f->nrb; d.ncb = f->ncb; d.N = f->N; d.n1 = f->n1; d.n1p = f->n1p; d.nr = f->nr; d.nc = f->nc;
-  d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.R = f->d_R; d.vec = f->d_vec;
-  d.rhs = f->d_rhs; d.pre = f->d_pre; d.T = f->T; d.nslots = f->nslots; d.kblk = f->nrb * f->ncb; d.dim = f->dim;
-  d.A0 = f->d_A0; d.Qp = f->d_Qp; d.kmax = f->d_kmax; d.epos = f->d_epos; d.yhat = f->d_yhat; d.Tm = f->d_Tm; d.W = f->d_W; d.g = f->d_g; d.desc = f->d_desc; d.extra = f->d_extra;
+  d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.nexp = f->nexp; d.ncross = f->ncross;
+  d.xb0 = f->xb0; d.pool = f->d_pool; d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
+  d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.T = f->T; d.nslots = f->nslots;
+  d.kblk = f->nrb * f->ncb; d.dim = f->dim;
+  d.A0 = f->d_A0; d.Qp = f->d_Qp; d.kmax = f->d_kmax; d.epos = f->d_epos; d.yhat = f->d_yhat; d.W = f->d_W;
+  d.g = f->d_g; d.desc = f->d_desc;
   d.kptr = f->d_kptr; d.kpair = f->d_kpair; d.colptr = f->d_colptr; d.colrow = f->d_colrow;
   d.colti = f->d_colti; d.sides = f->d_sides; d.vmap = f->d_vmap; d.L = f->d_L; d.invL = f->d_invL;
   d.y = f->d_y; d.status = f->ctx->d_status;
@@ -73,7 +91,7 @@ static FemDev make_dev(const rom_fem* f) {
 }
 
 // ============================================================================================
-// setup kernels
+// setup kernel
 // ============================================================================================
 // A0[((i-1)*n1 + (j-1)) * n1p + m] = Q[j-1][m] * rho[m][i]   (rho stored [m][i], i = 0..N)
 __global__ void k_build_A0(double* A0, const double* Qp, const double* rho, int n1, int n1p, int N) {
@@ -98,128 +116,62 @@ __host__ __device__ inline int h0_row(int s, int i, int j, int N, int n1) {
   return (ii - 1) * n1 + (jj - 1);
 }
 
-// Tm[sr*4+sc][t][k] = H_sc[adjacent interior vertex of node t+1 on side sr][k]
-__global__ void k_build_Tm(double* Tm, const double* H0, int n1, int n1p, int N) {
-  size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
-  size_t per = size_t(n1p) * n1p;
-  if (idx >= 16 * per) return;
-  int tm = int(idx / per);
-  int t = int((idx % per) / n1p), k = int(idx % n1p);
-  int sr = tm >> 2, sc = tm & 3;
-  double v = 0.0;
-  if (t < n1 && k < n1) {
-    int i, j;
-    switch (sr) {
-      case 0: i = 1; j = t + 1; break;
-      case 1: i = N - 1; j = t + 1; break;
-      case 2: i = t + 1; j = 1; break;
-      default: i = t + 1; j = N - 1; break;
-    }
-    v = H0[size_t(h0_row(sc, i, j, N, n1)) * n1p + k];
-  }
-  Tm[idx] = v;
-}
-
 // ============================================================================================
-// interface tile assembly  (A_GG(a) - sum_b a_b T_b, one entry)
+// reduced-system tile assembly
 // ============================================================================================
-// Per-system scalar coefficients of one tile (uniform over the workgroup, computed once per thread):
-// the tile is a linear combination of parameter-independent tables with these weights.
-struct TileCoef {
-  double cT[2];                             // - a_b                              (Schur terms)
-  double cEE[4], cEX[4], cXE[4], cXX[4];    // pre-eliminated edge terms by (row kind, col kind), negated
-  double dg, off;                           // tridiagonal A_GammaGamma part of a same-edge tile
-};
-
-__device__ inline void tile_coefs(TileCoef& tc, const TileDesc& d, const double* __restrict__ am) {
-#pragma unroll
-  for (int t = 0; t < 2; ++t) tc.cT[t] = t < d.nterms ? -am[d.term[t].blk] : 0.0;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    tc.cEE[t] = tc.cEX[t] = tc.cXE[t] = tc.cXX[t] = 0.0;
-    if (t < d.npre) {
-      const PreTerm& pt = d.pre[t];
-      const double se = am[pt.e0] + am[pt.e1];
-      const double ar = pt.brow >= 0 ? am[pt.brow] : 0.0, ac = pt.bcol >= 0 ? am[pt.bcol] : 0.0;
-      tc.cEE[t] = -(ar * ac / se);  // c_row c_col / s_e with c = a_b on edge nodes, s_e / 2 on cross slots
-      tc.cEX[t] = -(ar / 2);
-      tc.cXE[t] = -(ac / 2);
-      tc.cXX[t] = -(se / 4);
-    }
-  }
-  tc.dg = tc.off = 0.0;
-  if (d.same_edge) {
-    const double a0 = am[d.b0], a1 = am[d.b1];
-    // oracle order: k[r-1,c-1] + k[r-1,c] + k[r,c-1] + k[r,c]
-    tc.dg = d.hv == 0 ? ((a0 + a0) + a1) + a1 : ((a0 + a1) + a0) + a1;
-    tc.off = -(a1 + a0) / 2;
+// weight of one table, from the block coefficients of this system
+__device__ inline double term_coef(const GenTerm& g, const double* __restrict__ am) {
+  switch (g.kind) {
+    case 0: return -am[g.b[0]];                                             // Schur coupling through block b0
+    case 1: return am[g.b[0]] + am[g.b[1]];                                 // edge self block s_f K~
+    case 2: return -(am[g.b[0]] + am[g.b[1]]) / 2;                          // cross point <-> end node of an edge
+    case 3: return ((am[g.b[0]] + am[g.b[1]]) + am[g.b[2]]) + am[g.b[3]];   // cross point diagonal
+    case 4: return -(am[g.b[0]] * am[g.b[1]] / (am[g.b[2]] + am[g.b[3]]));  // closed-form edge: edge x edge
+    case 5: return -(am[g.b[0]] / 2);                                       //                   edge x cross
+    default: return -((am[g.b[2]] + am[g.b[3]]) / 4);                       //                   cross x cross
   }
 }
 
-// This thread's share of the assembled interface tile: row (t >> 2), 16 consecutive columns starting
-// at (t & 3) * 16.  In this layout every table is read with 16-byte loads, 128 contiguous bytes per
-// thread and table; the values wait in registers while the MFMA k-loop runs.
+// This thread's share of the assembled tile: row (t >> 2), 16 consecutive columns starting at
+// (t & 3) * 16.  Every table is read with 16-byte loads, 128 contiguous bytes per thread and table; the
+// values wait in registers while the MFMA k-loop runs.
 struct STile {
   double v[16];
 };
 
-__device__ inline void s_tile_load(STile& st, const TileDesc& d, const FemDev& f, const double* __restrict__ am) {
-  TileCoef tc;
-  tile_coefs(tc, d, am);
+constexpr int COEF_MAX = 64;  // term weights cached in LDS per pass
+
+__device__ inline void s_tile_load(STile& st, const TileDesc& d, const FemDev& f, const double* __restrict__ am,
+                                   double* coef) {
   const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
 #pragma unroll
   for (int x = 0; x < 16; ++x) st.v[x] = 0.0;
-  const bool re = r < d.nvr;
-  if (r < d.ndr) {
+  for (int tb = d.t0; tb < d.t1; tb += COEF_MAX) {
+    const int nt = min(COEF_MAX, d.t1 - tb);
+    __syncthreads();
+    if (int(threadIdx.x) < nt) coef[threadIdx.x] = term_coef(f.terms[tb + threadIdx.x], am);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      const GenTerm& g = f.terms[tb + t];
+      if (r < g.r_lo || r >= g.r_hi || c0 >= g.c_hi || c0 + 16 <= g.c_lo) continue;
+      const double cf = coef[t];
+      const double2* src = reinterpret_cast<const double2*>(f.pool + size_t(g.tab) * 4096 + r * 64 + c0);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (t < d.npre) {
-        const PreTerm& pt = d.pre[t];
-        const double2* src = reinterpret_cast<const double2*>(f.R + (size_t(pt.table) * f.n1p + (pt.r0 + r)) * f.n1p +
-                                                              (pt.c0 + c0));
-        const double ce_coef = re ? tc.cEE[t] : tc.cXE[t], cx_coef = re ? tc.cEX[t] : tc.cXX[t];
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-          const double2 w = src[x];
-          const int c = c0 + 2 * x;
-          st.v[2 * x] += (c < d.nvc ? ce_coef : (c < d.ndc ? cx_coef : 0.0)) * w.x;
-          st.v[2 * x + 1] += (c + 1 < d.nvc ? ce_coef : (c + 1 < d.ndc ? cx_coef : 0.0)) * w.y;
-        }
-      }
-  }
-  if (re) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      if (t < d.nterms) {
-        const TileTerm& tt = d.term[t];
-        const double2* src = reinterpret_cast<const double2*>(f.Tm + (size_t(tt.tmat) * f.n1p + (tt.r0 + r)) * f.n1p +
-                                                              (tt.c0 + c0));
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-          const double2 w = src[x];  // the tables are zero beyond the edge nodes: no column mask needed
-          st.v[2 * x] += tc.cT[t] * w.x;
-          st.v[2 * x + 1] += tc.cT[t] * w.y;
-        }
-      }
-    if (d.same_edge) {
-      const int gr = d.lr0 + r;
-#pragma unroll
-      for (int x = 0; x < 16; ++x) {
-        const int c = c0 + x, gc = d.lc0 + c;
-        if (c < d.nvc) st.v[x] += gr == gc ? tc.dg : ((gr - gc == 1 || gc - gr == 1) ? tc.off : 0.0);
+      for (int x = 0; x < 8; ++x) {
+        const double2 w = src[x];  // tables are zero outside their rectangle: no masks needed
+        st.v[2 * x] += cf * w.x;
+        st.v[2 * x + 1] += cf * w.y;
       }
     }
   }
   if (d.diag && r >= d.ndr) {
 #pragma unroll
-    for (int x = 0; x < 16; ++x)
-      if (c0 + x == r) st.v[x] = 1.0;  // padding unknowns: identity
+    for (int x = 0; x < 16; ++x) st.v[x] = (c0 + x == r) ? 1.0 : 0.0;  // padding unknowns: identity
   }
 }
 
-// C(LDS tile) = S_tile - acc ; then the sparse cross-point extras
-__device__ inline void tile_from_acc(double* Cb, const Acc& acc, const STile& st, const TileDesc& d, const FemDev& f,
-                                     const double* __restrict__ am, const WavePos& wp) {
+// C(LDS tile) = S_tile - acc
+__device__ inline void tile_from_acc(double* Cb, const Acc& acc, const STile& st, const WavePos& wp) {
   {
     double2* dst = reinterpret_cast<double2*>(Cb + (threadIdx.x >> 2) * LDC + (threadIdx.x & 3) * 16);
 #pragma unroll
@@ -232,13 +184,6 @@ __device__ inline void tile_from_acc(double* Cb, const Acc& acc, const STile& st
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) Cb[acc_row(wp, i, g) * LDC + acc_col(wp, j)] -= acc.c[i][j][g];
-  __syncthreads();
-  for (int x = d.x0 + threadIdx.x; x < d.x1; x += blockDim.x) {
-    const TileExtra& e = f.extra[x];
-    double v = e.kind == 0 ? -(am[e.b[0]] + am[e.b[1]]) / 2
-                           : ((am[e.b[0]] + am[e.b[1]]) + am[e.b[2]]) + am[e.b[3]];
-    Cb[e.r * LDC + e.c] += v;
-  }
   __syncthreads();
 }
 
@@ -268,29 +213,72 @@ __device__ inline void accumulate_klist(const FemDev& f, int slot, const double*
 // ============================================================================================
 // factorisation kernels
 // ============================================================================================
-__global__ void k_init_rhs(FemDev f, int Mc) {
-  size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
-  if (idx >= size_t(Mc) * f.nGp) return;
-  f.y[idx] = f.g[idx % f.nGp];
-}
-
-// rhs of the condensed system: g_f + sum_e diag(c_f) X_fe K^-1 g_e / s_e   (grid: 64 threads x (tile rows, Mc))
-__global__ void k_rhs_pre(FemDev f, const double* __restrict__ a, int ntile_rows) {
-  const int m = blockIdx.y, tile = blockIdx.x, r = threadIdx.x;
+// rhs of the reduced system: the parameter-independent part plus the contributions of the closed-form
+// edges.  One workgroup per system; the terms are applied one after another (they overlap).
+__global__ __launch_bounds__(256) void k_rhs(FemDev f, const double* __restrict__ a) {
+  const int m = blockIdx.x;
   const double* am = a + size_t(m) * f.kblk;
-  double acc = 0.0;
+  double* y = f.y + size_t(m) * f.nGp;
+  for (int v = threadIdx.x; v < f.nGa; v += blockDim.x) y[v] = f.g[v];
   for (int t = 0; t < f.nrhs; ++t) {
+    __syncthreads();
     const RhsTerm& rt = f.rhs[t];
-    if (rt.tile != tile || r >= rt.ndr) continue;
-    const double se = am[rt.e0] + am[rt.e1];
-    const double cr = r < rt.nvr ? (rt.brow >= 0 ? am[rt.brow] : 0.0) : se / 2;
-    acc += cr / se * f.vec[rt.qoff + rt.lr0 + r];
+    const double coef = rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5;
+    for (int i = threadIdx.x; i < rt.len; i += blockDim.x) y[rt.pos + i] += coef * f.vec[rt.voff + i];
   }
-  f.y[size_t(m) * f.nGp + tile * 64 + r] += acc;
 }
 
-// Back substitution of the pre-eliminated edges: x_e = (w_e + sum_f B_fe (c_f . x_f)) / s_e as one batched
-// MFMA GEMM: tile rows = systems, tile cols = nodes of e, K = positions on the neighbours.
+// 4 doubles from an address that is only 8-byte aligned (pointer may be null -> zeros)
+__device__ inline void load4_any(const double* __restrict__ p, double v[4]) {
+  if (p) {
+    v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
+  } else {
+    v[0] = v[1] = v[2] = v[3] = 0.0;
+  }
+}
+
+// Edge values of the active edges from the reduced solution, u_f = P_f z_f + p0_f / s_f, as one batched
+// MFMA GEMM (tile rows = systems, tile cols = nodes of f, K = compressed index), and the copy of the
+// cross points into their nodal block.   grid (n1p/64, ceil(Mc/64), nexp + 1)
+__global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restrict__ a, int Mc) {
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  if (int(blockIdx.z) == f.nexp) {
+    if (blockIdx.x != 0) return;
+    for (int idx = threadIdx.x; idx < 64 * f.ncross; idx += blockDim.x) {
+      const int m = blockIdx.y * 64 + idx / f.ncross, x = idx % f.ncross;
+      if (m < Mc) f.y[size_t(m) * f.nGp + f.xb0 + x] = f.y[size_t(m) * f.nGp + f.xred[x]];
+    }
+    return;
+  }
+  const WavePos wp;
+  const ExpEdge ee = f.exp[blockIdx.z];
+  const int srow = stage_row(), sseg = stage_seg();
+  const int mA = blockIdx.y * 64 + srow;
+  const double* pA = mA < Mc ? f.y + size_t(mA) * f.nGp + ee.zpos + sseg : nullptr;
+  const double* pB = f.P + (size_t(ee.ptab) * f.n1p + blockIdx.x * 64 + srow) * f.n1p + sseg;
+  Acc acc;
+  acc_zero(acc);
+  gemm_loop(
+      ee.nch, [&](int ch, double* v) { load4_any(pA ? pA + ch * BK : nullptr, v); },
+      [&](int ch, double* v) { load4_aligned(pB + ch * BK, v); }, acc, lds, wp);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m = blockIdx.y * 64 + acc_row(wp, i, g);
+      if (m >= Mc) continue;
+      const double* amr = a + size_t(m) * f.kblk;
+      const double inv = 1.0 / (amr[ee.b0] + amr[ee.b1]);
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const int node = blockIdx.x * 64 + acc_col(wp, jb);
+        f.y[size_t(m) * f.nGp + ee.npos + node] = node < f.n1 ? acc.c[i][jb][g] + f.vec[ee.p0off + node] * inv : 0.0;
+      }
+    }
+}
+
+// Back substitution of the closed-form edges: x_e = (w_e + sum_u B_ue^T (c_u . x_u)) / s_e as one batched
+// MFMA GEMM: tile rows = systems, tile cols = nodes of e, K = positions in the neighbours' nodal blocks.
 // grid (n1p/64, ceil(Mc/64), npre)
 __global__ __launch_bounds__(256) void k_back_pre(FemDev f, const double* __restrict__ a, int Mc) {
   __shared__ __align__(16) double lds[STAGE_TOTAL];
@@ -303,21 +291,17 @@ __global__ __launch_bounds__(256) void k_back_pre(FemDev f, const double* __rest
   const double seA = am ? am[pe.e0] + am[pe.e1] : 0.0;
   Acc acc;
   acc_zero(acc);
-  const int cps = f.n1p / BK;
   for (int q = 0; q < pe.nnb; ++q) {
     const PreNb nb = pe.nb[q];
     const double* pA = am ? f.y + size_t(mA) * f.nGp + nb.fpos + sseg : nullptr;
-    const double* pB = f.R + (size_t(nb.bt) * f.n1p + iB) * f.n1p + sseg;
-    const double cedge = (am && nb.blk >= 0) ? am[nb.blk] : 0.0;
+    const double* pB = f.Bt + (size_t(nb.bt) * f.n1p + iB) * f.n1p + sseg;
+    const double cu = !am ? 0.0 : (nb.blk >= 0 ? am[nb.blk] : seA / 2);
     gemm_loop(
-        cps,
+        nb.nch,
         [&](int ch, double* v) {
           load4_aligned(pA ? pA + ch * BK : nullptr, v);
 #pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const int k = ch * BK + sseg + x;
-            v[x] *= k < f.n1 ? cedge : (k < f.n1 + nb.nused ? seA / 2 : 0.0);
-          }
+          for (int x = 0; x < 4; ++x) v[x] *= cu;
         },
         [&](int ch, double* v) { load4_aligned(pB + ch * BK, v); }, acc, lds, wp);
   }
@@ -337,19 +321,6 @@ __global__ __launch_bounds__(256) void k_back_pre(FemDev f, const double* __rest
     }
 }
 
-// X_fe (n1p x n1p): rows = positions on the active edge f (edge nodes, then cross slots), cols = nodes of e
-__global__ void k_build_X(double* X, const double* Tm, int n1, int n1p, int tmat, int nx, const int* xrow,
-                          const int* xcol) {
-  size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
-  if (idx >= size_t(n1p) * n1p) return;
-  int r = int(idx / n1p), c = int(idx % n1p);
-  double v = 0.0;
-  if (tmat >= 0 && r < n1 && c < n1) v = Tm[(size_t(tmat) * n1p + r) * n1p + c];
-  for (int x = 0; x < nx; ++x)
-    if (r == xrow[x] && c == xcol[x]) v = 1.0;
-  X[idx] = v;
-}
-
 // Diagonal tile j, step 1 of 3 (MFMA): C = S_jj - sum_k L_jk L_jk^T, written to the tile's L slot.
 // Only the lower triangle is consumed by the factorisation: the wave owning the upper-right
 // quadrant skips its MFMAs.
@@ -357,6 +328,7 @@ __global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __r
   // 36.9 KB: four workgroups per CU, i.e. all 1024 systems of a C2 step resident in one round
   __shared__ __align__(16) double lds[STAGE_TOTAL];
   __shared__ int kp[2 * KP_MAX];
+  __shared__ double coef[COEF_MAX];
   double* stB = lds;
   double* stA = lds + 2 * STAGE_DOUBLES;
   double* Cb = lds;  // the C tile aliases the whole staging area (used after the k-loop only)
@@ -367,12 +339,12 @@ __global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __r
   const double* am = a + size_t(m) * f.kblk;
   double* Lm = f.L + size_t(m) * f.nslots * 4096;
   STile st;
-  s_tile_load(st, d, f, am);  // table reads fly under the MFMAs below
+  s_tile_load(st, d, f, am, coef);  // table reads fly under the MFMAs below
   Acc acc;
   acc_zero(acc);
   const bool lower = !(wp.wr == 0 && wp.wc == 1);
   accumulate_klist(f, slot, Lm, kp, [&](int) { return lower; }, acc, stA, stB, wp);
-  tile_from_acc(Cb, acc, st, d, f, am, wp);
+  tile_from_acc(Cb, acc, st, wp);
   double* Lout = Lm + size_t(slot) * 4096;
   for (int idx = threadIdx.x; idx < 4096; idx += 256) Lout[idx] = Cb[(idx >> 6) * LDC + (idx & 63)];
 }
@@ -485,6 +457,7 @@ __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __
   __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];
   __shared__ int kp[2 * KP_MAX];
   __shared__ double yj[64];
+  __shared__ double coef[COEF_MAX];
   double* stB = lds;
   double* stA = lds + 2 * STAGE_DOUBLES;
   double* Cb = lds + 2 * STAGE_DOUBLES;
@@ -513,12 +486,12 @@ __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __
   double* Lm = f.L + size_t(m) * f.nslots * 4096;
   const int t = threadIdx.x;
   STile st;
-  s_tile_load(st, d, f, am);
+  s_tile_load(st, d, f, am, coef);
   if (t < 64) yj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
   Acc acc;
   acc_zero(acc);
   accumulate_klist(f, slot, Lm, kp, [](int) { return true; }, acc, stA, stB, wp);
-  tile_from_acc(Cb, acc, st, d, f, am, wp);
+  tile_from_acc(Cb, acc, st, wp);
 
   // X = C * invL_jj^T
   acc_zero(acc);
@@ -703,13 +676,40 @@ __global__ void k_assemble_stencil(FemDev f, const double* __restrict__ a, int M
 }
 
 // ============================================================================================
-// host: geometry, symbolic tile Cholesky, tables
+// host: geometry, compression, symbolic tile Cholesky, tables
 // ============================================================================================
 namespace {
+
+using hostla::ld;
+using hostla::Mat;
 
 struct Edge {
   int hv, p, q;  // hv 0: horizontal (r = pN, c in block column q); 1: vertical (c = qN, r in block row p)
   int b0, b1;    // up/dn or lf/rt block indices
+};
+
+// one parameter-independent block of the reduced matrix: coef(kind, b) * tab at (rpos, cpos)
+struct Small {
+  int rpos, cpos;
+  Mat tab;
+  int kind;
+  std::array<int, 4> b;
+};
+
+// compressed representation of an active edge (shared by all edges with the same surroundings)
+struct Comp {
+  int r = 0;
+  Mat W;               // n1 x r   orthonormal basis of the coupling range
+  Mat Kt;              // r x r    (W^T K^-1 W)^-1
+  Mat P;               // n1 x r   K^-1 W Kt
+  std::vector<ld> gt;  // r        Kt W^T K^-1 g_f
+  std::vector<ld> p0;  // n1       (K^-1 - P W^T K^-1) g_f
+};
+
+struct TermAcc {
+  std::array<int, 5> key;
+  std::vector<double> tab;
+  int r_lo, r_hi, c_lo, c_hi;
 };
 
 template <class Tp>
@@ -720,14 +720,24 @@ int upload(Tp** dptr, const std::vector<Tp>& h) {
   return ROM_OK;
 }
 
+// n1p x n1p fp64 table (zero padded) from a long double matrix of at most that size
+void put_table(std::vector<double>& pool, size_t idx, int n1p, const Mat& A, bool transposed) {
+  double* dst = pool.data() + idx * size_t(n1p) * n1p;
+  for (int i = 0; i < A.r; ++i)
+    for (int j = 0; j < A.c; ++j) {
+      if (transposed) dst[size_t(j) * n1p + i] = double(A(i, j));
+      else dst[size_t(i) * n1p + j] = double(A(i, j));
+    }
+}
+
 }  // namespace
 
 extern "C" int rom_fem_destroy(rom_fem* f) {
   if (!f) return ROM_OK;
   hipStreamSynchronize(f->ctx->stream);
-  void* ptrs[] = {f->d_A0, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_Tm, f->d_W, f->d_g, f->d_desc, f->d_extra, f->d_slot_of, f->d_kptr, f->d_kpair,
-                  f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L, f->d_invL, f->d_y, f->d_R, f->d_vec,
-                  f->d_rhs, f->d_pre};
+  void* ptrs[] = {f->d_A0, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
+                  f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
+                  f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete f;
@@ -744,12 +754,11 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   f->nrb = nrb; f->ncb = ncb; f->N = N;
   const int n1 = N - 1;
   f->n1 = n1;
-  f->tpe = (n1 + TB - 1) / TB;
-  f->n1p = f->tpe * TB;
+  f->n1p = (n1 + TB - 1) / TB * TB;
   f->nr = nrb * N - 1;
   f->nc = ncb * N - 1;
   f->dim = int64_t(f->nr) * f->nc;
-  const int n1p = f->n1p, tpe = f->tpe;
+  const int n1p = f->n1p;
 
   // ---- edges, crosses ------------------------------------------------------------------------
   std::vector<Edge> edges;
@@ -773,7 +782,8 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   const int E = int(edges.size());
   const int ncross = int(crosses.size());
   f->nG = E * n1 + ncross;
-  // block -> side -> edge id
+  f->ncross = ncross;
+  // block -> side -> edge id   (sides: 0 top, 1 bottom, 2 left, 3 right)
   std::vector<std::array<int, 4>> bside(nrb * ncb);
   for (int p = 0; p < nrb; ++p)
     for (int q = 0; q < ncb; ++q) {
@@ -814,25 +824,26 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         if (b1 == b2) return b1;
     return -1;
   };
-  const int free_per_edge = n1p - n1;
 
-  // Everything below depends on which edges are eliminated in closed form (`pre`); if the cross points
-  // cannot all be hosted in padding slots of active edges the set is dropped and the layout redone.
+  // ---- edges eliminated in closed form: a maximal set no two of which touch the same block (greedy);
+  //      their self-interaction is (a_b0 + a_b1) K with K parameter independent and they do not couple
+  //      to each other ------------------------------------------------------------------------------------
   std::vector<char> is_pre(E, 0);
-  if (free_per_edge >= 1 && !getenv("ROMHC_NO_PREELIM")) {
-    // maximal set of edges no two of which touch the same block (greedy): their self-interaction is
-    // (a_b0 + a_b1) K with K parameter independent and they do not couple to each other
+  if (!getenv("ROMHC_NO_PREELIM")) {
     std::vector<char> busy(nrb * ncb, 0);
     for (int e = 0; e < E; ++e)
       if (!busy[edges[e].b0] && !busy[edges[e].b1]) { is_pre[e] = 1; busy[edges[e].b0] = busy[edges[e].b1] = 1; }
   }
-  std::vector<int> order, tile0, epos, used, xpos, overflow, pre_list, ppos;
-  int nact = 0, xt0 = 0, nxt = 0, T = 0;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    pre_list.clear();
-    for (int e = 0; e < E; ++e)
-      if (is_pre[e]) pre_list.push_back(e);
-    // ordering graph of the active edges: shared block, or common neighbour of an eliminated edge
+  std::vector<int> pre_list, pre_index(E, -1);
+  for (int e = 0; e < E; ++e)
+    if (is_pre[e]) { pre_index[e] = int(pre_list.size()); pre_list.push_back(e); }
+  const int npre = int(pre_list.size());
+  const int nact = E - npre;
+
+  // ---- elimination order of the active edges (greedy minimum degree on the graph: shared block, or
+  //      common neighbour of a closed-form edge) ----------------------------------------------------------
+  std::vector<int> order, ord_of(E, -1);
+  {
     std::vector<std::set<int>> g(E);
     for (int e = 0; e < E; ++e)
       if (!is_pre[e])
@@ -842,10 +853,8 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       for (int x : adj[e])
         for (int y : adj[e])
           if (x != y && !is_pre[x] && !is_pre[y]) g[x].insert(y);
-    order.clear();
     std::vector<char> done(E, 0);
-    nact = E - int(pre_list.size());
-    for (int step = 0; step < nact; ++step) {  // greedy minimum degree
+    for (int step = 0; step < nact; ++step) {
       int best = -1;
       size_t bd = 0;
       for (int e = 0; e < E; ++e) {
@@ -853,6 +862,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         if (best < 0 || g[e].size() < bd) { best = e; bd = g[e].size(); }
       }
       done[best] = 1;
+      ord_of[best] = int(order.size());
       order.push_back(best);
       std::vector<int> nb(g[best].begin(), g[best].end());
       for (int x : nb) {
@@ -861,103 +871,301 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
           if (x != y) g[x].insert(y);
       }
     }
-    tile0.assign(E, -1);
-    epos.assign(E, -1);
-    for (int pos = 0; pos < nact; ++pos) { tile0[order[pos]] = pos * tpe; epos[order[pos]] = pos; }
-    // cross points go into the padding slots behind an adjacent active edge (the one eliminated last)
-    used.assign(E, 0);
-    xpos.assign(ncross, -1);
-    overflow.clear();
-    for (int x = 0; x < ncross; ++x) {
-      int best = -1;
-      for (auto& c : xc)
-        if (c.cross == x && !is_pre[c.edge] && used[c.edge] < free_per_edge &&
-            (best < 0 || epos[c.edge] > epos[best]))
-          best = c.edge;
-      if (best >= 0) xpos[x] = tile0[best] * TB + n1 + used[best]++;
-      else overflow.push_back(x);
-    }
-    if (!overflow.empty() && !pre_list.empty()) {  // keep the closed-form elimination simple: no overflow tiles
-      std::fill(is_pre.begin(), is_pre.end(), 0);
-      continue;
-    }
-    break;
   }
-  xt0 = nact * tpe;                                    // first overflow tile
-  nxt = (int(overflow.size()) + TB - 1) / TB;          // overflow tiles
-  for (size_t o = 0; o < overflow.size(); ++o) xpos[overflow[o]] = xt0 * TB + int(o);
-  T = xt0 + nxt;
-  const int npre = int(pre_list.size());
+
+  // ---- unit-block tables in long double ----------------------------------------------------------------
+  const ld PI = acosl(-1.0L);
+  Mat Q(n1, n1), rho(n1, N + 1);
+  std::vector<ld> lam(n1), kappa(n1);
+  for (int j = 1; j <= n1; ++j) {
+    lam[j - 1] = 2.0L - 2.0L * cosl(PI * j / N);
+    for (int m = 1; m <= n1; ++m) Q(j - 1, m - 1) = sqrtl(2.0L / N) * sinl(PI * j * m / (ld)N);
+  }
+  for (int m = 0; m < n1; ++m) {
+    ld phi = acoshl(1.0L + lam[m] / 2.0L);
+    ld den = -expm1l(-2.0L * N * phi);  // 1 - exp(-2 N phi)
+    for (int i = 0; i <= N; ++i) rho(m, i) = expl(-phi * i) * (-expm1l(-2.0L * (N - i) * phi)) / den;
+    kappa[m] = 1.0L + lam[m] / 2.0L - rho(m, 1);
+  }
+  std::vector<double> rho_d(rho.v.size());
+  for (size_t i = 0; i < rho.v.size(); ++i) rho_d[i] = double(rho.v[i]);
+  // W = L^{-1} 1 = Q (s s^T / (lam_l + lam_m)) Q
+  std::vector<double> Wd(size_t(n1) * n1);
+  Mat Wl(n1, n1);
+  {
+    std::vector<ld> sv(n1, 0.0L);
+    Mat Z(n1, n1);
+    for (int m = 0; m < n1; ++m)
+      for (int j = 0; j < n1; ++j) sv[m] += Q(j, m);
+    for (int l = 0; l < n1; ++l)
+      for (int m = 0; m < n1; ++m) Z(l, m) = sv[l] * sv[m] / (lam[l] + lam[m]);
+    Wl = hostla::mul(Q, hostla::mul_nt(Z, Q));
+    for (size_t i = 0; i < Wd.size(); ++i) Wd[i] = double(Wl.v[i]);
+  }
+  const double h2 = 1.0 / (double(N) * double(N));
+  // interface rhs of an edge: h^2 (1 + W at the two adjacent interior lines), by orientation
+  std::vector<ld> gE[2];
+  for (int hv = 0; hv < 2; ++hv) {
+    gE[hv].resize(n1);
+    for (int t = 0; t < n1; ++t)
+      gE[hv][t] = (ld)h2 * (1.0L + (hv == 0 ? Wl(N - 2, t) + Wl(0, t) : Wl(t, N - 2) + Wl(t, 0)));
+  }
+  // K = tridiag(-1/2, 2, -1/2) - T_same = Q diag(kappa) Q, kappa_m = 1 + lam_m/2 - rho_m(1)
+  Mat Kmat(n1, n1), Kinv(n1, n1);
+  if (E > 0) {
+    Mat QK(n1, n1), QKi(n1, n1);
+    for (int j = 0; j < n1; ++j)
+      for (int m = 0; m < n1; ++m) {
+        QK(j, m) = Q(j, m) * kappa[m];
+        QKi(j, m) = Q(j, m) / kappa[m];
+      }
+    Kmat = hostla::mul_nt(QK, Q);
+    Kinv = hostla::mul_nt(QKi, Q);
+  }
+  // Dirichlet-to-Neumann tables T[sr*4+sc][t][k] = H_sc[interior vertex next to node t of side sr][k]
+  // and their products with K^-1, built on first use
+  std::array<Mat, 16> Tm_, TK_;
+  std::array<char, 16> haveT{}, haveTK{};
+  auto Tm = [&](int id) -> const Mat& {
+    if (!haveT[id]) {
+      const int sr = id >> 2, sc = id & 3;
+      Mat V(n1, n1);
+      for (int t = 0; t < n1; ++t) {
+        int i, j;
+        switch (sr) {
+          case 0: i = 1; j = t + 1; break;
+          case 1: i = N - 1; j = t + 1; break;
+          case 2: i = t + 1; j = 1; break;
+          default: i = t + 1; j = N - 1; break;
+        }
+        const int hr = h0_row(sc, i, j, N, n1);
+        const int ii = hr / n1 + 1, jj = hr % n1 + 1;
+        for (int m = 0; m < n1; ++m) V(t, m) = Q(jj - 1, m) * rho(m, ii);
+      }
+      Tm_[id] = hostla::mul_nt(V, Q);
+      haveT[id] = 1;
+    }
+    return Tm_[id];
+  };
+  auto TK = [&](int id) -> const Mat& {
+    if (!haveTK[id]) {
+      TK_[id] = hostla::mul(Tm(id), Kinv);
+      haveTK[id] = 1;
+    }
+    return TK_[id];
+  };
+
+  // ---- compression of the active edges -----------------------------------------------------------------
+  const bool compress = !getenv("ROMHC_NO_COMPRESS");
+  ld ctol = 1e-17L;
+  if (const char* s = getenv("ROMHC_COMPRESS_TOL")) ctol = (ld)atof(s);
+  std::map<std::vector<int>, int> sig_id;
+  std::vector<Comp> comps;
+  std::vector<int> comp_of(E, -1);
+  for (int e = 0; e < E; ++e) {
+    if (is_pre[e]) continue;
+    const Edge& ed = edges[e];
+    std::vector<int> sig{ed.hv};
+    for (int blk : {ed.b0, ed.b1}) {
+      const int sf = side_of(blk, e);
+      for (int s2 = 0; s2 < 4; ++s2)
+        if (s2 != sf && bside[blk][s2] >= 0) sig.push_back(sf * 4 + s2);
+    }
+    bool x0 = false, x1 = false;
+    for (auto& c : xc)
+      if (c.edge == e) (c.node == 0 ? x0 : x1) = true;
+    sig.push_back(100 + (x0 ? 1 : 0) + (x1 ? 2 : 0));
+    auto it = sig_id.find(sig);
+    if (it != sig_id.end()) { comp_of[e] = it->second; continue; }
+    Comp cp;
+    Mat Wb;
+    if (compress) {
+      const int ntab = int(sig.size()) - 2;
+      Mat C(n1, ntab * n1 + 2);
+      for (int t = 0; t < ntab; ++t) {
+        const Mat& Tt = Tm(sig[1 + t]);
+        ld mx = 0;
+        for (ld v : Tt.v) mx = std::max(mx, fabsl(v));
+        if (mx == 0.0L) mx = 1.0L;
+        for (int i = 0; i < n1; ++i)
+          for (int k = 0; k < n1; ++k) C(i, t * n1 + k) = Tt(i, k) / mx;
+      }
+      if (x0) C(0, ntab * n1) = 1.0L;
+      if (x1) C(n1 - 1, ntab * n1 + 1) = 1.0L;
+      Wb = hostla::range_basis(C, ctol);
+    }
+    if (!compress || Wb.c >= n1) {  // nothing to gain: nodal unknowns
+      cp.r = n1;
+      cp.W = hostla::identity(n1);
+      cp.Kt = Kmat;
+      cp.P = hostla::identity(n1);
+      cp.gt = gE[ed.hv];
+      cp.p0.assign(n1, 0.0L);
+    } else {
+      cp.r = Wb.c;
+      cp.W = Wb;
+      Mat KiW = hostla::mul(Kinv, Wb);
+      Mat G = hostla::mul_tn(Wb, KiW);
+      for (int i = 0; i < G.r; ++i)
+        for (int j = 0; j < i; ++j) G(i, j) = G(j, i) = (G(i, j) + G(j, i)) / 2;
+      if (!hostla::spd_inverse(G, cp.Kt)) { rom_set_error("internal: compressed edge block not positive definite"); return ROM_ERR_INVALID; }
+      cp.P = hostla::mul(KiW, cp.Kt);
+      std::vector<ld> v = hostla::matvec(Kinv, gE[ed.hv]);
+      std::vector<ld> wv = hostla::matvec(hostla::transpose(Wb), v);
+      cp.gt = hostla::matvec(cp.Kt, wv);
+      std::vector<ld> pw = hostla::matvec(cp.P, wv);
+      cp.p0.resize(n1);
+      for (int i = 0; i < n1; ++i) cp.p0[i] = v[i] - pw[i];
+    }
+    comp_of[e] = int(comps.size());
+    sig_id[sig] = comp_of[e];
+    comps.push_back(std::move(cp));
+  }
+
+  // ---- layout of the reduced vector: edge groups in elimination order, every cross point right behind
+  //      the adjacent active edge that is eliminated last ------------------------------------------------------
+  std::vector<int> zpos(E, -1), rk(E, 0), xred(ncross, -1), xhost(ncross, -1);
+  for (int x = 0; x < ncross; ++x)
+    for (auto& c : xc)
+      if (c.cross == x && !is_pre[c.edge] && (xhost[x] < 0 || ord_of[c.edge] > ord_of[xhost[x]])) xhost[x] = c.edge;
+  int nred = 0;
+  for (int e : order) {
+    zpos[e] = nred;
+    rk[e] = comps[comp_of[e]].r;
+    nred += rk[e];
+    f->ranks.push_back(rk[e]);
+    for (int x = 0; x < ncross; ++x)
+      if (xhost[x] == e) xred[x] = nred++;
+  }
+  for (int x = 0; x < ncross; ++x)
+    if (xred[x] < 0) xred[x] = nred++;
+  const int T = (nred + TB - 1) / TB;
+  f->nred = nred;
   f->T = T;
   f->nGa = T * TB;
   f->npre = npre;
-  f->nGp = f->nGa + npre * n1p;
-  ppos.assign(E, -1);  // position of an edge's n1p block in the interface vectors
-  for (int e = 0; e < E; ++e)
-    if (!is_pre[e]) ppos[e] = tile0[e] * TB;
-  for (int i = 0; i < npre; ++i) ppos[pre_list[i]] = f->nGa + i * n1p;
-  // tile -> (edge id or -1 for an overflow tile, local tile index, number of defined rows)
-  std::vector<int> tile_edge(T, -1), tile_loc(T, 0), tile_ndr(T, 0);
-  for (int e = 0; e < E; ++e) {
-    if (is_pre[e]) continue;
-    for (int x = 0; x < tpe; ++x) {
-      tile_edge[tile0[e] + x] = e;
-      tile_loc[tile0[e] + x] = x;
-      tile_ndr[tile0[e] + x] = std::max(0, std::min(TB, n1 + used[e] - x * TB));
+  f->nexp = nact;
+  // nodal layout behind the reduced part: one n1p block per edge, then the cross block
+  std::vector<int> npos(E, -1);
+  for (int e = 0; e < E; ++e) npos[e] = f->nGa + e * n1p;
+  f->xb0 = f->nGa + E * n1p;
+  f->nGp = E > 0 ? f->xb0 + (ncross > 0 ? (ncross + TB - 1) / TB * TB : 0) : 0;
+
+  // ---- blocks of the reduced matrix --------------------------------------------------------------------
+  std::vector<Small> smalls;
+  auto add_small = [&](int rpos, int cpos, const Mat& tab, int kind, std::array<int, 4> b) {
+    smalls.push_back(Small{rpos, cpos, tab, kind, b});
+    if (rpos != cpos) smalls.push_back(Small{cpos, rpos, hostla::transpose(tab), kind, b});
+  };
+  for (int e : order) {
+    const Edge& ed = edges[e];
+    const Comp& ce = comps[comp_of[e]];
+    add_small(zpos[e], zpos[e], ce.Kt, 1, {ed.b0, ed.b1, 0, 0});
+    for (int e2 : adj[e]) {
+      if (is_pre[e2] || e2 <= e) continue;
+      const int blk = shared_block(e, e2);
+      const int id = side_of(blk, e) * 4 + side_of(blk, e2);
+      const Comp& c2 = comps[comp_of[e2]];
+      add_small(zpos[e], zpos[e2], hostla::mul(hostla::mul_tn(ce.W, Tm(id)), c2.W), 0, {blk, 0, 0, 0});
     }
   }
-  for (int x = 0; x < nxt; ++x) {
-    tile_loc[xt0 + x] = x;
-    tile_ndr[xt0 + x] = std::min(TB, int(overflow.size()) - x * TB);
+  for (auto& c : xc) {
+    if (is_pre[c.edge]) continue;  // folded into the closed-form tables
+    const Comp& ce = comps[comp_of[c.edge]];
+    Mat row(1, ce.r);
+    for (int k = 0; k < ce.r; ++k) row(0, k) = ce.W(c.node, k);
+    add_small(xred[c.cross], zpos[c.edge], row, 2, {edges[c.edge].b1, edges[c.edge].b0, 0, 0});
+  }
+  for (int x = 0; x < ncross; ++x) {
+    const int p = crosses[x].first, q = crosses[x].second;
+    Mat one(1, 1);
+    one(0, 0) = 1.0L;
+    add_small(xred[x], xred[x], one, 3, {(p - 1) * ncb + (q - 1), (p - 1) * ncb + q, p * ncb + (q - 1), p * ncb + q});
   }
 
-  // ---- neighbours of every eliminated edge: active edges sharing a block, or hosting a cross point
-  //      that touches one of its ends -------------------------------------------------------------------
-  struct Nb { int f; int blk; std::vector<std::pair<int, int>> xs; };  // xs: (row on f, end node on e)
-  std::vector<std::vector<Nb>> nbs(npre);
+  // ---- closed-form edges: neighbours, reduced-matrix blocks, rhs terms, back substitution ---------------------------
+  std::vector<double> vecs;  // vector table
+  auto push_vec = [&](const std::vector<ld>& v, int padded) {
+    const int off = int(vecs.size());
+    for (ld x : v) vecs.push_back(double(x));
+    for (int i = int(v.size()); i < padded; ++i) vecs.push_back(0.0);
+    return off;
+  };
+  std::vector<RhsTerm> rhs_terms;
+  std::vector<PreEdge> pre_edges(npre);
+  std::map<int, int> bt_of_id;               // T table id -> B^T table index
+  std::vector<std::pair<int, Mat>> bt_extra;  // cross-block tables (index, n1 x ncross)
+  int nbt = 0;
+  double pre_flops = 0;
   for (int i = 0; i < npre; ++i) {
     const int e = pre_list[i];
-    std::map<int, Nb> m;
-    for (int x : adj[e])
-      if (!is_pre[x]) m[x] = Nb{x, shared_block(e, x), {}};
+    const Edge& pe = edges[e];
+    PreEdge& P = pre_edges[i];
+    memset(&P, 0, sizeof(P));
+    P.pos = npos[e];
+    P.e0 = pe.b0;
+    P.e1 = pe.b1;
+    const std::vector<ld> we = hostla::matvec(Kinv, gE[pe.hv]);
+    P.woff = push_vec(we, n1p);
+    struct Ent { int pos, len, blk; Mat X, Y; };  // X: len x n1 coupling to e (without its weight), Y = X K^-1
+    std::vector<Ent> ents;
+    for (int u : adj[e]) {
+      const int blk = shared_block(e, u);
+      const int id = side_of(blk, u) * 4 + side_of(blk, e);
+      const Comp& cu = comps[comp_of[u]];
+      Ent en{zpos[u], cu.r, blk, hostla::mul_tn(cu.W, Tm(id)), hostla::mul_tn(cu.W, TK(id))};
+      ents.push_back(std::move(en));
+      if (!bt_of_id.count(id)) bt_of_id[id] = nbt++;
+      if (P.nnb >= 8) { rom_set_error("internal: more than 8 neighbours of an eliminated edge"); return ROM_ERR_INVALID; }
+      P.nb[P.nnb++] = PreNb{npos[u], blk, n1p / BK, bt_of_id[id]};
+      pre_flops += 2.0 * n1p * double(n1p);
+    }
+    Mat Btx(n1, std::max(ncross, 1));
+    bool has_x = false;
     for (auto& c : xc) {
       if (c.edge != e) continue;
-      const int host = tile_edge[xpos[c.cross] / TB];
-      if (!m.count(host)) m[host] = Nb{host, -1, {}};
-      m[host].xs.push_back({xpos[c.cross] - tile0[host] * TB, c.node});
+      Ent en{xred[c.cross], 1, -1, Mat(1, n1), Mat(1, n1)};
+      en.X(0, c.node) = 1.0L;
+      for (int k = 0; k < n1; ++k) {
+        en.Y(0, k) = Kinv(c.node, k);
+        Btx(k, c.cross) = Kinv(k, c.node);
+      }
+      ents.push_back(std::move(en));
+      has_x = true;
     }
-    for (auto& kv : m) nbs[i].push_back(kv.second);
-    if (nbs[i].size() > 8) { rom_set_error("internal: more than 8 neighbours of an eliminated edge"); return ROM_ERR_INVALID; }
+    if (has_x) {
+      if (P.nnb >= 8) { rom_set_error("internal: more than 8 neighbours of an eliminated edge"); return ROM_ERR_INVALID; }
+      P.nb[P.nnb++] = PreNb{f->xb0, -1, (ncross + BK - 1) / BK, nbt};
+      bt_extra.push_back({nbt++, Btx});
+      pre_flops += 2.0 * n1p * double((ncross + BK - 1) / BK * BK);
+    }
+    for (size_t u = 0; u < ents.size(); ++u) {
+      const Ent& eu = ents[u];
+      rhs_terms.push_back(RhsTerm{eu.pos, eu.len, push_vec(hostla::matvec(eu.Y, gE[pe.hv]), eu.len), eu.blk >= 0 ? 0 : 1,
+                                  std::max(eu.blk, 0), pe.b0, pe.b1});
+      for (size_t v = 0; v <= u; ++v) {
+        const Ent& ev = ents[v];
+        Mat R = hostla::mul_nt(eu.Y, ev.X);
+        if (u == v)
+          for (int a = 0; a < R.r; ++a)
+            for (int b = 0; b < a; ++b) R(a, b) = R(b, a) = (R(a, b) + R(b, a)) / 2;
+        if (eu.blk >= 0 && ev.blk >= 0)
+          add_small(eu.pos, ev.pos, R, 4, {std::min(eu.blk, ev.blk), std::max(eu.blk, ev.blk), pe.b0, pe.b1});
+        else if (eu.blk >= 0 || ev.blk >= 0)
+          add_small(eu.pos, ev.pos, R, 5, {std::max(eu.blk, ev.blk), 0, 0, 0});
+        else
+          add_small(eu.pos, ev.pos, R, 6, {0, 0, pe.b0, pe.b1});
+      }
+    }
   }
-  auto nb_tiles = [&](const Nb& nb) {  // tiles of the neighbour that actually couple to e
-    std::set<int> t;
-    if (nb.blk >= 0)
-      for (int x = 0; x < tpe; ++x) t.insert(tile0[nb.f] + x);
-    for (auto& xr : nb.xs) t.insert(tile0[nb.f] + xr.first / TB);
-    return t;
-  };
 
   // ---- tile mask + symbolic fill --------------------------------------------------------------------
   std::vector<char> mask(size_t(T) * T, 0);
   auto M_ = [&](int i, int j) -> char& { return mask[size_t(i) * T + j]; };
-  for (int e = 0; e < E; ++e)
-    for (int e2 = 0; e2 < E; ++e2)
-      if (!is_pre[e] && !is_pre[e2] && (e == e2 || adj[e].count(e2)))
-        for (int x = 0; x < tpe; ++x)
-          for (int y = 0; y < tpe; ++y) M_(tile0[e] + x, tile0[e2] + y) = 1;
-  for (int x = 0; x < ncross; ++x) M_(xpos[x] / TB, xpos[x] / TB) = 1;
-  for (auto& c : xc) {
-    if (is_pre[c.edge]) continue;
-    int ti = xpos[c.cross] / TB, tj = tile0[c.edge] + c.node / TB;
-    M_(ti, tj) = M_(tj, ti) = 1;
-  }
-  for (int i = 0; i < npre; ++i) {  // fill created by the closed-form elimination
-    std::set<int> ts;
-    for (auto& nb : nbs[i])
-      for (int t : nb_tiles(nb)) ts.insert(t);
-    for (int x : ts)
-      for (int y : ts) M_(x, y) = 1;
-  }
+  for (int t = 0; t < T; ++t) M_(t, t) = 1;
+  for (const Small& s : smalls)
+    for (int tr = s.rpos / TB; tr <= (s.rpos + s.tab.r - 1) / TB; ++tr)
+      for (int tc = s.cpos / TB; tc <= (s.cpos + s.tab.c - 1) / TB; ++tc) M_(tr, tc) = M_(tc, tr) = 1;
   for (int k = 0; k < T; ++k)
     for (int i = k + 1; i < T; ++i)
       if (M_(i, k))
@@ -996,17 +1204,33 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     flops += (i == j) ? TB * double(TB) * TB / 3.0 : 2.0 * TB * TB * TB;  // potrf | trsm-as-gemm
   }
 
-  // ---- tables of the eliminated edges: which R = X_f K^-1 X_f'^T are needed -----------------------------
-  // table ids: R tables first (one per (pre edge, f, f') actually used by a tile), then the B^T tables
-  std::map<std::array<int, 3>, int> rid;  // (pre index, f, f') -> table id
-  auto nb_index = [&](int i, int fedge) {
-    for (size_t q = 0; q < nbs[i].size(); ++q)
-      if (nbs[i][q].f == fedge) return int(q);
-    return -1;
-  };
-
-  // ---- tile descriptors + extras ------------------------------------------------------------------------
-  std::vector<TileExtra> extras;
+  // ---- distribute the blocks over the tiles: one 64x64 table per (tile, coefficient formula) ---------------------
+  std::vector<std::vector<TermAcc>> slot_terms(f->nslots);
+  for (const Small& s : smalls)
+    for (int tr = s.rpos / TB; tr <= (s.rpos + s.tab.r - 1) / TB; ++tr)
+      for (int tc = s.cpos / TB; tc <= (s.cpos + s.tab.c - 1) / TB && tc <= tr; ++tc) {
+        const int slot = f->slot_of[size_t(tr) * T + tc];
+        if (slot < 0) { rom_set_error("internal: reduced-matrix block outside the tile mask"); return ROM_ERR_INVALID; }
+        const std::array<int, 5> key{s.kind, s.b[0], s.b[1], s.b[2], s.b[3]};
+        TermAcc* ta = nullptr;
+        for (auto& cand : slot_terms[slot])
+          if (cand.key == key) ta = &cand;
+        if (!ta) {
+          slot_terms[slot].push_back(TermAcc{key, std::vector<double>(4096, 0.0), TB, 0, TB, 0});
+          ta = &slot_terms[slot].back();
+        }
+        const int i0 = std::max(s.rpos, tr * TB), i1 = std::min(s.rpos + s.tab.r, (tr + 1) * TB);
+        const int j0 = std::max(s.cpos, tc * TB), j1 = std::min(s.cpos + s.tab.c, (tc + 1) * TB);
+        for (int i = i0; i < i1; ++i)
+          for (int j = j0; j < j1; ++j)
+            ta->tab[size_t(i - tr * TB) * TB + (j - tc * TB)] += double(s.tab(i - s.rpos, j - s.cpos));
+        ta->r_lo = std::min(ta->r_lo, i0 - tr * TB);
+        ta->r_hi = std::max(ta->r_hi, i1 - tr * TB);
+        ta->c_lo = std::min(ta->c_lo, j0 - tc * TB);
+        ta->c_hi = std::max(ta->c_hi, j1 - tc * TB);
+      }
+  std::vector<GenTerm> terms;
+  std::vector<double> pool;
   f->desc.resize(f->nslots);
   for (int s = 0; s < f->nslots; ++s) {
     TileDesc d;
@@ -1014,72 +1238,27 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     d.ti = slots[s].first;
     d.tj = slots[s].second;
     d.diag = d.ti == d.tj;
-    int er = tile_edge[d.ti], ec = tile_edge[d.tj];
-    d.lr0 = tile_loc[d.ti] * TB;
-    d.lc0 = tile_loc[d.tj] * TB;
-    d.nvr = er >= 0 ? std::max(0, std::min(TB, n1 - d.lr0)) : 0;  // edge nodes in the tile rows / cols
-    d.nvc = ec >= 0 ? std::max(0, std::min(TB, n1 - d.lc0)) : 0;
-    d.ndr = tile_ndr[d.ti];                                        // + cross slots: rows that are unknowns
-    d.ndc = tile_ndr[d.tj];
-    if (er >= 0 && ec >= 0) {
-      // blocks adjacent to both edges
-      int cand[2] = {edges[er].b0, edges[er].b1};
-      for (int cb : cand) {
-        int sr = side_of(cb, er), sc = side_of(cb, ec);
-        if (sr >= 0 && sc >= 0) {
-          if (d.nterms >= 2) { rom_set_error("internal: more than 2 Schur terms per tile"); return ROM_ERR_INVALID; }
-          d.term[d.nterms++] = TileTerm{cb, sr * 4 + sc, d.lr0, d.lc0};
-        }
-      }
-      if (er == ec) {
-        d.same_edge = 1;
-        d.hv = edges[er].hv;
-        d.b0 = edges[er].b0;
-        d.b1 = edges[er].b1;
-      }
-      // closed-form contributions of the eliminated edges that see both er and ec
-      for (int i = 0; i < npre; ++i) {
-        int qr = nb_index(i, er), qc = nb_index(i, ec);
-        if (qr < 0 || qc < 0) continue;
-        if (!nb_tiles(nbs[i][qr]).count(d.ti) || !nb_tiles(nbs[i][qc]).count(d.tj)) continue;
-        std::array<int, 3> key{i, er, ec};
-        if (!rid.count(key)) { int id = int(rid.size()); rid[key] = id; }
-        if (d.npre >= 4) { rom_set_error("internal: more than 4 pre-elimination terms per tile"); return ROM_ERR_INVALID; }
-        const Edge& pe = edges[pre_list[i]];
-        d.pre[d.npre++] = PreTerm{rid[key], d.lr0, d.lc0, nbs[i][qr].blk, nbs[i][qc].blk, pe.b0, pe.b1};
-      }
+    d.ndr = std::max(0, std::min(TB, nred - d.ti * TB));
+    d.t0 = int(terms.size());
+    for (auto& ta : slot_terms[s]) {
+      GenTerm g;
+      g.tab = int(pool.size() / 4096);
+      g.r_lo = short(ta.r_lo); g.r_hi = short(ta.r_hi); g.c_lo = short(ta.c_lo); g.c_hi = short(ta.c_hi);
+      g.kind = ta.key[0];
+      for (int q = 0; q < 4; ++q) g.b[q] = ta.key[1 + q];
+      terms.push_back(g);
+      pool.insert(pool.end(), ta.tab.begin(), ta.tab.end());
     }
-    d.x0 = int(extras.size());
-    // entries that involve cross points (placed by interface position)
-    for (int x = 0; x < ncross; ++x) {
-      if (d.diag && xpos[x] / TB == d.ti) {
-        int p = crosses[x].first, q = crosses[x].second, l = xpos[x] % TB;
-        extras.push_back(TileExtra{l, l, 1, {(p - 1) * ncb + (q - 1), (p - 1) * ncb + q, p * ncb + (q - 1), p * ncb + q}});
-      }
-    }
-    for (auto& c : xc) {
-      if (is_pre[c.edge]) continue;  // folded into the R tables
-      int pa = xpos[c.cross], pb = tile0[c.edge] * TB + c.node;
-      // coupling value uses the two blocks of the edge: -(k[r,c] + k[r-1,c])/2 resp. -(k[r,c]+k[r,c-1])/2
-      const int ta = pa / TB, tb = pb / TB;
-      const TileExtra rc{pa % TB, pb % TB, 0, {edges[c.edge].b1, edges[c.edge].b0, 0, 0}};
-      const TileExtra cr{pb % TB, pa % TB, 0, {edges[c.edge].b1, edges[c.edge].b0, 0, 0}};
-      if (ta == tb) {
-        if (d.diag && d.ti == ta) { extras.push_back(rc); extras.push_back(cr); }
-      } else if (d.ti == ta && d.tj == tb) {
-        extras.push_back(rc);
-      } else if (d.ti == tb && d.tj == ta) {
-        extras.push_back(cr);
-      }
-    }
-    d.x1 = int(extras.size());
+    d.t1 = int(terms.size());
     f->desc[s] = d;
   }
+  slot_terms.clear();
+  smalls.clear();
 
-  // ---- block sides, vmap ------------------------------------------------------------------------------------
+  // ---- block sides, vmap, parameter-independent part of the reduced rhs --------------------------------------------
   f->sides.resize(nrb * ncb);
   for (int b = 0; b < nrb * ncb; ++b)
-    for (int s = 0; s < 4; ++s) f->sides[b].off[s] = bside[b][s] >= 0 ? ppos[bside[b][s]] : -1;
+    for (int s = 0; s < 4; ++s) f->sides[b].off[s] = bside[b][s] >= 0 ? npos[bside[b][s]] : -1;
   std::vector<int> vmap(std::max(f->nGp, 1), -1);
   for (int e = 0; e < E; ++e) {
     const Edge& ed = edges[e];
@@ -1087,100 +1266,66 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       int r, c;  // 1-based inner vertex coordinates
       if (ed.hv == 0) { r = ed.p * N; c = ed.q * N + t + 1; }
       else { r = ed.p * N + t + 1; c = ed.q * N; }
-      vmap[ppos[e] + t] = (r - 1) * f->nc + (c - 1);
+      vmap[npos[e] + t] = (r - 1) * f->nc + (c - 1);
     }
   }
   for (int x = 0; x < ncross; ++x) {
     int r = crosses[x].first * N, c = crosses[x].second * N;
-    vmap[xpos[x]] = (r - 1) * f->nc + (c - 1);
+    vmap[f->xb0 + x] = (r - 1) * f->nc + (c - 1);
+  }
+  std::vector<double> g_red(std::max(f->nGa, 1), 0.0);
+  for (int e : order) {
+    const Comp& ce = comps[comp_of[e]];
+    for (int k = 0; k < ce.r; ++k) g_red[zpos[e] + k] = double(ce.gt[k]);
+  }
+  for (int x = 0; x < ncross; ++x) g_red[xred[x]] = h2;
+
+  // ---- expansion tables of the active edges, back substitution tables of the closed-form ones ------------------------
+  const size_t tsz = size_t(n1p) * n1p;
+  std::vector<ExpEdge> exps;
+  std::vector<int> p0_of(comps.size(), -1);
+  for (size_t c = 0; c < comps.size(); ++c) p0_of[c] = push_vec(comps[c].p0, n1p);
+  for (int e : order)
+    exps.push_back(ExpEdge{zpos[e], (rk[e] + BK - 1) / BK, npos[e], comp_of[e], p0_of[comp_of[e]], edges[e].b0, edges[e].b1});
+  {
+    std::vector<double> Ptab(std::max<size_t>(comps.size() * tsz, 1), 0.0);
+    for (size_t c = 0; c < comps.size(); ++c) put_table(Ptab, c, n1p, comps[c].P, false);
+    ROM_TRY(upload(&f->d_P, Ptab));
+    std::vector<double> Bt(std::max<size_t>(size_t(nbt) * tsz, 1), 0.0);
+    for (auto& kv : bt_of_id) put_table(Bt, kv.second, n1p, TK(kv.first), true);  // (T K^-1)^T: row = node of e
+    for (auto& kv : bt_extra) put_table(Bt, kv.first, n1p, kv.second, false);
+    ROM_TRY(upload(&f->d_Bt, Bt));
   }
 
-  // ---- unit-block tables in long double ----------------------------------------------------------------
-  typedef long double ld;
-  const ld PI = acosl(-1.0L);
-  std::vector<ld> Q(size_t(n1) * n1), lam(n1);
-  for (int j = 1; j <= n1; ++j) {
-    lam[j - 1] = 2.0L - 2.0L * cosl(PI * j / N);
-    for (int m = 1; m <= n1; ++m) Q[size_t(j - 1) * n1 + (m - 1)] = sqrtl(2.0L / N) * sinl(PI * j * m / (ld)N);
-  }
-  std::vector<double> rho(size_t(n1) * (N + 1));
-  for (int m = 0; m < n1; ++m) {
-    ld phi = acoshl(1.0L + lam[m] / 2.0L);
-    ld den = -expm1l(-2.0L * N * phi);  // 1 - exp(-2 N phi)
-    for (int i = 0; i <= N; ++i) {
-      ld num = expl(-phi * i) * (-expm1l(-2.0L * (N - i) * phi));
-      rho[size_t(m) * (N + 1) + i] = double(num / den);
-    }
-  }
-  // W = L^{-1} 1 = Q (s s^T / (lam_l + lam_m)) Q
-  std::vector<ld> sv(n1, 0.0L), Z(size_t(n1) * n1), ZQ(size_t(n1) * n1);
-  for (int m = 0; m < n1; ++m)
-    for (int j = 0; j < n1; ++j) sv[m] += Q[size_t(j) * n1 + m];
-  for (int l = 0; l < n1; ++l)
-    for (int m = 0; m < n1; ++m) Z[size_t(l) * n1 + m] = sv[l] * sv[m] / (lam[l] + lam[m]);
-  for (int l = 0; l < n1; ++l)
-    for (int j = 0; j < n1; ++j) {
-      ld s = 0;
-      for (int m = 0; m < n1; ++m) s += Z[size_t(l) * n1 + m] * Q[size_t(j) * n1 + m];
-      ZQ[size_t(l) * n1 + j] = s;
-    }
-  std::vector<double> W(size_t(n1) * n1);
-  for (int i = 0; i < n1; ++i)
-    for (int j = 0; j < n1; ++j) {
-      ld s = 0;
-      for (int l = 0; l < n1; ++l) s += Q[size_t(i) * n1 + l] * ZQ[size_t(l) * n1 + j];
-      W[size_t(i) * n1 + j] = double(s);
-    }
-  const double h2 = 1.0 / (double(N) * double(N));
-  f->g_host.assign(std::max(f->nGp, 1), 0.0);
-  auto Wat = [&](int i, int j) { return W[size_t(i - 1) * n1 + (j - 1)]; };
-  for (int e = 0; e < E; ++e) {
-    const Edge& ed = edges[e];
-    for (int t = 1; t <= n1; ++t) {
-      double w = ed.hv == 0 ? Wat(N - 1, t) + Wat(1, t) : Wat(t, N - 1) + Wat(t, 1);
-      f->g_host[ppos[e] + t - 1] = h2 * (1.0 + w);
-    }
-  }
-  for (int x = 0; x < ncross; ++x) f->g_host[xpos[x]] = h2;
-
-  // ---- device tables -------------------------------------------------------------------------------------
+  // ---- device tables of the harmonic extension ---------------------------------------------------------------
   std::vector<double> Qp(size_t(n1p) * n1p, 0.0);
   for (int j = 0; j < n1; ++j)
-    for (int m = 0; m < n1; ++m) Qp[size_t(j) * n1p + m] = double(Q[size_t(j) * n1 + m]);
-  double *d_Qp = nullptr, *d_rho = nullptr, *d_A0 = nullptr, *d_H0 = nullptr;
-  ROM_TRY(upload(&d_Qp, Qp));
-  ROM_TRY(upload(&d_rho, rho));
+    for (int m = 0; m < n1; ++m) Qp[size_t(j) * n1p + m] = double(Q(j, m));
+  double* d_rho = nullptr;
+  ROM_TRY(upload(&f->d_Qp, Qp));
+  ROM_TRY(upload(&d_rho, rho_d));
   const size_t hrows = size_t(n1) * n1;
-  ROM_HIP(hipMalloc(&d_A0, std::max<size_t>(hrows * n1p, 1) * sizeof(double)));
-  ROM_HIP(hipMalloc(&d_H0, std::max<size_t>(hrows * n1p, 1) * sizeof(double)));
-  ROM_HIP(hipMalloc(&f->d_Tm, size_t(16) * n1p * n1p * sizeof(double)));
-  {
+  ROM_HIP(hipMalloc(&f->d_A0, std::max<size_t>(hrows * n1p, 1) * sizeof(double)));
+  if (hrows > 0) {
     size_t total = hrows * n1p;
-    k_build_A0<<<unsigned((total + 255) / 256), 256, 0, ctx->stream>>>(d_A0, d_Qp, d_rho, n1, n1p, N);
-    ROM_HIP(hipGetLastError());
-    ROM_TRY(rom_launch_gemm_nt(ctx, int64_t(hrows), n1p, n1p, 1.0, d_A0, n1p, d_Qp, n1p, 0.0, d_H0, n1p,
-                               "setup_gemm_H0"));
-    size_t tt = size_t(16) * n1p * n1p;
-    k_build_Tm<<<unsigned((tt + 255) / 256), 256, 0, ctx->stream>>>(f->d_Tm, d_H0, n1, n1p, N);
+    k_build_A0<<<unsigned((total + 255) / 256), 256, 0, ctx->stream>>>(f->d_A0, f->d_Qp, d_rho, n1, n1p, N);
     ROM_HIP(hipGetLastError());
     ROM_HIP(hipStreamSynchronize(ctx->stream));
   }
   hipFree(d_rho);
-  hipFree(d_H0);  // only needed for the Dirichlet-to-Neumann tables; the extension runs in the sine basis (A0)
-  f->d_A0 = d_A0;
   {
     // kmax[d]: modes with rho_mode(d) >= 1e-24, rounded up to the K chunk
     std::vector<int> kmax(N + 1, n1p);
     for (int dd = 1; dd <= N; ++dd) {
       int last = -1;
       for (int m = 0; m < n1; ++m)
-        if (rho[size_t(m) * (N + 1) + std::min(dd, N)] >= 1e-24) last = m;
+        if (rho_d[size_t(m) * (N + 1) + std::min(dd, N)] >= 1e-24) last = m;
       kmax[dd] = std::min(n1p, std::max(BK, (last + 1 + BK - 1) / BK * BK));
     }
     kmax[0] = n1p;
     ROM_TRY(upload(&f->d_kmax, kmax));
     std::vector<int> eposv(std::max(E, 1), 0);
-    for (int e = 0; e < E; ++e) eposv[e] = ppos[e];
+    for (int e = 0; e < E; ++e) eposv[e] = npos[e];
     ROM_TRY(upload(&f->d_epos, eposv));
     f->n_edges = E;
     // flops of the truncated extension, per system (for the work accounting)
@@ -1196,116 +1341,17 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         }
     f->ext_flops = fl + 2.0 * E * double(n1p) * n1p;
   }
-  ROM_TRY(upload(&f->d_W, W));
-  ROM_TRY(upload(&f->d_g, f->g_host));
-
-  // ---- closed-form elimination tables ------------------------------------------------------------------------
-  // K = tridiag(-1/2, 2, -1/2) - T_same = Q diag(1 + lam_m/2 - rho_m(1)) Q   =>   K^-1 = Q diag(1/kappa_m) Q
-  std::vector<RhsTerm> rhs_terms;
-  std::vector<PreEdge> pre_edges(npre);
-  double pre_flops = 0;
-  if (npre > 0) {
-    std::vector<double> Kinv(size_t(n1p) * n1p, 0.0);
-    {
-      std::vector<ld> QD(size_t(n1) * n1);
-      for (int j = 0; j < n1; ++j)
-        for (int m = 0; m < n1; ++m) {
-          ld kappa = 1.0L + lam[m] / 2.0L - (ld)rho[size_t(m) * (N + 1) + 1];
-          QD[size_t(j) * n1 + m] = Q[size_t(j) * n1 + m] / kappa;
-        }
-      for (int i = 0; i < n1; ++i)
-        for (int j = 0; j <= i; ++j) {
-          ld sacc = 0;
-          for (int m = 0; m < n1; ++m) sacc += QD[size_t(i) * n1 + m] * Q[size_t(j) * n1 + m];
-          Kinv[size_t(i) * n1p + j] = Kinv[size_t(j) * n1p + i] = double(sacc);
-        }
-    }
-    double* d_Kinv = nullptr;
-    ROM_TRY(upload(&d_Kinv, Kinv));
-    const size_t tsz = size_t(n1p) * n1p;
-    // per (pre edge, neighbour): X_fe, B_fe = X_fe K^-1 ; tables kept: B^T (back substitution), R (tiles)
-    int nbt = 0;
-    for (int i = 0; i < npre; ++i) nbt += int(nbs[i].size());
-    const int nR = int(rid.size());
-    ROM_HIP(hipMalloc(&f->d_R, std::max<size_t>(size_t(nR + nbt) * tsz, 1) * sizeof(double)));
-    int nvec = 0;
-    for (int i = 0; i < npre; ++i) nvec += 1 + int(nbs[i].size());
-    ROM_HIP(hipMalloc(&f->d_vec, std::max<size_t>(size_t(nvec) * n1p, 1) * sizeof(double)));
-    ROM_HIP(hipMemsetAsync(f->d_vec, 0, size_t(nvec) * n1p * sizeof(double), ctx->stream));
-    double *d_X = nullptr, *d_B = nullptr;
-    int maxnb = 0;
-    for (int i = 0; i < npre; ++i) maxnb = std::max(maxnb, int(nbs[i].size()));
-    ROM_HIP(hipMalloc(&d_X, size_t(maxnb) * tsz * sizeof(double)));
-    ROM_HIP(hipMalloc(&d_B, size_t(maxnb) * tsz * sizeof(double)));
-    int* d_xrc = nullptr;
-    ROM_HIP(hipMalloc(&d_xrc, 64 * sizeof(int)));
-    int bt_next = nR, vec_next = 0;
-    for (int i = 0; i < npre; ++i) {
-      const int e = pre_list[i];
-      const Edge& pe = edges[e];
-      PreEdge& P = pre_edges[i];
-      memset(&P, 0, sizeof(P));
-      P.pos = ppos[e];
-      P.e0 = pe.b0;
-      P.e1 = pe.b1;
-      P.nnb = int(nbs[i].size());
-      // w_e = K^-1 g_e
-      P.woff = (vec_next++) * n1p;
-      ROM_TRY(rom_launch_gemm_nt(ctx, n1p, 1, n1p, 1.0, d_Kinv, n1p, f->d_g + ppos[e], n1p, 0.0, f->d_vec + P.woff, 1,
-                                 "setup_gemm"));
-      for (int q = 0; q < P.nnb; ++q) {
-        const Nb& nb = nbs[i][q];
-        int tmat = -1;
-        if (nb.blk >= 0) tmat = side_of(nb.blk, nb.f) * 4 + side_of(nb.blk, e);
-        std::vector<int> xrc;
-        for (auto& xr : nb.xs) xrc.push_back(xr.first);
-        for (auto& xr : nb.xs) xrc.push_back(xr.second);
-        if (xrc.size() > 64) { rom_set_error("internal: too many cross points on one edge"); return ROM_ERR_INVALID; }
-        if (!xrc.empty()) ROM_HIP(hipMemcpy(d_xrc, xrc.data(), xrc.size() * sizeof(int), hipMemcpyHostToDevice));
-        double* Xq = d_X + size_t(q) * tsz;
-        double* Bq = d_B + size_t(q) * tsz;
-        k_build_X<<<unsigned((tsz + 255) / 256), 256, 0, ctx->stream>>>(Xq, f->d_Tm, n1, n1p, tmat, int(nb.xs.size()),
-                                                                      d_xrc, d_xrc + nb.xs.size());
-        ROM_HIP(hipGetLastError());
-        ROM_HIP(hipStreamSynchronize(ctx->stream));  // d_xrc is reused
-        // B_fe = X_fe K^-1 (K^-1 symmetric)
-        ROM_TRY(rom_launch_gemm_nt(ctx, n1p, n1p, n1p, 1.0, Xq, n1p, d_Kinv, n1p, 0.0, Bq, n1p, "setup_gemm"));
-        // B^T table for the back substitution: (K^-1 X_fe^T)[node of e][position on f]
-        const int bt = bt_next++;
-        ROM_TRY(rom_launch_gemm_nt(ctx, n1p, n1p, n1p, 1.0, d_Kinv, n1p, Xq, n1p, 0.0, f->d_R + size_t(bt) * tsz, n1p,
-                                   "setup_gemm"));
-        P.nb[q] = PreNb{ppos[nb.f], nb.blk, used[nb.f], bt};
-        // q_{e,f} = B_fe g_e : rhs correction of the active unknowns on f
-        const int qoff = (vec_next++) * n1p;
-        ROM_TRY(rom_launch_gemm_nt(ctx, n1p, 1, n1p, 1.0, Bq, n1p, f->d_g + ppos[e], n1p, 0.0, f->d_vec + qoff, 1,
-                                   "setup_gemm"));
-        for (int t : nb_tiles(nb)) {
-          const int lr0 = tile_loc[t] * TB;
-          rhs_terms.push_back(RhsTerm{t, lr0, std::max(0, std::min(TB, n1 - lr0)), tile_ndr[t], qoff, nb.blk, pe.b0, pe.b1});
-        }
-        pre_flops += 2.0 * n1p * double(n1p);  // back substitution GEMM share of this neighbour
-      }
-      // R tables of this edge
-      for (auto& kv : rid) {
-        if (kv.first[0] != i) continue;
-        const int qr = nb_index(i, kv.first[1]), qc = nb_index(i, kv.first[2]);
-        ROM_TRY(rom_launch_gemm_nt(ctx, n1p, n1p, n1p, 1.0, d_B + size_t(qr) * tsz, n1p, d_X + size_t(qc) * tsz, n1p, 0.0,
-                                   f->d_R + size_t(kv.second) * tsz, n1p, "setup_gemm"));
-      }
-      ROM_HIP(hipStreamSynchronize(ctx->stream));  // d_X / d_B are reused by the next edge
-    }
-    hipFree(d_X);
-    hipFree(d_B);
-    hipFree(d_xrc);
-    hipFree(d_Kinv);
-  }
-  f->d_Qp = d_Qp;
+  ROM_TRY(upload(&f->d_W, Wd));
+  ROM_TRY(upload(&f->d_g, g_red));
+  ROM_TRY(upload(&f->d_vec, vecs));
+  ROM_TRY(upload(&f->d_pool, pool));
+  ROM_TRY(upload(&f->d_terms, terms));
   f->nrhs = int(rhs_terms.size());
   ROM_TRY(upload(&f->d_rhs, rhs_terms));
   ROM_TRY(upload(&f->d_pre, pre_edges));
+  ROM_TRY(upload(&f->d_exp, exps));
+  ROM_TRY(upload(&f->d_xred, xred));
   ROM_TRY(upload(&f->d_desc, f->desc));
-  ROM_TRY(upload(&f->d_extra, extras));
-  ROM_TRY(upload(&f->d_slot_of, f->slot_of));
   ROM_TRY(upload(&f->d_kptr, f->kptr));
   ROM_TRY(upload(&f->d_kpair, f->kpair));
   ROM_TRY(upload(&f->d_colptr, f->colptr));
@@ -1315,9 +1361,10 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   ROM_TRY(upload(&f->d_vmap, vmap));
 
   // ---- work accounting of this algorithm, per snapshot solve ------------------------------------------------
-  const double ext_flops = f->ext_flops;
-  double back_flops = 2.0 * 4096.0 * (f->nslots + T);
-  f->flops_solve = flops + ext_flops + back_flops + pre_flops;
+  double exp_flops = 0;
+  for (int e : order) exp_flops += 2.0 * n1p * double((rk[e] + BK - 1) / BK * BK);
+  const double back_flops = 2.0 * 4096.0 * (f->nslots + T);
+  f->flops_solve = flops + f->ext_flops + back_flops + pre_flops + exp_flops;
   // HBM bytes: factor tiles written once + read once by the back substitution, inverse tiles w+r,
   // the snapshot row written once, the coefficients read.
   f->bytes_solve = 8.0 * (2.0 * 4096.0 * f->nslots + 2.0 * 4096.0 * T + double(f->dim) + nrb * ncb);
@@ -1379,6 +1426,7 @@ extern "C" int rom_assemble_batch(rom_fem* f, rom_buf* a, int M, rom_buf* diag, 
   return ROM_OK;
 }
 
+
 static int ensure_workspace(rom_fem* f, int Mc) {
   if (f->ws_M >= Mc) return ROM_OK;
   ROM_HIP(hipStreamSynchronize(f->ctx->stream));
@@ -1391,6 +1439,8 @@ static int ensure_workspace(rom_fem* f, int Mc) {
   ROM_HIP(hipMalloc(&f->d_L, std::max<size_t>(size_t(Mc) * f->nslots * 4096, 1) * sizeof(double)));
   ROM_HIP(hipMalloc(&f->d_invL, std::max<size_t>(size_t(Mc) * f->T * 4096, 1) * sizeof(double)));
   ROM_HIP(hipMalloc(&f->d_y, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
+  // zeroed once: padding slots are read (against zero table entries) before anything writes them
+  ROM_HIP(hipMemset(f->d_y, 0, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
   ROM_HIP(hipMalloc(&f->d_yhat, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
   f->ws_M = Mc;
   return ROM_OK;
@@ -1405,10 +1455,8 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   char nm[4][48];
   if (f->nGp > 0) {
     {
-      ROM_PROF(ctx, "init_rhs", 0, 8.0 * Mc * f->nGp);
-      size_t tot = size_t(Mc) * f->nGp;
-      k_init_rhs<<<unsigned((tot + 255) / 256), 256, 0, st>>>(d, Mc);
-      if (f->nrhs > 0) k_rhs_pre<<<dim3(f->T, Mc), 64, 0, st>>>(d, am, f->T);
+      ROM_PROF(ctx, "rhs", 0, 8.0 * Mc * f->nGa);
+      k_rhs<<<Mc, 256, 0, st>>>(d, am);
     }
     for (int j = 0; j < f->T; ++j) {
       {
@@ -1440,6 +1488,10 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
     if (f->T > 0) {
       ROM_PROF(ctx, "backsolve", Mc * 2.0 * 4096 * (f->nslots + f->T), Mc * 8.0 * 4096 * (f->nslots + f->T));
       k_backsolve<<<Mc, 256, lds_back, st>>>(d);
+    }
+    if (f->nexp > 0 || f->ncross > 0) {
+      ROM_PROF(ctx, "expand", Mc * 2.0 * f->n1p * 32.0 * f->nexp, 8.0 * Mc * f->n1p * f->nexp);
+      k_expand<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->nexp + 1), 256, 0, st>>>(d, am, Mc);
     }
     if (f->npre > 0) {
       ROM_PROF(ctx, "back_pre", Mc * 2.0 * f->n1p * double(f->n1p) * 3.0 * f->npre, 8.0 * Mc * f->n1p * 4.0 * f->npre);

@@ -97,82 +97,71 @@ struct ProfScope {
 #define ROM_PROF(ctx, name, flops, bytes) ProfScope _prof_scope_##__LINE__(ctx, name, flops, bytes)
 
 // ---- assembly descriptors (host-built, device-read) --------------------------------------------
-struct TileTerm {
-  int blk;   // block index p*ncb+q whose coefficient scales the term
-  int tmat;  // sr*4+sc : which Dirichlet-to-Neumann table
-  int r0;    // row offset inside the table (= local node offset of the tile rows on its edge)
-  int c0;    // col offset inside the table
-};
-
-// Contribution of one pre-eliminated edge e (closed-form elimination, D_e = (a_e0 + a_e1) K) to a tile:
-//   - c_row c_col / (a_e0 + a_e1) * R[table][r0 + r][c0 + c],   c = a[blk] on edge-node rows/cols,
-//   (a_e0 + a_e1)/2 on cross-point slots (R = X_f K^-1 X_f'^T, parameter independent).
-struct PreTerm {
-  int table;       // index of the R table (n1p x n1p doubles each)
-  int r0, c0;      // offset of the tile inside the table
-  int brow, bcol;  // blocks scaling edge-node rows / cols (-1: the edge shares no block with e)
-  int e0, e1;      // the two blocks of the eliminated edge
+// The factorised ("reduced") interface vector is a packed sequence of groups: the compressed unknowns
+// z_f = W_f^T u_f of every active edge f, each followed by the cross points it hosts.  A tile of the
+// reduced matrix is a linear combination of parameter-independent 64x64 tables:
+//   tile = sum_t coef_t(a) * pool[tab_t],   table t zero outside its rectangle [r_lo,r_hi) x [c_lo,c_hi)
+struct GenTerm {
+  int tab;                         // index of the 64x64 table in the pool
+  short r_lo, r_hi, c_lo, c_hi;    // bounding rectangle inside the tile
+  int kind;                        // coefficient formula, see term_coef() in rom_fem.hip
+  int b[4];                        // block indices it uses
 };
 
 struct TileDesc {
-  int ti, tj;        // tile coordinates in the (permuted) interface ordering, ti >= tj
-  int nterms;        // 0..2 Schur terms  - a[blk] * T[tmat][r0+r][c0+c]
-  TileTerm term[2];
-  int npre;          // 0..4 pre-eliminated-edge terms
-  PreTerm pre[4];
-  int ndc;           // cols [0, ndc) are unknowns (as ndr for rows)
-  int same_edge;     // 1: rows and cols lie on the same edge -> tridiagonal A_GammaGamma part
-  int hv;            // 0 horizontal edge (blocks up/down), 1 vertical (left/right)
-  int b0, b1;        // the two blocks of that edge: (up, dn) or (lf, rt)
-  int lr0, lc0;      // local node index (on the edge) of tile row 0 / col 0
-  int nvr, nvc;      // number of edge nodes among the tile rows / cols
-  int ndr;           // rows [0, ndr) are unknowns (edge nodes + cross slots); beyond: identity padding
-  int x0, x1;        // range in the extras list
-  int diag;          // 1 if ti == tj
+  int ti, tj;   // tile coordinates in the reduced ordering, ti >= tj
+  int t0, t1;   // range in the term list
+  int ndr;      // rows [0, ndr) are unknowns; beyond: identity padding (last tile only)
+  int diag;     // 1 if ti == tj
 };
 
-struct TileExtra {  // entries touching cross points
-  int r, c;         // position inside the tile
-  int kind;         // 0: -(a[b0]+a[b1])/2 ; 1: ((a[b0]+a[b1])+a[b2])+a[b3]
-  int b[4];
-};
-
-struct BlockSide {  // per block, per side: where its interface values live (or -1)
+struct BlockSide {  // per block, per side: where its nodal interface values live (or -1)
   int off[4];
 };
 
-// rhs correction of one tile of active unknowns by one pre-eliminated edge:
-//   y[tile*64 + r] += c_row / (a_e0 + a_e1) * q[qoff + lr0 + r]
+// rhs of the reduced system:  y[pos + i] += coef * vec[voff + i], i < len
+//   kind 0: coef = a[b0] / (a[e0] + a[e1])   (edge group rows, pre-eliminated edge (e0|e1))
+//   kind 1: coef = 1/2                        (cross point row)
 struct RhsTerm {
-  int tile, lr0, nvr, ndr;  // tile row, its local offset on the edge, edge-node rows, defined rows
-  int qoff;                 // offset of the q vector (n1p doubles) in the vector table
-  int brow, e0, e1;
+  int pos, len, voff, kind, b0, e0, e1;
 };
 
-// back substitution of one pre-eliminated edge:  x_e = (w_e + sum_f B_fe (c_f . x_f)) / (a_e0 + a_e1)
+// back substitution of one pre-eliminated edge:  x_e = (w_e + sum_u B_ue^T (c_u . x_u)) / (a_e0 + a_e1)
 struct PreNb {
-  int fpos;    // position of the neighbour's n1p block in the interface vector
-  int blk;     // block scaling its edge nodes (-1: none)
-  int nused;   // cross-point slots behind the edge nodes (scaled by (a_e0+a_e1)/2)
-  int bt;      // index of the B^T table (n1p x n1p): row = node of e, col = position on the neighbour
+  int fpos;    // position of the neighbour's nodal block (or of the cross block) in the interface vector
+  int blk;     // block scaling an edge neighbour (c_u = a[blk]); -1: the cross block (c_u = (a_e0+a_e1)/2)
+  int nch;     // K chunks (of BK) to run over
+  int bt;      // index of the B^T table (n1p x n1p): row = node of e, col = position in the neighbour block
 };
 struct PreEdge {
-  int pos;     // position of e's n1p block in the interface vector
+  int pos;     // position of e's nodal block in the interface vector
   int e0, e1;
   int woff;    // offset of w_e = K^-1 g_e in the vector table
   int nnb;
   PreNb nb[8];
 };
 
+// nodal values of an active edge from its compressed unknowns:  u_f = P z_f + p0 / (a_b0 + a_b1)
+struct ExpEdge {
+  int zpos, nch;  // position of z_f in the reduced vector, K chunks (rank rounded up to BK)
+  int npos;       // position of the nodal block
+  int ptab;       // index of the P table (n1p x n1p, row = node, col = compressed index)
+  int p0off;      // offset of p0 in the vector table
+  int b0, b1;
+};
+
 struct rom_fem {
   rom_ctx* ctx;
-  int nrb, ncb, N, n1, n1p, tpe;  // n1 = N-1, n1p = padded to TB multiple, tpe tiles per edge
+  int nrb, ncb, N, n1, n1p;  // n1 = N-1, n1p = n1 padded to a TB multiple
   int nr, nc;
   int64_t dim;
   int nG;      // real interface unknowns
-  int nGp;     // stride of the interface vectors = T*TB + (pre-eliminated edges)*n1p
-  int nGa;     // active (factorised) part = T*TB
+  int nGp;     // stride of the interface vectors = nGa + (edges)*n1p + cross block
+  int nGa;     // reduced (factorised) part = T*TB
+  int nred;    // reduced unknowns (<= nGa)
   int npre;    // edges eliminated in closed form
+  int nexp;    // active edges
+  int ncross, xb0;  // cross points and the position of their block in the interface vectors
   int T;       // tiles per dimension
   int nslots;  // nonzero lower tiles
   // device tables
@@ -183,29 +172,31 @@ struct rom_fem {
   int n_edges = 0;
   double ext_flops = 0;
   double* d_yhat = nullptr;  // [ws_M][nGp]
-  double* d_Tm = nullptr;    // 16 x n1p x n1p
   double* d_W = nullptr;     // n1*n1 : L^{-1} 1
-  double* d_g = nullptr;     // nGp : parameter independent interface rhs
+  double* d_g = nullptr;     // nGa : parameter independent part of the reduced rhs
   TileDesc* d_desc = nullptr;
-  TileExtra* d_extra = nullptr;
-  int* d_slot_of = nullptr;  // T*T -> slot or -1 (lower)
+  GenTerm* d_terms = nullptr;
+  double* d_pool = nullptr;  // 64x64 tables of the tile terms
   int* d_kptr = nullptr;     // nslots+1
   int* d_kpair = nullptr;    // 2*entries (slotA, slotB)
   int* d_colptr = nullptr;   // T+1 : rows below the diagonal in column j
   int* d_colrow = nullptr;   // slots of those tiles (and their tile row in d_colti)
   int* d_colti = nullptr;
-  double* d_R = nullptr;       // R / B^T tables of the pre-eliminated edges (n1p*n1p each)
-  double* d_vec = nullptr;     // q / w vectors of the pre-eliminated edges (n1p each)
+  double* d_Bt = nullptr;      // B^T tables of the pre-eliminated edges (n1p*n1p each)
+  double* d_P = nullptr;       // expansion tables of the active edges (n1p*n1p each)
+  double* d_vec = nullptr;     // vectors: w_e, p0_f, rhs corrections
   RhsTerm* d_rhs = nullptr;
   PreEdge* d_pre = nullptr;
+  ExpEdge* d_exp = nullptr;
+  int* d_xred = nullptr;       // reduced position of every cross point
   int nrhs = 0;
   BlockSide* d_sides = nullptr;  // nrb*ncb
-  int* d_vmap = nullptr;         // nG real interface unknowns: padded position -> global dof (or -1), size nGp
+  int* d_vmap = nullptr;         // interface position -> global dof (or -1), size nGp
   // host copies
   std::vector<TileDesc> desc;
   std::vector<int> slot_of, kptr, kpair, colptr, colrow, colti, diag_slot;
   std::vector<BlockSide> sides;
-  std::vector<double> g_host;
+  std::vector<int> ranks;        // compressed size of every active edge (elimination order)
   // work accounting
   double flops_solve = 0, bytes_solve = 0;
   // factor workspace (grown on demand)
