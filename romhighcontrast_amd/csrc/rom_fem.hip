@@ -54,10 +54,19 @@ struct FemDev {
   const PreEdge* pre;
   const ExpEdge* exp;
   const int* xred;
+  const RowEnt* rowent;
+  int nrowent;
+  int dbg;
+  const CoefGroup* groups;
+  const double* cm;
+  const int* item_group;
+  const int* item_k;
+  int ncoef;
+  const double* G;     // extension tables of the compressed edges: per table (n1*n1) x (rank+1 padded)
   const double* A0;    // (n1*n1) x n1p : Q[j,mode] rho_mode(i), harmonic extension in the sine basis
   const double* Qp;    // n1p x n1p sine matrix (zero padded)
   const int* kmax;     // [N+1] modes (multiple of 16) that matter at distance d from a side
-  const int* epos;     // position of every edge's nodal n1p block in the interface vectors
+  const int* epos;     // nodal n1p block of every edge whose sine coefficients are needed
   double* yhat;        // [Mc][nGp] sine coefficients of the interface values
   const double* W;
   const double* g;
@@ -68,6 +77,8 @@ struct FemDev {
   const int* colrow;
   const int* colti;
   const BlockSide* sides;
+  const int* lr_blocks;   // blocks whose sides are all compressed: extended in mesh-row tiles
+  const int* gen_blocks;  // all others: 4 x 16 patches
   const int* vmap;
   double* L;     // [Mc][nslots][64*64]
   double* invL;  // [Mc][T][64*64]
@@ -80,12 +91,13 @@ static FemDev make_dev(const rom_fem* f) {
   d.nrb = f->nrb; d.ncb = f->ncb; d.N = f->N; d.n1 = f->n1; d.n1p = f->n1p; d.nr = f->nr; d.nc = f->nc;
   d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.nexp = f->nexp; d.ncross = f->ncross;
   d.xb0 = f->xb0; d.pool = f->d_pool; d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
-  d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.T = f->T; d.nslots = f->nslots;
+  d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.groups = f->d_groups; d.cm = f->d_cm; d.item_group = f->d_item_group;
+  d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.rowent = f->d_rowent; d.nrowent = f->nrowent; d.dbg = getenv("ROMHC_DBG") ? atoi(getenv("ROMHC_DBG")) : 0; d.T = f->T; d.nslots = f->nslots;
   d.kblk = f->nrb * f->ncb; d.dim = f->dim;
-  d.A0 = f->d_A0; d.Qp = f->d_Qp; d.kmax = f->d_kmax; d.epos = f->d_epos; d.yhat = f->d_yhat; d.W = f->d_W;
+  d.G = f->d_G; d.A0 = f->d_A0; d.Qp = f->d_Qp; d.kmax = f->d_kmax; d.epos = f->d_epos; d.yhat = f->d_yhat; d.W = f->d_W;
   d.g = f->d_g; d.desc = f->d_desc;
   d.kptr = f->d_kptr; d.kpair = f->d_kpair; d.colptr = f->d_colptr; d.colrow = f->d_colrow;
-  d.colti = f->d_colti; d.sides = f->d_sides; d.vmap = f->d_vmap; d.L = f->d_L; d.invL = f->d_invL;
+  d.colti = f->d_colti; d.sides = f->d_sides; d.lr_blocks = f->d_lr_blocks; d.gen_blocks = f->d_gen_blocks; d.vmap = f->d_vmap; d.L = f->d_L; d.invL = f->d_invL;
   d.y = f->d_y; d.status = f->ctx->d_status;
   return d;
 }
@@ -139,7 +151,8 @@ struct STile {
   double v[16];
 };
 
-constexpr int COEF_MAX = 64;  // term weights cached in LDS per pass
+constexpr int COEF_MAX = 64;   // term weights cached in LDS per pass
+constexpr int ROW_BATCH = 64;  // loads in flight per wave in the single-tile assembly
 
 __device__ inline void s_tile_load(STile& st, const TileDesc& d, const FemDev& f, const double* __restrict__ am,
                                    double* coef) {
@@ -228,6 +241,45 @@ __global__ __launch_bounds__(256) void k_rhs(FemDev f, const double* __restrict_
   }
 }
 
+// Coefficient blocks read by the extension and the expansion, and the nodal copy of the cross points.
+//   active edge f:      [z_f, 1/s_f, 0...]
+//   closed-form edge e: [c_e / s_e, 1/s_e, 0...],  s_e K u_e = g_e + W_e c_e,
+//                       c_e = sum_u a_u (M_eu z_u + m_eu / s_u) + (s_e/2) sum_x W_e[node_x,:]^T u_x
+// one workgroup per system, one thread per entry
+__global__ __launch_bounds__(256) void k_coef(FemDev f, const double* __restrict__ a) {
+  const int m = blockIdx.x;
+  const double* am = a + size_t(m) * f.kblk;
+  double* y = f.y + size_t(m) * f.nGp;
+  for (int x = threadIdx.x; x < f.ncross; x += blockDim.x) y[f.xb0 + x] = y[f.xred[x]];
+  for (int it = threadIdx.x; it < f.ncoef; it += blockDim.x) {
+    const CoefGroup& cg = f.groups[f.item_group[it]];
+    const int k = f.item_k[it];
+    const double s = am[cg.b0] + am[cg.b1];
+    double out = 0.0;
+    if (k == cg.r) {
+      out = 1.0 / s;
+    } else if (k < cg.r) {
+      if (cg.kind == 0) {
+        out = y[cg.zpos + k];
+      } else {
+        double acc = 0.0;
+        for (int t = 0; t < cg.nterm; ++t) {
+          const CoefTerm& ct = cg.t[t];
+          const double* Mt = f.cm + ct.moff + k;
+          const double* src = y + ct.src;
+          double dot = 0.0;
+#pragma unroll 16
+          for (int j = 0; j < ct.len; ++j) dot += Mt[size_t(j) * cg.r] * src[j];
+          if (ct.voff >= 0) dot += f.vec[ct.voff + k] / (am[ct.u0] + am[ct.u1]);
+          acc += (ct.blk >= 0 ? am[ct.blk] : s / 2) * dot;
+        }
+        out = acc / s;
+      }
+    }
+    y[cg.cpos + k] = out;
+  }
+}
+
 // 4 doubles from an address that is only 8-byte aligned (pointer may be null -> zeros)
 __device__ inline void load4_any(const double* __restrict__ p, double v[4]) {
   if (p) {
@@ -238,18 +290,10 @@ __device__ inline void load4_any(const double* __restrict__ p, double v[4]) {
 }
 
 // Edge values of the active edges from the reduced solution, u_f = P_f z_f + p0_f / s_f, as one batched
-// MFMA GEMM (tile rows = systems, tile cols = nodes of f, K = compressed index), and the copy of the
-// cross points into their nodal block.   grid (n1p/64, ceil(Mc/64), nexp + 1)
+// MFMA GEMM (tile rows = systems, tile cols = nodes of f, K = compressed index); closed-form edges kept in
+// compressed form enter the same way with z = c_e / s_e, P = K^-1 W_e, p0 = K^-1 g_e.   grid (n1p/64, ceil(Mc/64), nexp)
 __global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restrict__ a, int Mc) {
   __shared__ __align__(16) double lds[STAGE_TOTAL];
-  if (int(blockIdx.z) == f.nexp) {
-    if (blockIdx.x != 0) return;
-    for (int idx = threadIdx.x; idx < 64 * f.ncross; idx += blockDim.x) {
-      const int m = blockIdx.y * 64 + idx / f.ncross, x = idx % f.ncross;
-      if (m < Mc) f.y[size_t(m) * f.nGp + f.xb0 + x] = f.y[size_t(m) * f.nGp + f.xred[x]];
-    }
-    return;
-  }
   const WavePos wp;
   const ExpEdge ee = f.exp[blockIdx.z];
   const int srow = stage_row(), sseg = stage_seg();
@@ -450,6 +494,145 @@ __global__ __launch_bounds__(64) void k_diag_inverse(FemDev f, int slot, int j) 
   }
 }
 
+// Whole reduced solve of a system whose reduced matrix is ONE tile (e.g. 2x2 blocks at N = 128: 2 x 31
+// compressed unknowns + the cross point), one wave per system, nothing but the solution leaves the CU:
+//   assemble (lane c accumulates column c of the upper triangle = row c of the lower one, coalesced table reads) ->
+//   in-register Cholesky with the forward substitution fused in -> L through LDS -> back substitution ->
+//   coefficient blocks for the extension (what k_coef does on the general path).
+__global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restrict__ a) {
+  __shared__ __align__(16) double Ls[64 * LDC];
+  __shared__ __align__(16) double lv[2][64];
+  __shared__ double rinv[64];
+  __shared__ double zs[64];
+  const int m = blockIdx.x, lane = threadIdx.x;
+  const double* am = a + size_t(m) * f.kblk;
+  double* ym = f.y + size_t(m) * f.nGp;
+  const TileDesc& d = f.desc[0];
+  // Assembly, upper triangle only (row <= col), by the host-built row program: lane c owns column c, entries
+  // are (table row segment, term) pairs sorted by tile row; ROW_BATCH independent coalesced loads are in flight
+  // before the first is consumed (one wave per SIMD: nothing else hides the latency).
+  for (int r = 0; r < 64; ++r) Ls[r * LDC + lane] = 0.0;
+  const double mycoef = lane < d.t1 - d.t0 ? term_coef(f.terms[d.t0 + lane], am) : 0.0;  // lane t: weight of term t
+  __syncthreads();
+  {
+    static_assert(ROW_BATCH == 64, "one row-program entry per lane and batch");
+    double acc = 0.0;
+    const int4* ents = reinterpret_cast<const int4*>(f.rowent);
+    int4 mine = f.nrowent > 0 ? ents[lane] : int4{0, 0, 0, 0};  // lane i holds entry i of the batch
+    for (int e0 = 0; e0 < ((f.dbg & 1) ? 0 : f.nrowent); e0 += ROW_BATCH) {
+      const int4 cur = mine;
+      if (e0 + ROW_BATCH < f.nrowent) mine = ents[e0 + ROW_BATCH + lane];  // next batch's entries fly meanwhile
+      double v[ROW_BATCH];
+#pragma unroll
+      for (int i = 0; i < ROW_BATCH; ++i) {
+        const int off = __builtin_amdgcn_readlane(cur.x, i);
+        const int c_lo = __builtin_amdgcn_readlane(cur.z, i), c_hi = __builtin_amdgcn_readlane(cur.w, i);
+        v[i] = (f.dbg & 32) ? 1.0 : ((lane >= c_lo && lane < c_hi) ? f.pool[off + lane] : 0.0);
+      }
+      if (f.dbg & 16) {
+#pragma unroll
+        for (int i = 0; i < ROW_BATCH; ++i) acc += v[i];
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < ROW_BATCH; ++i) {
+        const int meta = __builtin_amdgcn_readlane(cur.y, i);  // r | term << 8 | last << 16
+        acc += readlane_f64(mycoef, (meta >> 8) & 0xff) * v[i];  // (an LDS lookup here costs its full latency per entry)
+        if (meta >> 16) {
+          Ls[(meta & 0xff) * LDC + lane] = acc;
+          acc = 0.0;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  double arow[64];  // row `lane` of the symmetric tile = column `lane` of its upper triangle
+#pragma unroll
+  for (int c = 0; c < 64; ++c) arow[c] = c <= lane ? Ls[c * LDC + lane] : 0.0;
+  if (lane >= d.ndr || (f.dbg & 49)) {
+#pragma unroll
+    for (int c = 0; c < 64; ++c) arow[c] = (c == lane) ? 1.0 : 0.0;  // padding unknowns: identity
+  }
+  // rhs of the reduced system (k_rhs)
+  double y = f.g[lane];
+  for (int t = 0; t < f.nrhs; ++t) {
+    const RhsTerm& rt = f.rhs[t];
+    const double cr = rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5;
+    if (lane >= rt.pos && lane < rt.pos + rt.len) y += cr * f.vec[rt.voff + lane - rt.pos];
+  }
+  // Cholesky (as k_diag_potrf) with y carried along: after step jj, y holds L^-1 g in lanes <= jj
+  bool bad = false;
+  double myrs = 0.0;
+#pragma unroll
+  for (int jj = 0; jj < 64; ++jj) {
+    const double dj = readlane_f64(arow[jj], jj);
+    bad = bad || !(dj > 0.0);
+    const double rs = rsqrt_newton(dj);
+    const double l = arow[jj] * rs;  // L[lane][jj] for lane >= jj
+    arow[jj] = l;
+    const double yj = readlane_f64(y, jj) * rs;
+    if (lane == jj) {
+      y = yj;
+      myrs = rs;  // (an LDS store here makes hipcc spill the whole tile)
+    } else if (lane > jj) {
+      y -= l * yj;
+    }
+    if (jj < 63) {
+      double* bv = lv[jj & 1];
+      bv[lane] = l;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < 64; ++c)
+        if (c > jj) arow[c] -= l * bv[c];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (bad && lane == 0) atomicOr(f.status, 1);
+  rinv[lane] = myrs;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) Ls[lane * LDC + c] = c <= lane ? arow[c] : 0.0;
+  __syncthreads();
+  // back substitution x = L^-T y: row j of L is read from LDS (conflict free), x_j broadcast by readlane
+  if (!(f.dbg & 4))
+#pragma unroll
+  for (int j = 63; j >= 0; --j) {
+    const double xj = readlane_f64(y, j) * rinv[j];
+    if (lane == j) y = xj;
+    else if (lane < j) y -= Ls[j * LDC + lane] * xj;
+  }
+  ym[lane] = y;
+  zs[lane] = y;
+  __syncthreads();
+  // coefficient blocks + nodal copy of the cross points (k_coef)
+  for (int x = lane; x < f.ncross; x += 64) ym[f.xb0 + x] = zs[f.xred[x]];
+  for (int it = lane; it < ((f.dbg & 8) ? 0 : f.ncoef); it += 64) {
+    const CoefGroup& cg = f.groups[f.item_group[it]];
+    const int k = f.item_k[it];
+    const double s = am[cg.b0] + am[cg.b1];
+    double out = 0.0;
+    if (k == cg.r) {
+      out = 1.0 / s;
+    } else if (k < cg.r) {
+      if (cg.kind == 0) {
+        out = zs[cg.zpos + k];
+      } else {
+        double acc = 0.0;
+        for (int t = 0; t < cg.nterm; ++t) {
+          const CoefTerm& ct = cg.t[t];
+          const double* Mt = f.cm + ct.moff + k;
+          double dot = 0.0;
+#pragma unroll 16
+          for (int j = 0; j < ct.len; ++j) dot += Mt[size_t(j) * cg.r] * zs[ct.src + j];
+          if (ct.voff >= 0) dot += f.vec[ct.voff + k] / (am[ct.u0] + am[ct.u1]);
+          acc += (ct.blk >= 0 ? am[ct.blk] : s / 2) * dot;
+        }
+        out = acc / s;
+      }
+    }
+    ym[cg.cpos + k] = out;
+  }
+}
+
 // Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;
 // y_i -= L_ij y_j.  invL_jj is lower triangular: the waves owning output columns 0..31 only need
 // k < 32 of the second product.
@@ -583,49 +766,80 @@ __global__ __launch_bounds__(256) void k_edge_transform(FemDev f, int Mc) {
     }
 }
 
-// Harmonic extension in the sine basis of each side:
-//   U_I,b[m,(i,j)] = (h^2/a_b) W[i,j] + sum_{sides s} sum_mode yhat_s[m, mode] * A0[pi_s(i,j)][mode],
-//   A0[(i',j'), mode] = Q[j', mode] rho_mode(i'),   rho_mode(i') ~ exp(-i' phi_mode).
-// Far from a side only the low modes survive in fp64: kmax[d] (multiple of 16) is the number of modes with
-// rho_mode(d) above 1e-24, so a tile whose vertices are at distance >= d from side s stops its K loop
-// there (terms below 1e-24 of the leading ones cannot change an fp64 sum).
-// Tile columns = a 4 x 16 patch of interior vertices (so that the distance to all four sides is bounded
-// below per tile and rows are still written in 128-byte segments); tile rows = systems.
-// grid (patches, ceil(Mc/64), nblocks)
+// Harmonic extension, one batched MFMA GEMM over all blocks:
+//   U_I,b[m,(i,j)] = (h^2/a_b) W[i,j] + sum_{sides s} sum_k c_s[m, k] * Tab_s[pi_s(i,j)][k]
+// with one of two parameter-independent representations per side (ExtSide::mode):
+//   1  sine modes:  c = yhat_s (sine coefficients of the edge values), Tab = A0[(i',j'), mode] = Q[j', mode] rho_mode(i').
+//      rho_mode(i') ~ exp(-i' phi_mode): far from a side only the low modes survive in fp64; kmax[d] (multiple
+//      of 16) is the number of modes with rho_mode(d) above 1e-18, so a tile whose vertices are at distance >= d
+//      from side s stops its K loop there (terms below 1e-18 of the leading ones cannot change an fp64 sum).
+//   2  compressed edge:  c = [z_f, 1/s_f] (the reduced unknowns themselves), Tab = H_0 [P_f, p0_f]: K = rank + 1,
+//      no edge values or sine transform needed.
+// Tile rows = systems; tile columns = 64 interior vertices of one block, either a 4 x 16 patch (pw_log2 = 4:
+// the distance to all four sides is bounded below per tile, which is what the mode truncation needs) or
+// 64 consecutive vertices of one mesh row (pw_log2 = 6, blocks whose sides are all compressed: K does not
+// depend on the position, and 512 contiguous bytes per system are written -- measured 2.8 instead of
+// 2.1 TB/s for the store stream alone, tools/hbm_write_bw.hip).
+// grid (patches, ceil(Mc/64), blocks in the list)
 __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restrict__ a, int Mc,
-                                                double* __restrict__ U, long long row0) {
+                                                double* __restrict__ U, long long row0, const int* __restrict__ blocks,
+                                                int pw_log2) {
   __shared__ __align__(16) double lds[STAGE_TOTAL];
   double* stage = lds;
   const WavePos wp;
-  const int b = blockIdx.z;
+  const int b = blocks[blockIdx.z];
   const int p = b / f.ncb, q = b % f.ncb;
   const int n1 = f.n1, N = f.N;
-  const BlockSide sd = f.sides[b];
+  const BlockSide& sd = f.sides[b];
   const int srow = stage_row(), sseg = stage_seg();
-  const int npj = (n1 + 15) / 16;                     // patches per patch row
+  const int pw = 1 << pw_log2, ph = 64 >> pw_log2;    // patch width / height in vertices
+  const int npj = (n1 + pw - 1) >> pw_log2;           // patches per patch row
   const int pi = blockIdx.x / npj, pj = blockIdx.x % npj;
-  const int i0 = 4 * pi + 1, j0 = 16 * pj + 1;        // first vertex of the patch (1-based)
-  const int i1 = min(i0 + 3, n1), j1 = min(j0 + 15, n1);
+  const int i0 = ph * pi + 1, j0 = pw * pj + 1;       // first vertex of the patch (1-based)
+  const int i1 = min(i0 + ph - 1, n1), j1 = min(j0 + pw - 1, n1);
 
   const int mA = blockIdx.y * 64 + srow;
-  const double* Arow = mA < Mc ? f.yhat + size_t(mA) * f.nGp + sseg : nullptr;
-  const int iB = i0 + (srow >> 4), jB = j0 + (srow & 15);  // vertex of this thread's B row
+  const bool vA = mA < Mc;
+  const int iB = i0 + (srow >> pw_log2), jB = j0 + (srow & (pw - 1));  // vertex of this thread's B row
   const bool vB = iB <= n1 && jB <= n1;
 
-  Acc acc;
-  acc_zero(acc);
+  // one merged, pipelined K loop over the chunks of all four sides
+  int cend[4];
+  const double* pAs[4];
+  const double* pBs[4];
+  int tot = 0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int off = s == 0 ? sd.off[0] : s == 1 ? sd.off[1] : s == 2 ? sd.off[2] : sd.off[3];
-    if (off < 0) continue;  // side on the domain boundary (uniform branch)
-    const int dist = s == 0 ? i0 : s == 1 ? N - i1 : s == 2 ? j0 : N - j1;  // closest vertex of the patch
-    const int nch = f.kmax[dist] / BK;
-    const double* pA = Arow ? Arow + off : nullptr;
-    const double* pB = vB ? f.A0 + size_t(h0_row(s, iB, jB, N, n1)) * f.n1p + sseg : nullptr;
-    gemm_loop(
-        nch, [&](int ch, double* v) { load4_aligned(pA ? pA + ch * BK : nullptr, v); },
-        [&](int ch, double* v) { load4_aligned(pB ? pB + ch * BK : nullptr, v); }, acc, stage, wp);
+    const ExtSide es = sd.s[s];
+    int nch = 0;
+    pAs[s] = pBs[s] = nullptr;
+    if (es.mode != 0) {  // (mode 0: side on the domain boundary)
+      const int hrow = vB ? h0_row(s, iB, jB, N, n1) : 0;
+      if (es.mode == 1) {
+        const int dist = s == 0 ? i0 : s == 1 ? N - i1 : s == 2 ? j0 : N - j1;  // closest vertex of the patch
+        nch = f.kmax[dist] / BK;
+        if (vA) pAs[s] = f.yhat + size_t(mA) * f.nGp + es.off + sseg;
+        if (vB) pBs[s] = f.A0 + size_t(hrow) * f.n1p + sseg;
+      } else {
+        nch = es.nch;
+        if (vA) pAs[s] = f.y + size_t(mA) * f.nGp + es.off + sseg;
+        if (vB) pBs[s] = f.G + es.gtab + size_t(hrow) * (es.nch * BK) + sseg;
+      }
+    }
+    tot += nch;
+    cend[s] = tot;
   }
+  Acc acc;
+  acc_zero(acc);
+  auto pick = [&](int ch, const double* const* ps) -> const double* {
+    const int s = (ch >= cend[0]) + (ch >= cend[1]) + (ch >= cend[2]);
+    const int lc = ch - (s == 0 ? 0 : s == 1 ? cend[0] : s == 2 ? cend[1] : cend[2]);
+    const double* p = s == 0 ? ps[0] : s == 1 ? ps[1] : s == 2 ? ps[2] : ps[3];
+    return p ? p + lc * BK : nullptr;
+  };
+  gemm_loop(
+      tot, [&](int ch, double* v) { load4_aligned(pick(ch, pAs), v); },
+      [&](int ch, double* v) { load4_aligned(pick(ch, pBs), v); }, acc, stage, wp);
 
   const double h2 = 1.0 / (double(N) * double(N));
 #pragma unroll
@@ -638,7 +852,7 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
         const int cidx = acc_col(wp, jb);
-        const int ii = i0 + (cidx >> 4) - 1, jj = j0 + (cidx & 15) - 1;  // 0-based interior indices
+        const int ii = i0 + (cidx >> pw_log2) - 1, jj = j0 + (cidx & (pw - 1)) - 1;  // 0-based interior indices
         if (ii >= n1 || jj >= n1) continue;
         long long gidx = (long long)(p * N + ii) * f.nc + (q * N + jj);
         U[(row0 + m) * f.dim + gidx] = acc.c[i][jb][g] + sc * f.W[ii * n1 + jj];
@@ -704,6 +918,8 @@ struct Comp {
   Mat P;               // n1 x r   K^-1 W Kt
   std::vector<ld> gt;  // r        Kt W^T K^-1 g_f
   std::vector<ld> p0;  // n1       (K^-1 - P W^T K^-1) g_f
+  Mat KiW;             // n1 x r   K^-1 W          (closed-form edges: u_e = (KiW c_e + wK) / s_e)
+  std::vector<ld> wK;  // n1       K^-1 g_f
 };
 
 struct TermAcc {
@@ -735,9 +951,10 @@ void put_table(std::vector<double>& pool, size_t idx, int n1p, const Mat& A, boo
 extern "C" int rom_fem_destroy(rom_fem* f) {
   if (!f) return ROM_OK;
   hipStreamSynchronize(f->ctx->stream);
-  void* ptrs[] = {f->d_A0, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
+  void* ptrs[] = {f->d_A0, f->d_G, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
                   f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
-                  f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred};
+                  f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred, f->d_groups, f->d_cm,
+                  f->d_item_group, f->d_item_k, f->d_rowent, f->d_lr_blocks, f->d_gen_blocks};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete f;
@@ -955,7 +1172,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     return TK_[id];
   };
 
-  // ---- compression of the active edges -----------------------------------------------------------------
+  // ---- compression of the edges (shared by all edges with the same surroundings) -------------------------------
   const bool compress = !getenv("ROMHC_NO_COMPRESS");
   ld ctol = 1e-17L;
   if (const char* s = getenv("ROMHC_COMPRESS_TOL")) ctol = (ld)atof(s);
@@ -963,7 +1180,6 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   std::vector<Comp> comps;
   std::vector<int> comp_of(E, -1);
   for (int e = 0; e < E; ++e) {
-    if (is_pre[e]) continue;
     const Edge& ed = edges[e];
     std::vector<int> sig{ed.hv};
     for (int blk : {ed.b0, ed.b1}) {
@@ -1001,6 +1217,8 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       cp.P = hostla::identity(n1);
       cp.gt = gE[ed.hv];
       cp.p0.assign(n1, 0.0L);
+      cp.KiW = Kinv;
+      cp.wK = hostla::matvec(Kinv, gE[ed.hv]);
     } else {
       cp.r = Wb.c;
       cp.W = Wb;
@@ -1016,10 +1234,33 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       std::vector<ld> pw = hostla::matvec(cp.P, wv);
       cp.p0.resize(n1);
       for (int i = 0; i < n1; ++i) cp.p0[i] = v[i] - pw[i];
+      cp.KiW = KiW;
+      cp.wK = v;
     }
     comp_of[e] = int(comps.size());
     sig_id[sig] = comp_of[e];
     comps.push_back(std::move(cp));
+  }
+
+
+  // kmax[d]: sine modes with rho_mode(d) >= 1e-18 (rounded up to the K chunk): what the extension needs at
+  // distance d from a side.  A compressed edge enters the extension through its reduced unknowns instead
+  // when rank + 1 (padded) is below the average mode count.
+  std::vector<int> kmax(N + 1, n1p);
+  double kavg = 0;
+  for (int dd = 1; dd <= N; ++dd) {
+    int last = -1;
+    for (int m = 0; m < n1; ++m)
+      if (rho_d[size_t(m) * (N + 1) + std::min(dd, N)] >= 1e-18) last = m;
+    kmax[dd] = std::min(n1p, std::max(BK, (last + 1 + BK - 1) / BK * BK));
+    if (dd <= n1) kavg += kmax[dd] / double(std::max(n1, 1));
+  }
+  kmax[0] = n1p;
+  std::vector<int> rp(comps.size(), 0);
+  std::vector<char> use_lr(comps.size(), 0);
+  for (size_t c = 0; c < comps.size(); ++c) {
+    rp[c] = (comps[c].r + 1 + BK - 1) / BK * BK;
+    use_lr[c] = comps[c].r < n1 && rp[c] < kavg && n1 > 0 && !getenv("ROMHC_NO_LOWRANK_EXT");
   }
 
   // ---- layout of the reduced vector: edge groups in elimination order, every cross point right behind
@@ -1043,13 +1284,22 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   f->nred = nred;
   f->T = T;
   f->nGa = T * TB;
-  f->npre = npre;
-  f->nexp = nact;
   // nodal layout behind the reduced part: one n1p block per edge, then the cross block
   std::vector<int> npos(E, -1);
   for (int e = 0; e < E; ++e) npos[e] = f->nGa + e * n1p;
   f->xb0 = f->nGa + E * n1p;
   f->nGp = E > 0 ? f->xb0 + (ncross > 0 ? (ncross + TB - 1) / TB * TB : 0) : 0;
+  std::vector<int> cpos(E, -1);  // [z_f, 1/s_f] blocks of the edges that enter the extension in compressed form
+  for (int e : order)
+    if (use_lr[comp_of[e]]) {
+      cpos[e] = f->nGp;
+      f->nGp += rp[comp_of[e]];
+    }
+  for (int e : pre_list)  // closed-form edges kept in compressed form: [c_e / s_e, 1/s_e]
+    if (use_lr[comp_of[e]]) {
+      cpos[e] = f->nGp;
+      f->nGp += rp[comp_of[e]];
+    }
 
   // ---- blocks of the reduced matrix --------------------------------------------------------------------
   std::vector<Small> smalls;
@@ -1092,7 +1342,9 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     return off;
   };
   std::vector<RhsTerm> rhs_terms;
-  std::vector<PreEdge> pre_edges(npre);
+  std::vector<PreEdge> pre_edges;   // closed-form edges recovered node by node (k_back_pre)
+  std::vector<CoefGroup> groups;    // coefficient blocks built by k_coef
+  std::vector<double> cm;           // matrices of the closed-form edges kept in compressed form
   std::map<int, int> bt_of_id;               // T table id -> B^T table index
   std::vector<std::pair<int, Mat>> bt_extra;  // cross-block tables (index, n1 x ncross)
   int nbt = 0;
@@ -1100,8 +1352,19 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   for (int i = 0; i < npre; ++i) {
     const int e = pre_list[i];
     const Edge& pe = edges[e];
-    PreEdge& P = pre_edges[i];
+    const bool lr_e = cpos[e] >= 0;
+    PreEdge P;
     memset(&P, 0, sizeof(P));
+    CoefGroup cg;
+    memset(&cg, 0, sizeof(cg));
+    const Comp& cpe = comps[comp_of[e]];
+    cg.kind = 1; cg.cpos = cpos[e]; cg.r = cpe.r; cg.w = rp[comp_of[e]]; cg.b0 = pe.b0; cg.b1 = pe.b1;
+    auto add_cterm = [&](int src, int blk, const Mat& Mt, int voff, int u0, int u1) {  // Mt: len x r_e
+      if (cg.nterm >= 8) return false;
+      cg.t[cg.nterm++] = CoefTerm{src, Mt.r, blk, int(cm.size()), voff, u0, u1};
+      for (ld v : Mt.v) cm.push_back(double(v));
+      return true;
+    };
     P.pos = npos[e];
     P.e0 = pe.b0;
     P.e1 = pe.b1;
@@ -1115,10 +1378,19 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       const Comp& cu = comps[comp_of[u]];
       Ent en{zpos[u], cu.r, blk, hostla::mul_tn(cu.W, Tm(id)), hostla::mul_tn(cu.W, TK(id))};
       ents.push_back(std::move(en));
-      if (!bt_of_id.count(id)) bt_of_id[id] = nbt++;
-      if (P.nnb >= 8) { rom_set_error("internal: more than 8 neighbours of an eliminated edge"); return ROM_ERR_INVALID; }
-      P.nb[P.nnb++] = PreNb{npos[u], blk, n1p / BK, bt_of_id[id]};
-      pre_flops += 2.0 * n1p * double(n1p);
+      if (lr_e) {
+        // c_e += a_blk * (W_e^T T^(e,u) P_u z_u + W_e^T T^(e,u) p0_u / s_u)
+        const Mat WT = hostla::mul_tn(cpe.W, Tm(side_of(blk, e) * 4 + side_of(blk, u)));  // r_e x n1
+        const Mat Mt = hostla::transpose(hostla::mul(WT, cu.P));                           // r_u x r_e
+        const int voff = push_vec(hostla::matvec(WT, cu.p0), cpe.r);
+        if (!add_cterm(zpos[u], blk, Mt, voff, edges[u].b0, edges[u].b1)) { rom_set_error("internal: more than 8 neighbours of an eliminated edge"); return ROM_ERR_INVALID; }
+        pre_flops += 2.0 * cpe.r * double(cu.r);
+      } else {
+        if (!bt_of_id.count(id)) bt_of_id[id] = nbt++;
+        if (P.nnb >= 8) { rom_set_error("internal: more than 8 neighbours of an eliminated edge"); return ROM_ERR_INVALID; }
+        P.nb[P.nnb++] = PreNb{npos[u], blk, n1p / BK, bt_of_id[id]};
+        pre_flops += 2.0 * n1p * double(n1p);
+      }
     }
     Mat Btx(n1, std::max(ncross, 1));
     bool has_x = false;
@@ -1132,8 +1404,14 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       }
       ents.push_back(std::move(en));
       has_x = true;
+      if (lr_e) {  // c_e += (s_e / 2) W_e[node, :]^T u_x
+        Mat Mt(1, cpe.r);
+        for (int k = 0; k < cpe.r; ++k) Mt(0, k) = cpe.W(c.node, k);
+        if (!add_cterm(xred[c.cross], -1, Mt, -1, 0, 0)) { rom_set_error("internal: more than 8 neighbours of an eliminated edge"); return ROM_ERR_INVALID; }
+      }
     }
-    if (has_x) {
+    if (lr_e) groups.push_back(cg);
+    if (has_x && !lr_e) {
       if (P.nnb >= 8) { rom_set_error("internal: more than 8 neighbours of an eliminated edge"); return ROM_ERR_INVALID; }
       P.nb[P.nnb++] = PreNb{f->xb0, -1, (ncross + BK - 1) / BK, nbt};
       bt_extra.push_back({nbt++, Btx});
@@ -1157,7 +1435,9 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
           add_small(eu.pos, ev.pos, R, 6, {0, 0, pe.b0, pe.b1});
       }
     }
+    if (!lr_e) pre_edges.push_back(P);
   }
+  f->npre = int(pre_edges.size());
 
   // ---- tile mask + symbolic fill --------------------------------------------------------------------
   std::vector<char> mask(size_t(T) * T, 0);
@@ -1254,11 +1534,31 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
   slot_terms.clear();
   smalls.clear();
+  // row program of the single-tile solve (k_solve1): per tile row, the table row segments with col >= row
+  std::vector<RowEnt> rowents;
+  f->fused1 = T == 1 && f->desc[0].t1 - f->desc[0].t0 <= COEF_MAX && f->nGa == TB;
+  if (f->fused1) {
+    const TileDesc& d0 = f->desc[0];
+    for (int r = 0; r < TB; ++r) {
+      const size_t first = rowents.size();
+      for (int t = d0.t0; t < d0.t1; ++t) {
+        const GenTerm& g = terms[t];
+        if (r < g.r_lo || r >= g.r_hi) continue;
+        const double* rowp = pool.data() + size_t(g.tab) * 4096 + size_t(r) * TB;
+        int lo = TB, hi = 0;
+        for (int c = std::max<int>(r, g.c_lo); c < g.c_hi; ++c)
+          if (rowp[c] != 0.0) { lo = std::min(lo, c); hi = c + 1; }
+        if (hi <= lo) continue;
+        rowents.push_back(RowEnt{int(size_t(g.tab) * 4096 + size_t(r) * TB), r | ((t - d0.t0) << 8), lo, hi});
+      }
+      if (rowents.size() > first) rowents.back().meta |= 1 << 16;
+    }
+    while (rowents.size() % ROW_BATCH) rowents.push_back(RowEnt{0, 0, 0, 0});  // no-ops
+  }
+  f->nrowent = int(rowents.size());
+  ROM_TRY(upload(&f->d_rowent, rowents));
 
   // ---- block sides, vmap, parameter-independent part of the reduced rhs --------------------------------------------
-  f->sides.resize(nrb * ncb);
-  for (int b = 0; b < nrb * ncb; ++b)
-    for (int s = 0; s < 4; ++s) f->sides[b].off[s] = bside[b][s] >= 0 ? npos[bside[b][s]] : -1;
   std::vector<int> vmap(std::max(f->nGp, 1), -1);
   for (int e = 0; e < E; ++e) {
     const Edge& ed = edges[e];
@@ -1282,14 +1582,42 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
 
   // ---- expansion tables of the active edges, back substitution tables of the closed-form ones ------------------------
   const size_t tsz = size_t(n1p) * n1p;
+  // table variants of a compressed-edge type: 0 = active edge (P, p0), 1 = closed-form edge (K^-1 W, K^-1 g)
+  std::map<std::pair<int, int>, int> ptab_of, p0_of;
+  std::vector<std::pair<int, int>> ptab_list;
+  auto variant = [&](int c, int v) {
+    if (!ptab_of.count({c, v})) {
+      ptab_of[{c, v}] = int(ptab_list.size());
+      ptab_list.push_back({c, v});
+      p0_of[{c, v}] = push_vec(v == 0 ? comps[c].p0 : comps[c].wK, n1p);
+    }
+    return ptab_of[{c, v}];
+  };
   std::vector<ExpEdge> exps;
-  std::vector<int> p0_of(comps.size(), -1);
-  for (size_t c = 0; c < comps.size(); ++c) p0_of[c] = push_vec(comps[c].p0, n1p);
-  for (int e : order)
-    exps.push_back(ExpEdge{zpos[e], (rk[e] + BK - 1) / BK, npos[e], comp_of[e], p0_of[comp_of[e]], edges[e].b0, edges[e].b1});
+  for (int e : order) {
+    const int c = comp_of[e], pt = variant(c, 0);
+    exps.push_back(ExpEdge{zpos[e], (rk[e] + BK - 1) / BK, npos[e], pt, p0_of[{c, 0}], edges[e].b0, edges[e].b1});
+    if (cpos[e] >= 0) {
+      CoefGroup cg;
+      memset(&cg, 0, sizeof(cg));
+      cg.kind = 0; cg.cpos = cpos[e]; cg.r = rk[e]; cg.w = rp[c]; cg.b0 = edges[e].b0; cg.b1 = edges[e].b1; cg.zpos = zpos[e];
+      groups.push_back(cg);
+    }
+  }
+  for (int e : pre_list)
+    if (cpos[e] >= 0) {
+      const int c = comp_of[e], pt = variant(c, 1);
+      exps.push_back(ExpEdge{cpos[e], (comps[c].r + BK - 1) / BK, npos[e], pt, p0_of[{c, 1}], edges[e].b0, edges[e].b1});
+    }
+  f->nexp = int(exps.size());
+  std::vector<int> item_group, item_k;
+  for (size_t g = 0; g < groups.size(); ++g)
+    for (int k = 0; k < groups[g].w; ++k) { item_group.push_back(int(g)); item_k.push_back(k); }
+  f->ncoef = int(item_group.size());
   {
-    std::vector<double> Ptab(std::max<size_t>(comps.size() * tsz, 1), 0.0);
-    for (size_t c = 0; c < comps.size(); ++c) put_table(Ptab, c, n1p, comps[c].P, false);
+    std::vector<double> Ptab(std::max<size_t>(ptab_list.size() * tsz, 1), 0.0);
+    for (size_t t = 0; t < ptab_list.size(); ++t)
+      put_table(Ptab, t, n1p, ptab_list[t].second == 0 ? comps[ptab_list[t].first].P : comps[ptab_list[t].first].KiW, false);
     ROM_TRY(upload(&f->d_P, Ptab));
     std::vector<double> Bt(std::max<size_t>(size_t(nbt) * tsz, 1), 0.0);
     for (auto& kv : bt_of_id) put_table(Bt, kv.second, n1p, TK(kv.first), true);  // (T K^-1)^T: row = node of e
@@ -1314,32 +1642,96 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
   hipFree(d_rho);
   {
-    // kmax[d]: modes with rho_mode(d) >= 1e-24, rounded up to the K chunk
-    std::vector<int> kmax(N + 1, n1p);
-    for (int dd = 1; dd <= N; ++dd) {
-      int last = -1;
-      for (int m = 0; m < n1; ++m)
-        if (rho_d[size_t(m) * (N + 1) + std::min(dd, N)] >= 1e-24) last = m;
-      kmax[dd] = std::min(n1p, std::max(BK, (last + 1 + BK - 1) / BK * BK));
-    }
-    kmax[0] = n1p;
     ROM_TRY(upload(&f->d_kmax, kmax));
-    std::vector<int> eposv(std::max(E, 1), 0);
-    for (int e = 0; e < E; ++e) eposv[e] = npos[e];
-    ROM_TRY(upload(&f->d_epos, eposv));
-    f->n_edges = E;
-    // flops of the truncated extension, per system (for the work accounting)
+
+    // Representation of every block side in the extension.  A compressed edge enters through its reduced
+    // unknowns when that is cheaper than the distance-truncated sine modes: table G_c = H_0 [P_c, p0_c]
+    // = A0 (Q [P_c, p0_c]), one (n1*n1) x rp_c table per compressed-edge type.
+    // one table per (compressed-edge type, variant) that a block side actually uses
+    std::map<std::pair<int, int>, long long> goff;
+    long long gtotal = 0;
+    for (int e = 0; e < E; ++e)
+      if (cpos[e] >= 0 && !goff.count({comp_of[e], int(is_pre[e])})) {
+        goff[{comp_of[e], int(is_pre[e])}] = gtotal;
+        gtotal += (long long)hrows * rp[comp_of[e]];
+      }
+    ROM_CHECK(gtotal < (1ll << 31), "rom_fem_create: extension tables too large");
+    ROM_HIP(hipMalloc(&f->d_G, std::max<size_t>(size_t(gtotal), 1) * sizeof(double)));
+    for (auto& kv : goff) {
+      const int c = kv.first.first;
+      const Comp& cp = comps[c];
+      const Mat& Pm = kv.first.second == 0 ? cp.P : cp.KiW;
+      const std::vector<ld>& pv = kv.first.second == 0 ? cp.p0 : cp.wK;
+      Mat Bm = hostla::mul_tn(Pm, Q);  // r x n1
+      std::vector<double> Bh(size_t(rp[c]) * n1p, 0.0);
+      for (int k = 0; k < cp.r; ++k)
+        for (int m = 0; m < n1; ++m) Bh[size_t(k) * n1p + m] = double(Bm(k, m));
+      for (int m = 0; m < n1; ++m) {
+        ld sacc = 0;
+        for (int t = 0; t < n1; ++t) sacc += pv[t] * Q(t, m);
+        Bh[size_t(cp.r) * n1p + m] = double(sacc);
+      }
+      double* d_B = nullptr;
+      ROM_TRY(upload(&d_B, Bh));
+      ROM_TRY(rom_launch_gemm_nt(ctx, int64_t(hrows), rp[c], n1p, 1.0, f->d_A0, n1p, d_B, n1p, 0.0, f->d_G + kv.second,
+                                 rp[c], "setup_gemm_G"));
+      ROM_HIP(hipStreamSynchronize(ctx->stream));
+      hipFree(d_B);
+    }
+    f->sides.resize(nrb * ncb);
+    std::vector<char> need_tr(E, 0);
     double fl = 0;
     const int npj = (n1 + 15) / 16, npi = (n1 + 3) / 4;
     for (int b = 0; b < nrb * ncb; ++b)
-      for (int pi = 0; pi < npi; ++pi)
-        for (int pj = 0; pj < npj; ++pj) {
-          int i0 = 4 * pi + 1, j0 = 16 * pj + 1, i1 = std::min(i0 + 3, n1), j1 = std::min(j0 + 15, n1);
-          int dist[4] = {i0, N - i1, j0, N - j1};
-          for (int sdx = 0; sdx < 4; ++sdx)
-            if (bside[b][sdx] >= 0) fl += 2.0 * 64 * kmax[dist[sdx]];
+      for (int sdx = 0; sdx < 4; ++sdx) {
+        ExtSide& es = f->sides[b].s[sdx];
+        memset(&es, 0, sizeof(es));
+        const int e = bside[b][sdx];
+        if (e < 0) continue;
+        const int c = comp_of[e];
+        if (cpos[e] >= 0) {
+          es = ExtSide{2, cpos[e], rp[c] / BK, comps[c].r, int(goff[{c, int(is_pre[e])}]), edges[e].b0, edges[e].b1};
+          fl += 2.0 * 64 * rp[c] * npi * npj;
+        } else {
+          es.mode = 1;
+          es.off = npos[e];
+          need_tr[e] = 1;
+          for (int pi = 0; pi < npi; ++pi)
+            for (int pj = 0; pj < npj; ++pj) {
+              int i0 = 4 * pi + 1, j0 = 16 * pj + 1, i1 = std::min(i0 + 3, n1), j1 = std::min(j0 + 15, n1);
+              int dist[4] = {i0, N - i1, j0, N - j1};
+              fl += 2.0 * 64 * kmax[dist[sdx]];
+            }
         }
-    f->ext_flops = fl + 2.0 * E * double(n1p) * n1p;
+      }
+    std::vector<int> lr_blocks, gen_blocks;
+    f->lr_nch = 0;
+    for (int b = 0; b < nrb * ncb; ++b) {
+      int nlr = 0, nother = 0, nch = 0;
+      for (int sdx = 0; sdx < 4; ++sdx) {
+        const ExtSide& es = f->sides[b].s[sdx];
+        if (es.mode == 2) { ++nlr; nch += es.nch; }
+        else if (es.mode != 0) ++nother;
+      }
+      if (nlr > 0 && nother == 0 && !getenv("ROMHC_NO_EXT_LR")) {
+        lr_blocks.push_back(b);
+        f->lr_nch = std::max(f->lr_nch, nch);
+      } else {
+        gen_blocks.push_back(b);
+      }
+    }
+    f->n_lr_blocks = int(lr_blocks.size());
+    f->n_gen_blocks = int(gen_blocks.size());
+    ROM_TRY(upload(&f->d_lr_blocks, lr_blocks));
+    ROM_TRY(upload(&f->d_gen_blocks, gen_blocks));
+    std::vector<int> eposv;
+    for (int e = 0; e < E; ++e)
+      if (need_tr[e]) eposv.push_back(npos[e]);
+    f->n_edges = int(eposv.size());
+    if (eposv.empty()) eposv.push_back(0);
+    ROM_TRY(upload(&f->d_epos, eposv));
+    // flops of the extension, per system (for the work accounting)
+    f->ext_flops = fl + 2.0 * f->n_edges * double(n1p) * n1p;
   }
   ROM_TRY(upload(&f->d_W, Wd));
   ROM_TRY(upload(&f->d_g, g_red));
@@ -1350,6 +1742,10 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   ROM_TRY(upload(&f->d_rhs, rhs_terms));
   ROM_TRY(upload(&f->d_pre, pre_edges));
   ROM_TRY(upload(&f->d_exp, exps));
+  ROM_TRY(upload(&f->d_groups, groups));
+  ROM_TRY(upload(&f->d_cm, cm));
+  ROM_TRY(upload(&f->d_item_group, item_group));
+  ROM_TRY(upload(&f->d_item_k, item_k));
   ROM_TRY(upload(&f->d_xred, xred));
   ROM_TRY(upload(&f->d_desc, f->desc));
   ROM_TRY(upload(&f->d_kptr, f->kptr));
@@ -1453,7 +1849,13 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   const int kblk = f->nrb * f->ncb;
   static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-column kernel names
   char nm[4][48];
-  if (f->nGp > 0) {
+  static const bool no_fused = getenv("ROMHC_NO_FUSED") != nullptr;
+  const bool fused1 = f->fused1 && !no_fused;  // the whole reduced solve in one wave-per-system kernel
+  if (f->nGp > 0 && fused1) {
+    ROM_PROF(ctx, "solve1", Mc * (262144 / 3.0 + 3 * 4096.0), Mc * 8.0 * 4096 * 3);
+    k_solve1<<<Mc, 64, 0, st>>>(d, am);
+  }
+  if (f->nGp > 0 && !fused1) {
     {
       ROM_PROF(ctx, "rhs", 0, 8.0 * Mc * f->nGa);
       k_rhs<<<Mc, 256, 0, st>>>(d, am);
@@ -1489,9 +1891,15 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
       ROM_PROF(ctx, "backsolve", Mc * 2.0 * 4096 * (f->nslots + f->T), Mc * 8.0 * 4096 * (f->nslots + f->T));
       k_backsolve<<<Mc, 256, lds_back, st>>>(d);
     }
-    if (f->nexp > 0 || f->ncross > 0) {
+    if (f->ncoef > 0 || f->ncross > 0) {
+      ROM_PROF(ctx, "coef", 0, 8.0 * Mc * f->ncoef);
+      k_coef<<<Mc, 256, 0, st>>>(d, am);
+    }
+  }
+  if (f->nGp > 0) {
+    if (f->nexp > 0) {
       ROM_PROF(ctx, "expand", Mc * 2.0 * f->n1p * 32.0 * f->nexp, 8.0 * Mc * f->n1p * f->nexp);
-      k_expand<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->nexp + 1), 256, 0, st>>>(d, am, Mc);
+      k_expand<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->nexp), 256, 0, st>>>(d, am, Mc);
     }
     if (f->npre > 0) {
       ROM_PROF(ctx, "back_pre", Mc * 2.0 * f->n1p * double(f->n1p) * 3.0 * f->npre, 8.0 * Mc * f->n1p * 4.0 * f->npre);
@@ -1506,9 +1914,17 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         k_edge_transform<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->n_edges), 256, 0, st>>>(d, Mc);
       }
       const int npatch = ((f->n1 + 3) / 4) * ((f->n1 + 15) / 16);
-      dim3 grid(npatch, (Mc + 63) / 64, kblk);
-      ROM_PROF(ctx, "extend", (f->ext_flops - 2.0 * f->n_edges * double(f->n1p) * f->n1p) * Mc, 8.0 * Mc * double(kblk) * nij);
-      k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row);
+      const double fl_ext = (f->ext_flops - 2.0 * f->n_edges * double(f->n1p) * f->n1p) * Mc / kblk;  // per block (average)
+      if (f->n_gen_blocks > 0) {
+        dim3 grid(npatch, (Mc + 63) / 64, f->n_gen_blocks);
+        ROM_PROF(ctx, "extend", fl_ext * f->n_gen_blocks, 8.0 * Mc * double(f->n_gen_blocks) * nij);
+        k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.gen_blocks, 4);
+      }
+      if (f->n_lr_blocks > 0) {
+        dim3 grid(f->n1 * ((f->n1 + 63) / 64), (Mc + 63) / 64, f->n_lr_blocks);
+        ROM_PROF(ctx, "extend_lr", fl_ext * f->n_lr_blocks, 8.0 * Mc * double(f->n_lr_blocks) * nij);
+        k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.lr_blocks, 6);
+      }
     }
     if (f->nGp > 0) {
       ROM_PROF(ctx, "scatter_interface", 0, 16.0 * Mc * f->nG);

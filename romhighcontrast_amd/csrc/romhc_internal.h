@@ -115,8 +115,24 @@ struct TileDesc {
   int diag;     // 1 if ti == tj
 };
 
-struct BlockSide {  // per block, per side: where its nodal interface values live (or -1)
-  int off[4];
+// How one side of a block enters the harmonic extension (k_extend)
+struct ExtSide {
+  int mode;    // 0: domain boundary; 1: sine modes of the edge values; 2: compressed edge [z_f, 1/s_f]
+  int off;     // mode 1: nodal block of the edge (in yhat); mode 2: its [z_f, 1/s_f] block (in y)
+  int nch;     // mode 2: K chunks = (rank + 1) rounded up to BK, / BK
+  int r;       // mode 2: rank
+  int gtab;    // mode 2: offset (doubles) of the (n1*n1) x (nch*BK) table H_0 [P_f, p0_f]
+  int b0, b1;  // mode 2: blocks of the edge (s_f = a_b0 + a_b1)
+};
+// one step of the single-tile assembly (k_solve1): acc += coef[term] * pool[off + lane] for lanes in
+// [c_lo, c_hi); `last` closes tile row r (acc is stored and reset)
+struct RowEnt {
+  int off;
+  int meta;  // r | term << 8 | last << 16
+  int c_lo, c_hi;
+};
+struct BlockSide {
+  ExtSide s[4];
 };
 
 // rhs of the reduced system:  y[pos + i] += coef * vec[voff + i], i < len
@@ -150,6 +166,23 @@ struct ExpEdge {
   int b0, b1;
 };
 
+// coefficient block [z, 1/s, 0...] of an edge that enters the extension in compressed form (k_coef)
+struct CoefTerm {
+  int src, len;  // source values in the interface vector (reduced unknowns of a neighbour, or one cross point)
+  int blk;       // >= 0: neighbouring edge, weight a[blk]; -1: cross point, weight s_e / 2
+  int moff;      // (len x r) matrix in the coefficient-matrix table
+  int voff;      // r-vector scaled by 1/(a[u0] + a[u1]) (the neighbour's p0 part), or -1
+  int u0, u1;
+};
+struct CoefGroup {
+  int kind;      // 0: active edge, z copied from the reduced vector at zpos; 1: closed-form edge
+  int cpos, r, w;  // position and padded width of the block, rank
+  int zpos;
+  int b0, b1;    // blocks of the edge (s = a_b0 + a_b1)
+  int nterm;
+  CoefTerm t[8];
+};
+
 struct rom_fem {
   rom_ctx* ctx;
   int nrb, ncb, N, n1, n1p;  // n1 = N-1, n1p = n1 padded to a TB multiple
@@ -165,6 +198,7 @@ struct rom_fem {
   int T;       // tiles per dimension
   int nslots;  // nonzero lower tiles
   // device tables
+  double* d_G = nullptr;     // extension tables of the compressed edges
   double* d_A0 = nullptr;    // (n1*n1) x n1p : Q[j,mode] rho_mode(i) (harmonic extension from side i=0, sine basis)
   double* d_Qp = nullptr;    // n1p x n1p sine matrix
   int* d_kmax = nullptr;     // [N+1]
@@ -189,8 +223,19 @@ struct rom_fem {
   PreEdge* d_pre = nullptr;
   ExpEdge* d_exp = nullptr;
   int* d_xred = nullptr;       // reduced position of every cross point
+  CoefGroup* d_groups = nullptr;
+  double* d_cm = nullptr;
+  int* d_item_group = nullptr;
+  int* d_item_k = nullptr;
+  int ncoef = 0;               // entries of all coefficient blocks
+  RowEnt* d_rowent = nullptr;  // row program of the single-tile solve
+  int nrowent = 0;
+  bool fused1 = false;         // the reduced matrix is one tile: whole solve in k_solve1
   int nrhs = 0;
   BlockSide* d_sides = nullptr;  // nrb*ncb
+  int* d_lr_blocks = nullptr;    // blocks whose sides are all in compressed form (k_extend_lr)
+  int* d_gen_blocks = nullptr;   // the others (k_extend)
+  int n_lr_blocks = 0, n_gen_blocks = 0, lr_nch = 0;
   int* d_vmap = nullptr;         // interface position -> global dof (or -1), size nGp
   // host copies
   std::vector<TileDesc> desc;

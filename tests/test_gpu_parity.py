@@ -230,7 +230,7 @@ def test_workspace_chunking_and_streams(api):
     a = 10.0 ** np.random.default_rng(2).uniform(0, 3, size=(300, 2, 2))
     ref = sm.generate_solutions(a)
     ctx = sm._ctx
-    per_sys = 40 * 4096 * 8  # generous estimate of the factor bytes of one system at this size
+    per_sys = 2 * 4096 * 8 + 2 * 640 * 8  # factor bytes of one system at this size (one tile + inverse + vectors)
     ctx.set_workspace_limit(70 * per_sys)
     try:
         sm2 = SM.SolutionsManagerFEM((2, 2), 20)
