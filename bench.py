@@ -135,11 +135,12 @@ def main():
         step_no[0] += 1
         if comm:
             ctx.comm_wait_slot(k)  # the all-gather that last read this shard buffer must have finished
-        fem.solve_batch(a_dev, M, U_pair[k])
+        fem.solve_batch(a_dev, M, U_pair[k], wait=False)  # enqueued only: no host round trip per step
         if comm:
             ctx.allgather_async(U_pair[k], 0, U_all[k], 0, M * dim, slot=k)
 
     def drain():
+        ctx.solve_status()  # waits for the compute stream; raises if any system was not positive definite
         if comm:
             ctx.comm_wait(True)
 

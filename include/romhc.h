@@ -94,6 +94,11 @@ int rom_assemble_batch(rom_fem* fem, rom_buf* a, int M, rom_buf* diag, rom_buf* 
 /* generate_solutions (:64-68) = map(galerkin (:17-40)) : U[row0+m, :] = A(a_m)^{-1} B_total.
  * Exact direct method (interface Schur complement + tile Cholesky + harmonic extension). */
 int rom_solve_batch(rom_fem* fem, rom_buf* a, int M, rom_buf* U, int64_t row0);
+/* The same sweep, only enqueued (no host synchronisation); a non-positive pivot -- the reference's
+ * scipy LinAlgError case -- is latched on the device and reported by the next rom_solve_status()
+ * (or rom_solve_batch()), which waits for the compute stream. */
+int rom_solve_batch_async(rom_fem* fem, rom_buf* a, int M, rom_buf* U, int64_t row0);
+int rom_solve_status(rom_ctx* ctx);
 /* flops / HBM bytes of the library's own algorithm for one snapshot solve, and the canonical
  * banded-Cholesky figures of SURVEY.md 8(d) for comparison */
 int rom_solve_work(rom_fem* fem, double* flops_own, double* bytes_own, double* flops_banded,

@@ -58,6 +58,8 @@ PROTOTYPES = {
     "rom_fem_load_vector_host": (C.c_int, [_vp, _vp]),
     "rom_assemble_batch": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
     "rom_solve_batch": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64]),
+    "rom_solve_batch_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64]),
+    "rom_solve_status": (C.c_int, [_vp]),
     "rom_solve_work": (C.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     "rom_stencil_apply": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _vp, C.c_int64]),
     "rom_h10norm": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, _vp]),
@@ -149,6 +151,10 @@ class Context:
 
     def synchronize(self):
         check(self.lib.rom_synchronize(self.h))
+
+    def solve_status(self):
+        """Wait for the sweeps enqueued with wait=False; raises (scipy LinAlgError) if any pivot was not positive."""
+        check(self.lib.rom_solve_status(self.h))
 
     def device_name(self) -> str:
         buf = C.create_string_buffer(256)
@@ -317,8 +323,10 @@ class Fem:
         check(self.ctx.lib.rom_fem_load_vector_host(self.h, B.ctypes.data))
         return B
 
-    def solve_batch(self, a: Buffer, M: int, U: Buffer, row0: int = 0):
-        check(self.ctx.lib.rom_solve_batch(self.h, a.h, M, U.h, row0))
+    def solve_batch(self, a: Buffer, M: int, U: Buffer, row0: int = 0, wait: bool = True):
+        """wait=False only enqueues the sweep; call Context.solve_status() before trusting the rows."""
+        fn = self.ctx.lib.rom_solve_batch if wait else self.ctx.lib.rom_solve_batch_async
+        check(fn(self.h, a.h, M, U.h, row0))
 
     def solve_work(self):
         v = [C.c_double(0) for _ in range(4)]

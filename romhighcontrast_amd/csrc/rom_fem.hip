@@ -56,7 +56,6 @@ struct FemDev {
   const int* xred;
   const RowEnt* rowent;
   int nrowent;
-  int dbg;
   const CoefGroup* groups;
   const double* cm;
   const int* item_group;
@@ -80,6 +79,8 @@ struct FemDev {
   const int* lr_blocks;   // blocks whose sides are all compressed: extended in mesh-row tiles
   const int* gen_blocks;  // all others: 4 x 16 patches
   const int* vmap;
+  const int* scat;  // interface positions copied to the snapshot rows by k_scatter_interface
+  int nscat;
   double* L;     // [Mc][nslots][64*64]
   double* invL;  // [Mc][T][64*64]
   double* y;     // [Mc][nGp]: reduced unknowns | nodal edge blocks | cross block
@@ -92,12 +93,12 @@ static FemDev make_dev(const rom_fem* f) {
   d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.nexp = f->nexp; d.ncross = f->ncross;
   d.xb0 = f->xb0; d.pool = f->d_pool; d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
   d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.groups = f->d_groups; d.cm = f->d_cm; d.item_group = f->d_item_group;
-  d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.rowent = f->d_rowent; d.nrowent = f->nrowent; d.dbg = getenv("ROMHC_DBG") ? atoi(getenv("ROMHC_DBG")) : 0; d.T = f->T; d.nslots = f->nslots;
+  d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.rowent = f->d_rowent; d.nrowent = f->nrowent; d.T = f->T; d.nslots = f->nslots;
   d.kblk = f->nrb * f->ncb; d.dim = f->dim;
   d.G = f->d_G; d.A0 = f->d_A0; d.Qp = f->d_Qp; d.kmax = f->d_kmax; d.epos = f->d_epos; d.yhat = f->d_yhat; d.W = f->d_W;
   d.g = f->d_g; d.desc = f->d_desc;
   d.kptr = f->d_kptr; d.kpair = f->d_kpair; d.colptr = f->d_colptr; d.colrow = f->d_colrow;
-  d.colti = f->d_colti; d.sides = f->d_sides; d.lr_blocks = f->d_lr_blocks; d.gen_blocks = f->d_gen_blocks; d.vmap = f->d_vmap; d.L = f->d_L; d.invL = f->d_invL;
+  d.colti = f->d_colti; d.sides = f->d_sides; d.lr_blocks = f->d_lr_blocks; d.gen_blocks = f->d_gen_blocks; d.vmap = f->d_vmap; d.scat = f->d_scat; d.nscat = f->nscat; d.L = f->d_L; d.invL = f->d_invL;
   d.y = f->d_y; d.status = f->ctx->d_status;
   return d;
 }
@@ -291,8 +292,10 @@ __device__ inline void load4_any(const double* __restrict__ p, double v[4]) {
 
 // Edge values of the active edges from the reduced solution, u_f = P_f z_f + p0_f / s_f, as one batched
 // MFMA GEMM (tile rows = systems, tile cols = nodes of f, K = compressed index); closed-form edges kept in
-// compressed form enter the same way with z = c_e / s_e, P = K^-1 W_e, p0 = K^-1 g_e.   grid (n1p/64, ceil(Mc/64), nexp)
-__global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restrict__ a, int Mc) {
+// compressed form enter the same way with z = c_e / s_e, P = K^-1 W_e, p0 = K^-1 g_e.  The values go to the
+// snapshot rows directly (and to the nodal blocks of the interface vector).   grid (n1p/64, ceil(Mc/64), nexp)
+__global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U,
+                                                long long row0) {
   __shared__ __align__(16) double lds[STAGE_TOTAL];
   const WavePos wp;
   const ExpEdge ee = f.exp[blockIdx.z];
@@ -316,7 +319,9 @@ __global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restri
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
         const int node = blockIdx.x * 64 + acc_col(wp, jb);
-        f.y[size_t(m) * f.nGp + ee.npos + node] = node < f.n1 ? acc.c[i][jb][g] + f.vec[ee.p0off + node] * inv : 0.0;
+        const double v = node < f.n1 ? acc.c[i][jb][g] + f.vec[ee.p0off + node] * inv : 0.0;
+        f.y[size_t(m) * f.nGp + ee.npos + node] = v;  // (read again by the node-by-node paths, if any)
+        if (node < f.n1) U[(row0 + m) * f.dim + f.vmap[ee.npos + node]] = v;
       }
     }
 }
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
     double acc = 0.0;
     const int4* ents = reinterpret_cast<const int4*>(f.rowent);
     int4 mine = f.nrowent > 0 ? ents[lane] : int4{0, 0, 0, 0};  // lane i holds entry i of the batch
-    for (int e0 = 0; e0 < ((f.dbg & 1) ? 0 : f.nrowent); e0 += ROW_BATCH) {
+    for (int e0 = 0; e0 < f.nrowent; e0 += ROW_BATCH) {
       const int4 cur = mine;
       if (e0 + ROW_BATCH < f.nrowent) mine = ents[e0 + ROW_BATCH + lane];  // next batch's entries fly meanwhile
       double v[ROW_BATCH];
@@ -527,12 +532,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
       for (int i = 0; i < ROW_BATCH; ++i) {
         const int off = __builtin_amdgcn_readlane(cur.x, i);
         const int c_lo = __builtin_amdgcn_readlane(cur.z, i), c_hi = __builtin_amdgcn_readlane(cur.w, i);
-        v[i] = (f.dbg & 32) ? 1.0 : ((lane >= c_lo && lane < c_hi) ? f.pool[off + lane] : 0.0);
-      }
-      if (f.dbg & 16) {
-#pragma unroll
-        for (int i = 0; i < ROW_BATCH; ++i) acc += v[i];
-        continue;
+        v[i] = (lane >= c_lo && lane < c_hi) ? f.pool[off + lane] : 0.0;
       }
 #pragma unroll
       for (int i = 0; i < ROW_BATCH; ++i) {
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   double arow[64];  // row `lane` of the symmetric tile = column `lane` of its upper triangle
 #pragma unroll
   for (int c = 0; c < 64; ++c) arow[c] = c <= lane ? Ls[c * LDC + lane] : 0.0;
-  if (lane >= d.ndr || (f.dbg & 49)) {
+  if (lane >= d.ndr) {
 #pragma unroll
     for (int c = 0; c < 64; ++c) arow[c] = (c == lane) ? 1.0 : 0.0;  // padding unknowns: identity
   }
@@ -593,7 +593,6 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   for (int c = 0; c < 64; ++c) Ls[lane * LDC + c] = c <= lane ? arow[c] : 0.0;
   __syncthreads();
   // back substitution x = L^-T y: row j of L is read from LDS (conflict free), x_j broadcast by readlane
-  if (!(f.dbg & 4))
 #pragma unroll
   for (int j = 63; j >= 0; --j) {
     const double xj = readlane_f64(y, j) * rinv[j];
@@ -605,7 +604,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   __syncthreads();
   // coefficient blocks + nodal copy of the cross points (k_coef)
   for (int x = lane; x < f.ncross; x += 64) ym[f.xb0 + x] = zs[f.xred[x]];
-  for (int it = lane; it < ((f.dbg & 8) ? 0 : f.ncoef); it += 64) {
+  for (int it = lane; it < f.ncoef; it += 64) {
     const CoefGroup& cg = f.groups[f.item_group[it]];
     const int k = f.item_k[it];
     const double s = am[cg.b0] + am[cg.b1];
@@ -766,6 +765,15 @@ __global__ __launch_bounds__(256) void k_edge_transform(FemDev f, int Mc) {
     }
 }
 
+// value of the neighbouring lane (lane ^ 1), by DPP quad permutation
+__device__ inline double lane_swap1(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// two doubles at an address that is only 8-byte aligned (snapshot rows have odd length)
+typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
+
 // Harmonic extension, one batched MFMA GEMM over all blocks:
 //   U_I,b[m,(i,j)] = (h^2/a_b) W[i,j] + sum_{sides s} sum_k c_s[m, k] * Tab_s[pi_s(i,j)][k]
 // with one of two parameter-independent representations per side (ExtSide::mode):
@@ -785,6 +793,7 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
                                                 double* __restrict__ U, long long row0, const int* __restrict__ blocks,
                                                 int pw_log2) {
   __shared__ __align__(16) double lds[STAGE_TOTAL];
+  __shared__ double scs[64];  // h^2 / a_b of the tile's systems
   double* stage = lds;
   const WavePos wp;
   const int b = blocks[blockIdx.z];
@@ -829,6 +838,11 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
     tot += nch;
     cend[s] = tot;
   }
+  if (threadIdx.x < 64) {
+    const int m = blockIdx.y * 64 + threadIdx.x;
+    scs[threadIdx.x] = m < Mc ? (1.0 / (double(N) * double(N))) / a[size_t(m) * f.kblk + b] : 0.0;
+  }
+  __syncthreads();
   Acc acc;
   acc_zero(acc);
   auto pick = [&](int ch, const double* const* ps) -> const double* {
@@ -841,31 +855,194 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
       tot, [&](int ch, double* v) { load4_aligned(pick(ch, pAs), v); },
       [&](int ch, double* v) { load4_aligned(pick(ch, pBs), v); }, acc, stage, wp);
 
-  const double h2 = 1.0 / (double(N) * double(N));
+  // Epilogue.  The MFMA result layout gives a lane one vertex of each of its two 16-vertex column blocks; lane
+  // pairs swap one value each (DPP) so that every lane owns two ADJACENT vertices of one block and the row is
+  // written with 16-byte stores: the store stream of this kernel is issue bound, half the instructions matter.
+  // (everything the epilogue needs from memory is fetched before the first store: a load after a store would
+  // make its s_waitcnt vmcnt wait for the stores as well -- one counter, in order)
+  const bool odd = wp.lane & 1;
+  const int cfirst = acc_col(wp, odd ? 1 : 0) - (odd ? 1 : 0);  // first of this lane's two tile columns
+  const int ii = i0 + (cfirst >> pw_log2) - 1, jj = j0 + (cfirst & (pw - 1)) - 1;  // 0-based interior indices
+  const bool v0 = ii < n1 && jj < n1, v1 = ii < n1 && jj + 1 < n1;
+  const long long gidx = (long long)(p * N + ii) * f.nc + (q * N + jj);
+  double w_own[2];  // particular solution at this lane's own accumulator columns
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    const int cidx = acc_col(wp, jb);
+    const int wi = i0 + (cidx >> pw_log2) - 1, wj = j0 + (cidx & (pw - 1)) - 1;
+    w_own[jb] = (wi < n1 && wj < n1) ? f.W[wi * n1 + wj] : 0.0;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      int m = blockIdx.y * 64 + acc_row(wp, i, g);
+      const int m = blockIdx.y * 64 + acc_row(wp, i, g);
+      const double sc = scs[acc_row(wp, i, g)];
+      const double x0 = acc.c[i][0][g] + sc * w_own[0], x1 = acc.c[i][1][g] + sc * w_own[1];
+      const double got = lane_swap1(odd ? x0 : x1);  // even lanes give away block 1, odd lanes block 0
       if (m >= Mc) continue;
-      double sc = h2 / a[size_t(m) * f.kblk + b];
+      double* dst = U + (row0 + m) * f.dim + gidx;
+      const double lo = odd ? got : x0, hi = odd ? x1 : got;
+      if (v1) *reinterpret_cast<double2_u*>(dst) = double2_u{lo, hi};
+      else if (v0) dst[0] = lo;
+    }
+}
+
+// The same extension for blocks whose sides are all compressed, with 128 x 128 workgroup tiles (128 systems x
+// one mesh row of up to 128 interior vertices; every wave a 64 x 64 quadrant = 4 x 4 MFMA accumulators): K is
+// only sum(rank + 1) ~ 64, so a 64 x 64 tile spends most of its life in its prologue and epilogue; four times
+// the outputs per workgroup amortise them and every LDS fragment feeds four MFMAs instead of two.
+// grid (mesh rows x column tiles, ceil(Mc/128), lr blocks); LDS 74,752 B -> 2 workgroups per CU
+constexpr int X128_STAGE = 128 * LDK;
+
+__global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __restrict__ a, int Mc,
+                                                      double* __restrict__ U, long long row0) {
+  __shared__ __align__(16) double lds[4 * X128_STAGE];  // {A,B} x 2 buffers
+  __shared__ double scs[128];                            // h^2 / a_b of the workgroup's systems
+  {
+    // The MFMA phase and the store phase of a workgroup take about equally long (the stores drain at the HBM
+    // write rate) and do not overlap within it.  Two workgroups share a CU; started together they stay in
+    // lockstep -- all computing, then all storing.  The second half of the first round therefore starts one
+    // MFMA phase late (about 64 cycles per MFMA), so that from then on one workgroup of a CU computes while
+    // the other drains: measured 274 -> 245 us at 256x256 / 2x2 / 1024 systems.  Placement only affects speed.
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (lin >= 256u && lin < 512u)
+      for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);  // 2 x 127 x 64 cycles
+  }
+  const int b = f.lr_blocks[blockIdx.z];
+  const int p = b / f.ncb, q = b % f.ncb;
+  const int n1 = f.n1, N = f.N;
+  const BlockSide& sd = f.sides[b];
+  const int nct = (n1 + 127) / 128;
+  const int iv = blockIdx.x / nct + 1;           // mesh row (1-based interior index)
+  const int jv0 = 128 * (blockIdx.x % nct) + 1;  // first vertex of the tile
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
+  // staging: thread t -> row t >> 1, eight consecutive k starting at (t & 1) * 8
+  const int srow = threadIdx.x >> 1, sseg = (threadIdx.x & 1) * 8;
+  const int mA = blockIdx.y * 128 + srow;
+  const bool vA = mA < Mc;
+  const int jB = jv0 + srow;
+  const bool vB = jB <= n1;
+  const double h2 = 1.0 / (double(N) * double(N));
+  if (threadIdx.x < 128) {
+    const int m = blockIdx.y * 128 + threadIdx.x;
+    scs[threadIdx.x] = m < Mc ? h2 / a[size_t(m) * f.kblk + b] : 0.0;  // (visible after the first barrier below)
+  }
+  int cend[4];
+  const double* pAs[4];
+  const double* pBs[4];
+  int tot = 0;
 #pragma unroll
-      for (int jb = 0; jb < 2; ++jb) {
-        const int cidx = acc_col(wp, jb);
-        const int ii = i0 + (cidx >> pw_log2) - 1, jj = j0 + (cidx & (pw - 1)) - 1;  // 0-based interior indices
-        if (ii >= n1 || jj >= n1) continue;
-        long long gidx = (long long)(p * N + ii) * f.nc + (q * N + jj);
-        U[(row0 + m) * f.dim + gidx] = acc.c[i][jb][g] + sc * f.W[ii * n1 + jj];
+  for (int s = 0; s < 4; ++s) {
+    const ExtSide es = sd.s[s];
+    pAs[s] = pBs[s] = nullptr;
+    if (es.mode == 2) {
+      tot += es.nch;
+      if (vA) pAs[s] = f.y + size_t(mA) * f.nGp + es.off + sseg;
+      if (vB) pBs[s] = f.G + es.gtab + size_t(h0_row(s, iv, jB, N, n1)) * (es.nch * BK) + sseg;
+    }
+    cend[s] = tot;
+  }
+  auto pick = [&](int ch, const double* const* ps) -> const double* {
+    const int s = (ch >= cend[0]) + (ch >= cend[1]) + (ch >= cend[2]);
+    const int lc = ch - (s == 0 ? 0 : s == 1 ? cend[0] : s == 2 ? cend[1] : cend[2]);
+    const double* ptr = s == 0 ? ps[0] : s == 1 ? ps[1] : s == 2 ? ps[2] : ps[3];
+    return ptr ? ptr + lc * BK : nullptr;
+  };
+  auto load8 = [&](const double* ptr, double* v) {
+    load4_aligned(ptr, v);
+    load4_aligned(ptr ? ptr + 4 : nullptr, v + 4);
+  };
+  auto store8 = [&](double* sbuf, const double* v) {
+    double2* dst = reinterpret_cast<double2*>(sbuf + srow * LDK + sseg);  // 144-byte rows, 64-byte segments
+#pragma unroll
+    for (int x = 0; x < 4; ++x) dst[x] = double2{v[2 * x], v[2 * x + 1]};
+  };
+  d4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+  double va[8], vb[8];
+  if (tot > 0) {
+    load8(pick(0, pAs), va);
+    load8(pick(0, pBs), vb);
+  }
+  const int fr = lane & 15, kq = lane >> 4;
+  // everything the epilogue needs from memory is fetched before the first store: a load after a store would
+  // make its s_waitcnt vmcnt wait for the stores as well (one counter, in order)
+  double w_own[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int jj = jv0 + wc * 64 + j * 16 + fr;  // 1-based
+    w_own[j] = jj <= n1 ? f.W[(iv - 1) * n1 + (jj - 1)] : 0.0;
+  }
+  for (int ch = 0; ch < tot; ++ch) {
+    double* sA = lds + (ch & 1) * 2 * X128_STAGE;
+    double* sB = sA + X128_STAGE;
+    store8(sA, va);
+    store8(sB, vb);
+    __syncthreads();
+    if (ch + 1 < tot) {
+      load8(pick(ch + 1, pAs), va);
+      load8(pick(ch + 1, pBs), vb);
+    }
+    const double* pa = sA + (wr * 64 + fr) * LDK + kq;
+    const double* pb = sB + (wc * 64 + fr) * LDK + kq;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = pa[i * 16 * LDK + kk];
+        bf[i] = pb[i * 16 * LDK + kk];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  if (tot == 0) __syncthreads();  // scs
+  // epilogue: add the particular solution, swap between lane pairs so that every lane owns two adjacent
+  // vertices of one 16-vertex block, 16-byte stores (see k_extend)
+  const bool odd = lane & 1;
+  const long long grow = (long long)(p * N + iv - 1) * f.nc + q * N - 1;
+  int jcol[2];
+  bool ok0[2], ok1[2];
+#pragma unroll
+  for (int hp = 0; hp < 2; ++hp) {  // pair hp of column blocks: (0,1) and (2,3); even lanes take the first, odd the second
+    jcol[hp] = jv0 + wc * 64 + (2 * hp + (odd ? 1 : 0)) * 16 + fr - (odd ? 1 : 0);  // first of the two vertices, 1-based
+    ok0[hp] = jcol[hp] <= n1;
+    ok1[hp] = jcol[hp] + 1 <= n1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ml = wr * 64 + i * 16 + kq + 4 * g;
+      const int m = blockIdx.y * 128 + ml;
+      const double sc = scs[ml];
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {
+        const double x0 = acc[i][2 * hp][g] + sc * w_own[2 * hp], x1 = acc[i][2 * hp + 1][g] + sc * w_own[2 * hp + 1];
+        const double got = lane_swap1(odd ? x0 : x1);
+        if (m >= Mc) continue;
+        double* dst = U + (row0 + m) * f.dim + grow + jcol[hp];
+        const double lo = odd ? got : x0, hi = odd ? x1 : got;
+        if (ok1[hp]) *reinterpret_cast<double2_u*>(dst) = double2_u{lo, hi};
+        else if (ok0[hp]) dst[0] = lo;
       }
     }
 }
 
+// interface values that k_expand does not write: cross points and the edges recovered node by node
 __global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0) {
-  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   int m = blockIdx.y;
-  if (v >= f.nGp || m >= Mc) return;
-  int gi = f.vmap[v];
-  if (gi >= 0) U[(row0 + m) * f.dim + gi] = f.y[size_t(m) * f.nGp + v];
+  if (i >= f.nscat || m >= Mc) return;
+  const int v = f.scat[i];
+  U[(row0 + m) * f.dim + f.vmap[v]] = f.y[size_t(m) * f.nGp + v];
 }
 
 // stencil arrays for the API (einsum('pqij,pq->ij') in stencil form)
@@ -954,7 +1131,7 @@ extern "C" int rom_fem_destroy(rom_fem* f) {
   void* ptrs[] = {f->d_A0, f->d_G, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
                   f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
                   f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred, f->d_groups, f->d_cm,
-                  f->d_item_group, f->d_item_k, f->d_rowent, f->d_lr_blocks, f->d_gen_blocks};
+                  f->d_item_group, f->d_item_k, f->d_rowent, f->d_lr_blocks, f->d_gen_blocks, f->d_scat};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete f;
@@ -1270,13 +1447,22 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     for (auto& c : xc)
       if (c.cross == x && !is_pre[c.edge] && (xhost[x] < 0 || ord_of[c.edge] > ord_of[xhost[x]])) xhost[x] = c.edge;
   int nred = 0;
+  {
+    // one tile in total: cross points first, so that their couplings are table ROWS of the upper triangle
+    // (the single-tile assembly reads row segments; a cross behind its edges would cost one 8-byte read per
+    // edge row instead)
+    int total = ncross;
+    for (int e : order) total += comps[comp_of[e]].r;
+    if (total <= TB)
+      for (int x = 0; x < ncross; ++x) xred[x] = nred++;
+  }
   for (int e : order) {
     zpos[e] = nred;
     rk[e] = comps[comp_of[e]].r;
     nred += rk[e];
     f->ranks.push_back(rk[e]);
     for (int x = 0; x < ncross; ++x)
-      if (xhost[x] == e) xred[x] = nred++;
+      if (xhost[x] == e && xred[x] < 0) xred[x] = nred++;
   }
   for (int x = 0; x < ncross; ++x)
     if (xred[x] < 0) xred[x] = nred++;
@@ -1755,6 +1941,19 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   ROM_TRY(upload(&f->d_colti, f->colti));
   ROM_TRY(upload(&f->d_sides, f->sides));
   ROM_TRY(upload(&f->d_vmap, vmap));
+  {
+    std::vector<char> expanded(E, 0);
+    for (int e : order) expanded[e] = 1;
+    for (int e : pre_list)
+      if (cpos[e] >= 0) expanded[e] = 1;
+    std::vector<int> scat;
+    for (int e = 0; e < E; ++e)
+      if (!expanded[e])
+        for (int t = 0; t < n1; ++t) scat.push_back(npos[e] + t);
+    for (int x = 0; x < ncross; ++x) scat.push_back(f->xb0 + x);
+    f->nscat = int(scat.size());
+    ROM_TRY(upload(&f->d_scat, scat));
+  }
 
   // ---- work accounting of this algorithm, per snapshot solve ------------------------------------------------
   double exp_flops = 0;
@@ -1899,7 +2098,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   if (f->nGp > 0) {
     if (f->nexp > 0) {
       ROM_PROF(ctx, "expand", Mc * 2.0 * f->n1p * 32.0 * f->nexp, 8.0 * Mc * f->n1p * f->nexp);
-      k_expand<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->nexp), 256, 0, st>>>(d, am, Mc);
+      k_expand<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->nexp), 256, 0, st>>>(d, am, Mc, U, row);
     }
     if (f->npre > 0) {
       ROM_PROF(ctx, "back_pre", Mc * 2.0 * f->n1p * double(f->n1p) * 3.0 * f->npre, 8.0 * Mc * f->n1p * 4.0 * f->npre);
@@ -1921,21 +2120,28 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.gen_blocks, 4);
       }
       if (f->n_lr_blocks > 0) {
-        dim3 grid(f->n1 * ((f->n1 + 63) / 64), (Mc + 63) / 64, f->n_lr_blocks);
+        static const bool no128 = getenv("ROMHC_NO_EXT128") != nullptr;
         ROM_PROF(ctx, "extend_lr", fl_ext * f->n_lr_blocks, 8.0 * Mc * double(f->n_lr_blocks) * nij);
-        k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.lr_blocks, 6);
+        if (f->n1 >= 96 && Mc >= 128 && !no128) {  // wide tiles need enough vertices per mesh row and systems to fill them
+          dim3 grid(f->n1 * ((f->n1 + 127) / 128), (Mc + 127) / 128, f->n_lr_blocks);
+          k_extend128<<<grid, 256, 0, st>>>(d, am, Mc, U, row);
+        } else {
+          dim3 grid(f->n1 * ((f->n1 + 63) / 64), (Mc + 63) / 64, f->n_lr_blocks);
+          k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.lr_blocks, 6);
+        }
       }
     }
-    if (f->nGp > 0) {
-      ROM_PROF(ctx, "scatter_interface", 0, 16.0 * Mc * f->nG);
-      k_scatter_interface<<<dim3((f->nGp + 255) / 256, Mc), 256, 0, st>>>(d, Mc, U, row);
+    if (f->nscat > 0) {
+      ROM_PROF(ctx, "scatter_interface", 0, 16.0 * Mc * f->nscat);
+      k_scatter_interface<<<dim3((f->nscat + 255) / 256, Mc), 256, 0, st>>>(d, Mc, U, row);
     }
   }
   ROM_HIP(hipGetLastError());
   return ROM_OK;
 }
 
-extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0) {
+// enqueue the sweep; `check` = also wait for it and report a non-positive pivot
+static int solve_batch_impl(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0, bool check) {
   ROM_CHECK(f && a && U, "rom_solve_batch: null argument");
   ROM_CHECK(M >= 0 && row0 >= 0, "rom_solve_batch: negative M or row offset");
   const int kblk = f->nrb * f->ncb;
@@ -1950,7 +2156,6 @@ extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_
   int Mc_max = int(std::max<size_t>(1, std::min<size_t>(size_t(M), ctx->ws_limit / std::max<size_t>(per_sys, 1))));
   if (f->ws_M > 0 && f->ws_M < Mc_max && f->ws_M >= 256) Mc_max = f->ws_M;  // reuse what we have
   ROM_TRY(ensure_workspace(f, Mc_max));
-  ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
   const size_t lds_back = size_t(std::max(f->nGa, 1)) * sizeof(double);
   ROM_CHECK(lds_back <= 60 * 1024, "rom_solve_batch: interface too large for the LDS-resident back substitution");
   // Sub-batches run on separate HIP streams: the wave-per-system diagonal kernels are latency bound
@@ -1988,11 +2193,26 @@ extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_
     ROM_HIP(hipEventRecord(ctx->ev_join[s - 1], ctx->aux[s - 1]));
     ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[s - 1], 0));
   }
-  hipStream_t st = ctx->stream;
+  return check ? rom_solve_status(ctx) : ROM_OK;
+}
+
+extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0) {
+  return solve_batch_impl(f, a, M, U, row0, true);
+}
+
+// Same without the host round trip: the sweep is only enqueued on the compute stream; a non-positive pivot
+// is remembered on the device until rom_solve_status() is asked.
+extern "C" int rom_solve_batch_async(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0) {
+  return solve_batch_impl(f, a, M, U, row0, false);
+}
+
+extern "C" int rom_solve_status(rom_ctx* ctx) {
+  ROM_CHECK(ctx, "rom_solve_status: null context");
   int status = 0;
-  ROM_HIP(hipMemcpyAsync(&status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
-  ROM_HIP(hipStreamSynchronize(st));
+  ROM_HIP(hipMemcpyAsync(&status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
   if (status != 0) {
+    ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
     rom_set_error("rom_solve_batch: interface matrix not positive definite (non-positive pivot); "
                   "all block coefficients must be > 0");
     return ROM_ERR_NOT_SPD;

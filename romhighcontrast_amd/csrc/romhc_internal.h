@@ -237,6 +237,8 @@ struct rom_fem {
   int* d_gen_blocks = nullptr;   // the others (k_extend)
   int n_lr_blocks = 0, n_gen_blocks = 0, lr_nch = 0;
   int* d_vmap = nullptr;         // interface position -> global dof (or -1), size nGp
+  int* d_scat = nullptr;         // positions k_scatter_interface copies to the snapshot rows
+  int nscat = 0;
   // host copies
   std::vector<TileDesc> desc;
   std::vector<int> slot_of, kptr, kpair, colptr, colrow, colti, diag_slot;

@@ -49,6 +49,42 @@ __global__ __launch_bounds__(256) void k_tile_row(double* U, int M, int N, int n
     }
 }
 
+typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
+// (i) k_extend128's pattern: 128 systems x one mesh row (127 vertices); D layout, lane pairs own 2 adjacent vertices
+__global__ __launch_bounds__(256) void k_tile128(double* U, int M, int N, int nc, long long dim, double v) {
+  const int n1 = N - 1;
+  const int b = blockIdx.z, p = b / 2, q = b % 2;
+  const int iv = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
+  const int fr = lane & 15, kq = lane >> 4, odd = lane & 1;
+  for (int i = 0; i < 4; ++i)
+    for (int g = 0; g < 4; ++g) {
+      const int m = blockIdx.y * 128 + wr * 64 + i * 16 + kq + 4 * g;
+      if (m >= M) continue;
+      for (int hp = 0; hp < 2; ++hp) {
+        const int jj = wc * 64 + (2 * hp + odd) * 16 + fr - odd;
+        double* dst = U + (long long)m * dim + (long long)(p * N + iv) * nc + (q * N + jj);
+        if (jj + 1 < n1) *reinterpret_cast<double2_u*>(dst) = double2_u{v, v};
+        else if (jj < n1) dst[0] = v;
+      }
+    }
+}
+// (j) same outputs, but every wave-instruction writes one system's whole 127-vertex run (16 bytes per lane)
+__global__ __launch_bounds__(256) void k_rowrun128(double* U, int M, int N, int nc, long long dim, double v) {
+  const int n1 = N - 1;
+  const int b = blockIdx.z, p = b / 2, q = b % 2;
+  const int iv = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int r = 0; r < 32; ++r) {
+    const int m = blockIdx.y * 128 + w * 32 + r;
+    if (m >= M) continue;
+    const int jj = 2 * lane;
+    double* dst = U + (long long)m * dim + (long long)(p * N + iv) * nc + (q * N + jj);
+    if (jj + 1 < n1) *reinterpret_cast<double2_u*>(dst) = double2_u{v, v};
+    else if (jj < n1) dst[0] = v;
+  }
+}
+
 // (c) grid (mesh rows 127 x segs, system tiles, blocks): each wave writes `run` consecutive doubles of one system row
 __global__ __launch_bounds__(256) void k_runs(double* U, int M, int N, int nc, long long dim, double v, int run) {
   const int n1 = N - 1, nseg = (n1 + run - 1) / run;
@@ -109,6 +145,18 @@ int main() {
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("1x64 tile, D layout: %.3f ms  %.2f TB/s\n", ms, 4.0 * 127 * 127 * M * 8.0 / ms * 1e-9);
+    CK(hipEventRecord(e0));
+    k_tile128<<<dim3(127, M / 128, 4), 256>>>(U, M, N, nc, dim, 6.0);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("1x128 tile, D layout, 16 B/lane: %.3f ms  %.2f TB/s\n", ms, 4.0 * 127 * 127 * M * 8.0 / ms * 1e-9);
+    CK(hipEventRecord(e0));
+    k_rowrun128<<<dim3(127, M / 128, 4), 256>>>(U, M, N, nc, dim, 7.0);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("1x128 tile, wave per run, 16 B/lane: %.3f ms  %.2f TB/s\n", ms, 4.0 * 127 * 127 * M * 8.0 / ms * 1e-9);
     for (int R : {1, 2, 4, 8}) {
       CK(hipEventRecord(e0));
       k_fullrows<<<dim3((nc + R - 1) / R, M / 64), 256>>>(U, M, nc, dim, 4.0, R);
