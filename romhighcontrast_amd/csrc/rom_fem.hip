@@ -1422,7 +1422,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
 
   // kmax[d]: sine modes with rho_mode(d) >= 1e-18 (rounded up to the K chunk): what the extension needs at
   // distance d from a side.  A compressed edge enters the extension through its reduced unknowns instead
-  // when rank + 1 (padded) is below the average mode count.
+  // when rank + 1 (padded) is not much above the average mode count.
   std::vector<int> kmax(N + 1, n1p);
   double kavg = 0;
   for (int dd = 1; dd <= N; ++dd) {
@@ -1437,7 +1437,8 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   std::vector<char> use_lr(comps.size(), 0);
   for (size_t c = 0; c < comps.size(); ++c) {
     rp[c] = (comps[c].r + 1 + BK - 1) / BK * BK;
-    use_lr[c] = comps[c].r < n1 && rp[c] < kavg && n1 > 0 && !getenv("ROMHC_NO_LOWRANK_EXT");
+    // (up to a quarter more K than the truncated modes is still a gain: flat K, wide tiles, no edge transforms)
+    use_lr[c] = comps[c].r < n1 && rp[c] <= 1.25 * kavg && n1 > 0 && !getenv("ROMHC_NO_LOWRANK_EXT");
   }
 
   // ---- layout of the reduced vector: edge groups in elimination order, every cross point right behind
@@ -1953,6 +1954,19 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     for (int x = 0; x < ncross; ++x) scat.push_back(f->xb0 + x);
     f->nscat = int(scat.size());
     ROM_TRY(upload(&f->d_scat, scat));
+  }
+
+  if (getenv("ROMHC_VERBOSE")) {
+    fprintf(stderr, "romhc: %dx%d blocks N=%d: %d edges (%d closed-form, %d of them compressed), reduced size %d -> %d tiles, "
+                    "%d slots, %zu terms, kavg %.1f\n", nrb, ncb, N, E, int(pre_list.size()), int(pre_list.size()) - f->npre, nred, T,
+            f->nslots, terms.size(), kavg);
+    for (size_t c = 0; c < comps.size(); ++c) {
+      int cnt = 0;
+      for (int e = 0; e < E; ++e) cnt += comp_of[e] == int(c);
+      fprintf(stderr, "romhc:   edge type %zu: rank %d (padded %d), %d edges, extension %s\n", c, comps[c].r, rp[c], cnt,
+              use_lr[c] ? "from the reduced unknowns" : "sine modes");
+    }
+    fprintf(stderr, "romhc:   blocks extended by the 128-tile kernel: %d, general kernel: %d\n", f->n_lr_blocks, f->n_gen_blocks);
   }
 
   // ---- work accounting of this algorithm, per snapshot solve ------------------------------------------------
