@@ -56,6 +56,12 @@ struct FemDev {
   const int* xred;
   const RowEnt* rowent;
   int nrowent;
+  const DenseGroup* dgroups;  // single-tile path: coefficient blocks of the closed-form edges as one dense product
+  const int* dweight;
+  const int* ditem_group;
+  const int* ditem_k;
+  const double* dmat;
+  int ndg, ndi;
   const CoefGroup* groups;
   const double* cm;
   const int* item_group;
@@ -93,7 +99,8 @@ static FemDev make_dev(const rom_fem* f) {
   d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.nexp = f->nexp; d.ncross = f->ncross;
   d.xb0 = f->xb0; d.pool = f->d_pool; d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
   d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.groups = f->d_groups; d.cm = f->d_cm; d.item_group = f->d_item_group;
-  d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.rowent = f->d_rowent; d.nrowent = f->nrowent; d.T = f->T; d.nslots = f->nslots;
+  d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.rowent = f->d_rowent; d.nrowent = f->nrowent; d.dgroups = f->d_dgroups; d.dweight = f->d_dweight;
+  d.ditem_group = f->d_ditem_group; d.ditem_k = f->d_ditem_k; d.dmat = f->d_dmat; d.ndg = f->ndg; d.ndi = f->ndi; d.T = f->T; d.nslots = f->nslots;
   d.kblk = f->nrb * f->ncb; d.dim = f->dim;
   d.G = f->d_G; d.A0 = f->d_A0; d.Qp = f->d_Qp; d.kmax = f->d_kmax; d.epos = f->d_epos; d.yhat = f->d_yhat; d.W = f->d_W;
   d.g = f->d_g; d.desc = f->d_desc;
@@ -153,6 +160,7 @@ struct STile {
 };
 
 constexpr int COEF_MAX = 64;   // term weights cached in LDS per pass
+constexpr int DENSE_GROUPS_MAX = 8;  // closed-form edges whose coefficient blocks k_solve1 builds
 constexpr int ROW_BATCH = 64;  // loads in flight per wave in the single-tile assembly
 
 __device__ inline void s_tile_load(STile& st, const TileDesc& d, const FemDev& f, const double* __restrict__ am,
@@ -507,8 +515,8 @@ __global__ __launch_bounds__(64) void k_diag_inverse(FemDev f, int slot, int j) 
 __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restrict__ a) {
   __shared__ __align__(16) double Ls[64 * LDC];
   __shared__ __align__(16) double lv[2][64];
-  __shared__ double rinv[64];
   __shared__ double zs[64];
+  __shared__ double wz[DENSE_GROUPS_MAX * 64];
   const int m = blockIdx.x, lane = threadIdx.x;
   const double* am = a + size_t(m) * f.kblk;
   double* ym = f.y + size_t(m) * f.nGp;
@@ -555,10 +563,22 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   }
   // rhs of the reduced system (k_rhs)
   double y = f.g[lane];
-  for (int t = 0; t < f.nrhs; ++t) {
-    const RhsTerm& rt = f.rhs[t];
-    const double cr = rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5;
-    if (lane >= rt.pos && lane < rt.pos + rt.len) y += cr * f.vec[rt.voff + lane - rt.pos];
+  for (int t0 = 0; t0 < f.nrhs; t0 += 8) {  // eight terms at a time: their vector loads are in flight together
+    double rv[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      rv[x] = 0.0;
+      if (t0 + x < f.nrhs) {
+        const RhsTerm& rt = f.rhs[t0 + x];
+        if (lane >= rt.pos && lane < rt.pos + rt.len) rv[x] = f.vec[rt.voff + lane - rt.pos];
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+      if (t0 + x < f.nrhs) {
+        const RhsTerm& rt = f.rhs[t0 + x];
+        y += (rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5) * rv[x];
+      }
   }
   // Cholesky (as k_diag_potrf) with y carried along: after step jj, y holds L^-1 g in lanes <= jj
   bool bad = false;
@@ -588,47 +608,50 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
     }
   }
   if (bad && lane == 0) atomicOr(f.status, 1);
-  rinv[lane] = myrs;
 #pragma unroll
   for (int c = 0; c < 64; ++c) Ls[lane * LDC + c] = c <= lane ? arow[c] : 0.0;
   __syncthreads();
-  // back substitution x = L^-T y: row j of L is read from LDS (conflict free), x_j broadcast by readlane
+  // back substitution x = L^-T y.  Column `lane` of L is fetched from LDS in one batch (conflict free), then the
+  // chain x_j = y_j / L_jj ; y_i -= L_ji x_j (i < j) runs on registers and readlane broadcasts only.
+  double lcol[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) lcol[j] = Ls[j * LDC + lane];
 #pragma unroll
   for (int j = 63; j >= 0; --j) {
-    const double xj = readlane_f64(y, j) * rinv[j];
+    const double xj = readlane_f64(y, j) * readlane_f64(myrs, j);
     if (lane == j) y = xj;
-    else if (lane < j) y -= Ls[j * LDC + lane] * xj;
+    else if (lane < j) y -= lcol[j] * xj;
   }
   ym[lane] = y;
   zs[lane] = y;
   __syncthreads();
-  // coefficient blocks + nodal copy of the cross points (k_coef)
+  // coefficient blocks + nodal copy of the cross points (what k_coef does on the general path).  The blocks of
+  // the closed-form edges are one dense product here: out[it] = sum_j D[j][it] * (w_g(j) z_j), D = all their
+  // matrices side by side (64 x items, coalesced in `it`), w_g(j) the weight of source j for group g.
   for (int x = lane; x < f.ncross; x += 64) ym[f.xb0 + x] = zs[f.xred[x]];
+  for (int idx = lane; idx < f.ndg * 64; idx += 64) {
+    const DenseGroup& dg = f.dgroups[idx >> 6];
+    const int wd = f.dweight[idx];
+    const double wgt = wd >= 0 ? am[wd] : (wd == -1 ? (am[dg.b0] + am[dg.b1]) / 2 : 0.0);
+    wz[idx] = wgt * zs[idx & 63];
+  }
+  __syncthreads();
+  for (int it = lane; it < f.ndi; it += 64) {
+    const int g = f.ditem_group[it], k = f.ditem_k[it];
+    const DenseGroup& dg = f.dgroups[g];
+    const double* D = f.dmat + it;
+    const double* wg = wz + g * 64;
+    double acc = 0.0;
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) acc += D[size_t(j) * f.ndi] * wg[j];
+    for (int v = 0; v < dg.nv; ++v) acc += am[dg.vblk[v]] / (am[dg.vu0[v]] + am[dg.vu1[v]]) * f.vec[dg.voff[v] + k];
+    ym[dg.cpos + k] = acc / (am[dg.b0] + am[dg.b1]);
+  }
   for (int it = lane; it < f.ncoef; it += 64) {
     const CoefGroup& cg = f.groups[f.item_group[it]];
     const int k = f.item_k[it];
-    const double s = am[cg.b0] + am[cg.b1];
-    double out = 0.0;
-    if (k == cg.r) {
-      out = 1.0 / s;
-    } else if (k < cg.r) {
-      if (cg.kind == 0) {
-        out = zs[cg.zpos + k];
-      } else {
-        double acc = 0.0;
-        for (int t = 0; t < cg.nterm; ++t) {
-          const CoefTerm& ct = cg.t[t];
-          const double* Mt = f.cm + ct.moff + k;
-          double dot = 0.0;
-#pragma unroll 16
-          for (int j = 0; j < ct.len; ++j) dot += Mt[size_t(j) * cg.r] * zs[ct.src + j];
-          if (ct.voff >= 0) dot += f.vec[ct.voff + k] / (am[ct.u0] + am[ct.u1]);
-          acc += (ct.blk >= 0 ? am[ct.blk] : s / 2) * dot;
-        }
-        out = acc / s;
-      }
-    }
-    ym[cg.cpos + k] = out;
+    if (cg.kind == 1 && k < cg.r) continue;  // done above
+    ym[cg.cpos + k] = k == cg.r ? 1.0 / (am[cg.b0] + am[cg.b1]) : (k < cg.r ? zs[cg.zpos + k] : 0.0);
   }
 }
 
@@ -1131,7 +1154,8 @@ extern "C" int rom_fem_destroy(rom_fem* f) {
   void* ptrs[] = {f->d_A0, f->d_G, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
                   f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
                   f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred, f->d_groups, f->d_cm,
-                  f->d_item_group, f->d_item_k, f->d_rowent, f->d_lr_blocks, f->d_gen_blocks, f->d_scat};
+                  f->d_item_group, f->d_item_k, f->d_rowent, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
+                  f->d_ditem_k, f->d_dmat};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete f;
@@ -1801,6 +1825,50 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   for (size_t g = 0; g < groups.size(); ++g)
     for (int k = 0; k < groups[g].w; ++k) { item_group.push_back(int(g)); item_k.push_back(k); }
   f->ncoef = int(item_group.size());
+  {
+    // single-tile path: the coefficient blocks of the closed-form edges as one dense product (k_solve1)
+    std::vector<DenseGroup> dgroups;
+    std::vector<int> dweight, ditem_group, ditem_k;
+    std::vector<std::pair<int, int>> dsrc;  // (group index in `groups`, first item)
+    for (size_t g = 0; g < groups.size(); ++g)
+      if (groups[g].kind == 1) {
+        DenseGroup dg;
+        memset(&dg, 0, sizeof(dg));
+        dg.cpos = groups[g].cpos; dg.r = groups[g].r; dg.b0 = groups[g].b0; dg.b1 = groups[g].b1;
+        dsrc.push_back({int(g), int(ditem_group.size())});
+        for (int k = 0; k < groups[g].r; ++k) { ditem_group.push_back(int(dgroups.size())); ditem_k.push_back(k); }
+        dgroups.push_back(dg);
+      }
+    const int ndi = int(ditem_group.size());
+    std::vector<double> dmat(size_t(TB) * std::max(ndi, 1), 0.0);
+    dweight.assign(dgroups.size() * TB, -2);
+    bool ok = f->fused1 && int(dgroups.size()) <= DENSE_GROUPS_MAX;
+    for (size_t dgi = 0; dgi < dgroups.size() && ok; ++dgi) {
+      const CoefGroup& cg = groups[dsrc[dgi].first];
+      for (int t = 0; t < cg.nterm && ok; ++t) {
+        const CoefTerm& ct = cg.t[t];
+        for (int j = 0; j < ct.len; ++j) {
+          if (ct.src + j >= TB) { ok = false; break; }
+          dweight[dgi * TB + ct.src + j] = ct.blk >= 0 ? ct.blk : -1;
+          for (int k = 0; k < cg.r; ++k) dmat[size_t(ct.src + j) * ndi + dsrc[dgi].second + k] = cm[ct.moff + size_t(j) * cg.r + k];
+        }
+        if (ct.voff >= 0) {
+          DenseGroup& dg = dgroups[dgi];
+          if (dg.nv >= 4) { ok = false; break; }
+          dg.voff[dg.nv] = ct.voff; dg.vblk[dg.nv] = ct.blk; dg.vu0[dg.nv] = ct.u0; dg.vu1[dg.nv] = ct.u1;
+          ++dg.nv;
+        }
+      }
+    }
+    if (!ok) f->fused1 = false;
+    f->ndg = f->fused1 ? int(dgroups.size()) : 0;
+    f->ndi = f->fused1 ? ndi : 0;
+    ROM_TRY(upload(&f->d_dgroups, dgroups));
+    ROM_TRY(upload(&f->d_dweight, dweight));
+    ROM_TRY(upload(&f->d_ditem_group, ditem_group));
+    ROM_TRY(upload(&f->d_ditem_k, ditem_k));
+    ROM_TRY(upload(&f->d_dmat, dmat));
+  }
   {
     std::vector<double> Ptab(std::max<size_t>(ptab_list.size() * tsz, 1), 0.0);
     for (size_t t = 0; t < ptab_list.size(); ++t)

@@ -124,6 +124,13 @@ struct ExtSide {
   int gtab;    // mode 2: offset (doubles) of the (n1*n1) x (nch*BK) table H_0 [P_f, p0_f]
   int b0, b1;  // mode 2: blocks of the edge (s_f = a_b0 + a_b1)
 };
+// coefficient block of one closed-form edge on the single-tile path (k_solve1): see the dense product there
+struct DenseGroup {
+  int cpos, r, b0, b1;
+  int nv;                                // parts scaled by a[vblk] / (a[vu0] + a[vu1]): the neighbours' p0
+  int voff[4], vblk[4], vu0[4], vu1[4];
+};
+
 // one step of the single-tile assembly (k_solve1): acc += coef[term] * pool[off + lane] for lanes in
 // [c_lo, c_hi); `last` closes tile row r (acc is stored and reset)
 struct RowEnt {
@@ -231,6 +238,12 @@ struct rom_fem {
   RowEnt* d_rowent = nullptr;  // row program of the single-tile solve
   int nrowent = 0;
   bool fused1 = false;         // the reduced matrix is one tile: whole solve in k_solve1
+  DenseGroup* d_dgroups = nullptr;
+  int* d_dweight = nullptr;    // per (dense group, source position): block of the weight, -1 cross point, -2 none
+  int* d_ditem_group = nullptr;
+  int* d_ditem_k = nullptr;
+  double* d_dmat = nullptr;    // TB x ndi
+  int ndg = 0, ndi = 0;
   int nrhs = 0;
   BlockSide* d_sides = nullptr;  // nrb*ncb
   int* d_lr_blocks = nullptr;    // blocks whose sides are all in compressed form (k_extend_lr)
