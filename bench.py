@@ -77,7 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pod", action="store_true")
     ap.add_argument("--force-comm", action="store_true",
-                    help="rehearsal: run the N>1 code path (RCCL communicator, overlapped all-gather) with one rank")
+                    help="rehearsal: run the N>1 code path (RCCL communicator, all-gather of the interface vectors, "
+                         "expansion of the gathered block) with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,25 +125,26 @@ def main():
     a_loc = a_all[rank * M:(rank + 1) * M]
     a_dev = ctx.upload(a_loc.reshape(M, -1))
     U_loc = ctx.alloc(M * dim)
-    # N > 1: two local shards and two gathered blocks so that the RCCL all-gather of step k (on the
-    # communication stream) overlaps the solves of step k+1 (on the compute stream)
-    U_pair = [U_loc, ctx.alloc(M * dim)] if comm else [U_loc]
-    U_all = [ctx.alloc(world * M * dim) for _ in range(2)] if comm else [U_loc]
-    step_no = [0]
+    # N > 1: what is exchanged is the factored form of the shard -- the interface vectors (fem.reduced_stride
+    # doubles per system, 1/85 of a snapshot row at C2) -- and every rank expands the gathered vectors of ALL
+    # ranks into the full (world*M, dim) snapshot block; see romhighcontrast_amd/sweep.py and DESIGN.md section 6.
+    stride = fem.reduced_stride
+    if comm:
+        Y_loc = ctx.alloc(max(M * stride, 1))
+        Y_all = ctx.alloc(max(world * M * stride, 1))
+        U_all = ctx.alloc(world * M * dim)
+        a_all_dev = ctx.upload(a_all.reshape(world * M, -1))
 
     def step():
-        k = step_no[0] & 1 if comm else 0
-        step_no[0] += 1
-        if comm:
-            ctx.comm_wait_slot(k)  # the all-gather that last read this shard buffer must have finished
-        fem.solve_batch(a_dev, M, U_pair[k], wait=False)  # enqueued only: no host round trip per step
-        if comm:
-            ctx.allgather_async(U_pair[k], 0, U_all[k], 0, M * dim, slot=k)
+        if not comm:
+            fem.solve_batch(a_dev, M, U_loc, wait=False)  # enqueued only: no host round trip per step
+            return
+        fem.solve_reduced(a_dev, M, Y_loc)                       # this rank's shard
+        ctx.allgather(Y_loc, 0, Y_all, 0, M * stride)            # RCCL over xGMI, on the compute stream
+        fem.expand(a_all_dev, world * M, Y_all, U_all)           # the whole block, on every rank
 
     def drain():
         ctx.solve_status()  # waits for the compute stream; raises if any system was not positive definite
-        if comm:
-            ctx.comm_wait(True)
 
     for _ in range(args.warmup):
         step()
@@ -174,11 +176,11 @@ def main():
     ctx.profile(False)
     barrier()
 
-    if comm:  # the gathered block must equal the local shard in this rank's slot
-        last = (step_no[0] - 1) & 1
+    if comm:  # this rank's slot of the gathered block must equal a plain local sweep, bit for bit
+        fem.solve_batch(a_dev, M, U_loc)
         probe = [0, (M // 2) * dim + 17, M * dim - 1]
         for off in probe:
-            assert U_all[last].download(1, offset=rank * M * dim + off)[0] == U_pair[last].download(1, offset=off)[0]
+            assert U_all.download(1, offset=rank * M * dim + off)[0] == U_loc.download(1, offset=off)[0]
     if rank != 0:
         if comm:
             ctx.comm_destroy()
@@ -227,7 +229,8 @@ def main():
         "config": {"workload": f"C{2 if world == 1 else 3}: {blocks[0]}x{blocks[1]} blocks, N={N} "
                                f"({blocks[0] * N}x{blocks[1] * N} cells, dim {dim}), {M}-parameter sweep per GPU "
                                f"({world * M} total), a=10**U(0,2) seed 20240807"
-                               + (", RCCL all-gather of the snapshot block each step" if world > 1 else ""),
+                               + (", RCCL all-gather of the interface vectors + expansion of the whole "
+                                  "snapshot block on every rank, each step" if world > 1 else ""),
                    "blocks_geometry": list(blocks), "N": N, "dim": dim, "M_per_gpu": M, "M_total": world * M,
                    "parallelism": f"sweep sharded over {world} GPU(s)"},
         "event_ms_per_step": round(ev_ms / args.steps, 4),

@@ -99,6 +99,14 @@ int rom_solve_batch(rom_fem* fem, rom_buf* a, int M, rom_buf* U, int64_t row0);
  * (or rom_solve_batch()), which waits for the compute stream. */
 int rom_solve_batch_async(rom_fem* fem, rom_buf* a, int M, rom_buf* U, int64_t row0);
 int rom_solve_status(rom_ctx* ctx);
+/* The sweep in two stages, for the multi-GPU exchange: a snapshot row is a fixed linear image of
+ * its system's "interface vector" (reduced unknowns + coefficient blocks, rom_fem_reduced_stride() doubles:
+ * 768 instead of 65,025 at 256x256 / 2x2).  Ranks all-gather the interface vectors and every rank expands all
+ * of them; the expansion is deterministic, so the gathered snapshot block is bit-identical on every rank.
+ * Both calls only enqueue work on the compute stream (rom_solve_status() reports a non-positive pivot). */
+int rom_fem_reduced_stride(rom_fem* fem, int64_t* stride);
+int rom_solve_reduced_async(rom_fem* fem, rom_buf* a, int M, rom_buf* Y, int64_t y_row0);
+int rom_expand_batch_async(rom_fem* fem, rom_buf* a, int M, rom_buf* Y, int64_t y_row0, rom_buf* U, int64_t row0);
 /* flops / HBM bytes of the library's own algorithm for one snapshot solve, and the canonical
  * banded-Cholesky figures of SURVEY.md 8(d) for comparison */
 int rom_solve_work(rom_fem* fem, double* flops_own, double* bytes_own, double* flops_banded,

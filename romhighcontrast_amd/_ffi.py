@@ -60,6 +60,9 @@ PROTOTYPES = {
     "rom_solve_batch": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64]),
     "rom_solve_batch_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64]),
     "rom_solve_status": (C.c_int, [_vp]),
+    "rom_fem_reduced_stride": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rom_solve_reduced_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64]),
+    "rom_expand_batch_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, _vp, C.c_int64]),
     "rom_solve_work": (C.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     "rom_stencil_apply": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _vp, C.c_int64]),
     "rom_h10norm": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, _vp]),
@@ -327,6 +330,21 @@ class Fem:
         """wait=False only enqueues the sweep; call Context.solve_status() before trusting the rows."""
         fn = self.ctx.lib.rom_solve_batch if wait else self.ctx.lib.rom_solve_batch_async
         check(fn(self.h, a.h, M, U.h, row0))
+
+    @property
+    def reduced_stride(self) -> int:
+        """doubles per system of the interface vector (what solve_reduced writes and expand reads)"""
+        v = C.c_int64(0)
+        check(self.ctx.lib.rom_fem_reduced_stride(self.h, C.byref(v)))
+        return v.value
+
+    def solve_reduced(self, a: Buffer, M: int, Y: Buffer, y_row0: int = 0):
+        """Stage 1 of the sweep (enqueued only): interface vectors of the M systems into Y[y_row0:y_row0+M]."""
+        check(self.ctx.lib.rom_solve_reduced_async(self.h, a.h, M, Y.h, y_row0))
+
+    def expand(self, a: Buffer, M: int, Y: Buffer, U: Buffer, y_row0: int = 0, row0: int = 0):
+        """Stage 2 (enqueued only): snapshot rows U[row0:row0+M] from the interface vectors Y[y_row0:y_row0+M]."""
+        check(self.ctx.lib.rom_expand_batch_async(self.h, a.h, M, Y.h, y_row0, U.h, row0))
 
     def solve_work(self):
         v = [C.c_double(0) for _ in range(4)]

@@ -2124,19 +2124,21 @@ static int ensure_workspace(rom_fem* f, int Mc) {
 }
 
 // enqueue every kernel of one sub-batch (Mc systems, workspace pointers already offset) on `st`
+// `stages`: 1 = reduced solve (interface vector: reduced unknowns, cross points, coefficient blocks),
+//           2 = expansion of the interface vector into snapshot rows, 3 = both
 static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, double* U, long long row,
-                         hipStream_t st, size_t lds_back) {
+                         hipStream_t st, size_t lds_back, int stages) {
   rom_ctx* ctx = f->ctx;
   const int kblk = f->nrb * f->ncb;
   static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-column kernel names
   char nm[4][48];
   static const bool no_fused = getenv("ROMHC_NO_FUSED") != nullptr;
   const bool fused1 = f->fused1 && !no_fused;  // the whole reduced solve in one wave-per-system kernel
-  if (f->nGp > 0 && fused1) {
+  if (f->nGp > 0 && fused1 && (stages & 1)) {
     ROM_PROF(ctx, "solve1", Mc * (262144 / 3.0 + 3 * 4096.0), Mc * 8.0 * 4096 * 3);
     k_solve1<<<Mc, 64, 0, st>>>(d, am);
   }
-  if (f->nGp > 0 && !fused1) {
+  if (f->nGp > 0 && !fused1 && (stages & 1)) {
     {
       ROM_PROF(ctx, "rhs", 0, 8.0 * Mc * f->nGa);
       k_rhs<<<Mc, 256, 0, st>>>(d, am);
@@ -2176,6 +2178,10 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
       ROM_PROF(ctx, "coef", 0, 8.0 * Mc * f->ncoef);
       k_coef<<<Mc, 256, 0, st>>>(d, am);
     }
+  }
+  if (!(stages & 2)) {
+    ROM_HIP(hipGetLastError());
+    return ROM_OK;
   }
   if (f->nGp > 0) {
     if (f->nexp > 0) {
@@ -2222,14 +2228,20 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   return ROM_OK;
 }
 
-// enqueue the sweep; `check` = also wait for it and report a non-positive pivot
-static int solve_batch_impl(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0, bool check) {
-  ROM_CHECK(f && a && U, "rom_solve_batch: null argument");
-  ROM_CHECK(M >= 0 && row0 >= 0, "rom_solve_batch: negative M or row offset");
+// enqueue the sweep; `check` = also wait for it and report a non-positive pivot.  `Y` (optional): the caller's
+// interface vectors (rows y_row0 .. of stride nGp) instead of the internal workspace; `stages` as in enqueue_solve.
+static int solve_batch_impl(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0, bool check, rom_buf* Y = nullptr,
+                            int64_t y_row0 = 0, int stages = 3) {
+  ROM_CHECK(f && a && (U || !(stages & 2)), "rom_solve_batch: null argument");
+  ROM_CHECK(M >= 0 && row0 >= 0 && y_row0 >= 0, "rom_solve_batch: negative M or row offset");
   const int kblk = f->nrb * f->ncb;
   ROM_CHECK(a->n >= size_t(M) * kblk, "rom_solve_batch: `a` holds %zu doubles, need %zu", a->n, size_t(M) * kblk);
-  ROM_CHECK(U->n >= size_t(row0 + M) * f->dim, "rom_solve_batch: U holds %zu doubles, need %zu", U->n,
-            size_t(row0 + M) * f->dim);
+  if (stages & 2)
+    ROM_CHECK(U->n >= size_t(row0 + M) * f->dim, "rom_solve_batch: U holds %zu doubles, need %zu", U->n,
+              size_t(row0 + M) * f->dim);
+  if (Y)
+    ROM_CHECK(Y->n >= size_t(y_row0 + M) * f->nGp, "rom_solve_batch: the interface-vector buffer holds %zu doubles, need %zu",
+              Y->n, size_t(y_row0 + M) * f->nGp);
   if (M == 0) return ROM_OK;
   rom_ctx* ctx = f->ctx;
   ROM_HIP(hipSetDevice(ctx->device));
@@ -2257,9 +2269,11 @@ static int solve_batch_impl(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t r
       FemDev d = make_dev(f);
       d.L += size_t(off) * f->nslots * 4096;
       d.invL += size_t(off) * f->T * 4096;
-      d.y += size_t(off) * f->nGp;
+      if (Y) d.y = Y->p + size_t(y_row0 + m0 + off) * f->nGp;
+      else d.y += size_t(off) * f->nGp;
       d.yhat += size_t(off) * f->nGp;
-      ROM_TRY(enqueue_solve(f, d, a->p + size_t(m0 + off) * kblk, Mc, U->p, (long long)(row0 + m0 + off), st, lds_back));
+      ROM_TRY(enqueue_solve(f, d, a->p + size_t(m0 + off) * kblk, Mc, U ? U->p : nullptr, (long long)(row0 + m0 + off), st,
+                            lds_back, stages));
     }
     ctx->prof_stream = nullptr;
     if (m0 + Mc_max < M) {  // the workspace is reused by the next chunk: join first
@@ -2286,6 +2300,29 @@ extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_
 // is remembered on the device until rom_solve_status() is asked.
 extern "C" int rom_solve_batch_async(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0) {
   return solve_batch_impl(f, a, M, U, row0, false);
+}
+
+extern "C" int rom_fem_reduced_stride(rom_fem* f, int64_t* stride) {
+  ROM_CHECK(f && stride, "rom_fem_reduced_stride: null argument");
+  *stride = f->nGp;
+  return ROM_OK;
+}
+
+// Stage 1 only: Y[y_row0 + m, :] = interface vector of system m (reduced unknowns, cross points, the coefficient
+// blocks the extension reads): everything that depends on the solve, 1/85 of a snapshot row at 256x256 / 2x2.
+extern "C" int rom_solve_reduced_async(rom_fem* f, rom_buf* a, int M, rom_buf* Y, int64_t y_row0) {
+  ROM_CHECK(f && Y, "rom_solve_reduced_async: null argument");
+  ROM_CHECK(M >= 0 && y_row0 >= 0 && Y->n >= size_t(y_row0 + M) * f->nGp, "rom_solve_reduced_async: Y too small");
+  if (M > 0 && f->nGp > 0)  // padding slots are read against zero table entries: they must hold finite numbers
+    ROM_HIP(hipMemsetAsync(Y->p + size_t(y_row0) * f->nGp, 0, size_t(M) * f->nGp * sizeof(double), f->ctx->stream));
+  return solve_batch_impl(f, a, M, nullptr, 0, false, Y, y_row0, 1);
+}
+
+// Stage 2 only: snapshot rows U[row0 + m, :] from the interface vectors Y[y_row0 + m, :] (of this or any other
+// rank: the expansion is deterministic, so every rank reproduces the owner's rows bit for bit).
+extern "C" int rom_expand_batch_async(rom_fem* f, rom_buf* a, int M, rom_buf* Y, int64_t y_row0, rom_buf* U, int64_t row0) {
+  ROM_CHECK(f && Y && U, "rom_expand_batch_async: null argument");
+  return solve_batch_impl(f, a, M, U, row0, false, Y, y_row0, 2);
 }
 
 extern "C" int rom_solve_status(rom_ctx* ctx) {

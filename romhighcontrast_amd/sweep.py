@@ -5,6 +5,12 @@ The reference's only parallelism is ``map`` over parameters through a process po
 [g*Mp, min(M,(g+1)*Mp)), Mp = ceil(M/G); the shards are exchanged with ONE all-gather (RCCL over
 xGMI on the GPU path) before the basis stage.  Because only the trailing shard(s) can be short, the
 gathered (G*Mp, dim) block holds the M valid rows contiguously at the front.
+
+What travels on the GPU path is the factored form of the shard: a snapshot row is a fixed linear image of
+its system's interface vector (libromhc: rom_solve_reduced_async / rom_expand_batch_async), 1/85 of the
+row at 256x256 / 2x2, so the ranks all-gather the interface vectors and every rank expands all of them
+(bit-identical rows on every rank: the expansion is deterministic).  xGMI moves 6 MB per rank and step
+instead of 528 MB; what remains is the HBM write of the full block on every rank.
 """
 from __future__ import annotations
 
@@ -27,16 +33,18 @@ def shard_bounds(M: int, world: int, rank: int):
     return lo, min(M, lo + mp)
 
 
-def sharded_sweep(a_all, world: int, rank: int, solve_local, allgather):
+def sharded_sweep(a_all, world: int, rank: int, solve_local, allgather, finish=None):
     """Run the sweep sharded: ``solve_local(a_shard, rows_padded)`` returns this rank's padded
-    (Mp, dim) block, ``allgather(block)`` returns the (world*Mp, dim) concatenation in rank order.
-    Returns (gathered block, M): rows [0, M) are the snapshots in the order of ``a_all``."""
+    (Mp, width) block, ``allgather(block)`` returns the (world*Mp, width) concatenation in rank order,
+    ``finish(gathered)`` (optional) turns the gathered block into snapshot rows when what was exchanged is
+    their factored form.  Returns (gathered block, M): rows [0, M) are the snapshots in the order of ``a_all``."""
     a_all = np.asarray(a_all)
     M = a_all.shape[0]
     mp = shard_rows(M, world)
     lo, hi = shard_bounds(M, world, rank)
     local = solve_local(a_all[lo:hi], mp)
-    return allgather(local), M
+    full = allgather(local)
+    return (finish(full) if finish is not None else full), M
 
 
 # ---- rendezvous for the RCCL unique id (one node, processes started by torch.distributed.run) ----
@@ -89,7 +97,8 @@ def cleanup_rendezvous(rank: int):
 
 
 class RcclSweep:
-    """GPU realisation: local shard solved by libromhc, exchanged with ncclAllGather."""
+    """GPU realisation: the interface vectors of the local shard are computed by libromhc, exchanged with
+    ncclAllGather, and expanded into the full snapshot block on every rank."""
 
     def __init__(self, sm, rank: int, world: int):
         self.sm, self.rank, self.world = sm, rank, world
@@ -97,23 +106,36 @@ class RcclSweep:
 
     def generate_solutions_device(self, a_all):
         from .lib.SolutionsManagers import DeviceArray
-        dim, ctx = self.sm.vspace_dim, self.ctx
+        dim, ctx, fem = self.sm.vspace_dim, self.ctx, self.sm._fem
+        stride = fem.reduced_stride
+        a_all = np.ascontiguousarray(np.asarray(a_all, dtype=np.float64).reshape(len(a_all), -1))
+        M = a_all.shape[0]
+        mp = shard_rows(M, self.world)
 
         def solve_local(a_shard, mp):
-            buf = ctx.alloc(max(mp * dim, 1))
+            Y = ctx.alloc(max(mp * stride, 1))
             if len(a_shard) < mp:
-                buf.fill(0.0)
-            if len(a_shard):
-                a = np.ascontiguousarray(np.asarray(a_shard, dtype=np.float64).reshape(len(a_shard), -1))
-                self.sm._fem.solve_batch(ctx.upload(a), len(a_shard), buf)
-            return DeviceArray(buf, mp, dim)
+                Y.fill(0.0)  # padding rows are expanded too (and ignored): they must hold finite numbers
+            if len(a_shard) and stride:
+                fem.solve_reduced(ctx.upload(a_shard), len(a_shard), Y)
+            return DeviceArray(Y, mp, stride)
 
         def allgather(local):
-            if self.world == 1:
+            if self.world == 1 or stride == 0:
                 return local
-            full = ctx.alloc(max(self.world * local.rows * dim, 1))
-            ctx.allgather(local.buf, 0, full, 0, local.rows * dim)
-            return DeviceArray(full, self.world * local.rows, dim)
+            full = ctx.alloc(self.world * mp * stride)
+            ctx.allgather(local.buf, 0, full, 0, mp * stride)
+            return DeviceArray(full, self.world * mp, stride)
 
-        full, M = sharded_sweep(a_all, self.world, self.rank, solve_local, allgather)
+        def finish(Yall):
+            rows = self.world * mp
+            a_pad = np.ones((rows, a_all.shape[1]))
+            a_pad[:M] = a_all  # the rows behind the M valid ones belong to short shards: any positive coefficient
+            U = ctx.alloc(max(rows * dim, 1))
+            if rows:
+                fem.expand(ctx.upload(a_pad), rows, Yall.buf, U)
+                ctx.solve_status()
+            return DeviceArray(U, rows, dim)
+
+        full, M = sharded_sweep(a_all, self.world, self.rank, solve_local, allgather, finish)
         return DeviceArray(full.buf, M, dim)

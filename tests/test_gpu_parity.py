@@ -339,6 +339,33 @@ def test_full_size_c4_properties(api):
     assert rb.basis.shape == (6, dim)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks,N,M", [((2, 2), 128, 200), ((3, 3), 20, 70), ((1, 2), 6, 5), ((2, 2), 16, 130), ((1, 1), 8, 3)])
+def test_two_stage_sweep_is_bit_identical(api, blocks, N, M):
+    """rom_solve_reduced_async + rom_expand_batch_async (the factored form that travels between GPUs) must
+    reproduce rom_solve_batch bit for bit, also when the interface vectors are expanded in a different batch
+    composition than they were solved in (rows of several 'ranks' concatenated, different row offsets)."""
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)
+    a = 10.0 ** np.random.default_rng(N + M).uniform(0, 3, size=(M, blocks[0] * blocks[1]))
+    ab = ctx.upload(a)
+    U = ctx.alloc(M * fem.dim)
+    fem.solve_batch(ab, M, U)
+    ref = U.download(shape=(M, fem.dim))
+    stride = fem.reduced_stride
+    # "two ranks": the second half is solved first and lands behind the first in the gathered buffer
+    h = M // 2
+    Y = ctx.alloc(max((M + 3) * stride, 1))
+    Y.fill(float("nan"))  # whatever was in the buffer must not matter
+    fem.solve_reduced(ctx.upload(a[h:]), M - h, Y, y_row0=3 + h)
+    fem.solve_reduced(ctx.upload(a[:h]), h, Y, y_row0=3)
+    U2 = ctx.alloc((M + 2) * fem.dim)
+    fem.expand(ab, M, Y, U2, y_row0=3, row0=2)
+    ctx.solve_status()
+    assert np.array_equal(U2.download(shape=(M + 2, fem.dim))[2:], ref)
+
+
 def test_rccl_single_rank_allgather(api):
     """The RCCL plumbing with a 1-rank communicator (a box has one GPU): id, init, all-gather, reduce."""
     from romhighcontrast_amd import _ffi, sweep
