@@ -206,14 +206,17 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / FP64_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_ms": round(d["total_ms"] / d["launches"], 5),
                 "flops_per_launch": d["flops"] / d["launches"],
-                "peak_measured_sustained": 48.8,
-                "note": "fp64 MFMA (v_mfma_f64_16x16x4_f64); peak = spec fp64 matrix rate; the instruction issues "
-                        "every ~100 cycles per SIMD at 2.35-2.4 GHz, i.e. 48.8 TFLOP/s with 8 waves/SIMD x 8 "
-                        "independent accumulators (tools/mfma_f64_peak2.hip, profiles/r01_mfma_f64_peak_microbench_v2.txt)"}
+                "store_bytes_per_launch": 8.0 * M * blocks[0] * blocks[1] * (N - 1) ** 2 if dom.startswith("extend") else None,
+                "note": "fp64 MFMA (v_mfma_f64_16x16x4_f64) against the spec fp64 matrix rate.  The same launch writes "
+                        "the snapshot rows (store_bytes_per_launch): with the store stream alone it takes 0.12-0.13 ms "
+                        "(tools/hbm_write_bw.hip: 4.2 TB/s for this pattern), with the MFMAs alone 0.13 ms at the "
+                        "64 cycles per instruction the counters show (SQ_VALU_MFMA_BUSY_CYCLES); the two phases of a "
+                        "workgroup do not overlap, see DESIGN.md section 5"}
     # PMC-measured memory-side traffic of the dominant kernel, if a summary of separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command is committed
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     kname = {"factor_panel": "k_factor_panel", "diag_update": "k_diag_update", "extend": "k_extend",
+             "extend_lr": "k_extend128" if N - 1 >= 96 and M >= 128 else "k_extend", "solve1": "k_solve1",
              "diag_potrf": "k_diag_potrf", "diag_inverse": "k_diag_inverse", "backsolve": "k_backsolve"}.get(dom)
     if os.path.exists(pmc_path) and (blocks, N, M) == ((2, 2), 128, 1024):
         pmc = json.load(open(pmc_path))["kernels"].get(kname)
