@@ -208,8 +208,8 @@ def main():
                 "flops_per_launch": d["flops"] / d["launches"],
                 "store_bytes_per_launch": 8.0 * M * blocks[0] * blocks[1] * (N - 1) ** 2 if dom.startswith("extend") else None,
                 "note": "fp64 MFMA (v_mfma_f64_16x16x4_f64) against the spec fp64 matrix rate.  The same launch writes "
-                        "the snapshot rows (store_bytes_per_launch): with the store stream alone it takes 0.12-0.13 ms "
-                        "(tools/hbm_write_bw.hip: 4.2 TB/s for this pattern), with the MFMAs alone 0.13 ms at the "
+                        "the snapshot rows (store_bytes_per_launch): with the store stream alone it takes 0.13-0.18 ms "
+                        "(tools/hbm_write_bw.hip: 3.0-4.2 TB/s for this pattern, box dependent), with the MFMAs alone 0.13 ms at the "
                         "64 cycles per instruction the counters show (SQ_VALU_MFMA_BUSY_CYCLES); the two phases of a "
                         "workgroup do not overlap, see DESIGN.md section 5"}
     # PMC-measured memory-side traffic of the dominant kernel, if a summary of separate
