@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--force-comm", action="store_true",
                     help="rehearsal: run the N>1 code path (RCCL communicator, all-gather of the interface vectors, "
                          "expansion of the gathered block) with one rank")
+    ap.add_argument("--replicate", action="store_true",
+                    help="N>1: also expand the gathered factored block into snapshot rows on every rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,22 +128,28 @@ def main():
     a_dev = ctx.upload(a_loc.reshape(M, -1))
     U_loc = ctx.alloc(M * dim)
     # N > 1: what is exchanged is the factored form of the shard -- the interface vectors (fem.reduced_stride
-    # doubles per system, 1/85 of a snapshot row at C2) -- and every rank expands the gathered vectors of ALL
-    # ranks into the full (world*M, dim) snapshot block; see romhighcontrast_amd/sweep.py and DESIGN.md section 6.
+    # doubles per system, 1/83 of a snapshot row at C2).  Every rank materialises the rows of its own shard (the
+    # (world*M, dim) block is resident in HBM across the ranks) and holds the WHOLE block in factored form, which
+    # is what the POD consumes (romhighcontrast_amd/factored.py).  --replicate also expands the gathered block
+    # on every rank (each rank then writes world x 528 MB per step); DESIGN.md section 7.
     stride = fem.reduced_stride
     if comm:
         Y_loc = ctx.alloc(max(M * stride, 1))
         Y_all = ctx.alloc(max(world * M * stride, 1))
-        U_all = ctx.alloc(world * M * dim)
-        a_all_dev = ctx.upload(a_all.reshape(world * M, -1))
+        if args.replicate:
+            U_all = ctx.alloc(world * M * dim)
+            a_all_dev = ctx.upload(a_all.reshape(world * M, -1))
 
     def step():
         if not comm:
             fem.solve_batch(a_dev, M, U_loc, wait=False)  # enqueued only: no host round trip per step
             return
-        fem.solve_reduced(a_dev, M, Y_loc)                       # this rank's shard
-        ctx.allgather(Y_loc, 0, Y_all, 0, M * stride)            # RCCL over xGMI, on the compute stream
-        fem.expand(a_all_dev, world * M, Y_all, U_all)           # the whole block, on every rank
+        fem.solve_reduced(a_dev, M, Y_loc)                       # this rank's shard: interface vectors ...
+        ctx.allgather(Y_loc, 0, Y_all, 0, M * stride)            # ... all-gathered (RCCL over xGMI, compute stream)
+        if args.replicate:
+            fem.expand(a_all_dev, world * M, Y_all, U_all)       # the whole block as rows, on every rank
+        else:
+            fem.expand(a_dev, M, Y_loc, U_loc)                   # the rows of the own shard
 
     def drain():
         ctx.solve_status()  # waits for the compute stream; raises if any system was not positive definite
@@ -176,11 +184,23 @@ def main():
     ctx.profile(False)
     barrier()
 
-    if comm:  # this rank's slot of the gathered block must equal a plain local sweep, bit for bit
-        fem.solve_batch(a_dev, M, U_loc)
+    if comm:  # the gathered factored block must reproduce a plain local sweep bit for bit, on every rank
+        ref = ctx.alloc(M * dim)
+        fem.solve_batch(a_dev, M, ref)
         probe = [0, (M // 2) * dim + 17, M * dim - 1]
-        for off in probe:
-            assert U_all.download(1, offset=rank * M * dim + off)[0] == U_loc.download(1, offset=off)[0]
+        if args.replicate:
+            for off in probe:
+                assert U_all.download(1, offset=rank * M * dim + off)[0] == ref.download(1, offset=off)[0]
+        else:
+            peer = (rank + 1) % world  # expand a few rows of the NEXT rank's shard from the gathered vectors
+            a_peer = ctx.upload(a_all[peer * M:peer * M + 4].reshape(4, -1))
+            rows = ctx.alloc(4 * dim)
+            fem.expand(a_peer, 4, Y_all, rows, y_row0=peer * M)
+            chk = ctx.alloc(4 * dim)
+            fem.solve_batch(a_peer, 4, chk)
+            assert np.array_equal(rows.download(), chk.download())
+            for off in probe:
+                assert U_loc.download(1, offset=off)[0] == ref.download(1, offset=off)[0]
     if rank != 0:
         if comm:
             ctx.comm_destroy()
@@ -232,8 +252,9 @@ def main():
         "config": {"workload": f"C{2 if world == 1 else 3}: {blocks[0]}x{blocks[1]} blocks, N={N} "
                                f"({blocks[0] * N}x{blocks[1] * N} cells, dim {dim}), {M}-parameter sweep per GPU "
                                f"({world * M} total), a=10**U(0,2) seed 20240807"
-                               + (", RCCL all-gather of the interface vectors + expansion of the whole "
-                                  "snapshot block on every rank, each step" if world > 1 else ""),
+                               + ((", RCCL all-gather of the snapshot block in factored form (interface vectors) each "
+                                   "step" + (" + expansion of the whole block on every rank" if args.replicate else
+                                             "; rows of the own shard materialised")) if world > 1 else ""),
                    "blocks_geometry": list(blocks), "N": N, "dim": dim, "M_per_gpu": M, "M_total": world * M,
                    "parallelism": f"sweep sharded over {world} GPU(s)"},
         "event_ms_per_step": round(ev_ms / args.steps, 4),

@@ -105,6 +105,10 @@ int rom_solve_status(rom_ctx* ctx);
  * of them; the expansion is deterministic, so the gathered snapshot block is bit-identical on every rank.
  * Both calls only enqueue work on the compute stream (rom_solve_status() reports a non-positive pivot). */
 int rom_fem_reduced_stride(rom_fem* fem, int64_t* stride);
+/* 1 if rom_expand_batch_async is a LINEAR map of the interface vectors (it then ignores `a`): U = Y B^T with a fixed
+ * B, so Gram matrices, means and POD modes of snapshots can be formed from Y alone (every geometry whose
+ * closed-form edges are all kept in compressed form, e.g. 2x2/N>=16, 3x3/N=171, 4x4/N=256). */
+int rom_fem_expansion_is_linear(rom_fem* fem, int* flag);
 int rom_solve_reduced_async(rom_fem* fem, rom_buf* a, int M, rom_buf* Y, int64_t y_row0);
 int rom_expand_batch_async(rom_fem* fem, rom_buf* a, int M, rom_buf* Y, int64_t y_row0, rom_buf* U, int64_t row0);
 /* flops / HBM bytes of the library's own algorithm for one snapshot solve, and the canonical

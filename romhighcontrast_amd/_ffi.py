@@ -61,6 +61,7 @@ PROTOTYPES = {
     "rom_solve_batch_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64]),
     "rom_solve_status": (C.c_int, [_vp]),
     "rom_fem_reduced_stride": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rom_fem_expansion_is_linear": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "rom_solve_reduced_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64]),
     "rom_expand_batch_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, _vp, C.c_int64]),
     "rom_solve_work": (C.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
@@ -337,6 +338,13 @@ class Fem:
         v = C.c_int64(0)
         check(self.ctx.lib.rom_fem_reduced_stride(self.h, C.byref(v)))
         return v.value
+
+    @property
+    def expansion_is_linear(self) -> bool:
+        """True if expand() is a linear map of the interface vectors (U = Y B^T, `a` ignored)."""
+        v = C.c_int(0)
+        check(self.ctx.lib.rom_fem_expansion_is_linear(self.h, C.byref(v)))
+        return bool(v.value)
 
     def solve_reduced(self, a: Buffer, M: int, Y: Buffer, y_row0: int = 0):
         """Stage 1 of the sweep (enqueued only): interface vectors of the M systems into Y[y_row0:y_row0+M]."""

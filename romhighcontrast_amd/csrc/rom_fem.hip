@@ -54,6 +54,8 @@ struct FemDev {
   const PreEdge* pre;
   const ExpEdge* exp;
   const int* xred;
+  const int* scb;         // scalar block: (b0, b1) per entry
+  int spos0, nsc, sblk0;  // its position / length in the interface vector, position of the h^2/a_b part
   const RowEnt* rowent;
   int nrowent;
   const DenseGroup* dgroups;  // single-tile path: coefficient blocks of the closed-form edges as one dense product
@@ -98,7 +100,8 @@ static FemDev make_dev(const rom_fem* f) {
   d.nrb = f->nrb; d.ncb = f->ncb; d.N = f->N; d.n1 = f->n1; d.n1p = f->n1p; d.nr = f->nr; d.nc = f->nc;
   d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.nexp = f->nexp; d.ncross = f->ncross;
   d.xb0 = f->xb0; d.pool = f->d_pool; d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
-  d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.groups = f->d_groups; d.cm = f->d_cm; d.item_group = f->d_item_group;
+  d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.scb = f->d_scb; d.spos0 = f->spos0; d.nsc = f->nsc;
+  d.sblk0 = f->spos0 + f->n_all_edges; d.groups = f->d_groups; d.cm = f->d_cm; d.item_group = f->d_item_group;
   d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.rowent = f->d_rowent; d.nrowent = f->nrowent; d.dgroups = f->d_dgroups; d.dweight = f->d_dweight;
   d.ditem_group = f->d_ditem_group; d.ditem_k = f->d_ditem_k; d.dmat = f->d_dmat; d.ndg = f->ndg; d.ndi = f->ndi; d.T = f->T; d.nslots = f->nslots;
   d.kblk = f->nrb * f->ncb; d.dim = f->dim;
@@ -260,6 +263,10 @@ __global__ __launch_bounds__(256) void k_coef(FemDev f, const double* __restrict
   const double* am = a + size_t(m) * f.kblk;
   double* y = f.y + size_t(m) * f.nGp;
   for (int x = threadIdx.x; x < f.ncross; x += blockDim.x) y[f.xb0 + x] = y[f.xred[x]];
+  for (int i = threadIdx.x; i < f.nsc; i += blockDim.x) {
+    const int b0 = f.scb[2 * i], b1 = f.scb[2 * i + 1];
+    y[f.spos0 + i] = b1 >= 0 ? 1.0 / (am[b0] + am[b1]) : (1.0 / (double(f.N) * double(f.N))) / am[b0];
+  }
   for (int it = threadIdx.x; it < f.ncoef; it += blockDim.x) {
     const CoefGroup& cg = f.groups[f.item_group[it]];
     const int k = f.item_k[it];
@@ -322,8 +329,7 @@ __global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restri
     for (int g = 0; g < 4; ++g) {
       const int m = blockIdx.y * 64 + acc_row(wp, i, g);
       if (m >= Mc) continue;
-      const double* amr = a + size_t(m) * f.kblk;
-      const double inv = 1.0 / (amr[ee.b0] + amr[ee.b1]);
+      const double inv = f.y[size_t(m) * f.nGp + ee.spos];  // 1 / (a_b0 + a_b1), from the scalar block
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
         const int node = blockIdx.x * 64 + acc_col(wp, jb);
@@ -629,6 +635,10 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   // the closed-form edges are one dense product here: out[it] = sum_j D[j][it] * (w_g(j) z_j), D = all their
   // matrices side by side (64 x items, coalesced in `it`), w_g(j) the weight of source j for group g.
   for (int x = lane; x < f.ncross; x += 64) ym[f.xb0 + x] = zs[f.xred[x]];
+  for (int i = lane; i < f.nsc; i += 64) {
+    const int b0 = f.scb[2 * i], b1 = f.scb[2 * i + 1];
+    ym[f.spos0 + i] = b1 >= 0 ? 1.0 / (am[b0] + am[b1]) : (1.0 / (double(f.N) * double(f.N))) / am[b0];
+  }
   for (int idx = lane; idx < f.ndg * 64; idx += 64) {
     const DenseGroup& dg = f.dgroups[idx >> 6];
     const int wd = f.dweight[idx];
@@ -863,7 +873,7 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
   }
   if (threadIdx.x < 64) {
     const int m = blockIdx.y * 64 + threadIdx.x;
-    scs[threadIdx.x] = m < Mc ? (1.0 / (double(N) * double(N))) / a[size_t(m) * f.kblk + b] : 0.0;
+    scs[threadIdx.x] = m < Mc ? f.y[size_t(m) * f.nGp + f.sblk0 + b] : 0.0;  // h^2 / a_b, from the scalar block
   }
   __syncthreads();
   Acc acc;
@@ -946,10 +956,9 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
   const bool vA = mA < Mc;
   const int jB = jv0 + srow;
   const bool vB = jB <= n1;
-  const double h2 = 1.0 / (double(N) * double(N));
   if (threadIdx.x < 128) {
     const int m = blockIdx.y * 128 + threadIdx.x;
-    scs[threadIdx.x] = m < Mc ? h2 / a[size_t(m) * f.kblk + b] : 0.0;  // (visible after the first barrier below)
+    scs[threadIdx.x] = m < Mc ? f.y[size_t(m) * f.nGp + f.sblk0 + b] : 0.0;  // h^2 / a_b (visible after the first barrier below)
   }
   int cend[4];
   const double* pAs[4];
@@ -1155,7 +1164,7 @@ extern "C" int rom_fem_destroy(rom_fem* f) {
                   f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
                   f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred, f->d_groups, f->d_cm,
                   f->d_item_group, f->d_item_k, f->d_rowent, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
-                  f->d_ditem_k, f->d_dmat};
+                  f->d_ditem_k, f->d_dmat, f->d_scb};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete f;
@@ -1499,7 +1508,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   std::vector<int> npos(E, -1);
   for (int e = 0; e < E; ++e) npos[e] = f->nGa + e * n1p;
   f->xb0 = f->nGa + E * n1p;
-  f->nGp = E > 0 ? f->xb0 + (ncross > 0 ? (ncross + TB - 1) / TB * TB : 0) : 0;
+  f->nGp = f->xb0 + (ncross > 0 ? (ncross + TB - 1) / TB * TB : 0);
   std::vector<int> cpos(E, -1);  // [z_f, 1/s_f] blocks of the edges that enter the extension in compressed form
   for (int e : order)
     if (use_lr[comp_of[e]]) {
@@ -1511,6 +1520,12 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       cpos[e] = f->nGp;
       f->nGp += rp[comp_of[e]];
     }
+  // scalar block: 1/(a_p + a_q) of every edge, then h^2/a_b of every block -- with it the expansion stage is a
+  // LINEAR map of the interface vector (it never reads the parameters)
+  f->spos0 = f->nGp;
+  f->n_all_edges = E;
+  f->nsc = E + nrb * ncb;
+  f->nGp += (f->nsc + BK - 1) / BK * BK;
 
   // ---- blocks of the reduced matrix --------------------------------------------------------------------
   std::vector<Small> smalls;
@@ -1807,7 +1822,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   std::vector<ExpEdge> exps;
   for (int e : order) {
     const int c = comp_of[e], pt = variant(c, 0);
-    exps.push_back(ExpEdge{zpos[e], (rk[e] + BK - 1) / BK, npos[e], pt, p0_of[{c, 0}], edges[e].b0, edges[e].b1});
+    exps.push_back(ExpEdge{zpos[e], (rk[e] + BK - 1) / BK, npos[e], pt, p0_of[{c, 0}], f->spos0 + e});
     if (cpos[e] >= 0) {
       CoefGroup cg;
       memset(&cg, 0, sizeof(cg));
@@ -1818,7 +1833,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   for (int e : pre_list)
     if (cpos[e] >= 0) {
       const int c = comp_of[e], pt = variant(c, 1);
-      exps.push_back(ExpEdge{cpos[e], (comps[c].r + BK - 1) / BK, npos[e], pt, p0_of[{c, 1}], edges[e].b0, edges[e].b1});
+      exps.push_back(ExpEdge{cpos[e], (comps[c].r + BK - 1) / BK, npos[e], pt, p0_of[{c, 1}], f->spos0 + e});
     }
   f->nexp = int(exps.size());
   std::vector<int> item_group, item_k;
@@ -2002,6 +2017,12 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   ROM_TRY(upload(&f->d_item_group, item_group));
   ROM_TRY(upload(&f->d_item_k, item_k));
   ROM_TRY(upload(&f->d_xred, xred));
+  {
+    std::vector<int> scb;  // (b0, b1) per scalar: an edge's two blocks, or (block, -1)
+    for (int e = 0; e < E; ++e) { scb.push_back(edges[e].b0); scb.push_back(edges[e].b1); }
+    for (int b = 0; b < nrb * ncb; ++b) { scb.push_back(b); scb.push_back(-1); }
+    ROM_TRY(upload(&f->d_scb, scb));
+  }
   ROM_TRY(upload(&f->d_desc, f->desc));
   ROM_TRY(upload(&f->d_kptr, f->kptr));
   ROM_TRY(upload(&f->d_kpair, f->kpair));
@@ -2174,7 +2195,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
       ROM_PROF(ctx, "backsolve", Mc * 2.0 * 4096 * (f->nslots + f->T), Mc * 8.0 * 4096 * (f->nslots + f->T));
       k_backsolve<<<Mc, 256, lds_back, st>>>(d);
     }
-    if (f->ncoef > 0 || f->ncross > 0) {
+    {
       ROM_PROF(ctx, "coef", 0, 8.0 * Mc * f->ncoef);
       k_coef<<<Mc, 256, 0, st>>>(d, am);
     }
@@ -2300,6 +2321,12 @@ extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_
 // is remembered on the device until rom_solve_status() is asked.
 extern "C" int rom_solve_batch_async(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0) {
   return solve_batch_impl(f, a, M, U, row0, false);
+}
+
+extern "C" int rom_fem_expansion_is_linear(rom_fem* f, int* flag) {
+  ROM_CHECK(f && flag, "rom_fem_expansion_is_linear: null argument");
+  *flag = f->npre == 0 ? 1 : 0;  // no edge is recovered node by node (k_back_pre weights its inputs with the parameters)
+  return ROM_OK;
 }
 
 extern "C" int rom_fem_reduced_stride(rom_fem* f, int64_t* stride) {

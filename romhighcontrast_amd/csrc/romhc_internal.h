@@ -170,7 +170,7 @@ struct ExpEdge {
   int npos;       // position of the nodal block
   int ptab;       // index of the P table (n1p x n1p, row = node, col = compressed index)
   int p0off;      // offset of p0 in the vector table
-  int b0, b1;
+  int spos;       // position of 1/(a_b0 + a_b1) in the scalar block of the interface vector
 };
 
 // coefficient block [z, 1/s, 0...] of an edge that enters the extension in compressed form (k_coef)
@@ -230,6 +230,8 @@ struct rom_fem {
   PreEdge* d_pre = nullptr;
   ExpEdge* d_exp = nullptr;
   int* d_xred = nullptr;       // reduced position of every cross point
+  int* d_scb = nullptr;        // scalar block descriptors
+  int spos0 = 0, nsc = 0, n_all_edges = 0;
   CoefGroup* d_groups = nullptr;
   double* d_cm = nullptr;
   int* d_item_group = nullptr;

@@ -1,0 +1,157 @@
+"""Snapshot blocks in factored form.
+
+A snapshot row of libromhc is a fixed linear image of its system's *interface vector* (reduced unknowns,
+cross-point values, coefficient blocks and the scalars 1/(a_p+a_q), h^2/a_b; ``Fem.reduced_stride`` doubles:
+784 against 65 025 at 256x256 / 2x2):
+
+    U = Y B^T ,     B (dim x K) parameter independent  (``Fem.expansion_is_linear``)
+
+so everything the basis stage needs from a snapshot block can be formed from ``Y``:
+
+    Gram      U U^T            = Y S Y^T ,  S = B^T B   (K x K, once per FE space)
+    mean row  mean(U)          = expand(mean(Y))
+    POD mode  sum_m w_m U_m    = expand(sum_m w_m Y_m)
+
+The (M, dim) block itself is never needed: it is what the GPUs of a node exchange (sweep.py) and what the
+POD of a gathered sweep works on (``pod_modes_factored``); rows are materialised on demand (``rows``).
+The reference has no counterpart (its snapshots are plain NumPy rows, src/lib/SolutionsManagers.py:64-68).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _ffi
+
+
+class ExpansionMap:
+    """S = B^T B of one FE space (device, K x K) and the expansion itself."""
+
+    def __init__(self, sm):
+        fem, ctx = sm._fem, sm._ctx
+        if not fem.expansion_is_linear:
+            raise _ffi.RomLibraryError("this geometry recovers some edges node by node: its expansion is not a "
+                                       "linear map of the interface vectors (use snapshot rows)")
+        self.sm, self.fem, self.ctx = sm, fem, ctx
+        self.K, self.dim = fem.reduced_stride, fem.dim
+        self._ones = {}
+        K, dim = self.K, self.dim
+        eye = ctx.upload(np.eye(K))
+        Bt = ctx.alloc(K * dim)
+        self.expand_into(eye, K, Bt)
+        self.S = ctx.alloc(K * K)
+        ctx.gram(K, dim, Bt, 0, dim, self.S, 0, K)
+        ctx.synchronize()
+        del Bt
+
+    def _a_dummy(self, M):
+        if M not in self._ones:
+            self._ones = {M: self.ctx.upload(np.ones((M, self.fem.kblk)))}
+        return self._ones[M]
+
+    def expand_into(self, Y, M, U, y_row0=0, row0=0):
+        """U[row0:row0+M] = Y[y_row0:y_row0+M] B^T (the parameters are not read by a linear expansion)."""
+        self.fem.expand(self._a_dummy(M), M, Y, U, y_row0=y_row0, row0=row0)
+        self.ctx.solve_status()
+
+
+def expansion_map(sm) -> ExpansionMap:
+    em = getattr(sm, "_expansion_map", None)
+    if em is None:
+        em = sm._expansion_map = ExpansionMap(sm)
+    return em
+
+
+class FactoredSnapshots:
+    """M snapshots held as their interface vectors ``Y`` (device, (M, K) row-major)."""
+
+    def __init__(self, sm, Y: "_ffi.Buffer", M: int):
+        self.sm, self.Y, self.M = sm, Y, int(M)
+        self.map = expansion_map(sm)
+
+    @property
+    def K(self):
+        return self.map.K
+
+    def rows(self, lo=0, hi=None):
+        """Materialise snapshot rows [lo, hi) as a DeviceArray."""
+        from .lib.SolutionsManagers import DeviceArray
+        hi = self.M if hi is None else hi
+        n = max(hi - lo, 0)
+        U = self.map.ctx.alloc(max(n * self.map.dim, 1))
+        if n:
+            self.map.expand_into(self.Y, n, U, y_row0=lo)
+        return DeviceArray(U, n, self.map.dim)
+
+    def gram(self):
+        """U U^T as a device buffer (M x M), from Y alone."""
+        ctx, K, M = self.map.ctx, self.K, self.M
+        T = ctx.alloc(M * K)
+        ctx.gemm_nt(M, K, K, self.Y, 0, K, self.map.S, 0, K, T, 0, K)  # T = Y S (S symmetric)
+        G = ctx.alloc(M * M)
+        ctx.gemm_nt(M, M, K, T, 0, K, self.Y, 0, K, G, 0, M)
+        return G
+
+
+def pod_modes_factored(fs: FactoredSnapshots, n: int, center=True, passes=2):
+    """Leading ``n`` POD modes / singular values of the snapshot block ``fs`` without ever forming it:
+    the same algorithm as ``lib.ReducedBasis.pod_modes`` (Gram -> leading eigenpairs by subspace iteration
+    on the device -> lift, repeated on the deflated block because the Gram matrix squares the condition
+    number), carried out on the interface vectors in the S inner product.  Cost O(M^2 K + n K dim) instead of
+    O(M^2 dim).  Returns (modes (n, dim) NumPy, singular values); rows follow scikit-learn's
+    ``svd_flip(u_based_decision=False)`` sign convention (the PCA call at src/lib/ReducedBasis.py:196)."""
+    from .lib.ReducedBasis import _top_eigenpairs_device
+    em, M, K = fs.map, fs.M, fs.K
+    ctx, dim = em.ctx, em.dim
+    n = min(n, M, dim)
+    Yc = ctx.alloc(M * K).copy_from(fs.Y, M * K)
+    if center:
+        ctx.center_rows(Yc, M, K, ctx.alloc(K))
+    S_host = em.S.download(K * K, shape=(K, K))
+    Wm = np.zeros((0, K))  # modes found so far, as interface vectors (S-orthonormal)
+    sig = np.zeros(n)
+    found = 0
+    T = ctx.alloc(M * K)
+    for p in range(passes):
+        if found >= n:
+            break
+        ctx.gemm_nt(M, K, K, Yc, 0, K, em.S, 0, K, T, 0, K)  # T = Yc S
+        G = ctx.alloc(M * M)
+        ctx.gemm_nt(M, M, K, T, 0, K, Yc, 0, K, G, 0, M)     # G = Yc S Yc^T
+        lam, W = _top_eigenpairs_device(ctx, G, M, n - found)
+        lam = np.maximum(lam, 0.0)
+        floor = lam[0] * 1e-13 if lam[0] > 0 else 0.0
+        take = 0
+        while found + take < n and take < len(lam) and lam[take] > floor:
+            take += 1
+        if take == 0:
+            break
+        s = np.sqrt(lam[:take])
+        sig[found:found + take] = s
+        for i in range(take):
+            W.buf.scale(1.0 / s[i] if s[i] > 0 else 0.0, offset=i * M, n=M)
+        Wnew = ctx.alloc(take * K)
+        ctx.gemm_nn(take, K, M, W.buf, 0, M, Yc, 0, K, Wnew, 0, K)  # S^-1 W^T Yc : new modes in Y space
+        Wall = np.vstack((Wm, Wnew.download(take * K, shape=(take, K))))
+        # re-orthonormalise all modes in the S inner product (small: (found+take) x K on the host)
+        for _ in range(2):
+            Gm = Wall @ S_host @ Wall.T
+            L = np.linalg.cholesky((Gm + Gm.T) / 2)
+            Wall = np.linalg.solve(L, Wall)
+        Wm = Wall
+        found += take
+        if found < n and p < passes - 1:
+            # deflate in Y space: Yc <- Yc - (Yc S Wm^T) Wm
+            Wd = ctx.upload(Wm)
+            C = ctx.alloc(M * found)
+            ctx.gemm_nt(M, K, K, Yc, 0, K, em.S, 0, K, T, 0, K)
+            ctx.gemm_nt(M, found, K, T, 0, K, Wd, 0, K, C, 0, found)
+            ctx.gemm_nn(M, K, found, C, 0, found, Wd, 0, K, Yc, 0, K, alpha=-1.0, beta=1.0)
+    comps = np.zeros((n, dim))
+    if found:
+        V = ctx.alloc(found * dim)
+        em.expand_into(ctx.upload(Wm), found, V)
+        comps[:found] = V.download(found * dim, shape=(found, dim))
+    piv = np.argmax(np.abs(comps), axis=1)
+    signs = np.sign(comps[np.arange(n), piv])
+    signs[signs == 0] = 1.0
+    return comps * signs[:, None], sig

@@ -10,7 +10,8 @@ What travels on the GPU path is the factored form of the shard: a snapshot row i
 its system's interface vector (libromhc: rom_solve_reduced_async / rom_expand_batch_async), 1/85 of the
 row at 256x256 / 2x2, so the ranks all-gather the interface vectors and every rank expands all of them
 (bit-identical rows on every rank: the expansion is deterministic).  xGMI moves 6 MB per rank and step
-instead of 528 MB; what remains is the HBM write of the full block on every rank.
+instead of 528 MB.  `RcclSweep.generate_factored` stops there -- the gathered block stays in factored form,
+which is all the POD needs (factored.py) -- `generate_solutions_device` also expands it on every rank.
 """
 from __future__ import annotations
 
@@ -104,9 +105,9 @@ class RcclSweep:
         self.sm, self.rank, self.world = sm, rank, world
         self.ctx = sm._ctx
 
-    def generate_solutions_device(self, a_all):
-        from .lib.SolutionsManagers import DeviceArray
-        dim, ctx, fem = self.sm.vspace_dim, self.ctx, self.sm._fem
+    def _gather_interface_vectors(self, a_all):
+        """(Y_all buffer, rows = world*Mp, M, a padded to `rows`): every rank's interface vectors, all-gathered."""
+        ctx, fem = self.ctx, self.sm._fem
         stride = fem.reduced_stride
         a_all = np.ascontiguousarray(np.asarray(a_all, dtype=np.float64).reshape(len(a_all), -1))
         M = a_all.shape[0]
@@ -116,26 +117,37 @@ class RcclSweep:
             Y = ctx.alloc(max(mp * stride, 1))
             if len(a_shard) < mp:
                 Y.fill(0.0)  # padding rows are expanded too (and ignored): they must hold finite numbers
-            if len(a_shard) and stride:
+            if len(a_shard):
                 fem.solve_reduced(ctx.upload(a_shard), len(a_shard), Y)
-            return DeviceArray(Y, mp, stride)
+            return Y
 
-        def allgather(local):
-            if self.world == 1 or stride == 0:
-                return local
+        def allgather(Y):
+            if self.world == 1:
+                return Y
             full = ctx.alloc(self.world * mp * stride)
-            ctx.allgather(local.buf, 0, full, 0, mp * stride)
-            return DeviceArray(full, self.world * mp, stride)
+            ctx.allgather(Y, 0, full, 0, mp * stride)
+            return full
 
-        def finish(Yall):
-            rows = self.world * mp
-            a_pad = np.ones((rows, a_all.shape[1]))
-            a_pad[:M] = a_all  # the rows behind the M valid ones belong to short shards: any positive coefficient
-            U = ctx.alloc(max(rows * dim, 1))
-            if rows:
-                fem.expand(ctx.upload(a_pad), rows, Yall.buf, U)
-                ctx.solve_status()
-            return DeviceArray(U, rows, dim)
+        Yall, M = sharded_sweep(a_all, self.world, self.rank, solve_local, allgather)
+        rows = self.world * mp
+        a_pad = np.ones((rows, a_all.shape[1]))
+        a_pad[:M] = a_all  # the rows behind the M valid ones belong to short shards: any positive coefficient
+        return Yall, rows, M, a_pad
 
-        full, M = sharded_sweep(a_all, self.world, self.rank, solve_local, allgather, finish)
-        return DeviceArray(full.buf, M, dim)
+    def generate_factored(self, a_all):
+        """The gathered sweep in factored form (no snapshot row is materialised): see factored.py."""
+        from .factored import FactoredSnapshots
+        Yall, rows, M, _ = self._gather_interface_vectors(a_all)
+        self.ctx.solve_status()
+        return FactoredSnapshots(self.sm, Yall, M)
+
+    def generate_solutions_device(self, a_all):
+        """The gathered sweep as snapshot rows, replicated on every rank."""
+        from .lib.SolutionsManagers import DeviceArray
+        dim, ctx, fem = self.sm.vspace_dim, self.ctx, self.sm._fem
+        Yall, rows, M, a_pad = self._gather_interface_vectors(a_all)
+        U = ctx.alloc(max(rows * dim, 1))
+        if rows:
+            fem.expand(ctx.upload(a_pad), rows, Yall, U)
+        ctx.solve_status()
+        return DeviceArray(U, M, dim)

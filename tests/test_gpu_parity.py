@@ -339,7 +339,6 @@ def test_full_size_c4_properties(api):
     assert rb.basis.shape == (6, dim)
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("blocks,N,M", [((2, 2), 128, 200), ((3, 3), 20, 70), ((1, 2), 6, 5), ((2, 2), 16, 130), ((1, 1), 8, 3)])
 def test_two_stage_sweep_is_bit_identical(api, blocks, N, M):
     """rom_solve_reduced_async + rom_expand_batch_async (the factored form that travels between GPUs) must
@@ -364,6 +363,40 @@ def test_two_stage_sweep_is_bit_identical(api, blocks, N, M):
     fem.expand(ab, M, Y, U2, y_row0=3, row0=2)
     ctx.solve_status()
     assert np.array_equal(U2.download(shape=(M + 2, fem.dim))[2:], ref)
+
+
+def test_factored_snapshot_block(api):
+    """U = Y B^T: rows, Gram matrix and POD of a sweep formed from the interface vectors alone must agree with
+    the same quantities formed from the materialised snapshot rows."""
+    from romhighcontrast_amd import factored
+    SM, RB = api
+    sm = SM.SolutionsManagerFEM((2, 2), 32)
+    fem, ctx = sm._fem, sm._ctx
+    assert fem.expansion_is_linear
+    M = 150
+    a = 10.0 ** np.random.default_rng(11).uniform(0, 2, size=(M, 2, 2))
+    U = sm.generate_solutions(a)
+    Y = ctx.alloc(M * fem.reduced_stride)
+    fem.solve_reduced(ctx.upload(a.reshape(M, -1)), M, Y)
+    ctx.solve_status()
+    fs = factored.FactoredSnapshots(sm, Y, M)
+    assert np.array_equal(fs.rows().numpy(), U)                       # same kernels, same bits
+    assert np.array_equal(fs.rows(40, 47).numpy(), U[40:47])
+    G = fs.gram().download(M * M, shape=(M, M))
+    Gref = U @ U.T
+    assert np.abs(G - Gref).max() <= 1e-11 * np.abs(Gref).max()
+    n = 12
+    comps, sig = factored.pod_modes_factored(fs, n)
+    comps_ref, sig_ref = RB.pod_modes(ctx, SM.DeviceArray(ctx.upload(U), M, sm.vspace_dim), n)
+    np.testing.assert_allclose(sig, sig_ref, rtol=1e-7, atol=1e-12 * sig_ref[0])
+    big = sig_ref > 1e-6 * sig_ref[0]
+    assert np.abs(comps[big] - comps_ref[big]).max() < 1e-6
+    assert np.abs(comps @ comps.T - np.eye(n)).max() < 1e-9
+    # geometries with a node-by-node edge refuse the factored form
+    sm2 = SM.SolutionsManagerFEM((1, 2), 6)
+    if not sm2._fem.expansion_is_linear:
+        with pytest.raises(Exception):
+            factored.ExpansionMap(sm2)
 
 
 def test_rccl_single_rank_allgather(api):
@@ -392,6 +425,9 @@ def test_rccl_single_rank_allgather(api):
         a = 10.0 ** np.random.default_rng(3).uniform(0, 2, size=(5, 2, 2))
         U = sweep.RcclSweep(sm, 0, 1).generate_solutions_device(a)
         assert np.array_equal(U.numpy(), sm.generate_solutions(a))
+        sm32 = SM.SolutionsManagerFEM((2, 2), 32)             # (compressed edges: linear expansion)
+        fs = sweep.RcclSweep(sm32, 0, 1).generate_factored(a)  # the gathered block left in factored form
+        assert fs.M == 5 and np.array_equal(fs.rows().numpy(), sm32.generate_solutions(a))
     finally:
         ctx.comm_destroy()
 
