@@ -133,9 +133,12 @@ def main():
     # is what the POD consumes (romhighcontrast_amd/factored.py).  --replicate also expands the gathered block
     # on every rank (each rank then writes world x 528 MB per step); DESIGN.md section 7.
     stride = fem.reduced_stride
+    step_no = [0]
     if comm:
-        Y_loc = ctx.alloc(max(M * stride, 1))
-        Y_all = ctx.alloc(max(world * M * stride, 1))
+        # two buffer pairs: the all-gather of step k (communication stream) overlaps the expansion of step k and
+        # the reduced solves of step k+1 (compute stream)
+        Y_loc = [ctx.alloc(max(M * stride, 1)) for _ in range(2)]
+        Y_all = [ctx.alloc(max(world * M * stride, 1)) for _ in range(2)]
         if args.replicate:
             U_all = ctx.alloc(world * M * dim)
             a_all_dev = ctx.upload(a_all.reshape(world * M, -1))
@@ -144,15 +147,21 @@ def main():
         if not comm:
             fem.solve_batch(a_dev, M, U_loc, wait=False)  # enqueued only: no host round trip per step
             return
-        fem.solve_reduced(a_dev, M, Y_loc)                       # this rank's shard: interface vectors ...
-        ctx.allgather(Y_loc, 0, Y_all, 0, M * stride)            # ... all-gathered (RCCL over xGMI, compute stream)
+        k = step_no[0] & 1
+        step_no[0] += 1
+        ctx.comm_wait_slot(k)                                    # the all-gather that last read Y_loc[k] is done
+        fem.solve_reduced(a_dev, M, Y_loc[k])                    # this rank's shard: interface vectors ...
+        ctx.allgather_async(Y_loc[k], 0, Y_all[k], 0, M * stride, slot=k)   # ... all-gathered (RCCL over xGMI)
         if args.replicate:
-            fem.expand(a_all_dev, world * M, Y_all, U_all)       # the whole block as rows, on every rank
+            ctx.comm_wait(False)                                 # compute stream waits for the gathered vectors
+            fem.expand(a_all_dev, world * M, Y_all[k], U_all)    # the whole block as rows, on every rank
         else:
-            fem.expand(a_dev, M, Y_loc, U_loc)                   # the rows of the own shard
+            fem.expand(a_dev, M, Y_loc[k], U_loc)                # the rows of the own shard, while the vectors travel
 
     def drain():
         ctx.solve_status()  # waits for the compute stream; raises if any system was not positive definite
+        if comm:
+            ctx.comm_wait(True)
 
     for _ in range(args.warmup):
         step()
@@ -195,7 +204,7 @@ def main():
             peer = (rank + 1) % world  # expand a few rows of the NEXT rank's shard from the gathered vectors
             a_peer = ctx.upload(a_all[peer * M:peer * M + 4].reshape(4, -1))
             rows = ctx.alloc(4 * dim)
-            fem.expand(a_peer, 4, Y_all, rows, y_row0=peer * M)
+            fem.expand(a_peer, 4, Y_all[(step_no[0] - 1) & 1], rows, y_row0=peer * M)
             chk = ctx.alloc(4 * dim)
             fem.solve_batch(a_peer, 4, chk)
             assert np.array_equal(rows.download(), chk.download())

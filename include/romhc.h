@@ -101,7 +101,7 @@ int rom_solve_batch_async(rom_fem* fem, rom_buf* a, int M, rom_buf* U, int64_t r
 int rom_solve_status(rom_ctx* ctx);
 /* The sweep in two stages, for the multi-GPU exchange: a snapshot row is a fixed linear image of
  * its system's "interface vector" (reduced unknowns + coefficient blocks, rom_fem_reduced_stride() doubles:
- * 768 instead of 65,025 at 256x256 / 2x2).  Ranks all-gather the interface vectors and every rank expands all
+ * 784 instead of 65,025 at 256x256 / 2x2).  Ranks all-gather the interface vectors and every rank expands all
  * of them; the expansion is deterministic, so the gathered snapshot block is bit-identical on every rank.
  * Both calls only enqueue work on the compute stream (rom_solve_status() reports a non-positive pivot). */
 int rom_fem_reduced_stride(rom_fem* fem, int64_t* stride);
