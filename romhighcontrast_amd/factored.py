@@ -82,6 +82,14 @@ class FactoredSnapshots:
             self.map.expand_into(self.Y, n, U, y_row0=lo)
         return DeviceArray(U, n, self.map.dim)
 
+    def take(self, idx) -> "FactoredSnapshots":
+        """The sub-block of the snapshots ``idx`` (a gather of interface vectors)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        Y = self.map.ctx.alloc(max(idx.size * self.K, 1))
+        if idx.size:
+            Y.gather_rows_from(self.Y, idx, self.K)
+        return FactoredSnapshots(self.sm, Y, idx.size)
+
     def gram(self):
         """U U^T as a device buffer (M x M), from Y alone."""
         ctx, K, M = self.map.ctx, self.K, self.M

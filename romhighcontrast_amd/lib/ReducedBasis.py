@@ -370,6 +370,19 @@ class ReducedBasisPCA(BaseReducedBasis):
 
     def build(self, n: int, sm: SolutionsManager, solutions2train, a2train: List[np.ndarray] = (()),
               solutions2train_h1norm=1, add_inf_solutions=True, seed=42, **kwargs):
+        from ..factored import FactoredSnapshots, pod_modes_factored
+        if isinstance(solutions2train, FactoredSnapshots):
+            # the training block in factored form (e.g. gathered from several GPUs): the same peel-off of the
+            # INFINIT_A snapshots by index, POD on the interface vectors, only the basis rows are materialised
+            fs, a2train = solutions2train, np.asarray(a2train)
+            has_inf = (a2train == INFINIT_A).reshape(len(a2train), -1).any(axis=1)
+            lead_idx = np.flatnonzero(has_inf) if self.add_inf_solutions else np.zeros(0, dtype=np.int64)
+            pool = fs.take(np.flatnonzero(~has_inf))
+            comps, sigma = pod_modes_factored(pool, n)
+            self.singular_values_ = sigma
+            lead = fs.take(lead_idx).rows().numpy() if lead_idx.size else np.empty((0, sm.vspace_dim))
+            super().set(basis=np.vstack((lead, comps))[:n], a=np.vstack((a2train[lead_idx], a2train[~has_inf]))[:n])
+            return self
         if isinstance(solutions2train, DeviceArray):
             solutions2train = solutions2train.numpy()
         basis, a, solutions2train, a2train = get_starting_basis(solutions2train, a2train, self.add_inf_solutions)

@@ -392,6 +392,12 @@ def test_factored_snapshot_block(api):
     big = sig_ref > 1e-6 * sig_ref[0]
     assert np.abs(comps[big] - comps_ref[big]).max() < 1e-6
     assert np.abs(comps @ comps.T - np.eye(n)).max() < 1e-9
+    # the PCA builder takes the factored block as its training set (same basis as from rows)
+    rb_f = RB.ReducedBasisPCA().build(6, sm, fs, a, 1)
+    rb_r = RB.ReducedBasisPCA().build(6, sm, U, a, 1)
+    assert np.abs(rb_f.basis - rb_r.basis).max() < 1e-6 and np.array_equal(np.asarray(rb_f.a), np.asarray(rb_r.a))
+    sub = fs.take([3, 77, 5])
+    assert np.array_equal(sub.rows().numpy(), U[[3, 77, 5]])
     # geometries with a node-by-node edge refuse the factored form
     sm2 = SM.SolutionsManagerFEM((1, 2), 6)
     if not sm2._fem.expansion_is_linear:
