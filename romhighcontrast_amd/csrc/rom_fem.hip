@@ -2153,7 +2153,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   const int kblk = f->nrb * f->ncb;
   static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-column kernel names
   char nm[4][48];
-  static const bool no_fused = getenv("ROMHC_NO_FUSED") != nullptr;
+  const bool no_fused = getenv("ROMHC_NO_FUSED") != nullptr;  // (read per call: the tests toggle it)
   const bool fused1 = f->fused1 && !no_fused;  // the whole reduced solve in one wave-per-system kernel
   if (f->nGp > 0 && fused1 && (stages & 1)) {
     ROM_PROF(ctx, "solve1", Mc * (262144 / 3.0 + 3 * 4096.0), Mc * 8.0 * 4096 * 3);
@@ -2229,7 +2229,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.gen_blocks, 4);
       }
       if (f->n_lr_blocks > 0) {
-        static const bool no128 = getenv("ROMHC_NO_EXT128") != nullptr;
+        const bool no128 = getenv("ROMHC_NO_EXT128") != nullptr;
         ROM_PROF(ctx, "extend_lr", fl_ext * f->n_lr_blocks, 8.0 * Mc * double(f->n_lr_blocks) * nij);
         if (f->n1 >= 96 && Mc >= 128 && !no128) {  // wide tiles need enough vertices per mesh row and systems to fill them
           dim3 grid(f->n1 * ((f->n1 + 127) / 128), (Mc + 127) / 128, f->n_lr_blocks);

@@ -365,6 +365,33 @@ def test_two_stage_sweep_is_bit_identical(api, blocks, N, M):
     assert np.array_equal(U2.download(shape=(M + 2, fem.dim))[2:], ref)
 
 
+@pytest.mark.parametrize("env", ["ROMHC_NO_COMPRESS", "ROMHC_NO_PREELIM", "ROMHC_NO_FUSED", "ROMHC_NO_LOWRANK_EXT",
+                                 "ROMHC_NO_EXT128", "ROMHC_NO_EXT_LR"])
+def test_algorithm_switches_agree(api, env, monkeypatch):
+    """Every exact reduction of the solver can be switched off (A/B checks): the snapshots must not move beyond
+    rounding, and each variant must itself meet the parity bound against the oracle."""
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    for blocks, N, M in (((2, 2), 128, 130), ((3, 3), 24, 40), ((2, 3), 40, 20)):
+        a = 10.0 ** np.random.default_rng(N).uniform(0, 3, size=(M, blocks[0] * blocks[1]))
+        ab = ctx.upload(a)
+        monkeypatch.delenv(env, raising=False)
+        fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)
+        U = ctx.alloc(M * fem.dim)
+        fem.solve_batch(ab, M, U)
+        ref = U.download(shape=(M, fem.dim))
+        monkeypatch.setenv(env, "1")
+        fem2 = _ffi.Fem(ctx, blocks[0], blocks[1], N)
+        U2 = ctx.alloc(M * fem.dim)
+        fem2.solve_batch(ab, M, U2)
+        alt = U2.download(shape=(M, fem.dim))
+        monkeypatch.delenv(env, raising=False)
+        g = ro.Geometry(blocks, N)
+        assert relh10(g, alt, ref).max() < 1e-11, (env, blocks, N)
+        if N <= 40:
+            assert relh10(g, alt[:4], ro.generate_solutions(g, a[:4].reshape((4,) + blocks))).max() < SNAP_TOL
+
+
 def test_factored_snapshot_block(api):
     """U = Y B^T: rows, Gram matrix and POD of a sweep formed from the interface vectors alone must agree with
     the same quantities formed from the materialised snapshot rows."""
