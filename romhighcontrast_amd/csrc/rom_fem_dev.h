@@ -1,0 +1,98 @@
+// Device-side view of a rom_fem, shared constants and the kernels of the sweep (gfx950 only).
+// rom_fem_kernels.hip defines the kernels, rom_fem_setup.hip builds the tables (rom_fem_create),
+// rom_fem_solve.hip enqueues them (rom_solve_batch and friends).
+#pragma once
+#include "rom_mma.h"
+
+// ============================================================================================
+// device-side view of a rom_fem
+// ============================================================================================
+struct FemDev {
+  int nrb, ncb, N, n1, n1p, nr, nc, nGp, nGa, T, nslots, kblk, npre, nrhs, nexp, ncross, xb0;
+  long long dim;
+  const double* pool;  // 64x64 tables of the tile terms
+  const GenTerm* terms;
+  const double* Bt;    // back substitution tables of the closed-form edges
+  const double* P;     // expansion tables of the active edges
+  const double* vec;
+  const RhsTerm* rhs;
+  const PreEdge* pre;
+  const ExpEdge* exp;
+  const int* xred;
+  const int* scb;         // scalar block: (b0, b1) per entry
+  int spos0, nsc, sblk0;  // its position / length in the interface vector, position of the h^2/a_b part
+  const RowEnt* rowent;
+  int nrowent;
+  const DenseGroup* dgroups;  // single-tile path: coefficient blocks of the closed-form edges as one dense product
+  const int* dweight;
+  const int* ditem_group;
+  const int* ditem_k;
+  const double* dmat;
+  int ndg, ndi;
+  const CoefGroup* groups;
+  const double* cm;
+  const int* item_group;
+  const int* item_k;
+  int ncoef;
+  const double* G;     // extension tables of the compressed edges: per table (n1*n1) x (rank+1 padded)
+  const double* A0;    // (n1*n1) x n1p : Q[j,mode] rho_mode(i), harmonic extension in the sine basis
+  const double* Qp;    // n1p x n1p sine matrix (zero padded)
+  const int* kmax;     // [N+1] modes (multiple of 16) that matter at distance d from a side
+  const int* epos;     // nodal n1p block of every edge whose sine coefficients are needed
+  double* yhat;        // [Mc][nGp] sine coefficients of the interface values
+  const double* W;
+  const double* g;
+  const TileDesc* desc;
+  const int* kptr;
+  const int* kpair;
+  const int* colptr;
+  const int* colrow;
+  const int* colti;
+  const BlockSide* sides;
+  const int* lr_blocks;   // blocks whose sides are all compressed: extended in mesh-row tiles
+  const int* gen_blocks;  // all others: 4 x 16 patches
+  const int* vmap;
+  const int* scat;  // interface positions copied to the snapshot rows by k_scatter_interface
+  int nscat;
+  double* L;     // [Mc][nslots][64*64]
+  double* invL;  // [Mc][T][64*64]
+  double* y;     // [Mc][nGp]: reduced unknowns | nodal edge blocks | cross block
+  int* status;
+};
+
+
+FemDev make_dev(const rom_fem* f);
+
+constexpr int COEF_MAX = 64;   // term weights cached in LDS per pass
+constexpr int DENSE_GROUPS_MAX = 8;  // closed-form edges whose coefficient blocks k_solve1 builds
+constexpr int ROW_BATCH = 64;  // loads in flight per wave in the single-tile assembly
+
+// row of H0 that holds the extension from side s evaluated at interior vertex (i,j), 1-based
+__host__ __device__ inline int h0_row(int s, int i, int j, int N, int n1) {
+  int ii, jj;
+  switch (s) {
+    case 0: ii = i; jj = j; break;
+    case 1: ii = N - i; jj = j; break;
+    case 2: ii = j; jj = i; break;
+    default: ii = N - j; jj = i; break;
+  }
+  return (ii - 1) * n1 + (jj - 1);
+}
+
+// ---- kernels (rom_fem_kernels.hip) ----------------------------------------------------------------
+__global__ void k_build_A0(double* A0, const double* Qp, const double* rho, int n1, int n1p, int N);
+__global__ void k_rhs(FemDev f, const double* __restrict__ a);
+__global__ void k_coef(FemDev f, const double* __restrict__ a);
+__global__ void k_expand(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0);
+__global__ void k_back_pre(FemDev f, const double* __restrict__ a, int Mc);
+__global__ void k_diag_update(FemDev f, const double* __restrict__ a, int slot);
+__global__ void k_diag_potrf(FemDev f, int slot);
+__global__ void k_diag_inverse(FemDev f, int slot, int j);
+__global__ void k_solve1(FemDev f, const double* __restrict__ a);
+__global__ void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc);
+__global__ void k_backsolve(FemDev f);
+__global__ void k_edge_transform(FemDev f, int Mc);
+__global__ void k_extend(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, const int* __restrict__ blocks, int pw_log2);
+__global__ void k_extend128(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0);
+__global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0);
+__global__ void k_assemble_stencil(FemDev f, const double* __restrict__ a, int M, double* __restrict__ diag, double* __restrict__ east, double* __restrict__ north);

@@ -1,0 +1,1003 @@
+// FE space + batched parametric solve (the snapshot sweep).
+//
+// Replaces SolutionsManagerFEM.__init__ (src/lib/SolutionsManagers.py:146-219), galerkin (:17-40)
+// and generate_solutions (:64-68) of the reference.
+//
+// Algorithm (exact direct method, fp64): the coefficient is constant a_b on each unit block b, so
+// inside block b the operator is a_b * L with L the Dirichlet 5-point Laplacian of the block --
+// parameter independent.  Eliminating all block interiors leaves an SPD system on the interface
+// vertices (edges between blocks + cross points)
+//        S(a) u_G = g,      S(a) = A_GG(a) - sum_b a_b T_b,     g parameter independent,
+// with T_b the (dense) Dirichlet-to-Neumann blocks of the unit square, identical for all blocks
+// up to the side pairing (16 tables T[sr][sc]).  Two further reductions are parameter independent
+// up to scalar weights and therefore tabulated once per FE space:
+//   (1) an independent set of edges (no two on the same block) has the self block (a_p + a_q) K with K
+//       fixed, so it is eliminated in closed form (tables X K^-1 X^T);
+//   (2) on every remaining ("active") edge f all couplings to the rest of the interface act through a
+//       numerically low-rank range W_f (the smooth traces of the neighbouring sides + the end nodes
+//       that touch cross points), so u_f = P_f z_f + p0_f / s_f with z_f = W_f^T u_f of dimension
+//       rank(W_f) ~ 30 at N = 128, and the system that is actually factorised couples only the z_f
+//       and the cross points.
+// Per parameter the work is: assemble the reduced system tile by tile (never stored: each tile is
+// built in registers when it is factored), a left-looking 64x64 tile Cholesky on MFMA with the
+// forward substitution fused in, a backward substitution, the expansion z -> edge values, the back
+// substitution of the closed-form edges, and the harmonic extension
+//        u_I,b = (h^2/a_b) W + sum_sides H_s u_G|side
+// as one batched MFMA GEMM that writes the snapshot rows straight into the caller's (M, dim) matrix.
+//
+// Setup tables come from the sine (DST-I) eigenbasis of the block:  H_0[(i,j),k] =
+// sum_m Q[j,m] rho_m(i) Q[k,m], rho_m(i) = sinh((N-i) phi_m)/sinh(N phi_m), cosh phi_m = 2-cos(pi m/N);
+// the other three sides are row permutations of H_0.
+#include "rom_fem_dev.h"
+
+// ============================================================================================
+// setup kernel
+// ============================================================================================
+// A0[((i-1)*n1 + (j-1)) * n1p + m] = Q[j-1][m] * rho[m][i]   (rho stored [m][i], i = 0..N)
+__global__ void k_build_A0(double* A0, const double* Qp, const double* rho, int n1, int n1p, int N) {
+  size_t idx = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+  size_t total = size_t(n1) * n1 * n1p;
+  if (idx >= total) return;
+  int m = int(idx % n1p);
+  size_t ij = idx / n1p;
+  int j = int(ij % n1) + 1, i = int(ij / n1) + 1;
+  A0[idx] = (m < n1) ? Qp[size_t(j - 1) * n1p + m] * rho[size_t(m) * (N + 1) + i] : 0.0;
+}
+
+
+// ============================================================================================
+// reduced-system tile assembly
+// ============================================================================================
+// weight of one table, from the block coefficients of this system
+__device__ inline double term_coef(const GenTerm& g, const double* __restrict__ am) {
+  switch (g.kind) {
+    case 0: return -am[g.b[0]];                                             // Schur coupling through block b0
+    case 1: return am[g.b[0]] + am[g.b[1]];                                 // edge self block s_f K~
+    case 2: return -(am[g.b[0]] + am[g.b[1]]) / 2;                          // cross point <-> end node of an edge
+    case 3: return ((am[g.b[0]] + am[g.b[1]]) + am[g.b[2]]) + am[g.b[3]];   // cross point diagonal
+    case 4: return -(am[g.b[0]] * am[g.b[1]] / (am[g.b[2]] + am[g.b[3]]));  // closed-form edge: edge x edge
+    case 5: return -(am[g.b[0]] / 2);                                       //                   edge x cross
+    default: return -((am[g.b[2]] + am[g.b[3]]) / 4);                       //                   cross x cross
+  }
+}
+
+// This thread's share of the assembled tile: row (t >> 2), 16 consecutive columns starting at
+// (t & 3) * 16.  Every table is read with 16-byte loads, 128 contiguous bytes per thread and table; the
+// values wait in registers while the MFMA k-loop runs.
+struct STile {
+  double v[16];
+};
+
+
+__device__ inline void s_tile_load(STile& st, const TileDesc& d, const FemDev& f, const double* __restrict__ am,
+                                   double* coef) {
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
+#pragma unroll
+  for (int x = 0; x < 16; ++x) st.v[x] = 0.0;
+  for (int tb = d.t0; tb < d.t1; tb += COEF_MAX) {
+    const int nt = min(COEF_MAX, d.t1 - tb);
+    __syncthreads();
+    if (int(threadIdx.x) < nt) coef[threadIdx.x] = term_coef(f.terms[tb + threadIdx.x], am);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      const GenTerm& g = f.terms[tb + t];
+      if (r < g.r_lo || r >= g.r_hi || c0 >= g.c_hi || c0 + 16 <= g.c_lo) continue;
+      const double cf = coef[t];
+      const double2* src = reinterpret_cast<const double2*>(f.pool + size_t(g.tab) * 4096 + r * 64 + c0);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const double2 w = src[x];  // tables are zero outside their rectangle: no masks needed
+        st.v[2 * x] += cf * w.x;
+        st.v[2 * x + 1] += cf * w.y;
+      }
+    }
+  }
+  if (d.diag && r >= d.ndr) {
+#pragma unroll
+    for (int x = 0; x < 16; ++x) st.v[x] = (c0 + x == r) ? 1.0 : 0.0;  // padding unknowns: identity
+  }
+}
+
+// C(LDS tile) = S_tile - acc
+__device__ inline void tile_from_acc(double* Cb, const Acc& acc, const STile& st, const WavePos& wp) {
+  {
+    double2* dst = reinterpret_cast<double2*>(Cb + (threadIdx.x >> 2) * LDC + (threadIdx.x & 3) * 16);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) dst[x] = double2{st.v[2 * x], st.v[2 * x + 1]};
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Cb[acc_row(wp, i, g) * LDC + acc_col(wp, j)] -= acc.c[i][j][g];
+  __syncthreads();
+}
+
+// LDS carve-up of the factor kernels: B staging (2 buffers) | union { A staging (2 buffers), C tile }
+constexpr int FACT_LDS_DOUBLES = 2 * STAGE_DOUBLES + TILE_DOUBLES;  // 6528 doubles = 52,224 B -> 3 WG / CU
+constexpr int KP_MAX = 64;                                            // k-pairs cached in LDS per pass
+
+// acc += sum over the k-list of `slot` of L[slotA] * L[slotB]^T, one merged pipelined loop
+template <class FP>
+__device__ inline void accumulate_klist(const FemDev& f, int slot, const double* Lm, int* kp, FP active, Acc& acc,
+                                        double* stA, double* stB, const WavePos& wp) {
+  const int e0 = f.kptr[slot], e1 = f.kptr[slot + 1];
+  const int srow = stage_row(), sseg = stage_seg();
+  for (int eb = e0; eb < e1; eb += KP_MAX) {
+    const int np = min(KP_MAX, e1 - eb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * np; i += blockDim.x) kp[i] = f.kpair[2 * eb + i];
+    __syncthreads();
+    const double* base = Lm + srow * 64 + sseg;
+    gemm_loop2(
+        4 * np, [&](int ch, double* v) { load4_aligned(base + size_t(kp[2 * (ch >> 2)]) * 4096 + (ch & 3) * BK, v); },
+        [&](int ch, double* v) { load4_aligned(base + size_t(kp[2 * (ch >> 2) + 1]) * 4096 + (ch & 3) * BK, v); },
+        active, acc, stA, stB, wp);
+  }
+}
+
+// ============================================================================================
+// factorisation kernels
+// ============================================================================================
+// rhs of the reduced system: the parameter-independent part plus the contributions of the closed-form
+// edges.  One workgroup per system; the terms are applied one after another (they overlap).
+__global__ __launch_bounds__(256) void k_rhs(FemDev f, const double* __restrict__ a) {
+  const int m = blockIdx.x;
+  const double* am = a + size_t(m) * f.kblk;
+  double* y = f.y + size_t(m) * f.nGp;
+  for (int v = threadIdx.x; v < f.nGa; v += blockDim.x) y[v] = f.g[v];
+  for (int t = 0; t < f.nrhs; ++t) {
+    __syncthreads();
+    const RhsTerm& rt = f.rhs[t];
+    const double coef = rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5;
+    for (int i = threadIdx.x; i < rt.len; i += blockDim.x) y[rt.pos + i] += coef * f.vec[rt.voff + i];
+  }
+}
+
+// Coefficient blocks read by the extension and the expansion, and the nodal copy of the cross points.
+//   active edge f:      [z_f, 1/s_f, 0...]
+//   closed-form edge e: [c_e / s_e, 1/s_e, 0...],  s_e K u_e = g_e + W_e c_e,
+//                       c_e = sum_u a_u (M_eu z_u + m_eu / s_u) + (s_e/2) sum_x W_e[node_x,:]^T u_x
+// one workgroup per system, one thread per entry
+__global__ __launch_bounds__(256) void k_coef(FemDev f, const double* __restrict__ a) {
+  const int m = blockIdx.x;
+  const double* am = a + size_t(m) * f.kblk;
+  double* y = f.y + size_t(m) * f.nGp;
+  for (int x = threadIdx.x; x < f.ncross; x += blockDim.x) y[f.xb0 + x] = y[f.xred[x]];
+  for (int i = threadIdx.x; i < f.nsc; i += blockDim.x) {
+    const int b0 = f.scb[2 * i], b1 = f.scb[2 * i + 1];
+    y[f.spos0 + i] = b1 >= 0 ? 1.0 / (am[b0] + am[b1]) : (1.0 / (double(f.N) * double(f.N))) / am[b0];
+  }
+  for (int it = threadIdx.x; it < f.ncoef; it += blockDim.x) {
+    const CoefGroup& cg = f.groups[f.item_group[it]];
+    const int k = f.item_k[it];
+    const double s = am[cg.b0] + am[cg.b1];
+    double out = 0.0;
+    if (k == cg.r) {
+      out = 1.0 / s;
+    } else if (k < cg.r) {
+      if (cg.kind == 0) {
+        out = y[cg.zpos + k];
+      } else {
+        double acc = 0.0;
+        for (int t = 0; t < cg.nterm; ++t) {
+          const CoefTerm& ct = cg.t[t];
+          const double* Mt = f.cm + ct.moff + k;
+          const double* src = y + ct.src;
+          double dot = 0.0;
+#pragma unroll 16
+          for (int j = 0; j < ct.len; ++j) dot += Mt[size_t(j) * cg.r] * src[j];
+          if (ct.voff >= 0) dot += f.vec[ct.voff + k] / (am[ct.u0] + am[ct.u1]);
+          acc += (ct.blk >= 0 ? am[ct.blk] : s / 2) * dot;
+        }
+        out = acc / s;
+      }
+    }
+    y[cg.cpos + k] = out;
+  }
+}
+
+// 4 doubles from an address that is only 8-byte aligned (pointer may be null -> zeros)
+__device__ inline void load4_any(const double* __restrict__ p, double v[4]) {
+  if (p) {
+    v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
+  } else {
+    v[0] = v[1] = v[2] = v[3] = 0.0;
+  }
+}
+
+// Edge values of the active edges from the reduced solution, u_f = P_f z_f + p0_f / s_f, as one batched
+// MFMA GEMM (tile rows = systems, tile cols = nodes of f, K = compressed index); closed-form edges kept in
+// compressed form enter the same way with z = c_e / s_e, P = K^-1 W_e, p0 = K^-1 g_e.  The values go to the
+// snapshot rows directly (and to the nodal blocks of the interface vector).   grid (n1p/64, ceil(Mc/64), nexp)
+__global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U,
+                                                long long row0) {
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  const WavePos wp;
+  const ExpEdge ee = f.exp[blockIdx.z];
+  const int srow = stage_row(), sseg = stage_seg();
+  const int mA = blockIdx.y * 64 + srow;
+  const double* pA = mA < Mc ? f.y + size_t(mA) * f.nGp + ee.zpos + sseg : nullptr;
+  const double* pB = f.P + (size_t(ee.ptab) * f.n1p + blockIdx.x * 64 + srow) * f.n1p + sseg;
+  Acc acc;
+  acc_zero(acc);
+  gemm_loop(
+      ee.nch, [&](int ch, double* v) { load4_any(pA ? pA + ch * BK : nullptr, v); },
+      [&](int ch, double* v) { load4_aligned(pB + ch * BK, v); }, acc, lds, wp);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m = blockIdx.y * 64 + acc_row(wp, i, g);
+      if (m >= Mc) continue;
+      const double inv = f.y[size_t(m) * f.nGp + ee.spos];  // 1 / (a_b0 + a_b1), from the scalar block
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const int node = blockIdx.x * 64 + acc_col(wp, jb);
+        const double v = node < f.n1 ? acc.c[i][jb][g] + f.vec[ee.p0off + node] * inv : 0.0;
+        f.y[size_t(m) * f.nGp + ee.npos + node] = v;  // (read again by the node-by-node paths, if any)
+        if (node < f.n1) U[(row0 + m) * f.dim + f.vmap[ee.npos + node]] = v;
+      }
+    }
+}
+
+// Back substitution of the closed-form edges: x_e = (w_e + sum_u B_ue^T (c_u . x_u)) / s_e as one batched
+// MFMA GEMM: tile rows = systems, tile cols = nodes of e, K = positions in the neighbours' nodal blocks.
+// grid (n1p/64, ceil(Mc/64), npre)
+__global__ __launch_bounds__(256) void k_back_pre(FemDev f, const double* __restrict__ a, int Mc) {
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  const WavePos wp;
+  const PreEdge& pe = f.pre[blockIdx.z];
+  const int srow = stage_row(), sseg = stage_seg();
+  const int mA = blockIdx.y * 64 + srow;
+  const int iB = blockIdx.x * 64 + srow;  // node of e handled by this thread's B row
+  const double* am = mA < Mc ? a + size_t(mA) * f.kblk : nullptr;
+  const double seA = am ? am[pe.e0] + am[pe.e1] : 0.0;
+  Acc acc;
+  acc_zero(acc);
+  for (int q = 0; q < pe.nnb; ++q) {
+    const PreNb nb = pe.nb[q];
+    const double* pA = am ? f.y + size_t(mA) * f.nGp + nb.fpos + sseg : nullptr;
+    const double* pB = f.Bt + (size_t(nb.bt) * f.n1p + iB) * f.n1p + sseg;
+    const double cu = !am ? 0.0 : (nb.blk >= 0 ? am[nb.blk] : seA / 2);
+    gemm_loop(
+        nb.nch,
+        [&](int ch, double* v) {
+          load4_aligned(pA ? pA + ch * BK : nullptr, v);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) v[x] *= cu;
+        },
+        [&](int ch, double* v) { load4_aligned(pB + ch * BK, v); }, acc, lds, wp);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m = blockIdx.y * 64 + acc_row(wp, i, g);
+      if (m >= Mc) continue;
+      const double* amr = a + size_t(m) * f.kblk;
+      const double inv = 1.0 / (amr[pe.e0] + amr[pe.e1]);
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const int node = blockIdx.x * 64 + acc_col(wp, jb);
+        f.y[size_t(m) * f.nGp + pe.pos + node] = node < f.n1 ? (f.vec[pe.woff + node] + acc.c[i][jb][g]) * inv : 0.0;
+      }
+    }
+}
+
+// Diagonal tile j, step 1 of 3 (MFMA): C = S_jj - sum_k L_jk L_jk^T, written to the tile's L slot.
+// Only the lower triangle is consumed by the factorisation: the wave owning the upper-right
+// quadrant skips its MFMAs.
+__global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __restrict__ a, int slot) {
+  // 36.9 KB: four workgroups per CU, i.e. all 1024 systems of a C2 step resident in one round
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  __shared__ int kp[2 * KP_MAX];
+  __shared__ double coef[COEF_MAX];
+  double* stB = lds;
+  double* stA = lds + 2 * STAGE_DOUBLES;
+  double* Cb = lds;  // the C tile aliases the whole staging area (used after the k-loop only)
+  static_assert(TILE_DOUBLES <= STAGE_TOTAL, "C tile must fit in the staging area");
+  const int m = blockIdx.x;
+  const WavePos wp;
+  const TileDesc& d = f.desc[slot];
+  const double* am = a + size_t(m) * f.kblk;
+  double* Lm = f.L + size_t(m) * f.nslots * 4096;
+  STile st;
+  s_tile_load(st, d, f, am, coef);  // table reads fly under the MFMAs below
+  Acc acc;
+  acc_zero(acc);
+  const bool lower = !(wp.wr == 0 && wp.wc == 1);
+  accumulate_klist(f, slot, Lm, kp, [&](int) { return lower; }, acc, stA, stB, wp);
+  tile_from_acc(Cb, acc, st, wp);
+  double* Lout = Lm + size_t(slot) * 4096;
+  for (int idx = threadIdx.x; idx < 4096; idx += 256) Lout[idx] = Cb[(idx >> 6) * LDC + (idx & 63)];
+}
+
+// 1/sqrt(d) for a positive normal d: hardware seed (v_rsq_f64, ~2^-26 relative error) + two Newton
+// steps -> within 1-2 ulp; a fraction of the dependent-instruction chain of 1.0 / sqrt(d).
+__device__ inline double rsqrt_newton(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double hd = 0.5 * d;
+  y = y * fma(-hd * y, y, 1.5);
+  y = y * fma(-hd * y, y, 1.5);
+  return y;
+}
+
+__device__ inline double readlane_f64(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Diagonal tile j, step 2 of 3: in-register Cholesky, ONE WAVE per system (all systems of the batch
+// resident at once, one wave per SIMD).  Lane r keeps row r of the 64x64 tile in registers; the
+// elimination is fully unrolled (static register indices), column j of L is broadcast through LDS
+// each step; no barriers.  (Steps 2 and 3 are separate kernels because hipcc's register allocation
+// collapses into scratch when the two fully unrolled phases share one function.)
+__global__ __launch_bounds__(64) void k_diag_potrf(FemDev f, int slot) {
+  __shared__ __align__(16) double Ls[64 * LDC];
+  __shared__ __align__(16) double lv[2][64];
+  const int m = blockIdx.x, lane = threadIdx.x;
+  double* Lt = f.L + (size_t(m) * f.nslots + slot) * 4096;
+  for (int i = 0; i < 64; ++i) Ls[i * LDC + lane] = Lt[i * 64 + lane];
+  __syncthreads();
+  double a[64];
+#pragma unroll
+  for (int c = 0; c < 64; c += 2) {
+    double2 v = *reinterpret_cast<const double2*>(&Ls[lane * LDC + c]);
+    a[c] = v.x;
+    a[c + 1] = v.y;
+  }
+  bool bad = false;
+#pragma unroll
+  for (int jj = 0; jj < 64; ++jj) {
+    const double dj = readlane_f64(a[jj], jj);
+    bad = bad || !(dj > 0.0);
+    const double rs = rsqrt_newton(dj);
+    const double l = a[jj] * rs;  // L[lane][jj] for lane >= jj
+    a[jj] = l;
+    if (jj < 63) {
+      double* bv = lv[jj & 1];
+      bv[lane] = l;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < 64; ++c)
+        if (c > jj) a[c] -= l * bv[c];  // constant trip count so that both loops unroll fully
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (bad && lane == 0) atomicOr(f.status, 1);
+  __syncthreads();
+  // L (lower, zero above the diagonal) back through LDS, coalesced to HBM
+#pragma unroll
+  for (int c = 0; c < 64; ++c) Ls[lane * LDC + c] = c <= lane ? a[c] : 0.0;
+  __syncthreads();
+  for (int i = 0; i < 64; ++i) Lt[i * 64 + lane] = Ls[i * LDC + lane];
+}
+
+// Diagonal tile j, step 3 of 3 (one wave per system): y_j <- L_jj^-1 y_j by column-oriented
+// substitution, and X = L_jj^-1 with lane c owning column c of X in registers:
+// X[r][c] = (delta_rc - sum_{k<r} L[r][k] X[k][c]) / L[r][r]; L is read from LDS with wave-uniform
+// addresses (broadcast), every row of X is stored coalesced.
+__global__ __launch_bounds__(64) void k_diag_inverse(FemDev f, int slot, int j) {
+  __shared__ __align__(16) double Ls[64 * LDC];
+  __shared__ double rinv[64];
+  const int m = blockIdx.x, lane = threadIdx.x;
+  const double* Lt = f.L + (size_t(m) * f.nslots + slot) * 4096;
+  for (int i = 0; i < 64; ++i) Ls[i * LDC + lane] = Lt[i * 64 + lane];
+  __syncthreads();
+  rinv[lane] = 1.0 / Ls[lane * LDC + lane];
+  __syncthreads();
+  double g = f.y[size_t(m) * f.nGp + j * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    const double yk = readlane_f64(g, k) * rinv[k];
+    if (lane == k) g = yk;
+    else if (lane > k) g -= Ls[lane * LDC + k] * yk;
+  }
+  f.y[size_t(m) * f.nGp + j * 64 + lane] = g;
+  double* It = f.invL + (size_t(m) * f.T + j) * 4096;
+  double x[64];
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    // four independent partial sums: the dot product is otherwise one dependent FMA chain of length r
+    double s0 = (r == lane) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 64; k += 4) {
+      if (k < r) s0 -= Ls[r * LDC + k] * x[k];
+      if (k + 1 < r) s1 -= Ls[r * LDC + k + 1] * x[k + 1];
+      if (k + 2 < r) s2 -= Ls[r * LDC + k + 2] * x[k + 2];
+      if (k + 3 < r) s3 -= Ls[r * LDC + k + 3] * x[k + 3];
+    }
+    x[r] = ((s0 + s1) + (s2 + s3)) * rinv[r];
+    It[r * 64 + lane] = x[r];
+  }
+}
+
+// Whole reduced solve of a system whose reduced matrix is ONE tile (e.g. 2x2 blocks at N = 128: 2 x 31
+// compressed unknowns + the cross point), one wave per system, nothing but the solution leaves the CU:
+//   assemble (lane c accumulates column c of the upper triangle = row c of the lower one, coalesced table reads) ->
+//   in-register Cholesky with the forward substitution fused in -> L through LDS -> back substitution ->
+//   coefficient blocks for the extension (what k_coef does on the general path).
+__global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restrict__ a) {
+  __shared__ __align__(16) double Ls[64 * LDC];
+  __shared__ __align__(16) double lv[2][64];
+  __shared__ double zs[64];
+  __shared__ double wz[DENSE_GROUPS_MAX * 64];
+  const int m = blockIdx.x, lane = threadIdx.x;
+  const double* am = a + size_t(m) * f.kblk;
+  double* ym = f.y + size_t(m) * f.nGp;
+  const TileDesc& d = f.desc[0];
+  // Assembly, upper triangle only (row <= col), by the host-built row program: lane c owns column c, entries
+  // are (table row segment, term) pairs sorted by tile row; ROW_BATCH independent coalesced loads are in flight
+  // before the first is consumed (one wave per SIMD: nothing else hides the latency).
+  for (int r = 0; r < 64; ++r) Ls[r * LDC + lane] = 0.0;
+  const double mycoef = lane < d.t1 - d.t0 ? term_coef(f.terms[d.t0 + lane], am) : 0.0;  // lane t: weight of term t
+  __syncthreads();
+  {
+    static_assert(ROW_BATCH == 64, "one row-program entry per lane and batch");
+    double acc = 0.0;
+    const int4* ents = reinterpret_cast<const int4*>(f.rowent);
+    int4 mine = f.nrowent > 0 ? ents[lane] : int4{0, 0, 0, 0};  // lane i holds entry i of the batch
+    for (int e0 = 0; e0 < f.nrowent; e0 += ROW_BATCH) {
+      const int4 cur = mine;
+      if (e0 + ROW_BATCH < f.nrowent) mine = ents[e0 + ROW_BATCH + lane];  // next batch's entries fly meanwhile
+      double v[ROW_BATCH];
+#pragma unroll
+      for (int i = 0; i < ROW_BATCH; ++i) {
+        const int off = __builtin_amdgcn_readlane(cur.x, i);
+        const int c_lo = __builtin_amdgcn_readlane(cur.z, i), c_hi = __builtin_amdgcn_readlane(cur.w, i);
+        v[i] = (lane >= c_lo && lane < c_hi) ? f.pool[off + lane] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < ROW_BATCH; ++i) {
+        const int meta = __builtin_amdgcn_readlane(cur.y, i);  // r | term << 8 | last << 16
+        acc += readlane_f64(mycoef, (meta >> 8) & 0xff) * v[i];  // (an LDS lookup here costs its full latency per entry)
+        if (meta >> 16) {
+          Ls[(meta & 0xff) * LDC + lane] = acc;
+          acc = 0.0;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  double arow[64];  // row `lane` of the symmetric tile = column `lane` of its upper triangle
+#pragma unroll
+  for (int c = 0; c < 64; ++c) arow[c] = c <= lane ? Ls[c * LDC + lane] : 0.0;
+  if (lane >= d.ndr) {
+#pragma unroll
+    for (int c = 0; c < 64; ++c) arow[c] = (c == lane) ? 1.0 : 0.0;  // padding unknowns: identity
+  }
+  // rhs of the reduced system (k_rhs)
+  double y = f.g[lane];
+  for (int t0 = 0; t0 < f.nrhs; t0 += 8) {  // eight terms at a time: their vector loads are in flight together
+    double rv[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      rv[x] = 0.0;
+      if (t0 + x < f.nrhs) {
+        const RhsTerm& rt = f.rhs[t0 + x];
+        if (lane >= rt.pos && lane < rt.pos + rt.len) rv[x] = f.vec[rt.voff + lane - rt.pos];
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+      if (t0 + x < f.nrhs) {
+        const RhsTerm& rt = f.rhs[t0 + x];
+        y += (rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5) * rv[x];
+      }
+  }
+  // Cholesky (as k_diag_potrf) with y carried along: after step jj, y holds L^-1 g in lanes <= jj
+  bool bad = false;
+  double myrs = 0.0;
+#pragma unroll
+  for (int jj = 0; jj < 64; ++jj) {
+    const double dj = readlane_f64(arow[jj], jj);
+    bad = bad || !(dj > 0.0);
+    const double rs = rsqrt_newton(dj);
+    const double l = arow[jj] * rs;  // L[lane][jj] for lane >= jj
+    arow[jj] = l;
+    const double yj = readlane_f64(y, jj) * rs;
+    if (lane == jj) {
+      y = yj;
+      myrs = rs;  // (an LDS store here makes hipcc spill the whole tile)
+    } else if (lane > jj) {
+      y -= l * yj;
+    }
+    if (jj < 63) {
+      double* bv = lv[jj & 1];
+      bv[lane] = l;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < 64; ++c)
+        if (c > jj) arow[c] -= l * bv[c];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (bad && lane == 0) atomicOr(f.status, 1);
+#pragma unroll
+  for (int c = 0; c < 64; ++c) Ls[lane * LDC + c] = c <= lane ? arow[c] : 0.0;
+  __syncthreads();
+  // back substitution x = L^-T y.  Column `lane` of L is fetched from LDS in one batch (conflict free), then the
+  // chain x_j = y_j / L_jj ; y_i -= L_ji x_j (i < j) runs on registers and readlane broadcasts only.
+  double lcol[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) lcol[j] = Ls[j * LDC + lane];
+#pragma unroll
+  for (int j = 63; j >= 0; --j) {
+    const double xj = readlane_f64(y, j) * readlane_f64(myrs, j);
+    if (lane == j) y = xj;
+    else if (lane < j) y -= lcol[j] * xj;
+  }
+  ym[lane] = y;
+  zs[lane] = y;
+  __syncthreads();
+  // coefficient blocks + nodal copy of the cross points (what k_coef does on the general path).  The blocks of
+  // the closed-form edges are one dense product here: out[it] = sum_j D[j][it] * (w_g(j) z_j), D = all their
+  // matrices side by side (64 x items, coalesced in `it`), w_g(j) the weight of source j for group g.
+  for (int x = lane; x < f.ncross; x += 64) ym[f.xb0 + x] = zs[f.xred[x]];
+  for (int i = lane; i < f.nsc; i += 64) {
+    const int b0 = f.scb[2 * i], b1 = f.scb[2 * i + 1];
+    ym[f.spos0 + i] = b1 >= 0 ? 1.0 / (am[b0] + am[b1]) : (1.0 / (double(f.N) * double(f.N))) / am[b0];
+  }
+  for (int idx = lane; idx < f.ndg * 64; idx += 64) {
+    const DenseGroup& dg = f.dgroups[idx >> 6];
+    const int wd = f.dweight[idx];
+    const double wgt = wd >= 0 ? am[wd] : (wd == -1 ? (am[dg.b0] + am[dg.b1]) / 2 : 0.0);
+    wz[idx] = wgt * zs[idx & 63];
+  }
+  __syncthreads();
+  for (int it = lane; it < f.ndi; it += 64) {
+    const int g = f.ditem_group[it], k = f.ditem_k[it];
+    const DenseGroup& dg = f.dgroups[g];
+    const double* D = f.dmat + it;
+    const double* wg = wz + g * 64;
+    double acc = 0.0;
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) acc += D[size_t(j) * f.ndi] * wg[j];
+    for (int v = 0; v < dg.nv; ++v) acc += am[dg.vblk[v]] / (am[dg.vu0[v]] + am[dg.vu1[v]]) * f.vec[dg.voff[v] + k];
+    ym[dg.cpos + k] = acc / (am[dg.b0] + am[dg.b1]);
+  }
+  for (int it = lane; it < f.ncoef; it += 64) {
+    const CoefGroup& cg = f.groups[f.item_group[it]];
+    const int k = f.item_k[it];
+    if (cg.kind == 1 && k < cg.r) continue;  // done above
+    ym[cg.cpos + k] = k == cg.r ? 1.0 / (am[cg.b0] + am[cg.b1]) : (k < cg.r ? zs[cg.zpos + k] : 0.0);
+  }
+}
+
+// Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;
+// y_i -= L_ij y_j.  invL_jj is lower triangular: the waves owning output columns 0..31 only need
+// k < 32 of the second product.
+__global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc) {
+  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];
+  __shared__ int kp[2 * KP_MAX];
+  __shared__ double yj[64];
+  __shared__ double coef[COEF_MAX];
+  double* stB = lds;
+  double* stA = lds + 2 * STAGE_DOUBLES;
+  double* Cb = lds + 2 * STAGE_DOUBLES;
+  // XCD-aware mapping: block ids are dealt round-robin to the 8 XCDs (each with its own L2); all row
+  // tiles of one system are given ids of the same residue mod 8 so that the L_jk / invL_jj tiles they
+  // share are served by one L2.  (Placement only affects speed, never correctness.)
+  const int nrows = f.colptr[j + 1] - f.colptr[j];
+  int m, row;
+  {
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int full = (Mc >> 3) << 3;  // systems covered by complete groups of 8
+    m = xcd + 8 * (idx / nrows);
+    row = idx % nrows;
+    if (m >= full) {  // ragged tail (Mc % 8 systems): plain order
+      const int tb = b - full * nrows;
+      m = full + tb / nrows;
+      row = tb % nrows;
+    }
+  }
+  const int ent = f.colptr[j] + row;
+  const int slot = f.colrow[ent];
+  const int ti = f.colti[ent];
+  const WavePos wp;
+  const TileDesc& d = f.desc[slot];
+  const double* am = a + size_t(m) * f.kblk;
+  double* Lm = f.L + size_t(m) * f.nslots * 4096;
+  const int t = threadIdx.x;
+  STile st;
+  s_tile_load(st, d, f, am, coef);
+  if (t < 64) yj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
+  Acc acc;
+  acc_zero(acc);
+  accumulate_klist(f, slot, Lm, kp, [](int) { return true; }, acc, stA, stB, wp);
+  tile_from_acc(Cb, acc, st, wp);
+
+  // X = C * invL_jj^T
+  acc_zero(acc);
+  const double* I = f.invL + (size_t(m) * f.T + j) * 4096 + stage_row() * 64 + stage_seg();
+  const int kmax = (wp.wc + 1) * 32;  // invL[c][k] = 0 for k > c
+  gemm_loop_Atile(Cb, 4, [&](int ch, double* v) { load4_aligned(I + ch * BK, v); },
+                  [&](int ch) { return ch * BK < kmax; }, acc, stB, wp);
+
+  double* Lout = Lm + size_t(slot) * 4096;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int r = acc_row(wp, i, g), c = acc_col(wp, jb);
+        double v = acc.c[i][jb][g];
+        Lout[r * 64 + c] = v;
+        Cb[r * LDC + c] = v;
+      }
+  __syncthreads();
+  if (t < 64) {
+    double s = 0.0;
+    for (int k = 0; k < 64; ++k) s += Cb[t * LDC + k] * yj[k];
+    f.y[size_t(m) * f.nGp + ti * 64 + t] -= s;
+  }
+}
+
+// x = L^{-T} y, one workgroup per system, x kept in LDS, written back over y
+__global__ __launch_bounds__(256) void k_backsolve(FemDev f) {
+  extern __shared__ __align__(16) double xs[];  // nGa
+  __shared__ double red[4][64];
+  __shared__ double vs[64];
+  const int m = blockIdx.x;
+  const int t = threadIdx.x, c = t & 63, part = t >> 6;
+  const double* Lm = f.L + size_t(m) * f.nslots * 4096;
+  double* ym = f.y + size_t(m) * f.nGp;
+  for (int j = f.T - 1; j >= 0; --j) {
+    double s = 0.0;
+    for (int e = f.colptr[j]; e < f.colptr[j + 1]; ++e) {
+      const double* Lt = Lm + size_t(f.colrow[e]) * 4096;
+      const double* xi = xs + f.colti[e] * 64;
+#pragma unroll 4
+      for (int rr = part * 16; rr < part * 16 + 16; ++rr) s += Lt[rr * 64 + c] * xi[rr];
+    }
+    red[part][c] = s;
+    __syncthreads();
+    if (t < 64) vs[t] = ym[j * 64 + t] - (red[0][t] + red[1][t] + red[2][t] + red[3][t]);
+    __syncthreads();
+    const double* It = f.invL + (size_t(m) * f.T + j) * 4096;
+    s = 0.0;
+#pragma unroll 4
+    for (int rr = part * 16; rr < part * 16 + 16; ++rr) s += It[rr * 64 + c] * vs[rr];
+    red[part][c] = s;
+    __syncthreads();
+    if (t < 64) xs[j * 64 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    __syncthreads();
+  }
+  for (int v = t; v < f.nGa; v += 256) ym[v] = xs[v];
+}
+
+// ============================================================================================
+// harmonic extension + scatter: writes the snapshot rows
+// ============================================================================================
+// Sine transform of the interface values, edge by edge:  yhat[m, pos_e + mode] = sum_k y[m, pos_e + k] Q[k, mode]
+// (Q symmetric).  grid (n1p/64, ceil(Mc/64), n_edges); tile rows = systems, tile cols = modes.
+__global__ __launch_bounds__(256) void k_edge_transform(FemDev f, int Mc) {
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  const WavePos wp;
+  const int pos = f.epos[blockIdx.z];
+  const int srow = stage_row(), sseg = stage_seg();
+  const int mA = blockIdx.y * 64 + srow;
+  const double* pA = mA < Mc ? f.y + size_t(mA) * f.nGp + pos + sseg : nullptr;
+  const double* pB = f.Qp + size_t(blockIdx.x * 64 + srow) * f.n1p + sseg;
+  Acc acc;
+  acc_zero(acc);
+  gemm_loop(
+      f.n1p / BK, [&](int ch, double* v) { load4_aligned(pA ? pA + ch * BK : nullptr, v); },
+      [&](int ch, double* v) { load4_aligned(pB + ch * BK, v); }, acc, lds, wp);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m = blockIdx.y * 64 + acc_row(wp, i, g);
+      if (m >= Mc) continue;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+        f.yhat[size_t(m) * f.nGp + pos + blockIdx.x * 64 + acc_col(wp, jb)] = acc.c[i][jb][g];
+    }
+}
+
+// value of the neighbouring lane (lane ^ 1), by DPP quad permutation
+__device__ inline double lane_swap1(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// two doubles at an address that is only 8-byte aligned (snapshot rows have odd length)
+typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
+
+// Harmonic extension, one batched MFMA GEMM over all blocks:
+//   U_I,b[m,(i,j)] = (h^2/a_b) W[i,j] + sum_{sides s} sum_k c_s[m, k] * Tab_s[pi_s(i,j)][k]
+// with one of two parameter-independent representations per side (ExtSide::mode):
+//   1  sine modes:  c = yhat_s (sine coefficients of the edge values), Tab = A0[(i',j'), mode] = Q[j', mode] rho_mode(i').
+//      rho_mode(i') ~ exp(-i' phi_mode): far from a side only the low modes survive in fp64; kmax[d] (multiple
+//      of 16) is the number of modes with rho_mode(d) above 1e-18, so a tile whose vertices are at distance >= d
+//      from side s stops its K loop there (terms below 1e-18 of the leading ones cannot change an fp64 sum).
+//   2  compressed edge:  c = [z_f, 1/s_f] (the reduced unknowns themselves), Tab = H_0 [P_f, p0_f]: K = rank + 1,
+//      no edge values or sine transform needed.
+// Tile rows = systems; tile columns = 64 interior vertices of one block, either a 4 x 16 patch (pw_log2 = 4:
+// the distance to all four sides is bounded below per tile, which is what the mode truncation needs) or
+// 64 consecutive vertices of one mesh row (pw_log2 = 6, blocks whose sides are all compressed: K does not
+// depend on the position, and 512 contiguous bytes per system are written -- measured 2.8 instead of
+// 2.1 TB/s for the store stream alone, tools/hbm_write_bw.hip).
+// grid (patches, ceil(Mc/64), blocks in the list)
+__global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restrict__ a, int Mc,
+                                                double* __restrict__ U, long long row0, const int* __restrict__ blocks,
+                                                int pw_log2) {
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  __shared__ double scs[64];  // h^2 / a_b of the tile's systems
+  double* stage = lds;
+  const WavePos wp;
+  const int b = blocks[blockIdx.z];
+  const int p = b / f.ncb, q = b % f.ncb;
+  const int n1 = f.n1, N = f.N;
+  const BlockSide& sd = f.sides[b];
+  const int srow = stage_row(), sseg = stage_seg();
+  const int pw = 1 << pw_log2, ph = 64 >> pw_log2;    // patch width / height in vertices
+  const int npj = (n1 + pw - 1) >> pw_log2;           // patches per patch row
+  const int pi = blockIdx.x / npj, pj = blockIdx.x % npj;
+  const int i0 = ph * pi + 1, j0 = pw * pj + 1;       // first vertex of the patch (1-based)
+  const int i1 = min(i0 + ph - 1, n1), j1 = min(j0 + pw - 1, n1);
+
+  const int mA = blockIdx.y * 64 + srow;
+  const bool vA = mA < Mc;
+  const int iB = i0 + (srow >> pw_log2), jB = j0 + (srow & (pw - 1));  // vertex of this thread's B row
+  const bool vB = iB <= n1 && jB <= n1;
+
+  // one merged, pipelined K loop over the chunks of all four sides
+  int cend[4];
+  const double* pAs[4];
+  const double* pBs[4];
+  int tot = 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const ExtSide es = sd.s[s];
+    int nch = 0;
+    pAs[s] = pBs[s] = nullptr;
+    if (es.mode != 0) {  // (mode 0: side on the domain boundary)
+      const int hrow = vB ? h0_row(s, iB, jB, N, n1) : 0;
+      if (es.mode == 1) {
+        const int dist = s == 0 ? i0 : s == 1 ? N - i1 : s == 2 ? j0 : N - j1;  // closest vertex of the patch
+        nch = f.kmax[dist] / BK;
+        if (vA) pAs[s] = f.yhat + size_t(mA) * f.nGp + es.off + sseg;
+        if (vB) pBs[s] = f.A0 + size_t(hrow) * f.n1p + sseg;
+      } else {
+        nch = es.nch;
+        if (vA) pAs[s] = f.y + size_t(mA) * f.nGp + es.off + sseg;
+        if (vB) pBs[s] = f.G + es.gtab + size_t(hrow) * (es.nch * BK) + sseg;
+      }
+    }
+    tot += nch;
+    cend[s] = tot;
+  }
+  if (threadIdx.x < 64) {
+    const int m = blockIdx.y * 64 + threadIdx.x;
+    scs[threadIdx.x] = m < Mc ? f.y[size_t(m) * f.nGp + f.sblk0 + b] : 0.0;  // h^2 / a_b, from the scalar block
+  }
+  __syncthreads();
+  Acc acc;
+  acc_zero(acc);
+  auto pick = [&](int ch, const double* const* ps) -> const double* {
+    const int s = (ch >= cend[0]) + (ch >= cend[1]) + (ch >= cend[2]);
+    const int lc = ch - (s == 0 ? 0 : s == 1 ? cend[0] : s == 2 ? cend[1] : cend[2]);
+    const double* p = s == 0 ? ps[0] : s == 1 ? ps[1] : s == 2 ? ps[2] : ps[3];
+    return p ? p + lc * BK : nullptr;
+  };
+  gemm_loop(
+      tot, [&](int ch, double* v) { load4_aligned(pick(ch, pAs), v); },
+      [&](int ch, double* v) { load4_aligned(pick(ch, pBs), v); }, acc, stage, wp);
+
+  // Epilogue.  The MFMA result layout gives a lane one vertex of each of its two 16-vertex column blocks; lane
+  // pairs swap one value each (DPP) so that every lane owns two ADJACENT vertices of one block and the row is
+  // written with 16-byte stores: the store stream of this kernel is issue bound, half the instructions matter.
+  // (everything the epilogue needs from memory is fetched before the first store: a load after a store would
+  // make its s_waitcnt vmcnt wait for the stores as well -- one counter, in order)
+  const bool odd = wp.lane & 1;
+  const int cfirst = acc_col(wp, odd ? 1 : 0) - (odd ? 1 : 0);  // first of this lane's two tile columns
+  const int ii = i0 + (cfirst >> pw_log2) - 1, jj = j0 + (cfirst & (pw - 1)) - 1;  // 0-based interior indices
+  const bool v0 = ii < n1 && jj < n1, v1 = ii < n1 && jj + 1 < n1;
+  const long long gidx = (long long)(p * N + ii) * f.nc + (q * N + jj);
+  double w_own[2];  // particular solution at this lane's own accumulator columns
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    const int cidx = acc_col(wp, jb);
+    const int wi = i0 + (cidx >> pw_log2) - 1, wj = j0 + (cidx & (pw - 1)) - 1;
+    w_own[jb] = (wi < n1 && wj < n1) ? f.W[wi * n1 + wj] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int m = blockIdx.y * 64 + acc_row(wp, i, g);
+      const double sc = scs[acc_row(wp, i, g)];
+      const double x0 = acc.c[i][0][g] + sc * w_own[0], x1 = acc.c[i][1][g] + sc * w_own[1];
+      const double got = lane_swap1(odd ? x0 : x1);  // even lanes give away block 1, odd lanes block 0
+      if (m >= Mc) continue;
+      double* dst = U + (row0 + m) * f.dim + gidx;
+      const double lo = odd ? got : x0, hi = odd ? x1 : got;
+      if (v1) *reinterpret_cast<double2_u*>(dst) = double2_u{lo, hi};
+      else if (v0) dst[0] = lo;
+    }
+}
+
+// The same extension for blocks whose sides are all compressed, with 128 x 128 workgroup tiles (128 systems x
+// one mesh row of up to 128 interior vertices; every wave a 64 x 64 quadrant = 4 x 4 MFMA accumulators): K is
+// only sum(rank + 1) ~ 64, so a 64 x 64 tile spends most of its life in its prologue and epilogue; four times
+// the outputs per workgroup amortise them and every LDS fragment feeds four MFMAs instead of two.
+// grid (mesh rows x column tiles, ceil(Mc/128), lr blocks); LDS 74,752 B -> 2 workgroups per CU
+constexpr int X128_STAGE = 128 * LDK;
+
+__global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __restrict__ a, int Mc,
+                                                      double* __restrict__ U, long long row0) {
+  __shared__ __align__(16) double lds[4 * X128_STAGE];  // {A,B} x 2 buffers
+  __shared__ double scs[128];                            // h^2 / a_b of the workgroup's systems
+  {
+    // The MFMA phase and the store phase of a workgroup take about equally long (the stores drain at the HBM
+    // write rate) and do not overlap within it.  Two workgroups share a CU; started together they stay in
+    // lockstep -- all computing, then all storing.  The second half of the first round therefore starts one
+    // MFMA phase late (about 64 cycles per MFMA), so that from then on one workgroup of a CU computes while
+    // the other drains: measured 274 -> 245 us at 256x256 / 2x2 / 1024 systems.  Placement only affects speed.
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (lin >= 256u && lin < 512u)
+      for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);  // 2 x 127 x 64 cycles
+  }
+  const int b = f.lr_blocks[blockIdx.z];
+  const int p = b / f.ncb, q = b % f.ncb;
+  const int n1 = f.n1, N = f.N;
+  const BlockSide& sd = f.sides[b];
+  const int nct = (n1 + 127) / 128;
+  const int iv = blockIdx.x / nct + 1;           // mesh row (1-based interior index)
+  const int jv0 = 128 * (blockIdx.x % nct) + 1;  // first vertex of the tile
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
+  // staging: thread t -> row t >> 1, eight consecutive k starting at (t & 1) * 8
+  const int srow = threadIdx.x >> 1, sseg = (threadIdx.x & 1) * 8;
+  const int mA = blockIdx.y * 128 + srow;
+  const bool vA = mA < Mc;
+  const int jB = jv0 + srow;
+  const bool vB = jB <= n1;
+  if (threadIdx.x < 128) {
+    const int m = blockIdx.y * 128 + threadIdx.x;
+    scs[threadIdx.x] = m < Mc ? f.y[size_t(m) * f.nGp + f.sblk0 + b] : 0.0;  // h^2 / a_b (visible after the first barrier below)
+  }
+  int cend[4];
+  const double* pAs[4];
+  const double* pBs[4];
+  int tot = 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const ExtSide es = sd.s[s];
+    pAs[s] = pBs[s] = nullptr;
+    if (es.mode == 2) {
+      tot += es.nch;
+      if (vA) pAs[s] = f.y + size_t(mA) * f.nGp + es.off + sseg;
+      if (vB) pBs[s] = f.G + es.gtab + size_t(h0_row(s, iv, jB, N, n1)) * (es.nch * BK) + sseg;
+    }
+    cend[s] = tot;
+  }
+  auto pick = [&](int ch, const double* const* ps) -> const double* {
+    const int s = (ch >= cend[0]) + (ch >= cend[1]) + (ch >= cend[2]);
+    const int lc = ch - (s == 0 ? 0 : s == 1 ? cend[0] : s == 2 ? cend[1] : cend[2]);
+    const double* ptr = s == 0 ? ps[0] : s == 1 ? ps[1] : s == 2 ? ps[2] : ps[3];
+    return ptr ? ptr + lc * BK : nullptr;
+  };
+  auto load8 = [&](const double* ptr, double* v) {
+    load4_aligned(ptr, v);
+    load4_aligned(ptr ? ptr + 4 : nullptr, v + 4);
+  };
+  auto store8 = [&](double* sbuf, const double* v) {
+    double2* dst = reinterpret_cast<double2*>(sbuf + srow * LDK + sseg);  // 144-byte rows, 64-byte segments
+#pragma unroll
+    for (int x = 0; x < 4; ++x) dst[x] = double2{v[2 * x], v[2 * x + 1]};
+  };
+  d4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+  double va[8], vb[8];
+  if (tot > 0) {
+    load8(pick(0, pAs), va);
+    load8(pick(0, pBs), vb);
+  }
+  const int fr = lane & 15, kq = lane >> 4;
+  // everything the epilogue needs from memory is fetched before the first store: a load after a store would
+  // make its s_waitcnt vmcnt wait for the stores as well (one counter, in order)
+  double w_own[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int jj = jv0 + wc * 64 + j * 16 + fr;  // 1-based
+    w_own[j] = jj <= n1 ? f.W[(iv - 1) * n1 + (jj - 1)] : 0.0;
+  }
+  for (int ch = 0; ch < tot; ++ch) {
+    double* sA = lds + (ch & 1) * 2 * X128_STAGE;
+    double* sB = sA + X128_STAGE;
+    store8(sA, va);
+    store8(sB, vb);
+    __syncthreads();
+    if (ch + 1 < tot) {
+      load8(pick(ch + 1, pAs), va);
+      load8(pick(ch + 1, pBs), vb);
+    }
+    const double* pa = sA + (wr * 64 + fr) * LDK + kq;
+    const double* pb = sB + (wc * 64 + fr) * LDK + kq;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = pa[i * 16 * LDK + kk];
+        bf[i] = pb[i * 16 * LDK + kk];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  if (tot == 0) __syncthreads();  // scs
+  // epilogue: add the particular solution, swap between lane pairs so that every lane owns two adjacent
+  // vertices of one 16-vertex block, 16-byte stores (see k_extend)
+  const bool odd = lane & 1;
+  const long long grow = (long long)(p * N + iv - 1) * f.nc + q * N - 1;
+  int jcol[2];
+  bool ok0[2], ok1[2];
+#pragma unroll
+  for (int hp = 0; hp < 2; ++hp) {  // pair hp of column blocks: (0,1) and (2,3); even lanes take the first, odd the second
+    jcol[hp] = jv0 + wc * 64 + (2 * hp + (odd ? 1 : 0)) * 16 + fr - (odd ? 1 : 0);  // first of the two vertices, 1-based
+    ok0[hp] = jcol[hp] <= n1;
+    ok1[hp] = jcol[hp] + 1 <= n1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ml = wr * 64 + i * 16 + kq + 4 * g;
+      const int m = blockIdx.y * 128 + ml;
+      const double sc = scs[ml];
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {
+        const double x0 = acc[i][2 * hp][g] + sc * w_own[2 * hp], x1 = acc[i][2 * hp + 1][g] + sc * w_own[2 * hp + 1];
+        const double got = lane_swap1(odd ? x0 : x1);
+        if (m >= Mc) continue;
+        double* dst = U + (row0 + m) * f.dim + grow + jcol[hp];
+        const double lo = odd ? got : x0, hi = odd ? x1 : got;
+        if (ok1[hp]) *reinterpret_cast<double2_u*>(dst) = double2_u{lo, hi};
+        else if (ok0[hp]) dst[0] = lo;
+      }
+    }
+}
+
+// interface values that k_expand does not write: cross points and the edges recovered node by node
+__global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = blockIdx.y;
+  if (i >= f.nscat || m >= Mc) return;
+  const int v = f.scat[i];
+  U[(row0 + m) * f.dim + f.vmap[v]] = f.y[size_t(m) * f.nGp + v];
+}
+
+// stencil arrays for the API (einsum('pqij,pq->ij') in stencil form)
+__global__ void k_assemble_stencil(FemDev f, const double* __restrict__ a, int M, double* __restrict__ diag,
+                                   double* __restrict__ east, double* __restrict__ north) {
+  __shared__ double am[64];  // coefficients of this parameter staged in LDS
+  const int m = blockIdx.y;
+  for (int i = threadIdx.x; i < f.kblk; i += blockDim.x) am[i] = a[size_t(m) * f.kblk + i];
+  __syncthreads();
+  long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= f.dim) return;
+  int r = int(idx / f.nc) + 1, c = int(idx % f.nc) + 1;  // 1-based vertex coordinates
+  int N = f.N, ncb = f.ncb;
+  // kappa[line, col] = a[line / N][col / N]; the four cells around vertex (r, c)
+  double k00 = am[((r - 1) / N) * ncb + (c - 1) / N];
+  double k01 = am[((r - 1) / N) * ncb + c / N];
+  double k10 = am[(r / N) * ncb + (c - 1) / N];
+  double k11 = am[(r / N) * ncb + c / N];
+  diag[size_t(m) * f.dim + idx] = ((k00 + k01) + k10) + k11;
+  if (c < f.nc) east[size_t(m) * f.nr * (f.nc - 1) + size_t(r - 1) * (f.nc - 1) + (c - 1)] = -(k11 + k01) / 2;
+  if (r < f.nr) north[size_t(m) * (f.nr - 1) * f.nc + size_t(r - 1) * f.nc + (c - 1)] = -(k11 + k10) / 2;
+}
+

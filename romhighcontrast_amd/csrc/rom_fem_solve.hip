@@ -1,0 +1,304 @@
+// Entry points of the sweep: rom_solve_batch and its two stages, workspace management, kernel sequencing
+// (replaces generate_solutions, src/lib/SolutionsManagers.py:64-68, of the reference).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "rom_fem_dev.h"
+
+extern "C" int rom_fem_dims(rom_fem* f, int* nr, int* nc, int64_t* dim, int* n_interface, int* n_tiles) {
+  ROM_CHECK(f, "null fem");
+  if (nr) *nr = f->nr;
+  if (nc) *nc = f->nc;
+  if (dim) *dim = f->dim;
+  if (n_interface) *n_interface = f->nG;
+  if (n_tiles) *n_tiles = f->nslots;
+  return ROM_OK;
+}
+
+extern "C" int rom_fem_load_vector_host(rom_fem* f, double* B) {
+  ROM_CHECK(f && B, "bad arguments");
+  // (:177-185) every inner vertex collects area/6 + area/3 + area/3 + area/6 in this order
+  double area = (1.0 / f->N) * (1.0 / f->N);
+  double v = 0.0;
+  v += area / 6;
+  v += area / 3;
+  v += area / 3;
+  v += area / 6;
+  for (int64_t i = 0; i < f->dim; ++i) B[i] = v;
+  return ROM_OK;
+}
+
+extern "C" int rom_solve_work(rom_fem* f, double* flops_own, double* bytes_own, double* flops_banded,
+                              double* bytes_banded) {
+  ROM_CHECK(f, "null fem");
+  if (flops_own) *flops_own = f->flops_solve;
+  if (bytes_own) *bytes_own = f->bytes_solve;
+  double b = std::min(f->nr, f->nc), dim = double(f->dim);
+  double nnzL = dim * (b + 1) - b * (b + 1) / 2;
+  if (bytes_banded) *bytes_banded = 8.0 * (3 * nnzL + 5 * dim);
+  if (flops_banded) *flops_banded = dim * b * b + 4 * dim * b;
+  return ROM_OK;
+}
+
+extern "C" int rom_assemble_batch(rom_fem* f, rom_buf* a, int M, rom_buf* diag, rom_buf* east, rom_buf* north) {
+  ROM_CHECK(f && a && diag && east && north, "rom_assemble_batch: null argument");
+  ROM_CHECK(M >= 0, "rom_assemble_batch: negative M");
+  const int kblk = f->nrb * f->ncb;
+  ROM_CHECK(a->n >= size_t(M) * kblk, "rom_assemble_batch: `a` holds %zu doubles, need %zu", a->n, size_t(M) * kblk);
+  ROM_CHECK(diag->n >= size_t(M) * f->dim && east->n >= size_t(M) * f->nr * (f->nc - 1) &&
+                north->n >= size_t(M) * (f->nr - 1) * f->nc,
+            "rom_assemble_batch: output buffers too small");
+  if (M == 0) return ROM_OK;
+  FemDev d = make_dev(f);
+  dim3 grid(unsigned((f->dim + 255) / 256), M);
+  {
+    ROM_PROF(f->ctx, "assemble_stencil", 7.0 * f->dim * M, 24.0 * f->dim * M);
+    k_assemble_stencil<<<grid, 256, 0, f->ctx->stream>>>(d, a->p, M, diag->p, east->p, north->p);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+
+static int ensure_workspace(rom_fem* f, int Mc) {
+  if (f->ws_M >= Mc) return ROM_OK;
+  ROM_HIP(hipStreamSynchronize(f->ctx->stream));
+  if (f->d_L) hipFree(f->d_L);
+  if (f->d_invL) hipFree(f->d_invL);
+  if (f->d_y) hipFree(f->d_y);
+  if (f->d_yhat) hipFree(f->d_yhat);
+  f->d_L = f->d_invL = f->d_y = f->d_yhat = nullptr;
+  f->ws_M = 0;
+  ROM_HIP(hipMalloc(&f->d_L, std::max<size_t>(size_t(Mc) * f->nslots * 4096, 1) * sizeof(double)));
+  ROM_HIP(hipMalloc(&f->d_invL, std::max<size_t>(size_t(Mc) * f->T * 4096, 1) * sizeof(double)));
+  ROM_HIP(hipMalloc(&f->d_y, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
+  // zeroed once: padding slots are read (against zero table entries) before anything writes them
+  ROM_HIP(hipMemset(f->d_y, 0, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
+  ROM_HIP(hipMalloc(&f->d_yhat, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
+  f->ws_M = Mc;
+  return ROM_OK;
+}
+
+// enqueue every kernel of one sub-batch (Mc systems, workspace pointers already offset) on `st`
+// `stages`: 1 = reduced solve (interface vector: reduced unknowns, cross points, coefficient blocks),
+//           2 = expansion of the interface vector into snapshot rows, 3 = both
+static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, double* U, long long row,
+                         hipStream_t st, size_t lds_back, int stages) {
+  rom_ctx* ctx = f->ctx;
+  const int kblk = f->nrb * f->ncb;
+  static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-column kernel names
+  char nm[4][48];
+  const bool no_fused = getenv("ROMHC_NO_FUSED") != nullptr;  // (read per call: the tests toggle it)
+  const bool fused1 = f->fused1 && !no_fused;  // the whole reduced solve in one wave-per-system kernel
+  if (f->nGp > 0 && fused1 && (stages & 1)) {
+    ROM_PROF(ctx, "solve1", Mc * (262144 / 3.0 + 3 * 4096.0), Mc * 8.0 * 4096 * 3);
+    k_solve1<<<Mc, 64, 0, st>>>(d, am);
+  }
+  if (f->nGp > 0 && !fused1 && (stages & 1)) {
+    {
+      ROM_PROF(ctx, "rhs", 0, 8.0 * Mc * f->nGa);
+      k_rhs<<<Mc, 256, 0, st>>>(d, am);
+    }
+    for (int j = 0; j < f->T; ++j) {
+      {
+        int slot = f->diag_slot[j];
+        double nk = f->kptr[slot + 1] - f->kptr[slot];
+        const char* base[4] = {"diag_update", "diag_potrf", "diag_inverse", "factor_panel"};
+        for (int q = 0; q < 4; ++q) detail ? snprintf(nm[q], 48, "%s_j%02d", base[q], j) : snprintf(nm[q], 48, "%s", base[q]);
+        {
+          ROM_PROF(ctx, nm[0], Mc * nk * 2.0 * 262144, Mc * 8.0 * 4096 * (1 + 2 * nk));
+          k_diag_update<<<Mc, 256, 0, st>>>(d, am, slot);
+        }
+        {
+          ROM_PROF(ctx, nm[1], Mc * (262144 / 3.0), Mc * 8.0 * 4096 * 2);
+          k_diag_potrf<<<Mc, 64, 0, st>>>(d, slot);
+        }
+        {
+          ROM_PROF(ctx, nm[2], Mc * (262144 / 3.0 + 4096.0), Mc * 8.0 * 4096 * 2);
+          k_diag_inverse<<<Mc, 64, 0, st>>>(d, slot, j);
+        }
+      }
+      int nrows = f->colptr[j + 1] - f->colptr[j];
+      if (nrows > 0) {
+        double nk = 0;
+        for (int e = f->colptr[j]; e < f->colptr[j + 1]; ++e) nk += f->kptr[f->colrow[e] + 1] - f->kptr[f->colrow[e]];
+        ROM_PROF(ctx, nm[3], Mc * (nk + nrows) * 2.0 * 262144, Mc * 8.0 * 4096 * (2 * nk + 2 * nrows));
+        k_factor_panel<<<nrows * Mc, 256, 0, st>>>(d, am, j, Mc);
+      }
+    }
+    if (f->T > 0) {
+      ROM_PROF(ctx, "backsolve", Mc * 2.0 * 4096 * (f->nslots + f->T), Mc * 8.0 * 4096 * (f->nslots + f->T));
+      k_backsolve<<<Mc, 256, lds_back, st>>>(d);
+    }
+    {
+      ROM_PROF(ctx, "coef", 0, 8.0 * Mc * f->ncoef);
+      k_coef<<<Mc, 256, 0, st>>>(d, am);
+    }
+  }
+  if (!(stages & 2)) {
+    ROM_HIP(hipGetLastError());
+    return ROM_OK;
+  }
+  if (f->nGp > 0) {
+    if (f->nexp > 0) {
+      ROM_PROF(ctx, "expand", Mc * 2.0 * f->n1p * 32.0 * f->nexp, 8.0 * Mc * f->n1p * f->nexp);
+      k_expand<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->nexp), 256, 0, st>>>(d, am, Mc, U, row);
+    }
+    if (f->npre > 0) {
+      ROM_PROF(ctx, "back_pre", Mc * 2.0 * f->n1p * double(f->n1p) * 3.0 * f->npre, 8.0 * Mc * f->n1p * 4.0 * f->npre);
+      k_back_pre<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->npre), 256, 0, st>>>(d, am, Mc);
+    }
+  }
+  {
+    const int nij = f->n1 * f->n1;
+    if (nij > 0) {
+      if (f->n_edges > 0) {
+        ROM_PROF(ctx, "edge_transform", Mc * 2.0 * f->n_edges * double(f->n1p) * f->n1p, 16.0 * Mc * f->n_edges * f->n1p);
+        k_edge_transform<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->n_edges), 256, 0, st>>>(d, Mc);
+      }
+      const int npatch = ((f->n1 + 3) / 4) * ((f->n1 + 15) / 16);
+      const double fl_ext = (f->ext_flops - 2.0 * f->n_edges * double(f->n1p) * f->n1p) * Mc / kblk;  // per block (average)
+      if (f->n_gen_blocks > 0) {
+        dim3 grid(npatch, (Mc + 63) / 64, f->n_gen_blocks);
+        ROM_PROF(ctx, "extend", fl_ext * f->n_gen_blocks, 8.0 * Mc * double(f->n_gen_blocks) * nij);
+        k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.gen_blocks, 4);
+      }
+      if (f->n_lr_blocks > 0) {
+        const bool no128 = getenv("ROMHC_NO_EXT128") != nullptr;
+        ROM_PROF(ctx, "extend_lr", fl_ext * f->n_lr_blocks, 8.0 * Mc * double(f->n_lr_blocks) * nij);
+        if (f->n1 >= 96 && Mc >= 128 && !no128) {  // wide tiles need enough vertices per mesh row and systems to fill them
+          dim3 grid(f->n1 * ((f->n1 + 127) / 128), (Mc + 127) / 128, f->n_lr_blocks);
+          k_extend128<<<grid, 256, 0, st>>>(d, am, Mc, U, row);
+        } else {
+          dim3 grid(f->n1 * ((f->n1 + 63) / 64), (Mc + 63) / 64, f->n_lr_blocks);
+          k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.lr_blocks, 6);
+        }
+      }
+    }
+    if (f->nscat > 0) {
+      ROM_PROF(ctx, "scatter_interface", 0, 16.0 * Mc * f->nscat);
+      k_scatter_interface<<<dim3((f->nscat + 255) / 256, Mc), 256, 0, st>>>(d, Mc, U, row);
+    }
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// enqueue the sweep; `check` = also wait for it and report a non-positive pivot.  `Y` (optional): the caller's
+// interface vectors (rows y_row0 .. of stride nGp) instead of the internal workspace; `stages` as in enqueue_solve.
+static int solve_batch_impl(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0, bool check, rom_buf* Y = nullptr,
+                            int64_t y_row0 = 0, int stages = 3) {
+  ROM_CHECK(f && a && (U || !(stages & 2)), "rom_solve_batch: null argument");
+  ROM_CHECK(M >= 0 && row0 >= 0 && y_row0 >= 0, "rom_solve_batch: negative M or row offset");
+  const int kblk = f->nrb * f->ncb;
+  ROM_CHECK(a->n >= size_t(M) * kblk, "rom_solve_batch: `a` holds %zu doubles, need %zu", a->n, size_t(M) * kblk);
+  if (stages & 2)
+    ROM_CHECK(U->n >= size_t(row0 + M) * f->dim, "rom_solve_batch: U holds %zu doubles, need %zu", U->n,
+              size_t(row0 + M) * f->dim);
+  if (Y)
+    ROM_CHECK(Y->n >= size_t(y_row0 + M) * f->nGp, "rom_solve_batch: the interface-vector buffer holds %zu doubles, need %zu",
+              Y->n, size_t(y_row0 + M) * f->nGp);
+  if (M == 0) return ROM_OK;
+  rom_ctx* ctx = f->ctx;
+  ROM_HIP(hipSetDevice(ctx->device));
+  // chunk the sweep so that the factor workspace respects the budget
+  size_t per_sys = (size_t(f->nslots) * 4096 + size_t(f->T) * 4096 + 2 * size_t(f->nGp)) * sizeof(double);
+  int Mc_max = int(std::max<size_t>(1, std::min<size_t>(size_t(M), ctx->ws_limit / std::max<size_t>(per_sys, 1))));
+  if (f->ws_M > 0 && f->ws_M < Mc_max && f->ws_M >= 256) Mc_max = f->ws_M;  // reuse what we have
+  ROM_TRY(ensure_workspace(f, Mc_max));
+  const size_t lds_back = size_t(std::max(f->nGa, 1)) * sizeof(double);
+  ROM_CHECK(lds_back <= 60 * 1024, "rom_solve_batch: interface too large for the LDS-resident back substitution");
+  // Sub-batches run on separate HIP streams: the wave-per-system diagonal kernels are latency bound
+  // (one wave per SIMD), the MFMA kernels of another sub-batch fill the chip meanwhile.
+  const int nsub = std::max(1, std::min(ctx->n_streams, (M + 255) / 256));
+  ROM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+  for (int s = 1; s < nsub; ++s) ROM_HIP(hipStreamWaitEvent(ctx->aux[s - 1], ctx->ev_fork, 0));
+  for (int m0 = 0; m0 < M; m0 += Mc_max) {
+    const int Mchunk = std::min(Mc_max, M - m0);
+    const int per = ((Mchunk + nsub - 1) / nsub + 63) / 64 * 64;
+    for (int s = 0; s < nsub; ++s) {
+      const int off = s * per;
+      if (off >= Mchunk) break;
+      const int Mc = std::min(per, Mchunk - off);
+      hipStream_t st = s == 0 ? ctx->stream : ctx->aux[s - 1];
+      ctx->prof_stream = st;
+      FemDev d = make_dev(f);
+      d.L += size_t(off) * f->nslots * 4096;
+      d.invL += size_t(off) * f->T * 4096;
+      if (Y) d.y = Y->p + size_t(y_row0 + m0 + off) * f->nGp;
+      else d.y += size_t(off) * f->nGp;
+      d.yhat += size_t(off) * f->nGp;
+      ROM_TRY(enqueue_solve(f, d, a->p + size_t(m0 + off) * kblk, Mc, U ? U->p : nullptr, (long long)(row0 + m0 + off), st,
+                            lds_back, stages));
+    }
+    ctx->prof_stream = nullptr;
+    if (m0 + Mc_max < M) {  // the workspace is reused by the next chunk: join first
+      for (int s = 1; s < nsub; ++s) {
+        ROM_HIP(hipEventRecord(ctx->ev_join[s - 1], ctx->aux[s - 1]));
+        ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[s - 1], 0));
+      }
+      ROM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+      for (int s = 1; s < nsub; ++s) ROM_HIP(hipStreamWaitEvent(ctx->aux[s - 1], ctx->ev_fork, 0));
+    }
+  }
+  for (int s = 1; s < nsub; ++s) {
+    ROM_HIP(hipEventRecord(ctx->ev_join[s - 1], ctx->aux[s - 1]));
+    ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[s - 1], 0));
+  }
+  return check ? rom_solve_status(ctx) : ROM_OK;
+}
+
+extern "C" int rom_solve_batch(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0) {
+  return solve_batch_impl(f, a, M, U, row0, true);
+}
+
+// Same without the host round trip: the sweep is only enqueued on the compute stream; a non-positive pivot
+// is remembered on the device until rom_solve_status() is asked.
+extern "C" int rom_solve_batch_async(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t row0) {
+  return solve_batch_impl(f, a, M, U, row0, false);
+}
+
+extern "C" int rom_fem_expansion_is_linear(rom_fem* f, int* flag) {
+  ROM_CHECK(f && flag, "rom_fem_expansion_is_linear: null argument");
+  *flag = f->npre == 0 ? 1 : 0;  // no edge is recovered node by node (k_back_pre weights its inputs with the parameters)
+  return ROM_OK;
+}
+
+extern "C" int rom_fem_reduced_stride(rom_fem* f, int64_t* stride) {
+  ROM_CHECK(f && stride, "rom_fem_reduced_stride: null argument");
+  *stride = f->nGp;
+  return ROM_OK;
+}
+
+// Stage 1 only: Y[y_row0 + m, :] = interface vector of system m (reduced unknowns, cross points, the coefficient
+// blocks the extension reads): everything that depends on the solve, 1/85 of a snapshot row at 256x256 / 2x2.
+extern "C" int rom_solve_reduced_async(rom_fem* f, rom_buf* a, int M, rom_buf* Y, int64_t y_row0) {
+  ROM_CHECK(f && Y, "rom_solve_reduced_async: null argument");
+  ROM_CHECK(M >= 0 && y_row0 >= 0 && Y->n >= size_t(y_row0 + M) * f->nGp, "rom_solve_reduced_async: Y too small");
+  if (M > 0 && f->nGp > 0)  // padding slots are read against zero table entries: they must hold finite numbers
+    ROM_HIP(hipMemsetAsync(Y->p + size_t(y_row0) * f->nGp, 0, size_t(M) * f->nGp * sizeof(double), f->ctx->stream));
+  return solve_batch_impl(f, a, M, nullptr, 0, false, Y, y_row0, 1);
+}
+
+// Stage 2 only: snapshot rows U[row0 + m, :] from the interface vectors Y[y_row0 + m, :] (of this or any other
+// rank: the expansion is deterministic, so every rank reproduces the owner's rows bit for bit).
+extern "C" int rom_expand_batch_async(rom_fem* f, rom_buf* a, int M, rom_buf* Y, int64_t y_row0, rom_buf* U, int64_t row0) {
+  ROM_CHECK(f && Y && U, "rom_expand_batch_async: null argument");
+  return solve_batch_impl(f, a, M, U, row0, false, Y, y_row0, 2);
+}
+
+extern "C" int rom_solve_status(rom_ctx* ctx) {
+  ROM_CHECK(ctx, "rom_solve_status: null context");
+  int status = 0;
+  ROM_HIP(hipMemcpyAsync(&status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  if (status != 0) {
+    ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+    rom_set_error("rom_solve_batch: interface matrix not positive definite (non-positive pivot); "
+                  "all block coefficients must be > 0");
+    return ROM_ERR_NOT_SPD;
+  }
+  return ROM_OK;
+}
+

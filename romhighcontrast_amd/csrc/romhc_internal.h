@@ -104,7 +104,7 @@ struct ProfScope {
 struct GenTerm {
   int tab;                         // index of the 64x64 table in the pool
   short r_lo, r_hi, c_lo, c_hi;    // bounding rectangle inside the tile
-  int kind;                        // coefficient formula, see term_coef() in rom_fem.hip
+  int kind;                        // coefficient formula, see term_coef() in rom_fem_kernels.hip
   int b[4];                        // block indices it uses
 };
 
