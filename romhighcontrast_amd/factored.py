@@ -43,6 +43,48 @@ class ExpansionMap:
         ctx.synchronize()
         del Bt
 
+    # ---- H^1_0 geometry of the snapshots in coordinates of the interface vectors ----------------------------
+    def energy_coordinates(self):
+        """(E, Mb, beta): with xi = y E (k' numbers per snapshot) the H^1_0 inner product of two snapshots is the
+        EUCLIDEAN inner product of their xi (E = V Lambda^(1/2) from S1 = B^T A_1 B = V Lambda V^T, directions below
+        1e-15 of the largest eigenvalue dropped); Mb[b] (k' x k') is the form u^T A_b v of block b in these
+        coordinates and beta (k') the load functional u -> u . B_total.  Built once per FE space."""
+        if getattr(self, "_energy", None) is not None:
+            return self._energy
+        ctx, fem, K, dim = self.ctx, self.fem, self.K, self.dim
+        eye = ctx.upload(np.eye(K))
+        Bt = ctx.alloc(K * dim)
+        self.expand_into(eye, K, Bt)
+        ABt = ctx.alloc(K * dim)
+        Sd = ctx.alloc(K * K)
+        fem.stencil_apply(Bt, K, ABt)                      # rows: A_1 B e_i
+        ctx.gemm_nt(K, K, dim, Bt, 0, dim, ABt, 0, dim, Sd, 0, K)
+        S1 = Sd.download(K * K, shape=(K, K))
+        S1 = (S1 + S1.T) / 2
+        # the columns of B have wildly different energies (the slot of h^2/a_b carries L^-1 1 ~ N^2, others O(1)):
+        # equilibrate before the eigen-decomposition, otherwise its absolute error (eps * lambda_max) swamps
+        # the energy of ordinary snapshots
+        d = np.sqrt(np.maximum(np.diag(S1), 0.0))
+        d[d == 0] = 1.0
+        lam, V = np.linalg.eigh(S1 / np.outer(d, d))
+        keep = lam > 1e-15 * lam[-1]
+        lam, V = lam[keep][::-1], V[:, keep][:, ::-1]
+        E = (V * np.sqrt(lam)) * d[:, None]                # K x k'
+        Einv = (V / np.sqrt(lam)) / d[:, None]             # y-coordinates of the xi basis vectors, K x k'
+        Mb = []
+        for b in range(fem.kblk):
+            one = np.zeros(fem.kblk)
+            one[b] = 1.0
+            fem.stencil_apply(Bt, K, ABt, a_one=one)
+            ctx.gemm_nt(K, K, dim, Bt, 0, dim, ABt, 0, dim, Sd, 0, K)
+            Sb = Sd.download(K * K, shape=(K, K))
+            Mb.append(Einv.T @ ((Sb + Sb.T) / 2) @ Einv)
+        bt = ctx.alloc(K)
+        ctx.gemm_nt(K, 1, dim, Bt, 0, dim, ctx.upload(fem.load_vector()), 0, dim, bt, 0, 1)
+        beta = Einv.T @ bt.download(K)
+        self._energy = (E, np.array(Mb), beta)
+        return self._energy
+
     def _a_dummy(self, M):
         if M not in self._ones:
             self._ones = {M: self.ctx.upload(np.ones((M, self.fem.kblk)))}
@@ -163,3 +205,76 @@ def pod_modes_factored(fs: FactoredSnapshots, n: int, center=True, passes=2):
     signs = np.sign(comps[np.arange(n), piv])
     signs[signs == 0] = 1.0
     return comps * signs[:, None], sig
+
+
+def energy_coordinates_of(fs: FactoredSnapshots):
+    """Xi (device, (M, k')): the snapshots of ``fs`` in coordinates in which the H^1_0 inner product is Euclidean."""
+    em = fs.map
+    E, _, _ = em.energy_coordinates()
+    ctx, M, K, kp = em.ctx, fs.M, fs.K, E.shape[1]
+    Xi = ctx.alloc(max(M * kp, 1))
+    ctx.gemm_nn(M, kp, K, fs.Y, 0, K, ctx.upload(E), 0, kp, Xi, 0, kp)
+    return Xi, kp
+
+
+def h10norm_factored(fs: FactoredSnapshots) -> np.ndarray:
+    """H^1_0 norms of the snapshots from their interface vectors (= ``sm.H10norm(fs.rows())``)."""
+    Xi, kp = energy_coordinates_of(fs)
+    return fs.map.ctx.l2norm(Xi, 0, fs.M, kp)
+
+
+def greedy_factored(fs: FactoredSnapshots, a2train, n: int, galerkin: bool, h1norm):
+    """The strong greedy of ReducedBasisGreedy.build (src/lib/ReducedBasis.py:105-139) on a training block held in
+    factored form.  In energy coordinates the H^1_0-orthogonal projection onto the picked snapshots is a Euclidean
+    projection and the Galerkin ROM is a batch of small dense solves, so an iteration costs O(M k' n) instead of
+    O(M dim n).  Returns (picks, max relative errors per iteration)."""
+    em = fs.map
+    ctx, fem, M = em.ctx, em.fem, fs.M
+    E, Mb, beta = em.energy_coordinates()
+    Xi, kp = energy_coordinates_of(fs)
+    h1norm = np.broadcast_to(np.asarray(h1norm, dtype=np.float64), (M,))
+    a2train = np.ascontiguousarray(np.asarray(a2train, dtype=np.float64).reshape(M, -1))
+    picks, max_errors = [], []
+    Q = np.zeros((0, kp))                        # H^1_0-orthonormal basis of the picks (energy coordinates), host
+    R = ctx.alloc(M * kp).copy_from(Xi, M * kp)  # H10 mode: residuals of all training snapshots
+    Ahat = np.zeros((fem.kblk, 0, 0))
+    a_dev = ctx.upload(a2train)
+    for it in range(n):
+        if it == 0:
+            rel = np.ones(M)                     # empty basis: every relative error is exactly 1 (:129)
+        elif not galerkin:
+            rel = ctx.l2norm(R, 0, M, kp) / h1norm
+        else:
+            m = Q.shape[0]
+            c = ctx.alloc(M * m)
+            ctx.reduced_solve_batch(m, fem.kblk, M, ctx.upload(Ahat), a_dev, ctx.upload(Q @ beta), False, c)
+            D = ctx.alloc(M * kp).copy_from(Xi, M * kp)
+            ctx.gemm_nn(M, kp, m, c, 0, m, ctx.upload(Q), 0, kp, D, 0, kp, alpha=-1.0, beta=1.0)
+            rel = ctx.l2norm(D, 0, M, kp) / h1norm
+        ix = int(np.argmax(rel))
+        picks.append(ix)
+        max_errors.append(float(rel[ix]))
+        if it == n - 1:
+            break
+        # new basis vector: the pick, orthogonalised (twice) against the earlier ones
+        q = Xi.download(kp, offset=ix * kp)
+        for _ in range(2):
+            q = q - Q.T @ (Q @ q)
+        nq = np.linalg.norm(q)
+        if nq <= 1e-14 * np.linalg.norm(Xi.download(kp, offset=ix * kp)):
+            continue                             # a duplicate pick (errors at roundoff): the span does not grow
+        q /= nq
+        if galerkin:
+            t = Mb @ q                            # (kblk, k')
+            new = np.zeros((fem.kblk, Q.shape[0] + 1, Q.shape[0] + 1))
+            new[:, :-1, :-1] = Ahat
+            new[:, -1, :-1] = new[:, :-1, -1] = t @ Q.T
+            new[:, -1, -1] = t @ q
+            Ahat = new
+        else:
+            qd = ctx.upload(q)
+            cq = ctx.alloc(M)
+            ctx.gemm_nt(M, 1, kp, R, 0, kp, qd, 0, kp, cq, 0, 1)                        # (R q)
+            ctx.gemm_nn(M, kp, 1, cq, 0, 1, qd, 0, kp, R, 0, kp, alpha=-1.0, beta=1.0)  # R -= (R q) q^T
+        Q = np.vstack((Q, q))
+    return picks, max_errors

@@ -176,6 +176,16 @@ class ReducedBasisGreedy(BaseReducedBasis):
         if self.greedy_for not in (GREEDY_FOR_H10, GREEDY_FOR_GALERKIN):
             raise Exception(f"Not implemented greedy for {self.greedy_for}, "
                             f"should be one of [{GREEDY_FOR_H10}, {GREEDY_FOR_GALERKIN}]")
+        from ..factored import FactoredSnapshots, greedy_factored
+        if isinstance(solutions2train, FactoredSnapshots):
+            # training block in factored form: the same greedy in coordinates of the interface vectors
+            a2train = np.asarray(a2train)
+            self.picks, self.max_errors = greedy_factored(solutions2train, a2train, n,
+                                                          self.greedy_for == GREEDY_FOR_GALERKIN,
+                                                          solutions2train_h1norm)
+            basis = solutions2train.take(self.picks).rows().numpy()
+            super().set(basis=basis, a=[a2train[i] for i in self.picks])
+            return self
         ctx = sm._ctx
         dim = sm.vspace_dim
         a2train = np.asarray(a2train)

@@ -425,6 +425,15 @@ def test_factored_snapshot_block(api):
     assert np.abs(rb_f.basis - rb_r.basis).max() < 1e-6 and np.array_equal(np.asarray(rb_f.a), np.asarray(rb_r.a))
     sub = fs.take([3, 77, 5])
     assert np.array_equal(sub.rows().numpy(), U[[3, 77, 5]])
+    # H^1_0 norms and both greedy builders on the factored block: same picks, same error curves as on rows
+    h1 = sm.H10norm(U)
+    np.testing.assert_allclose(factored.h10norm_factored(fs), h1, rtol=1e-11)
+    for mode in (RB.GREEDY_FOR_H10, RB.GREEDY_FOR_GALERKIN):
+        g_r = RB.ReducedBasisGreedy(mode).build(10, sm, U, a, h1)
+        g_f = RB.ReducedBasisGreedy(mode).build(10, sm, fs, a, h1)
+        assert g_f.picks == g_r.picks, (mode, g_f.picks, g_r.picks)
+        np.testing.assert_allclose(g_f.max_errors, g_r.max_errors, rtol=1e-8, atol=1e-11)
+        assert np.array_equal(g_f.basis, g_r.basis)
     # geometries with a node-by-node edge refuse the factored form
     sm2 = SM.SolutionsManagerFEM((1, 2), 6)
     if not sm2._fem.expansion_is_linear:

@@ -28,3 +28,24 @@ for mode in (RB.GREEDY_FOR_H10, RB.GREEDY_FOR_GALERKIN):
     e = np.array(rb.max_errors)
     print(f"greedy {mode}: n={n} in {t:.2f} s; max rel H10 error: " + " ".join(f"{x:.1e}" for x in e[[0, 1, 2, 4, 9, 19, 29, 39, min(49, n - 1)]]))
     print("   first picks", rb.picks[:12])
+# the same builders on the training block held in factored form (interface vectors only)
+from romhighcontrast_amd import factored
+fem = sm._fem
+if fem.expansion_is_linear:
+    K = fem.reduced_stride
+    Y = ctx.alloc(M * K)
+    _, t = T(lambda: (fem.solve_reduced(ctx.upload(a.reshape(M, -1)), M, Y), ctx.solve_status()))
+    print(f"reduced solves (interface vectors, K = {K}): {t*1e3:.2f} ms")
+    fs = factored.FactoredSnapshots(sm, Y, M)
+    _, t = T(lambda: fs.map.energy_coordinates())
+    print(f"energy coordinates of the FE space (once): {t:.2f} s, k' = {fs.map.energy_coordinates()[0].shape[1]}")
+    h1f, t = T(lambda: factored.h10norm_factored(fs))
+    print(f"H10 norms from the interface vectors: {t*1e3:.2f} ms, max rel diff to the stencil norms {np.abs(h1f / h1 - 1).max():.1e}")
+    for mode in (RB.GREEDY_FOR_H10, RB.GREEDY_FOR_GALERKIN):
+        rbf = RB.ReducedBasisGreedy(mode)
+        _, t = T(lambda: rbf.build(n, sm, fs, a, h1))
+        rbr = RB.ReducedBasisGreedy(mode).build(n, sm, U, a, h1)
+        same = sum(p == q for p, q in zip(rbf.picks, rbr.picks))
+        e, er = np.array(rbf.max_errors), np.array(rbr.max_errors)
+        print(f"factored greedy {mode}: n={n} in {t:.3f} s; picks equal to the row-based build: {same}/{n}; "
+              f"max |error - error_rows| = {np.abs(e - er).max():.1e}; last error {e[-1]:.2e}")
