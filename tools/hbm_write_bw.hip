@@ -69,6 +69,25 @@ __global__ __launch_bounds__(256) void k_tile128(double* U, int M, int N, int nc
       }
     }
 }
+// (i') as (i) with non-temporal stores
+__global__ __launch_bounds__(256) void k_tile128_nt(double* U, int M, int N, int nc, long long dim, double v) {
+  const int n1 = N - 1;
+  const int b = blockIdx.z, p = b / 2, q = b % 2;
+  const int iv = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
+  const int fr = lane & 15, kq = lane >> 4, odd = lane & 1;
+  for (int i = 0; i < 4; ++i)
+    for (int g = 0; g < 4; ++g) {
+      const int m = blockIdx.y * 128 + wr * 64 + i * 16 + kq + 4 * g;
+      if (m >= M) continue;
+      for (int hp = 0; hp < 2; ++hp) {
+        const int jj = wc * 64 + (2 * hp + odd) * 16 + fr - odd;
+        double* dst = U + (long long)m * dim + (long long)(p * N + iv) * nc + (q * N + jj);
+        if (jj + 1 < n1) __builtin_nontemporal_store(double2_u{v, v}, reinterpret_cast<double2_u*>(dst));
+        else if (jj < n1) __builtin_nontemporal_store(v, dst);
+      }
+    }
+}
 // (j) same outputs, but every wave-instruction writes one system's whole 127-vertex run (16 bytes per lane)
 __global__ __launch_bounds__(256) void k_rowrun128(double* U, int M, int N, int nc, long long dim, double v) {
   const int n1 = N - 1;
@@ -151,6 +170,12 @@ int main() {
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("1x128 tile, D layout, 16 B/lane: %.3f ms  %.2f TB/s\n", ms, 4.0 * 127 * 127 * M * 8.0 / ms * 1e-9);
+    CK(hipEventRecord(e0));
+    k_tile128_nt<<<dim3(127, M / 128, 4), 256>>>(U, M, N, nc, dim, 6.5);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  ... non-temporal stores      : %.3f ms  %.2f TB/s\n", ms, 4.0 * 127 * 127 * M * 8.0 / ms * 1e-9);
     CK(hipEventRecord(e0));
     k_rowrun128<<<dim3(127, M / 128, 4), 256>>>(U, M, N, nc, dim, 7.0);
     CK(hipEventRecord(e1));
