@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64) void k_diag_inverse(FemDev f, int slot, int j) 
 //   coefficient blocks for the extension (what k_coef does on the general path).
 __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restrict__ a) {
   __shared__ __align__(16) double Ls[64 * LDC];
-  __shared__ __align__(16) double lv[2][64];
+  __shared__ __align__(16) double Pn[64 * 4];  // one 64 x 4 panel of the Cholesky
   __shared__ double zs[64];
   __shared__ double wz[DENSE_GROUPS_MAX * 64];
   const int m = blockIdx.x, lane = threadIdx.x;
@@ -463,13 +463,6 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
     }
   }
   __syncthreads();
-  double arow[64];  // row `lane` of the symmetric tile = column `lane` of its upper triangle
-#pragma unroll
-  for (int c = 0; c < 64; ++c) arow[c] = c <= lane ? Ls[c * LDC + lane] : 0.0;
-  if (lane >= d.ndr) {
-#pragma unroll
-    for (int c = 0; c < 64; ++c) arow[c] = (c == lane) ? 1.0 : 0.0;  // padding unknowns: identity
-  }
   // rhs of the reduced system (k_rhs)
   double y = f.g[lane];
   for (int t0 = 0; t0 < f.nrhs; t0 += 8) {  // eight terms at a time: their vector loads are in flight together
@@ -489,36 +482,85 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
         y += (rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5) * rv[x];
       }
   }
-  // Cholesky (as k_diag_potrf) with y carried along: after step jj, y holds L^-1 g in lanes <= jj
+  // The lower 16x16 blocks of the tile in MFMA accumulator layout: element g of C[ib][jb] is
+  // (row 16 ib + 4 g + (lane >> 4), column 16 jb + (lane & 15)).  The assembly left A[r][c], r <= c, at
+  // Ls[r][c] (zeros below): A[R][C] with R >= C is read from Ls[C][R].
+  const int l16 = lane & 15, l4 = lane >> 4;
+  d4_t C[4][4];
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+    for (int jb = 0; jb <= ib; ++jb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int R = 16 * ib + 4 * g + l4, Cc = 16 * jb + l16;
+        C[ib][jb][g] = (R >= d.ndr || Cc >= d.ndr) ? (R == Cc ? 1.0 : 0.0) : Ls[Cc * LDC + R];  // identity padding
+      }
+  __syncthreads();  // Ls is rewritten with L below
+  // Blocked right-looking Cholesky, 16 panels of 4 columns.  A panel goes through LDS into row-per-lane form
+  // (lane r holds its 4 entries), is factorised there with readlane broadcasts -- the forward substitution of y
+  // rides along -- and goes back through LDS as the A and B operand of v_mfma_f64_16x16x4_f64 (K = 4 is exactly
+  // one panel) for the rank-4 update of the trailing blocks: 8 LDS fragment reads + <= 10 MFMAs per panel instead
+  // of ~120 broadcast reads + 240 FMAs per lane in the column-by-column form.
   bool bad = false;
   double myrs = 0.0;
 #pragma unroll
-  for (int jj = 0; jj < 64; ++jj) {
-    const double dj = readlane_f64(arow[jj], jj);
-    bad = bad || !(dj > 0.0);
-    const double rs = rsqrt_newton(dj);
-    const double l = arow[jj] * rs;  // L[lane][jj] for lane >= jj
-    arow[jj] = l;
-    const double yj = readlane_f64(y, jj) * rs;
-    if (lane == jj) {
-      y = yj;
-      myrs = rs;  // (an LDS store here makes hipcc spill the whole tile)
-    } else if (lane > jj) {
-      y -= l * yj;
-    }
-    if (jj < 63) {
-      double* bv = lv[jj & 1];
-      bv[lane] = l;
-      __builtin_amdgcn_wave_barrier();
+  for (int p = 0; p < 16; ++p) {
+    const int jb = p >> 2, co = 4 * (p & 3), c0 = 4 * p;
+    // (a) panel columns out of the accumulators
+    if ((l16 >> 2) == (p & 3)) {
 #pragma unroll
-      for (int c = 0; c < 64; ++c)
-        if (c > jj) arow[c] -= l * bv[c];
-      __builtin_amdgcn_wave_barrier();
+      for (int ib = jb; ib < 4; ++ib)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Pn[(16 * ib + 4 * g + l4) * 4 + (l16 - co)] = C[ib][jb][g];
     }
+    __builtin_amdgcn_wave_barrier();
+    // (b) row-per-lane: lane r holds A[r][c0 .. c0+3]
+    double v[4];
+    {
+      const double2 v01 = *reinterpret_cast<const double2*>(&Pn[lane * 4]);
+      const double2 v23 = *reinterpret_cast<const double2*>(&Pn[lane * 4 + 2]);
+      v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = c0 + k;
+      const double dj = readlane_f64(v[k], j);
+      bad = bad || !(dj > 0.0);
+      const double rs = rsqrt_newton(dj);
+      const double l = lane >= j ? v[k] * rs : 0.0;  // L[lane][j]
+      v[k] = l;
+      const double yj = readlane_f64(y, j) * rs;
+      if (lane == j) {
+        y = yj;
+        myrs = rs;
+      } else if (lane > j) {
+        y -= l * yj;
+      }
+#pragma unroll
+      for (int kk = k + 1; kk < 4; ++kk) v[kk] -= l * readlane_f64(l, c0 + kk);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (c) the factorised panel: operand array for the MFMAs and the columns of L for the back substitution
+    *reinterpret_cast<double2*>(&Pn[lane * 4]) = double2{v[0], v[1]};
+    *reinterpret_cast<double2*>(&Pn[lane * 4 + 2]) = double2{v[2], v[3]};
+    *reinterpret_cast<double2*>(&Ls[lane * LDC + c0]) = double2{v[0], v[1]};
+    *reinterpret_cast<double2*>(&Ls[lane * LDC + c0 + 2]) = double2{v[2], v[3]};
+    __builtin_amdgcn_wave_barrier();
+    // (d) trailing update C[ib][jb'] -= Lp[ib] Lp[jb']^T for the blocks right of / below the panel
+    if (p < 15) {
+      double frag[4];
+#pragma unroll
+      for (int x = jb; x < 4; ++x) frag[x] = Pn[(16 * x + l16) * 4 + l4];  // same map for A (row, k) and B (k, col)
+#pragma unroll
+      for (int jb2 = jb; jb2 < 4; ++jb2)
+#pragma unroll
+        for (int ib = jb2; ib < 4; ++ib)
+          C[ib][jb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag[ib], frag[jb2], C[ib][jb2], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   if (bad && lane == 0) atomicOr(f.status, 1);
-#pragma unroll
-  for (int c = 0; c < 64; ++c) Ls[lane * LDC + c] = c <= lane ? arow[c] : 0.0;
   __syncthreads();
   // back substitution x = L^-T y.  Column `lane` of L is fetched from LDS in one batch (conflict free), then the
   // chain x_j = y_j / L_jj ; y_i -= L_ji x_j (i < j) runs on registers and readlane broadcasts only.
