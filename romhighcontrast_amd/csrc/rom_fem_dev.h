@@ -21,8 +21,6 @@ struct FemDev {
   const int* xred;
   const int* scb;         // scalar block: (b0, b1) per entry
   int spos0, nsc, sblk0;  // its position / length in the interface vector, position of the h^2/a_b part
-  const RowEnt* rowent;
-  int nrowent;
   const DenseGroup* dgroups;  // single-tile path: coefficient blocks of the closed-form edges as one dense product
   const int* dweight;
   const int* ditem_group;
@@ -65,7 +63,6 @@ FemDev make_dev(const rom_fem* f);
 
 constexpr int COEF_MAX = 64;   // term weights cached in LDS per pass
 constexpr int DENSE_GROUPS_MAX = 8;  // closed-form edges whose coefficient blocks k_solve1 builds
-constexpr int ROW_BATCH = 64;  // loads in flight per wave in the single-tile assembly
 
 // row of H0 that holds the extension from side s evaluated at interior vertex (i,j), 1-based
 __host__ __device__ inline int h0_row(int s, int i, int j, int N, int n1) {

@@ -418,8 +418,9 @@ __global__ __launch_bounds__(64) void k_diag_inverse(FemDev f, int slot, int j) 
 
 // Whole reduced solve of a system whose reduced matrix is ONE tile (e.g. 2x2 blocks at N = 128: 2 x 31
 // compressed unknowns + the cross point), one wave per system, nothing but the solution leaves the CU:
-//   assemble (lane c accumulates column c of the upper triangle = row c of the lower one, coalesced table reads) ->
-//   in-register Cholesky with the forward substitution fused in -> L through LDS -> back substitution ->
+//   assemble the lower 16x16 blocks in MFMA accumulator layout (term by term, double buffered) ->
+//   rank-4 blocked Cholesky (panel in row-per-lane form, trailing update on MFMA) with the forward substitution
+//   carried along -> back substitution on registers ->
 //   coefficient blocks for the extension (what k_coef does on the general path).
 __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restrict__ a) {
   __shared__ __align__(16) double Ls[64 * LDC];
@@ -430,39 +431,69 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   const double* am = a + size_t(m) * f.kblk;
   double* ym = f.y + size_t(m) * f.nGp;
   const TileDesc& d = f.desc[0];
-  // Assembly, upper triangle only (row <= col), by the host-built row program: lane c owns column c, entries
-  // are (table row segment, term) pairs sorted by tile row; ROW_BATCH independent coalesced loads are in flight
-  // before the first is consumed (one wave per SIMD: nothing else hides the latency).
-  for (int r = 0; r < 64; ++r) Ls[r * LDC + lane] = 0.0;
-  const double mycoef = lane < d.t1 - d.t0 ? term_coef(f.terms[d.t0 + lane], am) : 0.0;  // lane t: weight of term t
-  __syncthreads();
-  {
-    static_assert(ROW_BATCH == 64, "one row-program entry per lane and batch");
-    double acc = 0.0;
-    const int4* ents = reinterpret_cast<const int4*>(f.rowent);
-    int4 mine = f.nrowent > 0 ? ents[lane] : int4{0, 0, 0, 0};  // lane i holds entry i of the batch
-    for (int e0 = 0; e0 < f.nrowent; e0 += ROW_BATCH) {
-      const int4 cur = mine;
-      if (e0 + ROW_BATCH < f.nrowent) mine = ents[e0 + ROW_BATCH + lane];  // next batch's entries fly meanwhile
-      double v[ROW_BATCH];
+  // Assembly straight into the MFMA accumulator layout of the Cholesky below: element g of C[ib][jb] is
+  // (row 16 ib + 4 g + (lane >> 4), column 16 jb + (lane & 15)), lower blocks only.  Term by term: the blocks a
+  // term's rectangle touches are loaded (4 loads each, nothing waits between them) and the next term's loads
+  // are in flight while the current term is accumulated (one wave per SIMD: nothing else hides the latency).
+  const int l16 = lane & 15, l4 = lane >> 4;
+  const int nterm = d.t1 - d.t0;
+  const double mycoef = lane < nterm ? term_coef(f.terms[d.t0 + lane], am) : 0.0;  // lane t: weight of term t
+  d4_t C[4][4];
 #pragma unroll
-      for (int i = 0; i < ROW_BATCH; ++i) {
-        const int off = __builtin_amdgcn_readlane(cur.x, i);
-        const int c_lo = __builtin_amdgcn_readlane(cur.z, i), c_hi = __builtin_amdgcn_readlane(cur.w, i);
-        v[i] = (lane >= c_lo && lane < c_hi) ? f.pool[off + lane] : 0.0;
-      }
+  for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-      for (int i = 0; i < ROW_BATCH; ++i) {
-        const int meta = __builtin_amdgcn_readlane(cur.y, i);  // r | term << 8 | last << 16
-        acc += readlane_f64(mycoef, (meta >> 8) & 0xff) * v[i];  // (an LDS lookup here costs its full latency per entry)
-        if (meta >> 16) {
-          Ls[(meta & 0xff) * LDC + lane] = acc;
-          acc = 0.0;
+    for (int jb = 0; jb <= ib; ++jb) C[ib][jb] = d4_t{0.0, 0.0, 0.0, 0.0};
+  auto load_term = [&](int t, double (&v)[10][4]) {
+    // the term's table and rectangle as three dwords (wave-uniform: scalar loads; 16-bit fields would be
+    // fetched with vector loads and waited for one by one)
+    const int* gw = reinterpret_cast<const int*>(&f.terms[d.t0 + t]);
+    const int w0 = gw[0], w1 = gw[1], w2 = gw[2];
+    const int r_lo = w1 & 0xffff, r_hi = w1 >> 16, c_lo = w2 & 0xffff, c_hi = w2 >> 16;
+    const double* tab = f.pool + size_t(w0) * 4096 + l4 * 64 + l16;
+    int q = 0;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int jb = 0; jb <= ib; ++jb, ++q) {
+        const bool hit = (r_lo < 16 * ib + 16) & (r_hi > 16 * ib) & (c_lo < 16 * jb + 16) & (c_hi > 16 * jb);
+        if (hit) {  // (wave-uniform: a scalar branch, no wait between the loads of different blocks)
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg) v[q][gg] = tab[(16 * ib + 4 * gg) * 64 + 16 * jb];
+        } else {
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg) v[q][gg] = 0.0;
         }
       }
+  };
+  auto add_term = [&](int t, const double (&v)[10][4]) {
+    const double cf = readlane_f64(mycoef, t);
+    int q = 0;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int jb = 0; jb <= ib; ++jb, ++q)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) C[ib][jb][gg] += cf * v[q][gg];
+  };
+  {
+    double va[10][4], vb[10][4];
+    if (nterm > 0) load_term(0, va);
+    for (int t = 0; t < nterm; t += 2) {
+      if (t + 1 < nterm) load_term(t + 1, vb);
+      add_term(t, va);
+      if (t + 2 < nterm) load_term(t + 2, va);
+      if (t + 1 < nterm) add_term(t + 1, vb);
     }
   }
-  __syncthreads();
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+    for (int jb = 0; jb <= ib; ++jb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int R = 16 * ib + 4 * g + l4, Cc = 16 * jb + l16;
+        if (R >= d.ndr || Cc >= d.ndr) C[ib][jb][g] = R == Cc ? 1.0 : 0.0;  // padding unknowns: identity
+      }
   // rhs of the reduced system (k_rhs)
   double y = f.g[lane];
   for (int t0 = 0; t0 < f.nrhs; t0 += 8) {  // eight terms at a time: their vector loads are in flight together
@@ -482,21 +513,6 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
         y += (rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5) * rv[x];
       }
   }
-  // The lower 16x16 blocks of the tile in MFMA accumulator layout: element g of C[ib][jb] is
-  // (row 16 ib + 4 g + (lane >> 4), column 16 jb + (lane & 15)).  The assembly left A[r][c], r <= c, at
-  // Ls[r][c] (zeros below): A[R][C] with R >= C is read from Ls[C][R].
-  const int l16 = lane & 15, l4 = lane >> 4;
-  d4_t C[4][4];
-#pragma unroll
-  for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-    for (int jb = 0; jb <= ib; ++jb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int R = 16 * ib + 4 * g + l4, Cc = 16 * jb + l16;
-        C[ib][jb][g] = (R >= d.ndr || Cc >= d.ndr) ? (R == Cc ? 1.0 : 0.0) : Ls[Cc * LDC + R];  // identity padding
-      }
-  __syncthreads();  // Ls is rewritten with L below
   // Blocked right-looking Cholesky, 16 panels of 4 columns.  A panel goes through LDS into row-per-lane form
   // (lane r holds its 4 entries), is factorised there with readlane broadcasts -- the forward substitution of y
   // rides along -- and goes back through LDS as the A and B operand of v_mfma_f64_16x16x4_f64 (K = 4 is exactly

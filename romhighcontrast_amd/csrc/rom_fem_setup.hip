@@ -19,7 +19,7 @@ FemDev make_dev(const rom_fem* f) {
   d.xb0 = f->xb0; d.pool = f->d_pool; d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
   d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.scb = f->d_scb; d.spos0 = f->spos0; d.nsc = f->nsc;
   d.sblk0 = f->spos0 + f->n_all_edges; d.groups = f->d_groups; d.cm = f->d_cm; d.item_group = f->d_item_group;
-  d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.rowent = f->d_rowent; d.nrowent = f->nrowent; d.dgroups = f->d_dgroups; d.dweight = f->d_dweight;
+  d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.dgroups = f->d_dgroups; d.dweight = f->d_dweight;
   d.ditem_group = f->d_ditem_group; d.ditem_k = f->d_ditem_k; d.dmat = f->d_dmat; d.ndg = f->ndg; d.ndi = f->ndi; d.T = f->T; d.nslots = f->nslots;
   d.kblk = f->nrb * f->ncb; d.dim = f->dim;
   d.G = f->d_G; d.A0 = f->d_A0; d.Qp = f->d_Qp; d.kmax = f->d_kmax; d.epos = f->d_epos; d.yhat = f->d_yhat; d.W = f->d_W;
@@ -95,7 +95,7 @@ extern "C" int rom_fem_destroy(rom_fem* f) {
   void* ptrs[] = {f->d_A0, f->d_G, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
                   f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
                   f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred, f->d_groups, f->d_cm,
-                  f->d_item_group, f->d_item_k, f->d_rowent, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
+                  f->d_item_group, f->d_item_k, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
                   f->d_ditem_k, f->d_dmat, f->d_scb};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -692,29 +692,8 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
   slot_terms.clear();
   smalls.clear();
-  // row program of the single-tile solve (k_solve1): per tile row, the table row segments with col >= row
-  std::vector<RowEnt> rowents;
+  // the whole reduced solve in one wave (k_solve1) if the reduced matrix is a single tile
   f->fused1 = T == 1 && f->desc[0].t1 - f->desc[0].t0 <= COEF_MAX && f->nGa == TB;
-  if (f->fused1) {
-    const TileDesc& d0 = f->desc[0];
-    for (int r = 0; r < TB; ++r) {
-      const size_t first = rowents.size();
-      for (int t = d0.t0; t < d0.t1; ++t) {
-        const GenTerm& g = terms[t];
-        if (r < g.r_lo || r >= g.r_hi) continue;
-        const double* rowp = pool.data() + size_t(g.tab) * 4096 + size_t(r) * TB;
-        int lo = TB, hi = 0;
-        for (int c = std::max<int>(r, g.c_lo); c < g.c_hi; ++c)
-          if (rowp[c] != 0.0) { lo = std::min(lo, c); hi = c + 1; }
-        if (hi <= lo) continue;
-        rowents.push_back(RowEnt{int(size_t(g.tab) * 4096 + size_t(r) * TB), r | ((t - d0.t0) << 8), lo, hi});
-      }
-      if (rowents.size() > first) rowents.back().meta |= 1 << 16;
-    }
-    while (rowents.size() % ROW_BATCH) rowents.push_back(RowEnt{0, 0, 0, 0});  // no-ops
-  }
-  f->nrowent = int(rowents.size());
-  ROM_TRY(upload(&f->d_rowent, rowents));
 
   // ---- block sides, vmap, parameter-independent part of the reduced rhs --------------------------------------------
   std::vector<int> vmap(std::max(f->nGp, 1), -1);

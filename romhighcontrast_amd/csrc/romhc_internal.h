@@ -131,13 +131,6 @@ struct DenseGroup {
   int voff[4], vblk[4], vu0[4], vu1[4];
 };
 
-// one step of the single-tile assembly (k_solve1): acc += coef[term] * pool[off + lane] for lanes in
-// [c_lo, c_hi); `last` closes tile row r (acc is stored and reset)
-struct RowEnt {
-  int off;
-  int meta;  // r | term << 8 | last << 16
-  int c_lo, c_hi;
-};
 struct BlockSide {
   ExtSide s[4];
 };
@@ -237,8 +230,6 @@ struct rom_fem {
   int* d_item_group = nullptr;
   int* d_item_k = nullptr;
   int ncoef = 0;               // entries of all coefficient blocks
-  RowEnt* d_rowent = nullptr;  // row program of the single-tile solve
-  int nrowent = 0;
   bool fused1 = false;         // the reduced matrix is one tile: whole solve in k_solve1
   DenseGroup* d_dgroups = nullptr;
   int* d_dweight = nullptr;    // per (dense group, source position): block of the weight, -1 cross point, -2 none
