@@ -11,6 +11,8 @@ struct FemDev {
   int nrb, ncb, N, n1, n1p, nr, nc, nGp, nGa, T, nslots, kblk, npre, nrhs, nexp, ncross, xb0;
   long long dim;
   const double* pool;  // 64x64 tables of the tile terms
+  const int* pairs;    // single-tile solve: (term, block) pairs of the assembly, two ints each
+  int npairs;          // multiple of 64 (no-op padded), followed by 64 more no-ops
   const GenTerm* terms;
   const double* Bt;    // back substitution tables of the closed-form edges
   const double* P;     // expansion tables of the active edges
@@ -62,6 +64,7 @@ struct FemDev {
 FemDev make_dev(const rom_fem* f);
 
 constexpr int COEF_MAX = 64;   // term weights cached in LDS per pass
+constexpr int PAIR_RING = 8;          // (term, block) pairs in flight in the single-tile assembly
 constexpr int DENSE_GROUPS_MAX = 8;  // closed-form edges whose coefficient blocks k_solve1 builds
 
 // row of H0 that holds the extension from side s evaluated at interior vertex (i,j), 1-based

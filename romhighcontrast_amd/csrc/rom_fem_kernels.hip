@@ -431,59 +431,67 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   const double* am = a + size_t(m) * f.kblk;
   double* ym = f.y + size_t(m) * f.nGp;
   const TileDesc& d = f.desc[0];
-  // Assembly straight into the MFMA accumulator layout of the Cholesky below: element g of C[ib][jb] is
-  // (row 16 ib + 4 g + (lane >> 4), column 16 jb + (lane & 15)), lower blocks only.  Term by term: the blocks a
-  // term's rectangle touches are loaded (4 loads each, nothing waits between them) and the next term's loads
-  // are in flight while the current term is accumulated (one wave per SIMD: nothing else hides the latency).
+  // Assembly in the MFMA accumulator layout of the Cholesky below: element g of block q = (ib, jb), ib >= jb, is
+  // (row 16 ib + 4 g + (lane >> 4), column 16 jb + (lane & 15)).  The host lists the (term, block) pairs whose
+  // rectangle and block intersect (57 at 2x2 / N=128); a pair is exactly four loads, so a ring of PAIR_RING
+  // pairs keeps 4 * PAIR_RING loads in flight with statically known wait counts (one wave per SIMD: nothing
+  // else hides the latency).  The pairs are sorted by block; a block's sum is kept in four registers and
+  // stored to an LDS copy of the blocks when its last pair is done (the target block of a pair is a run-time
+  // index, which registers cannot have).
+  double* Cl = Ls;  // the ten lower blocks during the assembly, [block][g][lane] (Ls is not needed before the Cholesky)
+  static_assert(40 * 64 <= 64 * LDC, "block copy must fit in the tile buffer");
   const int l16 = lane & 15, l4 = lane >> 4;
   const int nterm = d.t1 - d.t0;
   const double mycoef = lane < nterm ? term_coef(f.terms[d.t0 + lane], am) : 0.0;  // lane t: weight of term t
-  d4_t C[4][4];
 #pragma unroll
-  for (int ib = 0; ib < 4; ++ib)
+  for (int x = 0; x < 40; ++x) Cl[x * 64 + lane] = 0.0;
+  {
+    const int2* pairs = reinterpret_cast<const int2*>(f.pairs);  // (element offset of the block in the pool, term | q << 8)
+    const double* pbase = f.pool + l4 * 64 + l16;
+    double v[PAIR_RING][4];
+    double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+    int2 mine = pairs[lane];  // lane i holds pair i of the current group of 64 (the list is padded with no-ops)
+    auto issue = [&](int2 pr_lane, int i, double (&dst)[4]) {
+      const double* pb = pbase + __builtin_amdgcn_readlane(pr_lane.x, i);
 #pragma unroll
-    for (int jb = 0; jb <= ib; ++jb) C[ib][jb] = d4_t{0.0, 0.0, 0.0, 0.0};
-  auto load_term = [&](int t, double (&v)[10][4]) {
-    // the term's table and rectangle as three dwords (wave-uniform: scalar loads; 16-bit fields would be
-    // fetched with vector loads and waited for one by one)
-    const int* gw = reinterpret_cast<const int*>(&f.terms[d.t0 + t]);
-    const int w0 = gw[0], w1 = gw[1], w2 = gw[2];
-    const int r_lo = w1 & 0xffff, r_hi = w1 >> 16, c_lo = w2 & 0xffff, c_hi = w2 >> 16;
-    const double* tab = f.pool + size_t(w0) * 4096 + l4 * 64 + l16;
-    int q = 0;
+      for (int g = 0; g < 4; ++g) dst[g] = pb[g * 256];  // rows 4 g + l4 of the block
+    };
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
+    for (int u = 0; u < PAIR_RING; ++u) issue(mine, u, v[u]);
+    for (int base = 0; base < f.npairs; base += 64) {
+      const int2 cur = mine;
+      const int2 nxt = pairs[base + 64 + lane];  // (the list carries 64 extra no-ops behind its end)
 #pragma unroll
-      for (int jb = 0; jb <= ib; ++jb, ++q) {
-        const bool hit = (r_lo < 16 * ib + 16) & (r_hi > 16 * ib) & (c_lo < 16 * jb + 16) & (c_hi > 16 * jb);
-        if (hit) {  // (wave-uniform: a scalar branch, no wait between the loads of different blocks)
+      for (int i = 0; i < 64; ++i) {
+        const int u = i % PAIR_RING;
+        const int meta = __builtin_amdgcn_readlane(cur.y, i);  // term | q << 8 | (last pair of block q) << 16
+        const double cf = readlane_f64(mycoef, meta & 0xff);
 #pragma unroll
-          for (int gg = 0; gg < 4; ++gg) v[q][gg] = tab[(16 * ib + 4 * gg) * 64 + 16 * jb];
-        } else {
+        for (int g = 0; g < 4; ++g) acc4[g] += cf * v[u][g];
+        if (meta >> 16) {  // the pairs are sorted by block: its sum is complete
+          double* dst = Cl + ((meta >> 8) & 0xff) * 256 + lane;
 #pragma unroll
-          for (int gg = 0; gg < 4; ++gg) v[q][gg] = 0.0;
+          for (int g = 0; g < 4; ++g) {
+            dst[g * 64] = acc4[g];
+            acc4[g] = 0.0;
+          }
         }
+        if (i + PAIR_RING < 64) issue(cur, i + PAIR_RING, v[u]);
+        else issue(nxt, i + PAIR_RING - 64, v[u]);
       }
-  };
-  auto add_term = [&](int t, const double (&v)[10][4]) {
-    const double cf = readlane_f64(mycoef, t);
+      mine = nxt;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  d4_t C[4][4];
+  {
     int q = 0;
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
       for (int jb = 0; jb <= ib; ++jb, ++q)
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) C[ib][jb][gg] += cf * v[q][gg];
-  };
-  {
-    double va[10][4], vb[10][4];
-    if (nterm > 0) load_term(0, va);
-    for (int t = 0; t < nterm; t += 2) {
-      if (t + 1 < nterm) load_term(t + 1, vb);
-      add_term(t, va);
-      if (t + 2 < nterm) load_term(t + 2, va);
-      if (t + 1 < nterm) add_term(t + 1, vb);
-    }
+        for (int g = 0; g < 4; ++g) C[ib][jb][g] = Cl[(q * 4 + g) * 64 + lane];
   }
 #pragma unroll
   for (int ib = 0; ib < 4; ++ib)
@@ -612,9 +620,12 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
     const DenseGroup& dg = f.dgroups[g];
     const double* D = f.dmat + it;
     const double* wg = wz + g * 64;
+    double dv[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) dv[j] = D[size_t(j) * f.ndi];  // all 64 coalesced loads in flight at once
     double acc = 0.0;
-#pragma unroll 16
-    for (int j = 0; j < 64; ++j) acc += D[size_t(j) * f.ndi] * wg[j];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc += dv[j] * wg[j];
     for (int v = 0; v < dg.nv; ++v) acc += am[dg.vblk[v]] / (am[dg.vu0[v]] + am[dg.vu1[v]]) * f.vec[dg.voff[v] + k];
     ym[dg.cpos + k] = acc / (am[dg.b0] + am[dg.b1]);
   }

@@ -16,7 +16,7 @@ FemDev make_dev(const rom_fem* f) {
   FemDev d;
   d.nrb = f->nrb; d.ncb = f->ncb; d.N = f->N; d.n1 = f->n1; d.n1p = f->n1p; d.nr = f->nr; d.nc = f->nc;
   d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.nexp = f->nexp; d.ncross = f->ncross;
-  d.xb0 = f->xb0; d.pool = f->d_pool; d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
+  d.xb0 = f->xb0; d.pool = f->d_pool; d.pairs = f->d_pairs; d.npairs = f->npairs; d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
   d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.scb = f->d_scb; d.spos0 = f->spos0; d.nsc = f->nsc;
   d.sblk0 = f->spos0 + f->n_all_edges; d.groups = f->d_groups; d.cm = f->d_cm; d.item_group = f->d_item_group;
   d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.dgroups = f->d_dgroups; d.dweight = f->d_dweight;
@@ -95,7 +95,7 @@ extern "C" int rom_fem_destroy(rom_fem* f) {
   void* ptrs[] = {f->d_A0, f->d_G, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
                   f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
                   f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred, f->d_groups, f->d_cm,
-                  f->d_item_group, f->d_item_k, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
+                  f->d_item_group, f->d_item_k, f->d_pairs, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
                   f->d_ditem_k, f->d_dmat, f->d_scb};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -692,8 +692,32 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
   slot_terms.clear();
   smalls.clear();
-  // the whole reduced solve in one wave (k_solve1) if the reduced matrix is a single tile
-  f->fused1 = T == 1 && f->desc[0].t1 - f->desc[0].t0 <= COEF_MAX && f->nGa == TB;
+  // the whole reduced solve in one wave (k_solve1) if the reduced matrix is a single tile; its assembly walks
+  // the (term, 16x16 block) pairs whose rectangle and block intersect
+  f->fused1 = T == 1 && f->desc[0].t1 - f->desc[0].t0 < COEF_MAX && f->nGa == TB;
+  std::vector<int> pairs;
+  if (f->fused1) {
+    const TileDesc& d0 = f->desc[0];
+    int q = 0;
+    for (int ib = 0; ib < 4; ++ib)
+      for (int jb = 0; jb <= ib; ++jb, ++q) {  // sorted by block: the kernel keeps a block's sum in registers
+        const size_t first = pairs.size();
+        for (int t = d0.t0; t < d0.t1; ++t) {
+          const GenTerm& g = terms[t];
+          bool any = false;  // (skip blocks where the table is all zero inside the rectangle, too)
+          for (int r = std::max<int>(g.r_lo, 16 * ib); r < std::min<int>(g.r_hi, 16 * ib + 16) && !any; ++r)
+            for (int c = std::max<int>(g.c_lo, 16 * jb); c < std::min<int>(g.c_hi, 16 * jb + 16); ++c)
+              if (pool[size_t(g.tab) * 4096 + size_t(r) * TB + c] != 0.0) { any = true; break; }
+          if (!any) continue;
+          pairs.push_back(int(size_t(g.tab) * 4096 + size_t(16 * ib) * TB + 16 * jb));
+          pairs.push_back((t - d0.t0) | (q << 8));
+        }
+        if (pairs.size() > first) pairs.back() |= 1 << 16;  // last pair of this block
+      }
+  }
+  f->npairs = int((pairs.size() / 2 + 63) / 64 * 64);
+  // no-op padding: term slot COEF_MAX - 1 is never a real term (its weight is 0), block 0 of the first table
+  while (int(pairs.size() / 2) < f->npairs + 64) { pairs.push_back(0); pairs.push_back(COEF_MAX - 1); }
 
   // ---- block sides, vmap, parameter-independent part of the reduced rhs --------------------------------------------
   std::vector<int> vmap(std::max(f->nGp, 1), -1);
@@ -919,6 +943,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   ROM_TRY(upload(&f->d_vec, vecs));
   ROM_TRY(upload(&f->d_pool, pool));
   ROM_TRY(upload(&f->d_terms, terms));
+  ROM_TRY(upload(&f->d_pairs, pairs));
   f->nrhs = int(rhs_terms.size());
   ROM_TRY(upload(&f->d_rhs, rhs_terms));
   ROM_TRY(upload(&f->d_pre, pre_edges));

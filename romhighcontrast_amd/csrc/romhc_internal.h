@@ -211,6 +211,8 @@ struct rom_fem {
   TileDesc* d_desc = nullptr;
   GenTerm* d_terms = nullptr;
   double* d_pool = nullptr;  // 64x64 tables of the tile terms
+  int* d_pairs = nullptr;    // (term, block) pairs of the single-tile assembly
+  int npairs = 0;
   int* d_kptr = nullptr;     // nslots+1
   int* d_kpair = nullptr;    // 2*entries (slotA, slotB)
   int* d_colptr = nullptr;   // T+1 : rows below the diagonal in column j
