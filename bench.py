@@ -237,10 +237,10 @@ def main():
                 "flops_per_launch": d["flops"] / d["launches"],
                 "store_bytes_per_launch": 8.0 * M * blocks[0] * blocks[1] * (N - 1) ** 2 if dom.startswith("extend") else None,
                 "note": "fp64 MFMA (v_mfma_f64_16x16x4_f64) against the spec fp64 matrix rate.  The same launch writes "
-                        "the snapshot rows (store_bytes_per_launch): with the store stream alone it takes 0.13-0.18 ms "
-                        "(tools/hbm_write_bw.hip: 3.0-4.2 TB/s for this pattern, box dependent), with the MFMAs alone 0.13 ms at the "
-                        "64 cycles per instruction the counters show (SQ_VALU_MFMA_BUSY_CYCLES); the two phases of a "
-                        "workgroup do not overlap, see DESIGN.md section 5"}
+                        "the snapshot rows (store_bytes_per_launch).  MFMAs alone: 0.11-0.13 ms (64 busy cycles per "
+                        "instruction, SQ_VALU_MFMA_BUSY_CYCLES); store stream alone: 0.13-0.18 ms (tools/hbm_write_bw.hip); "
+                        "kernel with its stores disabled: 0.198 ms -- two waves per SIMD leave the MFMA pipe about 60 % busy, "
+                        "see DESIGN.md section 5"}
     # PMC-measured memory-side traffic of the dominant kernel, if a summary of separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command is committed
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")

@@ -905,11 +905,10 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
   __shared__ __align__(16) double lds[4 * X128_STAGE];  // {A,B} x 2 buffers
   __shared__ double scs[128];                            // h^2 / a_b of the workgroup's systems
   {
-    // The MFMA phase and the store phase of a workgroup take about equally long (the stores drain at the HBM
-    // write rate) and do not overlap within it.  Two workgroups share a CU; started together they stay in
-    // lockstep -- all computing, then all storing.  The second half of the first round therefore starts one
-    // MFMA phase late (about 64 cycles per MFMA), so that from then on one workgroup of a CU computes while
-    // the other drains: measured 274 -> 245 us at 256x256 / 2x2 / 1024 systems.  Placement only affects speed.
+    // Two workgroups share a CU; started together they run in lockstep (both loading / multiplying, then both in
+    // the epilogue).  The second half of the first round starts one MFMA phase late (about 64 cycles per MFMA)
+    // so that the phases of the two interleave: measured 274 -> 245 us at 256x256 / 2x2 / 1024 systems.
+    // Placement only affects speed.
     const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     if (lin >= 256u && lin < 512u)
       for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);  // 2 x 127 x 64 cycles
