@@ -105,6 +105,9 @@ int rom_solve_status(rom_ctx* ctx);
  * of them; the expansion is deterministic, so the gathered snapshot block is bit-identical on every rank.
  * Both calls only enqueue work on the compute stream (rom_solve_status() reports a non-positive pivot). */
 int rom_fem_reduced_stride(rom_fem* fem, int64_t* stride);
+/* positions [nodal_begin, nodal_end) of an interface vector are outputs of the expansion (nodal edge values);
+ * only the rest is read by it */
+int rom_fem_reduced_layout(rom_fem* fem, int64_t* nodal_begin, int64_t* nodal_end);
 /* 1 if rom_expand_batch_async is a LINEAR map of the interface vectors (it then ignores `a`): U = Y B^T with a fixed
  * B, so Gram matrices, means and POD modes of snapshots can be formed from Y alone (every geometry whose
  * closed-form edges are all kept in compressed form, e.g. 2x2/N>=16, 3x3/N=171, 4x4/N=256). */

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "rom_solve_status": (C.c_int, [_vp]),
     "rom_fem_reduced_stride": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rom_fem_expansion_is_linear": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "rom_fem_reduced_layout": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rom_solve_reduced_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64]),
     "rom_expand_batch_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, _vp, C.c_int64]),
     "rom_solve_work": (C.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
@@ -345,6 +346,13 @@ class Fem:
         v = C.c_int(0)
         check(self.ctx.lib.rom_fem_expansion_is_linear(self.h, C.byref(v)))
         return bool(v.value)
+
+    @property
+    def reduced_inputs(self) -> np.ndarray:
+        """positions of an interface vector that the expansion reads (the nodal edge blocks are its outputs)"""
+        b, e = C.c_int64(0), C.c_int64(0)
+        check(self.ctx.lib.rom_fem_reduced_layout(self.h, C.byref(b), C.byref(e)))
+        return np.concatenate((np.arange(0, b.value), np.arange(e.value, self.reduced_stride)))
 
     def solve_reduced(self, a: Buffer, M: int, Y: Buffer, y_row0: int = 0):
         """Stage 1 of the sweep (enqueued only): interface vectors of the M systems into Y[y_row0:y_row0+M]."""

@@ -265,6 +265,15 @@ extern "C" int rom_fem_expansion_is_linear(rom_fem* f, int* flag) {
   return ROM_OK;
 }
 
+// [nodal_begin, nodal_end): the part of an interface vector that the expansion WRITES (nodal edge values) and never
+// reads; everything else is its input
+extern "C" int rom_fem_reduced_layout(rom_fem* f, int64_t* nodal_begin, int64_t* nodal_end) {
+  ROM_CHECK(f && nodal_begin && nodal_end, "rom_fem_reduced_layout: null argument");
+  *nodal_begin = f->nGa;
+  *nodal_end = f->xb0;
+  return ROM_OK;
+}
+
 extern "C" int rom_fem_reduced_stride(rom_fem* f, int64_t* stride) {
   ROM_CHECK(f && stride, "rom_fem_reduced_stride: null argument");
   *stride = f->nGp;

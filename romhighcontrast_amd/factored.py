@@ -34,14 +34,37 @@ class ExpansionMap:
         self.sm, self.fem, self.ctx = sm, fem, ctx
         self.K, self.dim = fem.reduced_stride, fem.dim
         self._ones = {}
-        K, dim = self.K, self.dim
-        eye = ctx.upload(np.eye(K))
-        Bt = ctx.alloc(K * dim)
-        self.expand_into(eye, K, Bt)
-        self.S = ctx.alloc(K * K)
-        ctx.gram(K, dim, Bt, 0, dim, self.S, 0, K)
+        # the expansion only reads part of an interface vector (not the nodal edge blocks): all algebra below
+        # runs on those Kc "input" coordinates; Sel (K x Kc, 0/1) moves between the two
+        self.inputs = fem.reduced_inputs
+        self.Kc = Kc = len(self.inputs)
+        sel = np.zeros((self.K, Kc))
+        sel[self.inputs, np.arange(Kc)] = 1.0
+        self.Sel = ctx.upload(sel)
+        Bt = self._basis_rows()
+        self.S = ctx.alloc(Kc * Kc)
+        ctx.gram(Kc, self.dim, Bt, 0, self.dim, self.S, 0, Kc)
         ctx.synchronize()
         del Bt
+
+    def _basis_rows(self):
+        """B^T restricted to the input coordinates: (Kc, dim) on the device."""
+        Bt = self.ctx.alloc(self.Kc * self.dim)
+        self.expand_compact(self.ctx.upload(np.eye(self.Kc)), self.Kc, Bt)
+        return Bt
+
+    def compact(self, Y, M):
+        """(M, Kc) input coordinates of the interface vectors Y (M, K)."""
+        Yc = self.ctx.alloc(max(M * self.Kc, 1))
+        if M:
+            self.ctx.gemm_nn(M, self.Kc, self.K, Y, 0, self.K, self.Sel, 0, self.Kc, Yc, 0, self.Kc)
+        return Yc
+
+    def expand_compact(self, Wc, n, U, row0=0):
+        """U[row0:row0+n] = expansion of n vectors given in input coordinates (n, Kc)."""
+        W = self.ctx.alloc(max(n * self.K, 1))
+        self.ctx.gemm_nt(n, self.K, self.Kc, Wc, 0, self.Kc, self.Sel, 0, self.Kc, W, 0, self.K)
+        self.expand_into(W, n, U, row0=row0)
 
     # ---- H^1_0 geometry of the snapshots in coordinates of the interface vectors ----------------------------
     def energy_coordinates(self):
@@ -51,10 +74,8 @@ class ExpansionMap:
         coordinates and beta (k') the load functional u -> u . B_total.  Built once per FE space."""
         if getattr(self, "_energy", None) is not None:
             return self._energy
-        ctx, fem, K, dim = self.ctx, self.fem, self.K, self.dim
-        eye = ctx.upload(np.eye(K))
-        Bt = ctx.alloc(K * dim)
-        self.expand_into(eye, K, Bt)
+        ctx, fem, K, dim = self.ctx, self.fem, self.Kc, self.dim
+        Bt = self._basis_rows()
         ABt = ctx.alloc(K * dim)
         Sd = ctx.alloc(K * K)
         fem.stencil_apply(Bt, K, ABt)                      # rows: A_1 B e_i
@@ -114,6 +135,13 @@ class FactoredSnapshots:
     def K(self):
         return self.map.K
 
+    @property
+    def Yc(self):
+        """(M, Kc) input coordinates of the interface vectors (what the Gram / POD / greedy algebra works on)."""
+        if getattr(self, "_Yc", None) is None:
+            self._Yc = self.map.compact(self.Y, self.M)
+        return self._Yc
+
     def rows(self, lo=0, hi=None):
         """Materialise snapshot rows [lo, hi) as a DeviceArray."""
         from .lib.SolutionsManagers import DeviceArray
@@ -134,11 +162,11 @@ class FactoredSnapshots:
 
     def gram(self):
         """U U^T as a device buffer (M x M), from Y alone."""
-        ctx, K, M = self.map.ctx, self.K, self.M
+        ctx, K, M = self.map.ctx, self.map.Kc, self.M
         T = ctx.alloc(M * K)
-        ctx.gemm_nt(M, K, K, self.Y, 0, K, self.map.S, 0, K, T, 0, K)  # T = Y S (S symmetric)
+        ctx.gemm_nt(M, K, K, self.Yc, 0, K, self.map.S, 0, K, T, 0, K)  # T = Y S (S symmetric)
         G = ctx.alloc(M * M)
-        ctx.gemm_nt(M, M, K, T, 0, K, self.Y, 0, K, G, 0, M)
+        ctx.gemm_nt(M, M, K, T, 0, K, self.Yc, 0, K, G, 0, M)
         return G
 
 
@@ -150,10 +178,10 @@ def pod_modes_factored(fs: FactoredSnapshots, n: int, center=True, passes=2):
     O(M^2 dim).  Returns (modes (n, dim) NumPy, singular values); rows follow scikit-learn's
     ``svd_flip(u_based_decision=False)`` sign convention (the PCA call at src/lib/ReducedBasis.py:196)."""
     from .lib.ReducedBasis import _top_eigenpairs_device
-    em, M, K = fs.map, fs.M, fs.K
+    em, M, K = fs.map, fs.M, fs.map.Kc
     ctx, dim = em.ctx, em.dim
     n = min(n, M, dim)
-    Yc = ctx.alloc(M * K).copy_from(fs.Y, M * K)
+    Yc = ctx.alloc(M * K).copy_from(fs.Yc, M * K)
     if center:
         ctx.center_rows(Yc, M, K, ctx.alloc(K))
     S_host = em.S.download(K * K, shape=(K, K))
@@ -199,7 +227,7 @@ def pod_modes_factored(fs: FactoredSnapshots, n: int, center=True, passes=2):
     comps = np.zeros((n, dim))
     if found:
         V = ctx.alloc(found * dim)
-        em.expand_into(ctx.upload(Wm), found, V)
+        em.expand_compact(ctx.upload(Wm), found, V)
         comps[:found] = V.download(found * dim, shape=(found, dim))
     piv = np.argmax(np.abs(comps), axis=1)
     signs = np.sign(comps[np.arange(n), piv])
@@ -211,9 +239,9 @@ def energy_coordinates_of(fs: FactoredSnapshots):
     """Xi (device, (M, k')): the snapshots of ``fs`` in coordinates in which the H^1_0 inner product is Euclidean."""
     em = fs.map
     E, _, _ = em.energy_coordinates()
-    ctx, M, K, kp = em.ctx, fs.M, fs.K, E.shape[1]
+    ctx, M, K, kp = em.ctx, fs.M, em.Kc, E.shape[1]
     Xi = ctx.alloc(max(M * kp, 1))
-    ctx.gemm_nn(M, kp, K, fs.Y, 0, K, ctx.upload(E), 0, kp, Xi, 0, kp)
+    ctx.gemm_nn(M, kp, K, fs.Yc, 0, K, ctx.upload(E), 0, kp, Xi, 0, kp)
     return Xi, kp
 
 

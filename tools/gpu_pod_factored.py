@@ -6,9 +6,10 @@ from romhighcontrast_amd import factored
 from romhighcontrast_amd.lib import SolutionsManagers as SM, ReducedBasis as RB
 
 M = int(os.environ.get("M", "4096"))
-sm = SM.SolutionsManagerFEM((2, 2), 128)
+nb, N = int(os.environ.get("NB", "2")), int(os.environ.get("N", "128"))  # C2/C3: NB=2 N=128; C5: NB=4 N=256
+sm = SM.SolutionsManagerFEM((nb, nb), N)
 fem, ctx = sm._fem, sm._ctx
-a = 10.0 ** np.random.default_rng(20240807).uniform(0, 2, size=(M, 4))
+a = 10.0 ** np.random.default_rng(20240807).uniform(0, 2 if nb == 2 else 3, size=(M, nb * nb))
 ad = ctx.upload(a)
 K = fem.reduced_stride
 t0 = time.perf_counter()
