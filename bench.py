@@ -296,6 +296,25 @@ def main():
                       "note": "centre + Gram on MFMA (lower tiles) + device subspace iteration + lift, with one "
                               "deflation pass for the modes below the Gram noise floor; F_pod = 2 M^2 D + 2 r M D "
                               "+ 10 M^3 (SURVEY 8d) over the wall time incl. the download of the r modes"}
+        if fem.expansion_is_linear:
+            # the same figure on the block held in factored form (interface vectors; no row is read)
+            from romhighcontrast_amd import factored
+            Yf = ctx.alloc(M * fem.reduced_stride)
+            fem.solve_reduced(a_dev, M, Yf)
+            ctx.solve_status()
+            fs = factored.FactoredSnapshots(sm, Yf, M)
+            dtf = 1e9
+            for _ in range(2):
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                comps_f, sig_f = factored.pod_modes_factored(fs, r)
+                ctx.synchronize()
+                dtf = min(dtf, time.perf_counter() - t0)
+            out["pod_factored"] = {"gflops": round(f_pod / dtf * 1e-9, 1), "seconds": round(dtf, 4), "modes": r,
+                                   "sigma_1_rel_diff": float(abs(sig_f[0] / sig[0] - 1)),
+                                   "note": "POD of the same block from its interface vectors (U = Y B^T, Gram = Y (B^T B) Y^T, "
+                                           "romhighcontrast_amd/factored.py); same F_pod accounting, i.e. the flops of "
+                                           "the row-based algorithm over this algorithm's wall time"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blocks, N, a_loc)
     if comm:
