@@ -211,10 +211,20 @@ __device__ inline void load4_any(const double* __restrict__ p, double v[4]) {
 // Edge values of the active edges from the reduced solution, u_f = P_f z_f + p0_f / s_f, as one batched
 // MFMA GEMM (tile rows = systems, tile cols = nodes of f, K = compressed index); closed-form edges kept in
 // compressed form enter the same way with z = c_e / s_e, P = K^-1 W_e, p0 = K^-1 g_e.  The values go to the
-// snapshot rows directly (and to the nodal blocks of the interface vector).   grid (n1p/64, ceil(Mc/64), nexp)
+// snapshot rows directly (and to the nodal blocks of the interface vector).   grid (n1p/64, ceil(Mc/64), nexp [+ 1])
 __global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U,
                                                 long long row0) {
   __shared__ __align__(16) double lds[STAGE_TOTAL];
+  if (int(blockIdx.z) == f.nexp) {
+    // extra slice of the grid: interface values that need no expansion (cross points; with fold_scatter also
+    // whatever k_scatter_interface would copy) go straight from the interface vector to the snapshot rows
+    if (blockIdx.x != 0) return;
+    for (int idx = threadIdx.x; idx < 64 * f.nscat; idx += blockDim.x) {
+      const int m = blockIdx.y * 64 + idx / f.nscat, v = f.scat[idx % f.nscat];
+      if (m < Mc) U[(row0 + m) * f.dim + f.vmap[v]] = f.y[size_t(m) * f.nGp + v];
+    }
+    return;
+  }
   const WavePos wp;
   const ExpEdge ee = f.exp[blockIdx.z];
   const int srow = stage_row(), sseg = stage_seg();

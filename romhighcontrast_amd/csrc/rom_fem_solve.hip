@@ -141,9 +141,12 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
     return ROM_OK;
   }
   if (f->nGp > 0) {
+    // the copy of the unexpanded interface values rides in an extra grid slice of k_expand when nothing later in
+    // the sequence produces them (no edge recovered node by node)
+    const bool fold_scatter = f->nexp > 0 && f->npre == 0 && f->nscat > 0;
     if (f->nexp > 0) {
       ROM_PROF(ctx, "expand", Mc * 2.0 * f->n1p * 32.0 * f->nexp, 8.0 * Mc * f->n1p * f->nexp);
-      k_expand<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->nexp), 256, 0, st>>>(d, am, Mc, U, row);
+      k_expand<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->nexp + (fold_scatter ? 1 : 0)), 256, 0, st>>>(d, am, Mc, U, row);
     }
     if (f->npre > 0) {
       ROM_PROF(ctx, "back_pre", Mc * 2.0 * f->n1p * double(f->n1p) * 3.0 * f->npre, 8.0 * Mc * f->n1p * 4.0 * f->npre);
@@ -176,7 +179,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         }
       }
     }
-    if (f->nscat > 0) {
+    if (f->nscat > 0 && !(f->nexp > 0 && f->npre == 0)) {
       ROM_PROF(ctx, "scatter_interface", 0, 16.0 * Mc * f->nscat);
       k_scatter_interface<<<dim3((f->nscat + 255) / 256, Mc), 256, 0, st>>>(d, Mc, U, row);
     }
