@@ -49,6 +49,7 @@ struct FemDev {
   const int* colrow;
   const int* colti;
   const BlockSide* sides;
+  int n_lr;               // blocks in lr_blocks
   const int* lr_blocks;   // blocks whose sides are all compressed: extended in mesh-row tiles
   const int* gen_blocks;  // all others: 4 x 16 patches
   const int* vmap;
@@ -93,6 +94,6 @@ __global__ void k_factor_panel(FemDev f, const double* __restrict__ a, int j, in
 __global__ void k_backsolve(FemDev f);
 __global__ void k_edge_transform(FemDev f, int Mc);
 __global__ void k_extend(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, const int* __restrict__ blocks, int pw_log2);
-__global__ void k_extend128(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0);
+__global__ void k_extend128(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, int with_expand);
 __global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0);
 __global__ void k_assemble_stencil(FemDev f, const double* __restrict__ a, int M, double* __restrict__ diag, double* __restrict__ east, double* __restrict__ north);

@@ -212,25 +212,24 @@ __device__ inline void load4_any(const double* __restrict__ p, double v[4]) {
 // MFMA GEMM (tile rows = systems, tile cols = nodes of f, K = compressed index); closed-form edges kept in
 // compressed form enter the same way with z = c_e / s_e, P = K^-1 W_e, p0 = K^-1 g_e.  The values go to the
 // snapshot rows directly (and to the nodal blocks of the interface vector).   grid (n1p/64, ceil(Mc/64), nexp [+ 1])
-__global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U,
-                                                long long row0) {
-  __shared__ __align__(16) double lds[STAGE_TOTAL];
-  if (int(blockIdx.z) == f.nexp) {
-    // extra slice of the grid: interface values that need no expansion (cross points; with fold_scatter also
-    // whatever k_scatter_interface would copy) go straight from the interface vector to the snapshot rows
-    if (blockIdx.x != 0) return;
+// one workgroup of the expansion: (64 nodes bx) x (64 systems by) of edge bz; bz == nexp: the slice that copies
+// the interface values that need no expansion (cross points) from the interface vector to the snapshot rows
+__device__ inline void expand_tile(const FemDev& f, int Mc, double* __restrict__ U, long long row0, double* lds,
+                                   int bx, int by, int bz) {
+  if (bz == f.nexp) {
+    if (bx != 0) return;
     for (int idx = threadIdx.x; idx < 64 * f.nscat; idx += blockDim.x) {
-      const int m = blockIdx.y * 64 + idx / f.nscat, v = f.scat[idx % f.nscat];
+      const int m = by * 64 + idx / f.nscat, v = f.scat[idx % f.nscat];
       if (m < Mc) U[(row0 + m) * f.dim + f.vmap[v]] = f.y[size_t(m) * f.nGp + v];
     }
     return;
   }
   const WavePos wp;
-  const ExpEdge ee = f.exp[blockIdx.z];
+  const ExpEdge ee = f.exp[bz];
   const int srow = stage_row(), sseg = stage_seg();
-  const int mA = blockIdx.y * 64 + srow;
+  const int mA = by * 64 + srow;
   const double* pA = mA < Mc ? f.y + size_t(mA) * f.nGp + ee.zpos + sseg : nullptr;
-  const double* pB = f.P + (size_t(ee.ptab) * f.n1p + blockIdx.x * 64 + srow) * f.n1p + sseg;
+  const double* pB = f.P + (size_t(ee.ptab) * f.n1p + bx * 64 + srow) * f.n1p + sseg;
   Acc acc;
   acc_zero(acc);
   gemm_loop(
@@ -240,17 +239,23 @@ __global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restri
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int m = blockIdx.y * 64 + acc_row(wp, i, g);
+      const int m = by * 64 + acc_row(wp, i, g);
       if (m >= Mc) continue;
       const double inv = f.y[size_t(m) * f.nGp + ee.spos];  // 1 / (a_b0 + a_b1), from the scalar block
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
-        const int node = blockIdx.x * 64 + acc_col(wp, jb);
+        const int node = bx * 64 + acc_col(wp, jb);
         const double v = node < f.n1 ? acc.c[i][jb][g] + f.vec[ee.p0off + node] * inv : 0.0;
         f.y[size_t(m) * f.nGp + ee.npos + node] = v;  // (read again by the node-by-node paths, if any)
         if (node < f.n1) U[(row0 + m) * f.dim + f.vmap[ee.npos + node]] = v;
       }
     }
+}
+
+__global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U,
+                                                long long row0) {
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  expand_tile(f, Mc, U, row0, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Back substitution of the closed-form edges: x_e = (w_e + sum_u B_ue^T (c_u . x_u)) / s_e as one batched
@@ -911,23 +916,33 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
 constexpr int X128_STAGE = 128 * LDK;
 
 __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __restrict__ a, int Mc,
-                                                      double* __restrict__ U, long long row0) {
+                                                      double* __restrict__ U, long long row0, int with_expand) {
   __shared__ __align__(16) double lds[4 * X128_STAGE];  // {A,B} x 2 buffers
   __shared__ double scs[128];                            // h^2 / a_b of the workgroup's systems
+  const int n1 = f.n1, N = f.N;
+  const int nct = (n1 + 127) / 128;
+  if (int(blockIdx.x) >= n1 * nct) {
+    // with_expand: the (small) expansion of the edge values rides in `with_expand` extra workgroups per (y, z) cell
+    // of this launch -- it depends on nothing here and nothing here depends on it
+    static_assert(STAGE_TOTAL <= 4 * X128_STAGE, "expansion staging must fit");
+    const int nx = f.n1p / 64, ny = (Mc + 63) / 64;
+    const int item = (blockIdx.x - n1 * nct) + with_expand * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (item < nx * ny * (f.nexp + 1)) expand_tile(f, Mc, U, row0, lds, item % nx, (item / nx) % ny, item / (nx * ny));
+    return;
+  }
+  const int bz = blockIdx.z;
   {
     // Two workgroups share a CU; started together they run in lockstep (both loading / multiplying, then both in
     // the epilogue).  The second half of the first round starts one MFMA phase late (about 64 cycles per MFMA)
     // so that the phases of the two interleave: measured 274 -> 245 us at 256x256 / 2x2 / 1024 systems.
     // Placement only affects speed.
-    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * bz);
     if (lin >= 256u && lin < 512u)
       for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);  // 2 x 127 x 64 cycles
   }
-  const int b = f.lr_blocks[blockIdx.z];
+  const int b = f.lr_blocks[bz];
   const int p = b / f.ncb, q = b % f.ncb;
-  const int n1 = f.n1, N = f.N;
   const BlockSide& sd = f.sides[b];
-  const int nct = (n1 + 127) / 128;
   const int iv = blockIdx.x / nct + 1;           // mesh row (1-based interior index)
   const int jv0 = 128 * (blockIdx.x % nct) + 1;  // first vertex of the tile
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;

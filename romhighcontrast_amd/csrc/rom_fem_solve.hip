@@ -140,11 +140,15 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
     ROM_HIP(hipGetLastError());
     return ROM_OK;
   }
+  // the copy of the unexpanded interface values rides in an extra grid slice of k_expand when nothing later in
+  // the sequence produces them (no edge recovered node by node) ...
+  const bool fold_scatter = f->nexp > 0 && f->npre == 0 && f->nscat > 0;
+  // ... and the whole expansion rides in the extension launch when that is one k_extend128 over all blocks
+  const bool wide = f->n1 >= 96 && Mc >= 128 && !getenv("ROMHC_NO_EXT128");
+  const bool fold_expand = f->nexp > 0 && f->npre == 0 && f->n_edges == 0 && f->n_gen_blocks == 0 && f->n_lr_blocks > 0 &&
+                           wide && !getenv("ROMHC_NO_FOLD_EXPAND");
   if (f->nGp > 0) {
-    // the copy of the unexpanded interface values rides in an extra grid slice of k_expand when nothing later in
-    // the sequence produces them (no edge recovered node by node)
-    const bool fold_scatter = f->nexp > 0 && f->npre == 0 && f->nscat > 0;
-    if (f->nexp > 0) {
+    if (f->nexp > 0 && !fold_expand) {
       ROM_PROF(ctx, "expand", Mc * 2.0 * f->n1p * 32.0 * f->nexp, 8.0 * Mc * f->n1p * f->nexp);
       k_expand<<<dim3(f->n1p / 64, (Mc + 63) / 64, f->nexp + (fold_scatter ? 1 : 0)), 256, 0, st>>>(d, am, Mc, U, row);
     }
@@ -168,11 +172,13 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.gen_blocks, 4);
       }
       if (f->n_lr_blocks > 0) {
-        const bool no128 = getenv("ROMHC_NO_EXT128") != nullptr;
         ROM_PROF(ctx, "extend_lr", fl_ext * f->n_lr_blocks, 8.0 * Mc * double(f->n_lr_blocks) * nij);
-        if (f->n1 >= 96 && Mc >= 128 && !no128) {  // wide tiles need enough vertices per mesh row and systems to fill them
-          dim3 grid(f->n1 * ((f->n1 + 127) / 128), (Mc + 127) / 128, f->n_lr_blocks);
-          k_extend128<<<grid, 256, 0, st>>>(d, am, Mc, U, row);
+        if (wide) {  // wide tiles need enough vertices per mesh row and systems to fill them
+          const int mt = (Mc + 127) / 128;
+          const int items = (f->n1p / 64) * ((Mc + 63) / 64) * (f->nexp + 1);  // workgroups of the folded expansion
+          const int extra = fold_expand ? (items + mt * f->n_lr_blocks - 1) / (mt * f->n_lr_blocks) : 0;
+          dim3 grid(f->n1 * ((f->n1 + 127) / 128) + extra, mt, f->n_lr_blocks);
+          k_extend128<<<grid, 256, 0, st>>>(d, am, Mc, U, row, extra);
         } else {
           dim3 grid(f->n1 * ((f->n1 + 63) / 64), (Mc + 63) / 64, f->n_lr_blocks);
           k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.lr_blocks, 6);
