@@ -63,6 +63,150 @@ struct Comp {
   std::vector<ld> wK;  // n1       K^-1 g_f
 };
 
+// Closed-form tables of one unit block (N x N cells, Dirichlet 5-point Laplacian L) in long double, from the sine
+// eigenbasis:  Q[j][m] = sqrt(2/N) sin(pi j m / N),  lam_m = 2 - 2 cos(pi m / N),
+// rho_m(i) = sinh((N-i) phi_m) / sinh(N phi_m) with cosh phi_m = 1 + lam_m / 2.
+struct UnitBlock {
+  int N, n1;
+  Mat Q, rho;                  // rho(m, i), i = 0..N
+  std::vector<ld> lam, kappa;  // kappa_m = 1 + lam_m/2 - rho_m(1): K = tridiag(-1/2, 2, -1/2) - T_same = Q diag(kappa) Q
+  Mat Wl;                      // L^-1 1
+  Mat Kmat, Kinv;
+  std::vector<ld> gE[2];       // interface rhs of a horizontal / vertical edge: h^2 (1 + W on the two adjacent lines)
+  std::vector<double> rho_d, Wd;
+
+  UnitBlock(int N_, bool with_edges) : N(N_), n1(N_ - 1), Q(n1, n1), rho(n1, N_ + 1), lam(n1), kappa(n1), Wl(n1, n1) {
+    const ld PI = acosl(-1.0L);
+    for (int j = 1; j <= n1; ++j) {
+      lam[j - 1] = 2.0L - 2.0L * cosl(PI * j / N);
+      for (int m = 1; m <= n1; ++m) Q(j - 1, m - 1) = sqrtl(2.0L / N) * sinl(PI * j * m / (ld)N);
+    }
+    for (int m = 0; m < n1; ++m) {
+      const ld phi = acoshl(1.0L + lam[m] / 2.0L);
+      const ld den = -expm1l(-2.0L * N * phi);  // 1 - exp(-2 N phi)
+      for (int i = 0; i <= N; ++i) rho(m, i) = expl(-phi * i) * (-expm1l(-2.0L * (N - i) * phi)) / den;
+      kappa[m] = 1.0L + lam[m] / 2.0L - rho(m, 1);
+    }
+    rho_d.resize(rho.v.size());
+    for (size_t i = 0; i < rho.v.size(); ++i) rho_d[i] = double(rho.v[i]);
+    {  // W = L^{-1} 1 = Q (s s^T / (lam_l + lam_m)) Q
+      std::vector<ld> sv(n1, 0.0L);
+      Mat Z(n1, n1);
+      for (int m = 0; m < n1; ++m)
+        for (int j = 0; j < n1; ++j) sv[m] += Q(j, m);
+      for (int l = 0; l < n1; ++l)
+        for (int m = 0; m < n1; ++m) Z(l, m) = sv[l] * sv[m] / (lam[l] + lam[m]);
+      Wl = hostla::mul(Q, hostla::mul_nt(Z, Q));
+      Wd.resize(size_t(n1) * n1);
+      for (size_t i = 0; i < Wd.size(); ++i) Wd[i] = double(Wl.v[i]);
+    }
+    const ld h2 = 1.0L / ((ld)N * (ld)N);
+    for (int hv = 0; hv < 2; ++hv) {
+      gE[hv].resize(n1);
+      for (int t = 0; t < n1; ++t)
+        gE[hv][t] = h2 * (1.0L + (hv == 0 ? Wl(N - 2, t) + Wl(0, t) : Wl(t, N - 2) + Wl(t, 0)));
+    }
+    Kmat = Mat(n1, n1);
+    Kinv = Mat(n1, n1);
+    if (with_edges) {
+      Mat QK(n1, n1), QKi(n1, n1);
+      for (int j = 0; j < n1; ++j)
+        for (int m = 0; m < n1; ++m) {
+          QK(j, m) = Q(j, m) * kappa[m];
+          QKi(j, m) = Q(j, m) / kappa[m];
+        }
+      Kmat = hostla::mul_nt(QK, Q);
+      Kinv = hostla::mul_nt(QKi, Q);
+    }
+  }
+
+  // Dirichlet-to-Neumann table T[sr*4+sc][t][k] = H_sc[interior vertex next to node t of side sr][k] (first use builds it)
+  const Mat& Tm(int id) {
+    if (!haveT[id]) {
+      const int sr = id >> 2, sc = id & 3;
+      Mat V(n1, n1);
+      for (int t = 0; t < n1; ++t) {
+        int i, j;
+        switch (sr) {
+          case 0: i = 1; j = t + 1; break;
+          case 1: i = N - 1; j = t + 1; break;
+          case 2: i = t + 1; j = 1; break;
+          default: i = t + 1; j = N - 1; break;
+        }
+        const int hr = h0_row(sc, i, j, N, n1);
+        const int ii = hr / n1 + 1, jj = hr % n1 + 1;
+        for (int m = 0; m < n1; ++m) V(t, m) = Q(jj - 1, m) * rho(m, ii);
+      }
+      Tm_[id] = hostla::mul_nt(V, Q);
+      haveT[id] = 1;
+    }
+    return Tm_[id];
+  }
+  // ... and its product with K^-1
+  const Mat& TK(int id) {
+    if (!haveTK[id]) {
+      TK_[id] = hostla::mul(Tm(id), Kinv);
+      haveTK[id] = 1;
+    }
+    return TK_[id];
+  }
+
+ private:
+  std::array<Mat, 16> Tm_, TK_;
+  std::array<char, 16> haveT{}, haveTK{};
+};
+
+// Compressed form of an edge whose couplings act through the tables `tabs` (ids sr*4+sc) and, if x0 / x1, through
+// its first / last node (cross points): W = orthonormal basis of the union of their ranges (tolerance `ctol` of the
+// first pivot); full rank or !compress: nodal unknowns (W = I).  False if the compressed self block is not SPD.
+bool compress_edge(UnitBlock& ub, const std::vector<int>& tabs, bool x0, bool x1, int hv, bool compress, ld ctol, Comp& cp) {
+  const int n1 = ub.n1;
+  Mat Wb;
+  if (compress) {
+    const int ntab = int(tabs.size());
+    Mat C(n1, ntab * n1 + 2);
+    for (int t = 0; t < ntab; ++t) {
+      const Mat& Tt = ub.Tm(tabs[t]);
+      ld mx = 0;
+      for (ld v : Tt.v) mx = std::max(mx, fabsl(v));
+      if (mx == 0.0L) mx = 1.0L;
+      for (int i = 0; i < n1; ++i)
+        for (int k = 0; k < n1; ++k) C(i, t * n1 + k) = Tt(i, k) / mx;
+    }
+    if (x0) C(0, ntab * n1) = 1.0L;
+    if (x1) C(n1 - 1, ntab * n1 + 1) = 1.0L;
+    Wb = hostla::range_basis(C, ctol);
+  }
+  if (!compress || Wb.c >= n1) {  // nothing to gain: nodal unknowns
+    cp.r = n1;
+    cp.W = hostla::identity(n1);
+    cp.Kt = ub.Kmat;
+    cp.P = hostla::identity(n1);
+    cp.gt = ub.gE[hv];
+    cp.p0.assign(n1, 0.0L);
+    cp.KiW = ub.Kinv;
+    cp.wK = hostla::matvec(ub.Kinv, ub.gE[hv]);
+    return true;
+  }
+  cp.r = Wb.c;
+  cp.W = Wb;
+  Mat KiW = hostla::mul(ub.Kinv, Wb);
+  Mat G = hostla::mul_tn(Wb, KiW);
+  for (int i = 0; i < G.r; ++i)
+    for (int j = 0; j < i; ++j) G(i, j) = G(j, i) = (G(i, j) + G(j, i)) / 2;
+  if (!hostla::spd_inverse(G, cp.Kt)) return false;
+  cp.P = hostla::mul(KiW, cp.Kt);
+  std::vector<ld> v = hostla::matvec(ub.Kinv, ub.gE[hv]);
+  std::vector<ld> wv = hostla::matvec(hostla::transpose(Wb), v);
+  cp.gt = hostla::matvec(cp.Kt, wv);
+  std::vector<ld> pw = hostla::matvec(cp.P, wv);
+  cp.p0.resize(n1);
+  for (int i = 0; i < n1; ++i) cp.p0[i] = v[i] - pw[i];
+  cp.KiW = KiW;
+  cp.wK = v;
+  return true;
+}
+
 struct TermAcc {
   std::array<int, 5> key;
   std::vector<double> tab;
@@ -232,93 +376,20 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     }
   }
 
-  // ---- unit-block tables in long double ----------------------------------------------------------------
-  const ld PI = acosl(-1.0L);
-  Mat Q(n1, n1), rho(n1, N + 1);
-  std::vector<ld> lam(n1), kappa(n1);
-  for (int j = 1; j <= n1; ++j) {
-    lam[j - 1] = 2.0L - 2.0L * cosl(PI * j / N);
-    for (int m = 1; m <= n1; ++m) Q(j - 1, m - 1) = sqrtl(2.0L / N) * sinl(PI * j * m / (ld)N);
-  }
-  for (int m = 0; m < n1; ++m) {
-    ld phi = acoshl(1.0L + lam[m] / 2.0L);
-    ld den = -expm1l(-2.0L * N * phi);  // 1 - exp(-2 N phi)
-    for (int i = 0; i <= N; ++i) rho(m, i) = expl(-phi * i) * (-expm1l(-2.0L * (N - i) * phi)) / den;
-    kappa[m] = 1.0L + lam[m] / 2.0L - rho(m, 1);
-  }
-  std::vector<double> rho_d(rho.v.size());
-  for (size_t i = 0; i < rho.v.size(); ++i) rho_d[i] = double(rho.v[i]);
-  // W = L^{-1} 1 = Q (s s^T / (lam_l + lam_m)) Q
-  std::vector<double> Wd(size_t(n1) * n1);
-  Mat Wl(n1, n1);
-  {
-    std::vector<ld> sv(n1, 0.0L);
-    Mat Z(n1, n1);
-    for (int m = 0; m < n1; ++m)
-      for (int j = 0; j < n1; ++j) sv[m] += Q(j, m);
-    for (int l = 0; l < n1; ++l)
-      for (int m = 0; m < n1; ++m) Z(l, m) = sv[l] * sv[m] / (lam[l] + lam[m]);
-    Wl = hostla::mul(Q, hostla::mul_nt(Z, Q));
-    for (size_t i = 0; i < Wd.size(); ++i) Wd[i] = double(Wl.v[i]);
-  }
+  // ---- unit-block tables in long double, compression of the edges --------------------------------------------
+  UnitBlock ub(N, E > 0);
+  const Mat& Q = ub.Q;
+  const Mat& Kinv = ub.Kinv;
+  const std::vector<ld>* gE = ub.gE;
+  const std::vector<double>& rho_d = ub.rho_d;
+  const std::vector<double>& Wd = ub.Wd;
   const double h2 = 1.0 / (double(N) * double(N));
-  // interface rhs of an edge: h^2 (1 + W at the two adjacent interior lines), by orientation
-  std::vector<ld> gE[2];
-  for (int hv = 0; hv < 2; ++hv) {
-    gE[hv].resize(n1);
-    for (int t = 0; t < n1; ++t)
-      gE[hv][t] = (ld)h2 * (1.0L + (hv == 0 ? Wl(N - 2, t) + Wl(0, t) : Wl(t, N - 2) + Wl(t, 0)));
-  }
-  // K = tridiag(-1/2, 2, -1/2) - T_same = Q diag(kappa) Q, kappa_m = 1 + lam_m/2 - rho_m(1)
-  Mat Kmat(n1, n1), Kinv(n1, n1);
-  if (E > 0) {
-    Mat QK(n1, n1), QKi(n1, n1);
-    for (int j = 0; j < n1; ++j)
-      for (int m = 0; m < n1; ++m) {
-        QK(j, m) = Q(j, m) * kappa[m];
-        QKi(j, m) = Q(j, m) / kappa[m];
-      }
-    Kmat = hostla::mul_nt(QK, Q);
-    Kinv = hostla::mul_nt(QKi, Q);
-  }
-  // Dirichlet-to-Neumann tables T[sr*4+sc][t][k] = H_sc[interior vertex next to node t of side sr][k]
-  // and their products with K^-1, built on first use
-  std::array<Mat, 16> Tm_, TK_;
-  std::array<char, 16> haveT{}, haveTK{};
-  auto Tm = [&](int id) -> const Mat& {
-    if (!haveT[id]) {
-      const int sr = id >> 2, sc = id & 3;
-      Mat V(n1, n1);
-      for (int t = 0; t < n1; ++t) {
-        int i, j;
-        switch (sr) {
-          case 0: i = 1; j = t + 1; break;
-          case 1: i = N - 1; j = t + 1; break;
-          case 2: i = t + 1; j = 1; break;
-          default: i = t + 1; j = N - 1; break;
-        }
-        const int hr = h0_row(sc, i, j, N, n1);
-        const int ii = hr / n1 + 1, jj = hr % n1 + 1;
-        for (int m = 0; m < n1; ++m) V(t, m) = Q(jj - 1, m) * rho(m, ii);
-      }
-      Tm_[id] = hostla::mul_nt(V, Q);
-      haveT[id] = 1;
-    }
-    return Tm_[id];
-  };
-  auto TK = [&](int id) -> const Mat& {
-    if (!haveTK[id]) {
-      TK_[id] = hostla::mul(Tm(id), Kinv);
-      haveTK[id] = 1;
-    }
-    return TK_[id];
-  };
-
-  // ---- compression of the edges (shared by all edges with the same surroundings) -------------------------------
+  auto Tm = [&](int id) -> const Mat& { return ub.Tm(id); };
+  auto TK = [&](int id) -> const Mat& { return ub.TK(id); };
   const bool compress = !getenv("ROMHC_NO_COMPRESS");
   ld ctol = 1e-17L;
   if (const char* s = getenv("ROMHC_COMPRESS_TOL")) ctol = (ld)atof(s);
-  std::map<std::vector<int>, int> sig_id;
+  std::map<std::vector<int>, int> sig_id;  // edges with the same surroundings share one compressed form
   std::vector<Comp> comps;
   std::vector<int> comp_of(E, -1);
   for (int e = 0; e < E; ++e) {
@@ -336,54 +407,14 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     auto it = sig_id.find(sig);
     if (it != sig_id.end()) { comp_of[e] = it->second; continue; }
     Comp cp;
-    Mat Wb;
-    if (compress) {
-      const int ntab = int(sig.size()) - 2;
-      Mat C(n1, ntab * n1 + 2);
-      for (int t = 0; t < ntab; ++t) {
-        const Mat& Tt = Tm(sig[1 + t]);
-        ld mx = 0;
-        for (ld v : Tt.v) mx = std::max(mx, fabsl(v));
-        if (mx == 0.0L) mx = 1.0L;
-        for (int i = 0; i < n1; ++i)
-          for (int k = 0; k < n1; ++k) C(i, t * n1 + k) = Tt(i, k) / mx;
-      }
-      if (x0) C(0, ntab * n1) = 1.0L;
-      if (x1) C(n1 - 1, ntab * n1 + 1) = 1.0L;
-      Wb = hostla::range_basis(C, ctol);
-    }
-    if (!compress || Wb.c >= n1) {  // nothing to gain: nodal unknowns
-      cp.r = n1;
-      cp.W = hostla::identity(n1);
-      cp.Kt = Kmat;
-      cp.P = hostla::identity(n1);
-      cp.gt = gE[ed.hv];
-      cp.p0.assign(n1, 0.0L);
-      cp.KiW = Kinv;
-      cp.wK = hostla::matvec(Kinv, gE[ed.hv]);
-    } else {
-      cp.r = Wb.c;
-      cp.W = Wb;
-      Mat KiW = hostla::mul(Kinv, Wb);
-      Mat G = hostla::mul_tn(Wb, KiW);
-      for (int i = 0; i < G.r; ++i)
-        for (int j = 0; j < i; ++j) G(i, j) = G(j, i) = (G(i, j) + G(j, i)) / 2;
-      if (!hostla::spd_inverse(G, cp.Kt)) { rom_set_error("internal: compressed edge block not positive definite"); return ROM_ERR_INVALID; }
-      cp.P = hostla::mul(KiW, cp.Kt);
-      std::vector<ld> v = hostla::matvec(Kinv, gE[ed.hv]);
-      std::vector<ld> wv = hostla::matvec(hostla::transpose(Wb), v);
-      cp.gt = hostla::matvec(cp.Kt, wv);
-      std::vector<ld> pw = hostla::matvec(cp.P, wv);
-      cp.p0.resize(n1);
-      for (int i = 0; i < n1; ++i) cp.p0[i] = v[i] - pw[i];
-      cp.KiW = KiW;
-      cp.wK = v;
+    if (!compress_edge(ub, std::vector<int>(sig.begin() + 1, sig.end() - 1), x0, x1, ed.hv, compress, ctol, cp)) {
+      rom_set_error("internal: compressed edge block not positive definite");
+      return ROM_ERR_INVALID;
     }
     comp_of[e] = int(comps.size());
     sig_id[sig] = comp_of[e];
     comps.push_back(std::move(cp));
   }
-
 
   // kmax[d]: sine modes with rho_mode(d) >= 1e-18 (rounded up to the K chunk): what the extension needs at
   // distance d from a side.  A compressed edge enters the extension through its reduced unknowns instead
