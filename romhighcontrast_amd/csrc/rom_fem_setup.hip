@@ -7,7 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <set>
+#include <thread>
 
 #include "rom_fem_dev.h"
 #include "rom_hostla.h"
@@ -63,6 +65,21 @@ struct Comp {
   std::vector<ld> wK;  // n1       K^-1 g_f
 };
 
+// run fn(0) ... fn(n-1) on up to hardware_concurrency host threads (the long-double table products are
+// independent of each other and dominate rom_fem_create)
+template <class F>
+void parallel_for(size_t n, F fn) {
+  const unsigned nthr = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), unsigned(n)));
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for (size_t i = next++; i < n; i = next++) fn(i);
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+}
+
 // Closed-form tables of one unit block (N x N cells, Dirichlet 5-point Laplacian L) in long double, from the sine
 // eigenbasis:  Q[j][m] = sqrt(2/N) sin(pi j m / N),  lam_m = 2 - 2 cos(pi m / N),
 // rho_m(i) = sinh((N-i) phi_m) / sinh(N phi_m) with cosh phi_m = 1 + lam_m / 2.
@@ -96,32 +113,53 @@ struct UnitBlock {
         for (int j = 0; j < n1; ++j) sv[m] += Q(j, m);
       for (int l = 0; l < n1; ++l)
         for (int m = 0; m < n1; ++m) Z(l, m) = sv[l] * sv[m] / (lam[l] + lam[m]);
-      Wl = hostla::mul(Q, hostla::mul_nt(Z, Q));
-      Wd.resize(size_t(n1) * n1);
-      for (size_t i = 0; i < Wd.size(); ++i) Wd[i] = double(Wl.v[i]);
+      Zs = Z;
     }
+    Kmat = Mat(n1, n1);
+    Kinv = Mat(n1, n1);
+    Mat QK(n1, n1), QKi(n1, n1);
+    for (int j = 0; j < n1; ++j)
+      for (int m = 0; m < n1; ++m) {
+        QK(j, m) = Q(j, m) * kappa[m];
+        QKi(j, m) = Q(j, m) / kappa[m];
+      }
+    parallel_for(with_edges ? 3 : 1, [&](size_t i) {
+      if (i == 0) Wl = hostla::mul(Q, hostla::mul_nt(Zs, Q));
+      else if (i == 1) Kmat = hostla::mul_nt(QK, Q);
+      else Kinv = hostla::mul_nt(QKi, Q);
+    });
+    Wd.resize(size_t(n1) * n1);
+    for (size_t i = 0; i < Wd.size(); ++i) Wd[i] = double(Wl.v[i]);
     const ld h2 = 1.0L / ((ld)N * (ld)N);
     for (int hv = 0; hv < 2; ++hv) {
       gE[hv].resize(n1);
       for (int t = 0; t < n1; ++t)
         gE[hv][t] = h2 * (1.0L + (hv == 0 ? Wl(N - 2, t) + Wl(0, t) : Wl(t, N - 2) + Wl(t, 0)));
     }
-    Kmat = Mat(n1, n1);
-    Kinv = Mat(n1, n1);
-    if (with_edges) {
-      Mat QK(n1, n1), QKi(n1, n1);
-      for (int j = 0; j < n1; ++j)
-        for (int m = 0; m < n1; ++m) {
-          QK(j, m) = Q(j, m) * kappa[m];
-          QKi(j, m) = Q(j, m) / kappa[m];
-        }
-      Kmat = hostla::mul_nt(QK, Q);
-      Kinv = hostla::mul_nt(QKi, Q);
-    }
+  }
+
+  // build the tables `ids` (and, if with_tk, their products with K^-1) on several threads
+  void prepare(const std::vector<int>& ids, bool with_tk) {
+    std::vector<int> todo;
+    for (int id : ids)
+      if (!(with_tk ? haveTK[id] : haveT[id]) && std::find(todo.begin(), todo.end(), id) == todo.end()) todo.push_back(id);
+    parallel_for(todo.size(), [&](size_t i) { build(todo[i], with_tk); });
   }
 
   // Dirichlet-to-Neumann table T[sr*4+sc][t][k] = H_sc[interior vertex next to node t of side sr][k] (first use builds it)
   const Mat& Tm(int id) {
+    if (!haveT[id]) build(id, false);
+    return Tm_[id];
+  }
+  const Mat& Tm_ready(int id) const { return Tm_[id]; }  // (read-only access for the worker threads: built before)
+  // ... and its product with K^-1
+  const Mat& TK(int id) {
+    if (!haveTK[id]) build(id, true);
+    return TK_[id];
+  }
+
+ private:
+  void build(int id, bool with_tk) {  // (distinct ids may be built concurrently)
     if (!haveT[id]) {
       const int sr = id >> 2, sc = id & 3;
       Mat V(n1, n1);
@@ -140,18 +178,12 @@ struct UnitBlock {
       Tm_[id] = hostla::mul_nt(V, Q);
       haveT[id] = 1;
     }
-    return Tm_[id];
-  }
-  // ... and its product with K^-1
-  const Mat& TK(int id) {
-    if (!haveTK[id]) {
-      TK_[id] = hostla::mul(Tm(id), Kinv);
+    if (with_tk && !haveTK[id]) {
+      TK_[id] = hostla::mul(Tm_[id], Kinv);
       haveTK[id] = 1;
     }
-    return TK_[id];
   }
-
- private:
+  Mat Zs;
   std::array<Mat, 16> Tm_, TK_;
   std::array<char, 16> haveT{}, haveTK{};
 };
@@ -159,14 +191,14 @@ struct UnitBlock {
 // Compressed form of an edge whose couplings act through the tables `tabs` (ids sr*4+sc) and, if x0 / x1, through
 // its first / last node (cross points): W = orthonormal basis of the union of their ranges (tolerance `ctol` of the
 // first pivot); full rank or !compress: nodal unknowns (W = I).  False if the compressed self block is not SPD.
-bool compress_edge(UnitBlock& ub, const std::vector<int>& tabs, bool x0, bool x1, int hv, bool compress, ld ctol, Comp& cp) {
+bool compress_edge(const UnitBlock& ub, const std::vector<int>& tabs, bool x0, bool x1, int hv, bool compress, ld ctol, Comp& cp) {
   const int n1 = ub.n1;
   Mat Wb;
   if (compress) {
     const int ntab = int(tabs.size());
     Mat C(n1, ntab * n1 + 2);
     for (int t = 0; t < ntab; ++t) {
-      const Mat& Tt = ub.Tm(tabs[t]);
+      const Mat& Tt = ub.Tm_ready(tabs[t]);
       ld mx = 0;
       for (ld v : Tt.v) mx = std::max(mx, fabsl(v));
       if (mx == 0.0L) mx = 1.0L;
@@ -390,7 +422,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   ld ctol = 1e-17L;
   if (const char* s = getenv("ROMHC_COMPRESS_TOL")) ctol = (ld)atof(s);
   std::map<std::vector<int>, int> sig_id;  // edges with the same surroundings share one compressed form
-  std::vector<Comp> comps;
+  std::vector<std::vector<int>> sigs;
   std::vector<int> comp_of(E, -1);
   for (int e = 0; e < E; ++e) {
     const Edge& ed = edges[e];
@@ -405,15 +437,43 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       if (c.edge == e) (c.node == 0 ? x0 : x1) = true;
     sig.push_back(100 + (x0 ? 1 : 0) + (x1 ? 2 : 0));
     auto it = sig_id.find(sig);
-    if (it != sig_id.end()) { comp_of[e] = it->second; continue; }
-    Comp cp;
-    if (!compress_edge(ub, std::vector<int>(sig.begin() + 1, sig.end() - 1), x0, x1, ed.hv, compress, ctol, cp)) {
-      rom_set_error("internal: compressed edge block not positive definite");
-      return ROM_ERR_INVALID;
+    if (it == sig_id.end()) {
+      it = sig_id.emplace(sig, int(sigs.size())).first;
+      sigs.push_back(sig);
     }
-    comp_of[e] = int(comps.size());
-    sig_id[sig] = comp_of[e];
-    comps.push_back(std::move(cp));
+    comp_of[e] = it->second;
+  }
+  // the edge types are independent: one host thread each (the tables they read are built first)
+  std::vector<Comp> comps(sigs.size());
+  {
+    std::vector<int> ids, ids_tk;
+    for (auto& sig : sigs)
+      for (size_t t = 1; t + 1 < sig.size(); ++t) ids.push_back(sig[t]);
+    for (int e : pre_list)  // the closed-form edges also need T K^-1 towards their neighbours
+      for (int u : adj[e]) {
+        const int blk = shared_block(e, u);
+        ids_tk.push_back(side_of(blk, u) * 4 + side_of(blk, e));
+        ids.push_back(side_of(blk, e) * 4 + side_of(blk, u));
+      }
+    ub.prepare(ids, false);
+    ub.prepare(ids_tk, true);
+    std::vector<char> ok(sigs.size(), 1);
+    const unsigned nthr = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), unsigned(sigs.size())));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      for (size_t c = next++; c < sigs.size(); c = next++) {
+        const std::vector<int>& sig = sigs[c];
+        const int flags = sig.back() - 100;
+        ok[c] = compress_edge(ub, std::vector<int>(sig.begin() + 1, sig.end() - 1), flags & 1, flags & 2, sig[0], compress,
+                              ctol, comps[c]);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    for (char o : ok)
+      if (!o) { rom_set_error("internal: compressed edge block not positive definite"); return ROM_ERR_INVALID; }
   }
 
   // kmax[d]: sine modes with rho_mode(d) >= 1e-18 (rounded up to the K chunk): what the extension needs at
