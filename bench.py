@@ -27,6 +27,9 @@ import time
 
 import numpy as np
 
+# multi-process GPU work on this platform needs dmabuf IPC (normally already exported by the launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
