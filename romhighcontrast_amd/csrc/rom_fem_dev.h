@@ -94,6 +94,7 @@ __global__ void k_factor_panel(FemDev f, const double* __restrict__ a, int j, in
 __global__ void k_backsolve(FemDev f);
 __global__ void k_edge_transform(FemDev f, int Mc);
 __global__ void k_extend(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, const int* __restrict__ blocks, int pw_log2);
+template <bool FLAT>
 __global__ void k_extend128(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, int with_expand);
 __global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0);
 __global__ void k_assemble_stencil(FemDev f, const double* __restrict__ a, int M, double* __restrict__ diag, double* __restrict__ east, double* __restrict__ north);

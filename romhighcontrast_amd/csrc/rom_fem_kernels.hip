@@ -915,18 +915,24 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
 // grid (mesh rows x column tiles, ceil(Mc/128), lr blocks); LDS 74,752 B -> 2 workgroups per CU
 constexpr int X128_STAGE = 128 * LDK;
 
+// FLAT: the 128 vertices of a tile are consecutive in the block's row-major vertex numbering instead of lying in
+// one mesh row -- no padding when n1 is not close to a multiple of 128 (n1 = 170: 226 tiles per block instead of
+// 340); a pair of adjacent vertices may then straddle two mesh rows and is stored as two 8-byte halves.
+template <bool FLAT>
 __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __restrict__ a, int Mc,
                                                       double* __restrict__ U, long long row0, int with_expand) {
   __shared__ __align__(16) double lds[4 * X128_STAGE];  // {A,B} x 2 buffers
   __shared__ double scs[128];                            // h^2 / a_b of the workgroup's systems
   const int n1 = f.n1, N = f.N;
   const int nct = (n1 + 127) / 128;
-  if (int(blockIdx.x) >= n1 * nct) {
+  const int nvert = n1 * n1;
+  const int ntile = FLAT ? (nvert + 127) / 128 : n1 * nct;
+  if (int(blockIdx.x) >= ntile) {
     // with_expand: the (small) expansion of the edge values rides in `with_expand` extra workgroups per (y, z) cell
     // of this launch -- it depends on nothing here and nothing here depends on it
     static_assert(STAGE_TOTAL <= 4 * X128_STAGE, "expansion staging must fit");
     const int nx = f.n1p / 64, ny = (Mc + 63) / 64;
-    const int item = (blockIdx.x - n1 * nct) + with_expand * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int item = (blockIdx.x - ntile) + with_expand * (blockIdx.y + gridDim.y * blockIdx.z);
     if (item < nx * ny * (f.nexp + 1)) expand_tile(f, Mc, U, row0, lds, item % nx, (item / nx) % ny, item / (nx * ny));
     return;
   }
@@ -943,15 +949,17 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
   const int b = f.lr_blocks[bz];
   const int p = b / f.ncb, q = b % f.ncb;
   const BlockSide& sd = f.sides[b];
-  const int iv = blockIdx.x / nct + 1;           // mesh row (1-based interior index)
-  const int jv0 = 128 * (blockIdx.x % nct) + 1;  // first vertex of the tile
+  const int iv = blockIdx.x / nct + 1;           // mesh row (1-based interior index)       (!FLAT)
+  const int jv0 = 128 * (blockIdx.x % nct) + 1;  // first vertex of the tile                (!FLAT)
+  const int vt0 = 128 * blockIdx.x;              // first vertex of the tile, block-local   (FLAT)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
   // staging: thread t -> row t >> 1, eight consecutive k starting at (t & 1) * 8
   const int srow = threadIdx.x >> 1, sseg = (threadIdx.x & 1) * 8;
   const int mA = blockIdx.y * 128 + srow;
   const bool vA = mA < Mc;
-  const int jB = jv0 + srow;
-  const bool vB = jB <= n1;
+  const int iB = FLAT ? (vt0 + srow) / n1 + 1 : iv;
+  const int jB = FLAT ? (vt0 + srow) % n1 + 1 : jv0 + srow;
+  const bool vB = FLAT ? vt0 + srow < nvert : jB <= n1;
   if (threadIdx.x < 128) {
     const int m = blockIdx.y * 128 + threadIdx.x;
     scs[threadIdx.x] = m < Mc ? f.y[size_t(m) * f.nGp + f.sblk0 + b] : 0.0;  // h^2 / a_b (visible after the first barrier below)
@@ -967,7 +975,7 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
     if (es.mode == 2) {
       tot += es.nch;
       if (vA) pAs[s] = f.y + size_t(mA) * f.nGp + es.off + sseg;
-      if (vB) pBs[s] = f.G + es.gtab + size_t(h0_row(s, iv, jB, N, n1)) * (es.nch * BK) + sseg;
+      if (vB) pBs[s] = f.G + es.gtab + size_t(h0_row(s, iB, jB, N, n1)) * (es.nch * BK) + sseg;
     }
     cend[s] = tot;
   }
@@ -1002,8 +1010,13 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
   double w_own[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int jj = jv0 + wc * 64 + j * 16 + fr;  // 1-based
-    w_own[j] = jj <= n1 ? f.W[(iv - 1) * n1 + (jj - 1)] : 0.0;
+    if (FLAT) {
+      const int v = vt0 + wc * 64 + j * 16 + fr;
+      w_own[j] = v < nvert ? f.W[v] : 0.0;
+    } else {
+      const int jj = jv0 + wc * 64 + j * 16 + fr;  // 1-based
+      w_own[j] = jj <= n1 ? f.W[(iv - 1) * n1 + (jj - 1)] : 0.0;
+    }
   }
   for (int ch = 0; ch < tot; ++ch) {
     double* sA = lds + (ch & 1) * 2 * X128_STAGE;
@@ -1035,14 +1048,26 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
   // epilogue: add the particular solution, swap between lane pairs so that every lane owns two adjacent
   // vertices of one 16-vertex block, 16-byte stores (see k_extend)
   const bool odd = lane & 1;
-  const long long grow = (long long)(p * N + iv - 1) * f.nc + q * N - 1;
-  int jcol[2];
+  // off0 / off1: positions of the lane's two vertices in a snapshot row (off1 = off0 + 1 unless the pair straddles
+  // two mesh rows, FLAT only)
+  long long off0[2], off1[2];
   bool ok0[2], ok1[2];
 #pragma unroll
   for (int hp = 0; hp < 2; ++hp) {  // pair hp of column blocks: (0,1) and (2,3); even lanes take the first, odd the second
-    jcol[hp] = jv0 + wc * 64 + (2 * hp + (odd ? 1 : 0)) * 16 + fr - (odd ? 1 : 0);  // first of the two vertices, 1-based
-    ok0[hp] = jcol[hp] <= n1;
-    ok1[hp] = jcol[hp] + 1 <= n1;
+    const int t = wc * 64 + (2 * hp + (odd ? 1 : 0)) * 16 + fr - (odd ? 1 : 0);  // first of the two vertices, tile-local
+    if (FLAT) {
+      const int v = vt0 + t, i0 = v / n1, j0 = v - i0 * n1;
+      off0[hp] = (long long)(p * N + i0) * f.nc + q * N + j0;
+      off1[hp] = j0 + 1 < n1 ? off0[hp] + 1 : (long long)(p * N + i0 + 1) * f.nc + q * N;
+      ok0[hp] = v < nvert;
+      ok1[hp] = v + 1 < nvert;
+    } else {
+      const int jcol = jv0 + t;  // 1-based
+      off0[hp] = (long long)(p * N + iv - 1) * f.nc + q * N - 1 + jcol;
+      off1[hp] = off0[hp] + 1;
+      ok0[hp] = jcol <= n1;
+      ok1[hp] = jcol + 1 <= n1;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1056,13 +1081,18 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
         const double x0 = acc[i][2 * hp][g] + sc * w_own[2 * hp], x1 = acc[i][2 * hp + 1][g] + sc * w_own[2 * hp + 1];
         const double got = lane_swap1(odd ? x0 : x1);
         if (m >= Mc) continue;
-        double* dst = U + (row0 + m) * f.dim + grow + jcol[hp];
+        double* dst = U + (row0 + m) * f.dim;
         const double lo = odd ? got : x0, hi = odd ? x1 : got;
-        if (ok1[hp]) *reinterpret_cast<double2_u*>(dst) = double2_u{lo, hi};
-        else if (ok0[hp]) dst[0] = lo;
+        if (FLAT && ok1[hp] && off1[hp] != off0[hp] + 1) {
+          dst[off0[hp]] = lo;
+          dst[off1[hp]] = hi;
+        } else if (ok1[hp]) *reinterpret_cast<double2_u*>(dst + off0[hp]) = double2_u{lo, hi};
+        else if (ok0[hp]) dst[off0[hp]] = lo;
       }
     }
 }
+template __global__ void k_extend128<false>(FemDev, const double*, int, double*, long long, int);
+template __global__ void k_extend128<true>(FemDev, const double*, int, double*, long long, int);
 
 // interface values that k_expand does not write: cross points and the edges recovered node by node
 __global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0) {

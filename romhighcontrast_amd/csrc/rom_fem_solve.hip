@@ -144,7 +144,12 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   // the sequence produces them (no edge recovered node by node) ...
   const bool fold_scatter = f->nexp > 0 && f->npre == 0 && f->nscat > 0;
   // ... and the whole expansion rides in the extension launch when that is one k_extend128 over all blocks
-  const bool wide = f->n1 >= 96 && Mc >= 128 && !getenv("ROMHC_NO_EXT128");
+  // 128 x 128 tiles (k_extend128) when there are systems to fill them and they pad no worse than 64-vertex tiles
+  // of one mesh row; their 128 vertices are one mesh row, or consecutive vertices of the block when rows pad badly
+  const int t_row = f->n1 * ((f->n1 + 127) / 128), t_flat = (f->n1 * f->n1 + 127) / 128;
+  const bool flat = getenv("ROMHC_EXT_FLAT") ? atoi(getenv("ROMHC_EXT_FLAT")) != 0 : 100 * t_flat < 97 * t_row;
+  const int t128 = flat ? t_flat : t_row;
+  const bool wide = Mc >= 128 && 100 * 128 * t128 <= 102 * 64 * f->n1 * ((f->n1 + 63) / 64) && !getenv("ROMHC_NO_EXT128");
   const bool fold_expand = f->nexp > 0 && f->npre == 0 && f->n_edges == 0 && f->n_gen_blocks == 0 && f->n_lr_blocks > 0 &&
                            wide && !getenv("ROMHC_NO_FOLD_EXPAND");
   if (f->nGp > 0) {
@@ -173,12 +178,13 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
       }
       if (f->n_lr_blocks > 0) {
         ROM_PROF(ctx, "extend_lr", fl_ext * f->n_lr_blocks, 8.0 * Mc * double(f->n_lr_blocks) * nij);
-        if (wide) {  // wide tiles need enough vertices per mesh row and systems to fill them
+        if (wide) {
           const int mt = (Mc + 127) / 128;
           const int items = (f->n1p / 64) * ((Mc + 63) / 64) * (f->nexp + 1);  // workgroups of the folded expansion
           const int extra = fold_expand ? (items + mt * f->n_lr_blocks - 1) / (mt * f->n_lr_blocks) : 0;
-          dim3 grid(f->n1 * ((f->n1 + 127) / 128) + extra, mt, f->n_lr_blocks);
-          k_extend128<<<grid, 256, 0, st>>>(d, am, Mc, U, row, extra);
+          dim3 grid(t128 + extra, mt, f->n_lr_blocks);
+          if (flat) k_extend128<true><<<grid, 256, 0, st>>>(d, am, Mc, U, row, extra);
+          else k_extend128<false><<<grid, 256, 0, st>>>(d, am, Mc, U, row, extra);
         } else {
           dim3 grid(f->n1 * ((f->n1 + 63) / 64), (Mc + 63) / 64, f->n_lr_blocks);
           k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.lr_blocks, 6);

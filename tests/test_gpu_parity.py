@@ -365,6 +365,34 @@ def test_two_stage_sweep_is_bit_identical(api, blocks, N, M):
     assert np.array_equal(U2.download(shape=(M + 2, fem.dim))[2:], ref)
 
 
+@pytest.mark.parametrize("blocks,N,M", [((2, 2), 128, 130), ((3, 3), 24, 140), ((2, 3), 40, 200), ((2, 2), 90, 128),
+                                        ((1, 2), 9, 129), ((3, 2), 171, 128)])
+def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
+    """The extension into the blocks has three tilings (128 vertices of one mesh row, 128 consecutive vertices of the
+    block, 64 vertices of one mesh row): same products in the same order, so the snapshots must be identical."""
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    a = 10.0 ** np.random.default_rng(N).uniform(0, 3, size=(M, blocks[0] * blocks[1]))
+    ab = ctx.upload(a)
+    fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)
+    out = {}
+    for name, env in (("row", {"ROMHC_EXT_FLAT": "0"}), ("flat", {"ROMHC_EXT_FLAT": "1"}), ("t64", {"ROMHC_NO_EXT128": "1"}),
+                      ("default", {})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        U = ctx.alloc(M * fem.dim)
+        U.fill(float("nan"))
+        fem.solve_batch(ab, M, U)
+        out[name] = U.download(shape=(M, fem.dim))
+        for k in env:
+            monkeypatch.delenv(k)
+    for name in ("flat", "t64", "default"):
+        assert np.array_equal(out[name], out["row"]), name
+    g = ro.Geometry(blocks, N)
+    if N <= 40:
+        assert relh10(g, out["default"][:3], ro.generate_solutions(g, a[:3].reshape((3,) + blocks))).max() < SNAP_TOL
+
+
 @pytest.mark.parametrize("env", ["ROMHC_NO_COMPRESS", "ROMHC_NO_PREELIM", "ROMHC_NO_FUSED", "ROMHC_NO_LOWRANK_EXT",
                                  "ROMHC_NO_EXT128", "ROMHC_NO_EXT_LR"])
 def test_algorithm_switches_agree(api, env, monkeypatch):

@@ -1,12 +1,13 @@
-"""Timing probe for rom_solve_batch at C2 (dev tool)."""
+"""Timing probe for rom_solve_batch (dev tool): env NB (blocks per side, default 2), N (cells per block), M."""
 import sys, os
 import numpy as np
 sys.path.insert(0, ".")
 from romhighcontrast_amd import _ffi
 ctx = _ffi.get_context(0)
-N, M = 128, int(os.environ.get("M", "1024"))
-fem = _ffi.Fem(ctx, 2, 2, N)
-a = 10.0 ** np.random.default_rng(20240807).uniform(0, 2, size=(M, 2, 2))
+NB = int(os.environ.get("NB", "2"))
+N, M = int(os.environ.get("N", "128")), int(os.environ.get("M", "1024"))
+fem = _ffi.Fem(ctx, NB, NB, N)
+a = 10.0 ** np.random.default_rng(20240807).uniform(0, float(os.environ.get("DEC", "2")), size=(M, NB, NB))
 ab = ctx.upload(a.reshape(M, -1))
 U = ctx.alloc(M * fem.dim)
 for _ in range(3):
