@@ -158,6 +158,12 @@ int rom_buf_scale(rom_buf* b, size_t offset, size_t n, double alpha);
 /* X[row0+m, :] -= mean over m (column means, kept in `mean`, dim doubles): the centring step of
  * sklearn PCA.fit called at src/lib/ReducedBasis.py:196 */
 int rom_center_rows(rom_ctx* ctx, rom_buf* X, int64_t row0, int M, int64_t dim, rom_buf* mean);
+/* X[row0+i, :] *= factors_host[i], i < rows: the 1/sigma scaling of the lifted POD modes (components_ of the PCA at
+ * src/lib/ReducedBasis.py:196-197 have unit norm) */
+int rom_rows_scale(rom_ctx* ctx, rom_buf* X, int64_t row0, int rows, int64_t dim, const double* factors_host);
+/* every row times the sign of its entry of largest magnitude: sklearn's svd_flip(u_based_decision=False) inside the
+ * same PCA call, which fixes the signs of `components_` */
+int rom_rows_sign_flip(rom_ctx* ctx, rom_buf* X, int64_t row0, int rows, int64_t dim);
 /* evaluate_solutions (src/lib/SolutionsManagers.py:221-244): P1 interpolation of K FE vectors at
  * npts points.  ix/iy = cell index of each point (searchsorted(points_c/points_r) - 1), tx/ty its
  * local coordinates in the cell; out_host is (K, npts). */

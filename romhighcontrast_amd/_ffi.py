@@ -77,6 +77,8 @@ PROTOTYPES = {
     "rom_reduced_solve_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "rom_buf_scale": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_double]),
     "rom_center_rows": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
+    "rom_rows_scale": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
+    "rom_rows_sign_flip": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64]),
     "rom_evaluate_points": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "rom_comm_unique_id": (C.c_int, [C.c_char_p, C.c_size_t]),
     "rom_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),
@@ -212,6 +214,13 @@ class Context:
 
     def center_rows(self, X: "Buffer", M, dim, mean: "Buffer", row0=0):
         check(self.lib.rom_center_rows(self.h, X.h, row0, M, dim, mean.h))
+
+    def rows_scale(self, X: "Buffer", rows, dim, factors, row0=0):
+        f = _host(np.asarray(factors, dtype=np.float64))
+        check(self.lib.rom_rows_scale(self.h, X.h, row0, rows, dim, f.ctypes.data))
+
+    def rows_sign_flip(self, X: "Buffer", rows, dim, row0=0):
+        check(self.lib.rom_rows_sign_flip(self.h, X.h, row0, rows, dim))
 
     def l2norm(self, U: "Buffer", row0, K, dim) -> np.ndarray:
         out = np.empty(K)

@@ -687,24 +687,103 @@ extern "C" int rom_buf_scale(rom_buf* b, size_t off, size_t n, double alpha) {
 
 // column means of the (M, dim) snapshot block, subtracted in place (PCA centring,
 // sklearn PCA.fit called at src/lib/ReducedBasis.py:196); mean[dim] is kept for the caller.
-__global__ void k_center_rows(double* __restrict__ X, int M, long long dim, double* __restrict__ mean) {
-  long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+// Two passes over row slabs so that the chip is full for any M x dim: partial column sums per slab
+// (fixed order: deterministic), then every slab subtracts the mean it recomputes from the partials.
+constexpr int CENTER_SLABS = 16;
+__global__ void k_center_partial(const double* __restrict__ X, int M, long long dim, double* __restrict__ part) {
+  const long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (j >= dim) return;
+  const int per = (M + CENTER_SLABS - 1) / CENTER_SLABS;
+  const int m0 = blockIdx.y * per, m1 = min(M, m0 + per);
+  double s = 0.0;
+  for (int m = m0; m < m1; ++m) s += X[m * dim + j];
+  part[blockIdx.y * dim + j] = s;
+}
+
+__global__ void k_center_apply(double* __restrict__ X, int M, long long dim, const double* __restrict__ part,
+                               double* __restrict__ mean) {
+  const long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (j >= dim) return;
   double s = 0.0;
-  for (int m = 0; m < M; ++m) s += X[m * dim + j];
+  for (int q = 0; q < CENTER_SLABS; ++q) s += part[q * dim + j];
   s /= double(M);
-  mean[j] = s;
-  for (int m = 0; m < M; ++m) X[m * dim + j] -= s;
+  if (blockIdx.y == 0) mean[j] = s;
+  const int per = (M + CENTER_SLABS - 1) / CENTER_SLABS;
+  const int m0 = blockIdx.y * per, m1 = min(M, m0 + per);
+  for (int m = m0; m < m1; ++m) X[m * dim + j] -= s;
 }
 
 extern "C" int rom_center_rows(rom_ctx* ctx, rom_buf* X, int64_t row0, int M, int64_t dim, rom_buf* mean) {
   ROM_CHECK(ctx && X && mean, "rom_center_rows: null argument");
   ROM_CHECK(M >= 1 && dim >= 1 && row0 >= 0, "rom_center_rows: bad sizes");
   ROM_CHECK(size_t(row0 + M) * dim <= X->n && size_t(dim) <= mean->n, "rom_center_rows: buffers too small");
+  double* part = nullptr;
+  ROM_TRY(rom_ctx_scratch(ctx, size_t(CENTER_SLABS) * dim, &part));
+  const dim3 grid(unsigned((dim + 255) / 256), CENTER_SLABS);
   {
     ROM_PROF(ctx, "center_rows", 2.0 * M * dim, 24.0 * M * dim);
-    k_center_rows<<<unsigned((dim + 255) / 256), 256, 0, ctx->stream>>>(X->p + row0 * dim, M, dim, mean->p);
+    k_center_partial<<<grid, 256, 0, ctx->stream>>>(X->p + row0 * dim, M, dim, part);
+    k_center_apply<<<grid, 256, 0, ctx->stream>>>(X->p + row0 * dim, M, dim, part, mean->p);
   }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// X[row0 + i, :] *= factors[i]  (i < rows; `factors` on the host): the 1/sigma scaling of the lifted POD modes
+__global__ void k_rows_scale(double* __restrict__ X, long long dim, const double* __restrict__ fac) {
+  const double a = fac[blockIdx.y];
+  double* row = X + blockIdx.y * dim;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < dim; j += (long long)gridDim.x * blockDim.x)
+    row[j] *= a;
+}
+
+extern "C" int rom_rows_scale(rom_ctx* ctx, rom_buf* X, int64_t row0, int rows, int64_t dim, const double* factors_host) {
+  ROM_CHECK(ctx && X && (factors_host || rows == 0), "rom_rows_scale: null argument");
+  ROM_CHECK(rows >= 0 && dim >= 1 && row0 >= 0 && size_t(row0 + rows) * dim <= X->n, "rom_rows_scale: bad sizes");
+  if (rows == 0) return ROM_OK;
+  double* fac = nullptr;
+  ROM_TRY(rom_ctx_scratch(ctx, size_t(rows), &fac));
+  ROM_HIP(hipMemcpyAsync(fac, factors_host, size_t(rows) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));  // the host array may be reused by the caller
+  k_rows_scale<<<dim3(unsigned(std::min<int64_t>((dim + 255) / 256, 64)), rows), 256, 0, ctx->stream>>>(X->p + row0 * dim, dim, fac);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// sklearn's svd_flip(u_based_decision=False) (PCA call at src/lib/ReducedBasis.py:196): every row is multiplied by
+// the sign of its entry of largest magnitude (first one on ties, like np.argmax).  One workgroup per row.
+__global__ __launch_bounds__(256) void k_rows_sign_flip(double* __restrict__ X, long long dim) {
+  __shared__ double bv[256];
+  __shared__ long long bi[256];
+  double* row = X + blockIdx.x * dim;
+  double best = -1.0;
+  long long at = 0;
+  for (long long j = threadIdx.x; j < dim; j += blockDim.x) {
+    const double v = fabs(row[j]);
+    if (v > best) { best = v; at = j; }  // ascending j per thread: keeps the first maximum
+  }
+  bv[threadIdx.x] = best;
+  bi[threadIdx.x] = at;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (int(threadIdx.x) < s) {
+      const double o = bv[threadIdx.x + s];
+      const long long oi = bi[threadIdx.x + s];
+      if (o > bv[threadIdx.x] || (o == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = o; bi[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  const bool neg = row[bi[0]] < 0.0;
+  __syncthreads();  // everybody has read the pivot before anybody flips it
+  if (neg)
+    for (long long j = threadIdx.x; j < dim; j += blockDim.x) row[j] = -row[j];
+}
+
+extern "C" int rom_rows_sign_flip(rom_ctx* ctx, rom_buf* X, int64_t row0, int rows, int64_t dim) {
+  ROM_CHECK(ctx && X, "rom_rows_sign_flip: null argument");
+  ROM_CHECK(rows >= 0 && dim >= 1 && row0 >= 0 && size_t(row0 + rows) * dim <= X->n, "rom_rows_sign_flip: bad sizes");
+  if (rows == 0) return ROM_OK;
+  k_rows_sign_flip<<<rows, 256, 0, ctx->stream>>>(X->p + row0 * dim, dim);
   ROM_HIP(hipGetLastError());
   return ROM_OK;
 }

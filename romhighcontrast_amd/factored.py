@@ -205,8 +205,7 @@ def pod_modes_factored(fs: FactoredSnapshots, n: int, center=True, passes=2):
             break
         s = np.sqrt(lam[:take])
         sig[found:found + take] = s
-        for i in range(take):
-            W.buf.scale(1.0 / s[i] if s[i] > 0 else 0.0, offset=i * M, n=M)
+        ctx.rows_scale(W.buf, take, M, np.where(s > 0, 1.0 / np.where(s > 0, s, 1.0), 0.0))
         Wnew = ctx.alloc(take * K)
         ctx.gemm_nn(take, K, M, W.buf, 0, M, Yc, 0, K, Wnew, 0, K)  # S^-1 W^T Yc : new modes in Y space
         Wall = np.vstack((Wm, Wnew.download(take * K, shape=(take, K))))
@@ -224,15 +223,15 @@ def pod_modes_factored(fs: FactoredSnapshots, n: int, center=True, passes=2):
             ctx.gemm_nt(M, K, K, Yc, 0, K, em.S, 0, K, T, 0, K)
             ctx.gemm_nt(M, found, K, T, 0, K, Wd, 0, K, C, 0, found)
             ctx.gemm_nn(M, K, found, C, 0, found, Wd, 0, K, Yc, 0, K, alpha=-1.0, beta=1.0)
-    comps = np.zeros((n, dim))
+    if n == 0:
+        return np.zeros((0, dim)), sig
+    V = ctx.alloc(n * dim)
+    if found < n:
+        V.fill(0.0)  # modes that stay unresolved are returned as zero rows
     if found:
-        V = ctx.alloc(found * dim)
         em.expand_compact(ctx.upload(Wm), found, V)
-        comps[:found] = V.download(found * dim, shape=(found, dim))
-    piv = np.argmax(np.abs(comps), axis=1)
-    signs = np.sign(comps[np.arange(n), piv])
-    signs[signs == 0] = 1.0
-    return comps * signs[:, None], sig
+        ctx.rows_sign_flip(V, found, dim)  # svd_flip(u_based_decision=False)
+    return V.download(n * dim, shape=(n, dim)), sig
 
 
 def energy_coordinates_of(fs: FactoredSnapshots):

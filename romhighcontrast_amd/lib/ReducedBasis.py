@@ -12,6 +12,7 @@ return negative diagonals in R); every consumer in the reference is sign-invaria
 """
 from __future__ import annotations
 
+import functools
 from logging import warning
 from typing import List
 
@@ -255,6 +256,14 @@ class ReducedBasisRandom(BaseReducedBasis):
         return self
 
 
+@functools.lru_cache(maxsize=8)
+def _start_block(b: int, M: int, seed: int) -> np.ndarray:
+    """Gaussian start block of the subspace iteration (cached: it only depends on its shape and the seed)."""
+    blk = np.random.default_rng(seed).standard_normal((b, M))
+    blk.setflags(write=False)
+    return blk
+
+
 def _top_eigenpairs_device(ctx: _ffi.Context, G: _ffi.Buffer, M: int, nev: int, oversample=12, tol=2e-14,
                            max_iter=30, seed=0):
     """Leading ``nev`` eigenpairs of the symmetric PSD matrix G (M x M, device) by orthogonal
@@ -266,8 +275,7 @@ def _top_eigenpairs_device(ctx: _ffi.Context, G: _ffi.Buffer, M: int, nev: int, 
     Returns (theta (nev,), W DeviceArray (nev, M) with orthonormal rows = eigenvectors).
     """
     b = int(min(M, nev + oversample))
-    rng = np.random.default_rng(seed)
-    Y = _cholqr2_device(ctx, DeviceArray(ctx.upload(rng.standard_normal((b, M))), b, M))  # Gaussian rows: kappa ~ 1
+    Y = _cholqr2_device(ctx, DeviceArray(ctx.upload(_start_block(b, M, seed)), b, M))  # Gaussian rows: kappa ~ 1
     Z, H = ctx.alloc(b * M), ctx.alloc(b * b)
     Zr, Yr = ctx.alloc(b * M), ctx.alloc(b * M)
     best, stall = np.inf, 0
@@ -328,6 +336,7 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=2):
     if center:
         ctx.center_rows(X.buf, M, dim, ctx.alloc(dim))
     V = ctx.alloc(max(n * dim, 1))
+    V.fill(0.0)  # modes that stay unresolved are returned as zero rows
     sig = np.zeros(n)
     found = 0
     for p in range(passes):
@@ -348,8 +357,7 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=2):
             break
         s = np.sqrt(lam[:take])
         sig[found:found + take] = s
-        for i in range(take):
-            W.buf.scale(1.0 / s[i] if s[i] > 0 else 0.0, offset=i * M, n=M)
+        ctx.rows_scale(W.buf, take, M, np.where(s > 0, 1.0 / np.where(s > 0, s, 1.0), 0.0))
         ctx.gemm_nn(take, dim, M, W.buf, 0, M, X.buf, 0, dim, V, found * dim, dim)   # V = S^-1 W^T Xc
         # re-orthonormalise the new modes against all earlier ones (keeps V orthonormal to ~eps)
         try:
@@ -363,11 +371,10 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=2):
             Y = ctx.alloc(M * found)
             ctx.gemm_nt(M, found, dim, X.buf, 0, dim, V, 0, dim, Y, 0, found)
             ctx.gemm_nn(M, dim, found, Y, 0, found, V, 0, dim, X.buf, 0, dim, alpha=-1.0, beta=1.0)
-    comps = V.download(n * dim, shape=(n, dim)) if n else np.zeros((0, dim))
-    piv = np.argmax(np.abs(comps), axis=1)
-    signs = np.sign(comps[np.arange(n), piv])
-    signs[signs == 0] = 1.0
-    return comps * signs[:, None], sig
+    if n == 0:
+        return np.zeros((0, dim)), sig
+    ctx.rows_sign_flip(V, n, dim)  # svd_flip(u_based_decision=False)
+    return V.download(n * dim, shape=(n, dim)), sig
 
 
 class ReducedBasisPCA(BaseReducedBasis):

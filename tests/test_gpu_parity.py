@@ -177,6 +177,43 @@ def test_g7_pca_random(api):
         assert np.array_equal(rr.basis, z[f"rnd_basis_{flag}"]) and np.array_equal(np.array(rr.a), z[f"rnd_a_{flag}"])
 
 
+@pytest.mark.parametrize("M,dim", [(1, 7), (5, 300), (37, 1025), (130, 4097)])
+def test_row_helpers_of_the_pca(M, dim):
+    """Centring (sklearn PCA.fit, src/lib/ReducedBasis.py:196), 1/sigma row scaling and svd_flip(u_based_decision=False)
+    on the device against NumPy."""
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    rng = np.random.default_rng(M * dim)
+    X = rng.standard_normal((M, dim)) + 3.0
+    Xd, mean = ctx.upload(X), ctx.alloc(dim)
+    ctx.center_rows(Xd, M, dim, mean)
+    np.testing.assert_allclose(mean.download(dim), X.mean(axis=0), rtol=0, atol=1e-14)
+    Xc = X - X.mean(axis=0)
+    np.testing.assert_allclose(Xd.download(shape=(M, dim)), Xc, rtol=0, atol=2e-14)
+    fac = rng.uniform(-2, 2, size=M)
+    fac[0] = 0.0
+    Xd = ctx.upload(X)
+    ctx.rows_scale(Xd, M, dim, fac)
+    assert np.array_equal(Xd.download(shape=(M, dim)), X * fac[:, None])
+    # sign convention: the entry of largest magnitude of every row becomes positive (first one on ties)
+    Y = X - 3.0
+    if dim > 20:
+        Y[0, 5] = -9.0
+        Y[0, 17] = 9.0   # tie in magnitude: np.argmax takes index 5 -> the row is negated
+    Yd = ctx.upload(Y)
+    ctx.rows_sign_flip(Yd, M, dim)
+    piv = np.argmax(np.abs(Y), axis=1)
+    sg = np.sign(Y[np.arange(M), piv])
+    assert np.array_equal(Yd.download(shape=(M, dim)), Y * sg[:, None])
+    # only a sub-range of rows
+    if M > 2:
+        Yd = ctx.upload(Y)
+        ctx.rows_sign_flip(Yd, M - 2, dim, row0=1)
+        ref = Y.copy()
+        ref[1:M - 1] *= sg[1:M - 1, None]
+        assert np.array_equal(Yd.download(shape=(M, dim)), ref)
+
+
 def test_pod_subspace_iteration_vs_oracle(api):
     """POD with M > n + oversampling, so that the device subspace iteration (not the one-step full-space
     Ritz solve) produces the modes; compared with the oracle's LAPACK SVD."""
