@@ -109,6 +109,7 @@ int rom_ctx_scratch(rom_ctx* c, size_t n, double** out) {
     ROM_HIP(hipMalloc(&c->d_scratch, n * sizeof(double)));
     c->scratch_doubles = n;
   }
+  if (getenv("ROMHC_POISON_WS")) ROM_HIP(hipMemsetAsync(c->d_scratch, 0xFF, n * sizeof(double), c->stream));
   *out = c->d_scratch;
   return ROM_OK;
 }
@@ -242,6 +243,8 @@ extern "C" int rom_buf_alloc(rom_ctx* c, size_t n, rom_buf** out) {
       return ROM_ERR_NOMEM;
     }
   }
+  if (getenv("ROMHC_POISON_WS"))  // debugging aid: a fresh buffer holds NaN patterns, never stale numbers
+    ROM_HIP(hipMemsetAsync(b->p, 0xFF, bytes, c->stream));
   *out = b;
   return ROM_OK;
 }

@@ -76,6 +76,11 @@ static int ensure_workspace(rom_fem* f, int Mc) {
   // zeroed once: padding slots are read (against zero table entries) before anything writes them
   ROM_HIP(hipMemset(f->d_y, 0, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
   ROM_HIP(hipMalloc(&f->d_yhat, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
+  if (getenv("ROMHC_POISON_WS")) {  // debugging aid: NaN patterns in everything a kernel must write before it reads
+    ROM_HIP(hipMemset(f->d_L, 0xFF, std::max<size_t>(size_t(Mc) * f->nslots * 4096, 1) * sizeof(double)));
+    ROM_HIP(hipMemset(f->d_invL, 0xFF, std::max<size_t>(size_t(Mc) * f->T * 4096, 1) * sizeof(double)));
+    ROM_HIP(hipMemset(f->d_yhat, 0xFF, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
+  }
   f->ws_M = Mc;
   return ROM_OK;
 }

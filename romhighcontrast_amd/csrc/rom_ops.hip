@@ -450,28 +450,55 @@ __device__ inline double block_reduce_sum(double v) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// partial[k][blk] = sum over this block's vertices of d * (A_1 d),  d = u - v (or u)
+// partial[k][blk] = this block's share of d^T A_1 d,  d = u - v (or u), in edge form: with zero boundary values
+//   d^T A_1 d = sum over horizontal mesh edges (d_w - d_e)^2 + sum over vertical mesh edges (d_n - d_s)^2
+// (A_1 = the unit-coefficient 5-point operator; the same number as d . (A_1 d) up to rounding, all terms >= 0).
+// A thread owns one mesh column and walks down a slab of rows: every entry is loaded exactly once (plus the row
+// above the slab), the east neighbour comes from the next lane, the north neighbour from the previous iteration.
+constexpr int H10_ROWS = 32;   // rows per slab
+constexpr int H10_UNROLL = 8;  // loads in flight per thread
+template <bool DIFF>
 __global__ __launch_bounds__(256) void k_h10_partial(StencilGeom g, const double* __restrict__ U,
                                                      const double* __restrict__ V, double* __restrict__ partial,
-                                                     int nblk, int per_thread) {
-  const double* u = U + blockIdx.y * g.dim;
-  const double* v = V ? V + blockIdx.y * g.dim : nullptr;
+                                                     int nblk) {
+  const double* u = U + blockIdx.z * g.dim;
+  const double* v = DIFF ? V + blockIdx.z * g.dim : nullptr;
+  const int c = blockIdx.x * 256 + threadIdx.x;  // 0-based interior column
+  const int r0 = blockIdx.y * H10_ROWS, r1 = min(g.nr, r0 + H10_ROWS);
+  const bool in = c < g.nc;
+  const int lane = threadIdx.x & 63;
+  auto at = [&](int r, int cc) -> double {
+    const long long i = (long long)r * g.nc + cc;
+    return DIFF ? u[i] - v[i] : u[i];
+  };
   double s = 0.0;
-  long long base = blockIdx.x * (long long)(256 * per_thread);
-  for (int it = 0; it < per_thread; ++it) {
-    long long idx = base + it * 256 + threadIdx.x;
-    if (idx < g.dim) {
-      if (v) {
-        auto xf = [&](long long i) { return u[i] - v[i]; };
-        s += xf(idx) * stencil_at(g, nullptr, true, idx, xf);
-      } else {
-        auto xf = [&](long long i) { return u[i]; };
-        s += xf(idx) * stencil_at(g, nullptr, true, idx, xf);
+  double north = (in && r0 > 0) ? at(r0 - 1, c) : 0.0;  // value above the slab (boundary: 0)
+  for (int rb = r0; rb < r1; rb += H10_UNROLL) {
+    double x[H10_UNROLL], xl[H10_UNROLL];
+#pragma unroll
+    for (int q = 0; q < H10_UNROLL; ++q) {
+      const int r = rb + q;
+      x[q] = (in && r < r1) ? at(r, c) : 0.0;
+      // the wave's last lane has its east neighbour in another wave: it loads it itself (same cache line)
+      xl[q] = (lane == 63 && c + 1 < g.nc && r < r1) ? at(r, c + 1) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < H10_UNROLL; ++q) {
+      const int r = rb + q;
+      double east = __shfl_down(x[q], 1, 64);
+      if (lane == 63) east = xl[q];
+      if (in && r < r1) {
+        if (c + 1 >= g.nc) east = 0.0;  // boundary
+        const double dh = x[q] - east, dv = x[q] - north;
+        s += dh * dh + dv * dv;
+        if (c == 0) s += x[q] * x[q];              // edge to the west boundary
+        if (r == g.nr - 1) s += x[q] * x[q];       // edge to the south boundary
+        north = x[q];
       }
     }
   }
   s = block_reduce_sum(s);
-  if (threadIdx.x == 0) partial[blockIdx.y * (long long)nblk + blockIdx.x] = s;
+  if (threadIdx.x == 0) partial[blockIdx.z * (long long)nblk + blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
 __global__ __launch_bounds__(256) void k_sq_partial(long long dim, const double* __restrict__ U,
@@ -541,16 +568,16 @@ extern "C" int rom_h10norm(rom_fem* f, rom_buf* U, int64_t u_row0, rom_buf* V, i
   if (K == 0) return ROM_OK;
   rom_ctx* ctx = f->ctx;
   StencilGeom g = make_geom(f->nrb, f->ncb, f->N);
-  const int per_thread = 8;
-  const int nblk = int((g.dim + 256 * per_thread - 1) / (256 * per_thread));
+  const dim3 grid((g.nc + 255) / 256, (g.nr + H10_ROWS - 1) / H10_ROWS, K);
+  const int nblk = int(grid.x * grid.y);
+  ROM_CHECK(K <= 65535, "rom_h10norm: at most 65535 vectors per call");
   double* scratch = nullptr;
   ROM_TRY(rom_ctx_scratch(ctx, size_t(K) * nblk + K, &scratch));
   double* d_out = scratch + size_t(K) * nblk;
   {
-    ROM_PROF(ctx, "h10norm", 16.0 * g.dim * K, (V ? 16.0 : 8.0) * g.dim * K);
-    k_h10_partial<<<dim3(nblk, K), 256, 0, ctx->stream>>>(g, U->p + u_row0 * f->dim,
-                                                         V ? V->p + v_row0 * f->dim : nullptr, scratch, nblk,
-                                                         per_thread);
+    ROM_PROF(ctx, "h10norm", 10.0 * g.dim * K, (V ? 16.0 : 8.0) * g.dim * K);
+    if (V) k_h10_partial<true><<<grid, 256, 0, ctx->stream>>>(g, U->p + u_row0 * f->dim, V->p + v_row0 * f->dim, scratch, nblk);
+    else k_h10_partial<false><<<grid, 256, 0, ctx->stream>>>(g, U->p + u_row0 * f->dim, nullptr, scratch, nblk);
     k_finish_norm<<<K, 256, 0, ctx->stream>>>(scratch, nblk, d_out);
   }
   ROM_HIP(hipGetLastError());

@@ -344,6 +344,7 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=2):
             break
         G = ctx.alloc(M * M)
         ctx.gram(M, dim, X.buf, 0, dim, G, 0, M)
+        pod_modes.last_gram_passes = p + 1
         lam, W = _top_eigenpairs_device(ctx, G, M, n - found)
         lam = np.maximum(lam, 0.0)
         # modes of this pass: those above the Gram roundoff floor of the current (deflated) block; what is
