@@ -55,6 +55,47 @@ def cpu_baseline(blocks, N, a, budget_s=15.0):
                       f"{dt:.1f} s on 1 of {os.cpu_count()} host cores"}
 
 
+def _pool_init():
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(1)
+    except Exception:
+        pass
+
+
+def _pool_solve(args):
+    from oracle import rom_oracle as ro
+    blocks, N, rows = args
+    g = ro.Geometry(blocks, N)
+    B = ro.load_vector(g)
+    for a in rows:
+        ro.solve_one(g, a, B, "lsqsparse")
+    return len(rows)
+
+
+def cpu_baseline_pool(blocks, N, a, per_worker=40):
+    """The same CPU path with the reference's num_cores > 1 semantics (a process pool over the parameters,
+    src/lib/SolutionsManagers.py:51,64-68) on this job's share of the host cores.  Runs BEFORE the GPU is
+    initialised: the pool forks."""
+    import multiprocessing as mp
+    try:
+        share = len(os.sched_getaffinity(0))
+    except AttributeError:
+        share = os.cpu_count() or 1
+    cores = max(1, min(16, share))  # a one-GPU job's CPU share on the bench box
+    n = min(len(a), cores * per_worker)
+    chunks = [(blocks, N, a[i::cores][: (n + cores - 1) // cores]) for i in range(cores)]
+    n = sum(len(c[2]) for c in chunks)
+    with mp.get_context("fork").Pool(cores, initializer=_pool_init) as pool:
+        pool.map(_pool_solve, [(blocks, N, a[:1])] * cores)  # imports + symbolic warm-up outside the timed region
+        t0 = time.perf_counter()
+        pool.map(_pool_solve, chunks, chunksize=1)
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of the {len(a)} C2 parameters over a pool of {cores} processes (one BLAS thread each), same "
+                      f"oracle path, {dt:.1f} s; host has {os.cpu_count()} cores, {share} usable by this job"}
+
+
 @contextlib.contextmanager
 def stdout_to_stderr():
     """RCCL prints a version banner on the C-level stdout at init; keep stdout for the one JSON line."""
@@ -94,6 +135,12 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
+
+    pool_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        # all-cores CPU figure first: it forks, which must happen before anything touches the GPU
+        a0 = 10.0 ** np.random.default_rng(20240807).uniform(0, 2, size=(args.M,) + tuple(args.blocks))
+        pool_baseline = cpu_baseline_pool(tuple(args.blocks), args.N, a0)
 
     from romhighcontrast_amd import _ffi, sweep
     from romhighcontrast_amd.lib.SolutionsManagers import DeviceArray, SolutionsManagerFEM
@@ -353,6 +400,7 @@ def main():
             del X3, U3
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blocks, N, a_loc)
+        out["cpu_baseline_all_cores"] = pool_baseline
     if comm:
         ctx.comm_destroy()
         sweep.cleanup_rendezvous(rank)

@@ -431,6 +431,163 @@ __global__ __launch_bounds__(64) void k_diag_inverse(FemDev f, int slot, int j) 
   }
 }
 
+// Diagonal tile j, steps 2 and 3 in one kernel on the matrix cores (one wave per system, LDS 36 KB: all 1024 systems
+// of a step resident at once):
+//   rank-4 blocked right-looking Cholesky of the tile held in MFMA accumulator layout (the scheme of k_solve1: a
+//   64 x 4 panel goes through LDS into row-per-lane form, is factorised with readlane broadcasts while the forward
+//   substitution y_j <- L_jj^-1 y_j rides along, and returns as A and B operand of the rank-4 trailing update);
+//   then X = L_jj^-1 in place, blocked 16 x 16: the four diagonal blocks by the column sweep of an unblocked
+//   in-place triangular inverse (lane = (block, row), its row of X in registers, the untouched columns of L
+//   broadcast from LDS), the six blocks below them as  X_ij = -sum_{k=j+1..i} X_ik (L_kj X_jj)  on MFMA.
+// Replaces k_diag_potrf + k_diag_inverse (column-by-column on the vector pipe: 2 x 32 us per 1024 systems).
+__global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
+  __shared__ __align__(16) double Ls[64 * LDC];
+  __shared__ __align__(16) double Pn[64 * 4];
+  __shared__ double rinv[64];
+  const int m = blockIdx.x, lane = threadIdx.x;
+  const int l16 = lane & 15, l4 = lane >> 4;
+  double* Lt = f.L + (size_t(m) * f.nslots + slot) * 4096;
+  // the lower blocks of the (symmetric) tile in accumulator layout; only its lower triangle is valid in memory
+  d4_t C[4][4];
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+    for (int jb = 0; jb <= ib; ++jb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int R = 16 * ib + 4 * g + l4, Cc = 16 * jb + l16;
+        C[ib][jb][g] = Lt[max(R, Cc) * 64 + min(R, Cc)];
+      }
+  double y = f.y[size_t(m) * f.nGp + j * 64 + lane];
+  bool bad = false;
+  double myrs = 0.0;
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int jb = p >> 2, co = 4 * (p & 3), c0 = 4 * p;
+    if ((l16 >> 2) == (p & 3)) {
+#pragma unroll
+      for (int ib = jb; ib < 4; ++ib)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Pn[(16 * ib + 4 * g + l4) * 4 + (l16 - co)] = C[ib][jb][g];
+    }
+    __builtin_amdgcn_wave_barrier();
+    double v[4];
+    {
+      const double2 v01 = *reinterpret_cast<const double2*>(&Pn[lane * 4]);
+      const double2 v23 = *reinterpret_cast<const double2*>(&Pn[lane * 4 + 2]);
+      v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int jc = c0 + k;
+      const double dj = readlane_f64(v[k], jc);
+      bad = bad || !(dj > 0.0);
+      const double rs = rsqrt_newton(dj);
+      const double l = lane >= jc ? v[k] * rs : 0.0;  // L[lane][jc]
+      v[k] = l;
+      const double yj = readlane_f64(y, jc) * rs;
+      if (lane == jc) {
+        y = yj;
+        myrs = rs;
+      } else if (lane > jc) {
+        y -= l * yj;
+      }
+#pragma unroll
+      for (int kk = k + 1; kk < 4; ++kk) v[kk] -= l * readlane_f64(l, c0 + kk);
+    }
+    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<double2*>(&Pn[lane * 4]) = double2{v[0], v[1]};
+    *reinterpret_cast<double2*>(&Pn[lane * 4 + 2]) = double2{v[2], v[3]};
+    *reinterpret_cast<double2*>(&Ls[lane * LDC + c0]) = double2{v[0], v[1]};
+    *reinterpret_cast<double2*>(&Ls[lane * LDC + c0 + 2]) = double2{v[2], v[3]};
+    __builtin_amdgcn_wave_barrier();
+    if (p < 15) {
+      double frag[4];
+#pragma unroll
+      for (int x = jb; x < 4; ++x) frag[x] = Pn[(16 * x + l16) * 4 + l4];
+#pragma unroll
+      for (int jb2 = jb; jb2 < 4; ++jb2)
+#pragma unroll
+        for (int ib = jb2; ib < 4; ++ib)
+          C[ib][jb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag[ib], frag[jb2], C[ib][jb2], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (bad && lane == 0) atomicOr(f.status, 1);
+  f.y[size_t(m) * f.nGp + j * 64 + lane] = y;
+  rinv[lane] = myrs;  // 1 / L[lane][lane]
+  __syncthreads();
+  // L (lower, zero above the diagonal) to HBM, coalesced
+  for (int i = 0; i < 64; ++i) Lt[i * 64 + lane] = Ls[i * LDC + lane];
+  // ---- X = L^-1 in place ----
+  // (1) diagonal blocks: lane = (block bi, row r) sweeps the columns c = 15 .. 0 of its block:
+  //     X[r][c] = -rinv_c * sum_{k=c+1..r} X[r][k] L[k][c]  (r > c),  X[c][c] = rinv_c
+  {
+    const int bi = lane >> 4, r = lane & 15;
+    const double* Lb = Ls + (16 * bi) * LDC + 16 * bi;
+    double xr[16];
+#pragma unroll
+    for (int c = 15; c >= 0; --c) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = c + 1; k < 16; k += 2) {
+        if (k <= r) s0 += xr[k] * Lb[k * LDC + c];
+        if (k + 1 < 16 && k + 1 <= r) s1 += xr[k + 1] * Lb[(k + 1) * LDC + c];
+      }
+      const double rc = rinv[16 * bi + c];
+      xr[c] = r == c ? rc : (r > c ? -rc * (s0 + s1) : 0.0);
+    }
+    __builtin_amdgcn_wave_barrier();  // every lane has read its block before anybody overwrites it
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(&Ls[lane * LDC + 16 * bi + c]) = double2{xr[c], xr[c + 1]};
+    __builtin_amdgcn_wave_barrier();
+  }
+  // (2) blocks below the diagonal, block column jb = 2, 1, 0: W_i = L_i,jb X_jb,jb (in place of L_i,jb), then
+  //     X_i,jb = -sum_{k=jb+1..i} X_ik W_k.  Fragments: A(row = l16, k = l4), B(k = l4, col = l16).
+#pragma unroll
+  for (int jb = 2; jb >= 0; --jb) {
+    d4_t W[4];
+#pragma unroll
+    for (int ib = jb + 1; ib < 4; ++ib) {
+      W[ib] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 4) {
+        const double af = Ls[(16 * ib + l16) * LDC + 16 * jb + kk + l4];
+        const double bf = Ls[(16 * jb + kk + l4) * LDC + 16 * jb + l16];
+        W[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, W[ib], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ib = jb + 1; ib < 4; ++ib)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Ls[(16 * ib + 4 * g + l4) * LDC + 16 * jb + l16] = W[ib][g];
+    __builtin_amdgcn_wave_barrier();
+    d4_t X[4];
+#pragma unroll
+    for (int ib = jb + 1; ib < 4; ++ib) {
+      X[ib] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kb = jb + 1; kb <= ib; ++kb)
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+          const double af = Ls[(16 * ib + l16) * LDC + 16 * kb + kk + l4];
+          const double bf = Ls[(16 * kb + kk + l4) * LDC + 16 * jb + l16];
+          X[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af, bf, X[ib], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ib = jb + 1; ib < 4; ++ib)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Ls[(16 * ib + 4 * g + l4) * LDC + 16 * jb + l16] = X[ib][g];
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  double* It = f.invL + (size_t(m) * f.T + j) * 4096;
+  for (int i = 0; i < 64; ++i) It[i * 64 + lane] = Ls[i * LDC + lane];
+}
+
 // Whole reduced solve of a system whose reduced matrix is ONE tile (e.g. 2x2 blocks at N = 128: 2 x 31
 // compressed unknowns + the cross point), one wave per system, nothing but the solution leaves the CU:
 //   assemble the lower 16x16 blocks in MFMA accumulator layout (term by term, double buffered) ->

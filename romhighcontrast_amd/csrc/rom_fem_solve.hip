@@ -96,6 +96,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   char nm[4][48];
   const bool no_fused = getenv("ROMHC_NO_FUSED") != nullptr;  // (read per call: the tests toggle it)
   const bool fused1 = f->fused1 && !no_fused;  // the whole reduced solve in one wave-per-system kernel
+  const bool no_mfma_diag = getenv("ROMHC_NO_MFMA_DIAG") != nullptr;  // A/B switch: vector-pipe potrf + inverse kernels
   if (f->nGp > 0 && fused1 && (stages & 1)) {
     ROM_PROF(ctx, "solve1", Mc * (262144 / 3.0 + 3 * 4096.0), Mc * 8.0 * 4096 * 3);
     k_solve1<<<Mc, 64, 0, st>>>(d, am);
@@ -109,19 +110,24 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
       {
         int slot = f->diag_slot[j];
         double nk = f->kptr[slot + 1] - f->kptr[slot];
-        const char* base[4] = {"diag_update", "diag_potrf", "diag_inverse", "factor_panel"};
+        const char* base[4] = {"diag_update", no_mfma_diag ? "diag_potrf" : "diag_factor", "diag_inverse", "factor_panel"};
         for (int q = 0; q < 4; ++q) detail ? snprintf(nm[q], 48, "%s_j%02d", base[q], j) : snprintf(nm[q], 48, "%s", base[q]);
         {
           ROM_PROF(ctx, nm[0], Mc * nk * 2.0 * 262144, Mc * 8.0 * 4096 * (1 + 2 * nk));
           k_diag_update<<<Mc, 256, 0, st>>>(d, am, slot);
         }
-        {
-          ROM_PROF(ctx, nm[1], Mc * (262144 / 3.0), Mc * 8.0 * 4096 * 2);
-          k_diag_potrf<<<Mc, 64, 0, st>>>(d, slot);
-        }
-        {
-          ROM_PROF(ctx, nm[2], Mc * (262144 / 3.0 + 4096.0), Mc * 8.0 * 4096 * 2);
-          k_diag_inverse<<<Mc, 64, 0, st>>>(d, slot, j);
+        if (!no_mfma_diag) {
+          ROM_PROF(ctx, nm[1], Mc * (2 * 262144 / 3.0 + 4096.0), Mc * 8.0 * 4096 * 3);
+          k_diag_factor<<<Mc, 64, 0, st>>>(d, slot, j);
+        } else {
+          {
+            ROM_PROF(ctx, nm[1], Mc * (262144 / 3.0), Mc * 8.0 * 4096 * 2);
+            k_diag_potrf<<<Mc, 64, 0, st>>>(d, slot);
+          }
+          {
+            ROM_PROF(ctx, nm[2], Mc * (262144 / 3.0 + 4096.0), Mc * 8.0 * 4096 * 2);
+            k_diag_inverse<<<Mc, 64, 0, st>>>(d, slot, j);
+          }
         }
       }
       int nrows = f->colptr[j + 1] - f->colptr[j];
