@@ -13,6 +13,7 @@ return negative diagonals in R); every consumer in the reference is sign-invaria
 from __future__ import annotations
 
 import functools
+import os
 from logging import warning
 from typing import List
 
@@ -53,6 +54,23 @@ def _orthonormalize_device(ctx: _ffi.Context, X: DeviceArray) -> DeviceArray:
         else:
             Q.fill(0.0, offset=off, n=dim)
     return DeviceArray(Q, n, dim)
+
+
+def _append_orthonormal_row(ctx: _ffi.Context, Q: _ffi.Buffer, k: int, src: _ffi.Buffer, src_row: int, dim: int):
+    """Q[k] <- row `src_row` of `src`, orthonormalised against the orthonormal rows Q[0:k] (CGS2, the inner step
+    of _orthonormalize_device)."""
+    off = k * dim
+    Q.copy_from(src, dim, dst_off=off, src_off=src_row * dim)
+    if k > 0:
+        h = ctx.alloc(k)
+        for _ in range(2):  # "twice is enough"
+            ctx.gemm_nt(k, 1, dim, Q, 0, dim, Q, off, dim, h, 0, 1)
+            ctx.gemm_nn(1, dim, k, h, 0, k, Q, 0, dim, Q, off, dim, alpha=-1.0, beta=1.0)
+    nrm = float(ctx.l2norm(Q, k, 1, dim)[0])
+    if nrm > 1e-300:
+        Q.scale(1.0 / nrm, offset=off, n=dim)
+    else:
+        Q.fill(0.0, offset=off, n=dim)
 
 
 def _cholqr2_device(ctx: _ffi.Context, X: DeviceArray) -> DeviceArray:
@@ -194,18 +212,30 @@ class ReducedBasisGreedy(BaseReducedBasis):
         U = _as_device(ctx, solutions2train, dim)  # training set stays in HBM for the whole build
         picks: List[int] = []
         self.max_errors = []
+        # The reference re-orthonormalises the contrast-sorted picks from scratch in every iteration (:135-136).
+        # Both approximations below depend on the SPAN of the basis only, so the orthonormal basis is grown by one
+        # vector per iteration instead (re-orthogonalised Gram-Schmidt of the new pick against the rows already
+        # there): n instead of n^2/2 vector steps.  ROMHC_GREEDY_RESORT=1 keeps the from-scratch variant (A/B).
+        resort = bool(os.environ.get("ROMHC_GREEDY_RESORT"))
+        Q = None if resort else ctx.alloc(max(n * dim, 1))
+        Ahat = None  # reduced tensor of the rows of Q, grown with them (Galerkin mode)
         for _ in range(n):
-            # orthonormal basis of the current picks, sorted by contrast (:135-136)
-            if picks:
+            if picks and resort:
                 contrast = np.ravel(high_contrast_a[picks])
                 order = np.argsort(1 / contrast)
                 rows = np.asarray(picks)[order][order]  # the reference permutes twice (:27-28)
                 sel = ctx.alloc(len(picks) * dim).gather_rows_from(U.buf, rows, dim)
                 C_orth = _orthonormalize_device(ctx, DeviceArray(sel, len(picks), dim))
+            elif picks:
+                _append_orthonormal_row(ctx, Q, len(picks) - 1, U.buf, picks[-1], dim)
+                C_orth = DeviceArray(Q, len(picks), dim)
             else:
                 C_orth = np.empty((0, 0))
             if self.greedy_for == GREEDY_FOR_H10:
                 approx = sm.project_solutions_device(U, C_orth)  # (:122)
+            elif picks and not resort:
+                Ahat = sm._reduced_tensor_grow(C_orth, Ahat)
+                approx = sm.generate_fm_solutions_device(a2train, C_orth, reduced_tensor=Ahat)  # (:124)
             else:
                 approx = sm.generate_fm_solutions_device(a2train, C_orth)  # (:124)
             rel = sm.H10norm_diff(approx, U) / solutions2train_h1norm  # (:129)

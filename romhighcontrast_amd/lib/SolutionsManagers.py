@@ -177,7 +177,29 @@ class SolutionsManager:
             ctx.gemm_nt(n, n, dim, AC, 0, dim, C.buf, 0, dim, Ahat, b * n * n, n)
         return Ahat
 
-    def generate_fm_solutions_device(self, a, coefficients_rom) -> DeviceArray:
+    def _reduced_tensor_grow(self, C: DeviceArray, Ahat_prev):
+        """The reduced tensor of the rows C[0:n] given the one of C[0:n-1] (host array (k, n-1, n-1) or None): only the
+        entries of the new row / column are computed (A_pq is symmetric).  Used by the greedy builder, whose
+        orthonormal basis grows by one row per iteration.  Returns the host array (k, n, n)."""
+        ctx, fem, n, dim = self._ctx, self._fem, C.rows, self.vspace_dim
+        k = fem.kblk
+        AC = ctx.alloc(k * dim)  # A_b q_new for every block b
+        for b in range(k):
+            e = np.zeros(k)
+            e[b] = 1.0
+            fem.stencil_apply(C.buf, 1, AC, a_one=e, x_row0=n - 1, y_row0=b)
+        col = ctx.alloc(n * k)
+        ctx.gemm_nt(n, k, dim, C.buf, 0, dim, AC, 0, dim, col, 0, k)  # col[i, b] = q_i . A_b q_new
+        colh = col.download(n * k, shape=(n, k))
+        out = np.zeros((k, n, n))
+        if Ahat_prev is not None and n > 1:
+            out[:, :n - 1, :n - 1] = Ahat_prev
+        out[:, n - 1, :] = colh.T
+        out[:, :, n - 1] = colh.T
+        return out
+
+    def generate_fm_solutions_device(self, a, coefficients_rom, reduced_tensor=None) -> DeviceArray:
+        """``reduced_tensor``: optional host array (k, n, n) = C A_pq C^T if the caller already has it."""
         _check_method(self.method)
         a = self._a_batch(a)
         M, dim, ctx = a.shape[0], self.vspace_dim, self._ctx
@@ -187,7 +209,7 @@ class SolutionsManager:
             return DeviceArray(out, M, dim)
         C = _as_device(ctx, coefficients_rom, dim)
         n, k = C.rows, self._fem.kblk
-        Ahat = self._reduced_tensor(C)
+        Ahat = self._reduced_tensor(C) if reduced_tensor is None else ctx.upload(reduced_tensor)
         Bk = ctx.alloc(n)  # B_k = C @ B_total (:103)
         ctx.gemm_nt(n, 1, dim, C.buf, 0, dim, ctx.upload(self.B_total), 0, dim, Bk, 0, 1)
         c = ctx.alloc(M * n)

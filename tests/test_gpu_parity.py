@@ -160,6 +160,28 @@ def test_g6_greedy(api, tag, mode_name):
         RB.ReducedBasisGreedy(greedy_for="x").build(n=1, sm=sm, solutions2train=z["U"], a2train=z["a"])
 
 
+@pytest.mark.parametrize("mode_name", ["GREEDY_FOR_H10", "GREEDY_FOR_GALERKIN"])
+def test_greedy_incremental_basis_equals_resorted(api, mode_name, monkeypatch):
+    """The builder grows its orthonormal basis by one row per iteration; the reference re-orthonormalises the
+    contrast-sorted picks from scratch (src/lib/ReducedBasis.py:135-136).  Same span, so the same picks and error
+    curve (ROMHC_GREEDY_RESORT=1 runs the from-scratch variant)."""
+    SM, RB = api
+    blocks, N, M, n = (2, 3), 12, 60, 10
+    sm = SM.SolutionsManagerFEM(blocks, N)
+    a = 10.0 ** np.random.default_rng(5).uniform(0, 4, size=(M,) + blocks)
+    a[0] = 1.0
+    U = sm.generate_solutions(a)
+    h1 = sm.H10norm(U)
+    mode = getattr(RB, mode_name)
+    monkeypatch.delenv("ROMHC_GREEDY_RESORT", raising=False)
+    inc = RB.ReducedBasisGreedy(greedy_for=mode).build(n=n, sm=sm, solutions2train=U, a2train=a, solutions2train_h1norm=h1)
+    monkeypatch.setenv("ROMHC_GREEDY_RESORT", "1")
+    ref = RB.ReducedBasisGreedy(greedy_for=mode).build(n=n, sm=sm, solutions2train=U, a2train=a, solutions2train_h1norm=h1)
+    assert inc.picks == ref.picks
+    np.testing.assert_allclose(inc.max_errors, ref.max_errors, rtol=1e-7, atol=1e-11)
+    assert np.array_equal(inc.basis, ref.basis)
+
+
 def test_g7_pca_random(api):
     SM, RB = api
     z = load_golden("g7_pca_random.npz")

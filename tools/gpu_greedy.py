@@ -24,7 +24,16 @@ h1, t = T(lambda: sm.H10norm(U)); h1, t = T(lambda: sm.H10norm(U))
 print(f"H10norm of {M} vectors: {t*1e3:.2f} ms -> {8.0*M*sm.vspace_dim/t*1e-9:.0f} GB/s algorithmic (8 B/entry read once)")
 for mode in (RB.GREEDY_FOR_H10, RB.GREEDY_FOR_GALERKIN):
     rb = RB.ReducedBasisGreedy(mode)
+    if os.environ.get("PROFILE"):
+        ctx.profile(True)
     _, t = T(lambda: rb.build(n, sm, U, a, h1))
+    if os.environ.get("PROFILE"):
+        rep = ctx.profile_report()
+        ctx.profile(False)
+        tot = sum(v["total_ms"] for v in rep.values())
+        print(f"   kernels of the build: {tot:.1f} ms in total")
+        for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])[:9]:
+            print(f"     {k:18s} {v['total_ms']:8.2f} ms  launches {v['launches']:6d}")
     e = np.array(rb.max_errors)
     print(f"greedy {mode}: n={n} in {t:.2f} s; max rel H10 error: " + " ".join(f"{x:.1e}" for x in e[[0, 1, 2, 4, 9, 19, 29, 39, min(49, n - 1)]]))
     print("   first picks", rb.picks[:12])

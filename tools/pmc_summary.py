@@ -14,7 +14,7 @@ import sys
 def agg(path):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        d[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+        d[r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return d
 
 
