@@ -72,6 +72,14 @@ int rom_buf_free(rom_buf* b);
 int rom_buf_size(rom_buf* b, size_t* n_doubles);
 int rom_buf_upload(rom_buf* b, size_t offset, const double* host, size_t n);
 int rom_buf_download(rom_buf* b, size_t offset, double* host, size_t n);
+/* Page-locked host arrays for large results (process-wide pool, thread safe): generate_solutions
+ * (src/lib/SolutionsManagers.py:64-68) returns the (M, dim) rows to the host, and rom_buf_download into such an
+ * array runs at the PCIe rate (48 vs 11-25 GB/s) -- but pinning 533 MB takes 110 ms, so the Python shim only pins for
+ * sizes it has seen repeatedly and otherwise takes what the pool has; the NumPy arrays it wraps around the blocks
+ * give them back when they are collected. */
+/* pooled_only != 0: hand out a block of the pool or *out = NULL (status 0), never pin new memory */
+int rom_host_alloc(size_t n, int pooled_only, double** out);
+int rom_host_free(double* p);
 int rom_buf_fill(rom_buf* b, size_t offset, size_t n, double value);
 int rom_buf_copy(rom_buf* dst, size_t dst_off, rom_buf* src, size_t src_off, size_t n);
 /* dst[i, :] = src[rows[i], :] for row length `dim` (host index list; used by the greedy) */

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 from scipy.linalg import LinAlgError
@@ -76,6 +77,8 @@ PROTOTYPES = {
                               _vp, C.c_size_t, C.c_int64, C.c_double, _vp, C.c_size_t, C.c_int64]),
     "rom_reduced_solve_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "rom_buf_scale": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_double]),
+    "rom_host_alloc": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_double))]),
+    "rom_host_free": (C.c_int, [C.POINTER(C.c_double)]),
     "rom_center_rows": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
     "rom_rows_scale": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
     "rom_rows_sign_flip": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64]),
@@ -123,6 +126,28 @@ def check(status: int):
     if status == ROM_ERR_NOMEM:
         raise MemoryError(msg)
     raise RomLibraryError(f"libromhc error {status}: {msg}")
+
+
+# downloads of at least this many bytes land in page-locked host memory (0 disables: ROMHC_PINNED_DOWNLOAD_BYTES)
+PINNED_DOWNLOAD_BYTES = int(os.environ.get("ROMHC_PINNED_DOWNLOAD_BYTES", str(8 << 20))) or (1 << 62)
+
+
+_download_sizes: dict = {}  # size -> number of large downloads of that size so far
+
+
+def _pinned_array(lib, n: int):
+    """A writable float64 array of n entries in page-locked memory from libromhc's pool; the block returns to the pool
+    when the array (and every view of it) is gone.  Pinning new memory costs ten copies' worth of time, so that only
+    happens for a size that keeps coming back (third request on); before, a block is used if the pool has one.
+    None: the caller falls back to np.empty."""
+    seen = _download_sizes[n] = _download_sizes.get(n, 0) + 1
+    p = C.POINTER(C.c_double)()
+    if lib.rom_host_alloc(n, 0 if seen >= 3 else 1, C.byref(p)) != 0 or not p:
+        return None
+    addr = C.cast(p, C.c_void_p).value
+    raw = (C.c_double * n).from_address(addr)
+    weakref.finalize(raw, lib.rom_host_free, C.cast(addr, C.POINTER(C.c_double)))
+    return np.frombuffer(raw, dtype=np.float64)
 
 
 def _host(arr: np.ndarray) -> np.ndarray:
@@ -274,7 +299,9 @@ class Buffer:
 
     def download(self, n=None, offset=0, shape=None) -> np.ndarray:
         n = self.n - offset if n is None else int(n)
-        out = np.empty(n, dtype=np.float64)
+        out = _pinned_array(self.ctx.lib, n) if n * 8 >= PINNED_DOWNLOAD_BYTES else None
+        if out is None:
+            out = np.empty(n, dtype=np.float64)
         check(self.ctx.lib.rom_buf_download(self.h, offset, out.ctypes.data, n))
         return out.reshape(shape) if shape is not None else out
 

@@ -1,3 +1,4 @@
+#include <mutex>
 // Context, device buffers, error strings, HIP-event stopwatch and per-kernel profiling.
 #include "romhc_internal.h"
 
@@ -261,6 +262,65 @@ extern "C" int rom_buf_free(rom_buf* b) {
     hipFree(b->p);
   }
   delete b;
+  return ROM_OK;
+}
+
+// ---- page-locked host arrays for large downloads ---------------------------------------------------
+// The reference API hands NumPy rows back to its caller (generate_solutions: (M, dim) doubles, 533 MB at C2), so the
+// device -> host copy is part of every such call; into pageable memory it runs at 11-25 GB/s, into page-locked
+// memory at the PCIe rate (48 GB/s measured).  Pinning is slow (page by page: 110 ms for 533 MB), so freed blocks
+// are kept in a process-wide pool (finalisers of the NumPy arrays may run on any thread, after their context is
+// gone: no rom_ctx here) and the caller decides when a new block is worth pinning (`pooled_only`).
+namespace {
+std::mutex g_host_mu;
+std::map<size_t, std::vector<void*>> g_host_free;   // rounded bytes -> blocks
+std::map<void*, size_t> g_host_live;                 // block -> rounded bytes
+size_t g_host_cached = 0;
+const size_t g_host_cache_limit = size_t(8) << 30;
+}  // namespace
+
+extern "C" int rom_host_alloc(size_t n, int pooled_only, double** out) {
+  ROM_CHECK(out, "rom_host_alloc: null argument");
+  *out = nullptr;
+  const size_t bytes = round_bytes((n ? n : 1) * sizeof(double));
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  void* p = nullptr;
+  auto it = g_host_free.find(bytes);
+  if (it != g_host_free.end() && !it->second.empty()) {
+    p = it->second.back();
+    it->second.pop_back();
+    g_host_cached -= bytes;
+  } else if (pooled_only) {
+    return ROM_OK;  // nothing of this size in the pool: *out stays null
+  } else {
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      rom_set_error("rom_host_alloc: hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+      return ROM_ERR_NOMEM;
+    }
+  }
+  g_host_live[p] = bytes;
+  *out = static_cast<double*>(p);
+  return ROM_OK;
+}
+
+extern "C" int rom_host_free(double* p) {
+  if (!p) return ROM_OK;
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  auto it = g_host_live.find(p);
+  if (it == g_host_live.end()) {
+    rom_set_error("rom_host_free: not a block of rom_host_alloc");
+    return ROM_ERR_INVALID;
+  }
+  const size_t bytes = it->second;
+  g_host_live.erase(it);
+  if (g_host_cached + bytes <= g_host_cache_limit) {
+    g_host_free[bytes].push_back(p);
+    g_host_cached += bytes;
+  } else {
+    (void)hipHostFree(p);
+  }
   return ROM_OK;
 }
 
