@@ -236,6 +236,28 @@ def test_row_helpers_of_the_pca(M, dim):
         assert np.array_equal(Yd.download(shape=(M, dim)), ref)
 
 
+def test_large_downloads_through_pinned_pool():
+    """Downloads of a size that keeps coming back land in page-locked arrays from libromhc's pool: same numbers,
+    ordinary writable NumPy arrays, a view keeps its block alive, blocks are recycled."""
+    import gc
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    n = (12 << 20) // 8 + 3
+    x = np.random.default_rng(0).standard_normal(n)
+    b = ctx.upload(x)
+    outs = [b.download() for _ in range(5)]  # the third request on may pin
+    for o in outs:
+        assert o.dtype == np.float64 and o.flags.writeable and np.array_equal(o, x)
+    view = outs[-1][5:1000]
+    keep = view.copy()
+    del outs, o
+    gc.collect()
+    again = [b.download(shape=(1, n)) for _ in range(3)]  # reuses pooled blocks; must not disturb the live view
+    assert np.array_equal(view, keep) and all(np.array_equal(a[0], x) for a in again)
+    again[0][0, :4] = 7.0  # writable, and private to this array
+    assert np.array_equal(again[1][0], x)
+
+
 def test_pod_subspace_iteration_vs_oracle(api):
     """POD with M > n + oversampling, so that the device subspace iteration (not the one-step full-space
     Ritz solve) produces the modes; compared with the oracle's LAPACK SVD."""
