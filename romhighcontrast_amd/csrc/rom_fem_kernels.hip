@@ -1121,26 +1121,34 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
     const int m = blockIdx.y * 128 + threadIdx.x;
     scs[threadIdx.x] = m < Mc ? f.y[size_t(m) * f.nGp + f.sblk0 + b] : 0.0;  // h^2 / a_b (visible after the first barrier below)
   }
-  int cend[4];
+  // K runs over the sides' rank + 1 coefficients in segments of 8 (a thread stages one segment per chunk): the
+  // tables are padded to 16 per side, but only ceil((rank + 1) / 8) segments of a side hold anything -- the second
+  // half of a side's last chunk is handed to the next side (7-17 % fewer MFMAs where rank + 1 is just above a
+  // multiple of 16; products with the zero padding add nothing, so the sums do not change)
+  int send[4];
   const double* pAs[4];
   const double* pBs[4];
-  int tot = 0;
+  int nseg = 0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const ExtSide es = sd.s[s];
     pAs[s] = pBs[s] = nullptr;
     if (es.mode == 2) {
-      tot += es.nch;
-      if (vA) pAs[s] = f.y + size_t(mA) * f.nGp + es.off + sseg;
-      if (vB) pBs[s] = f.G + es.gtab + size_t(h0_row(s, iB, jB, N, n1)) * (es.nch * BK) + sseg;
+      nseg += min(2 * es.nch, (es.r + 1 + 7) / 8);
+      if (vA) pAs[s] = f.y + size_t(mA) * f.nGp + es.off;
+      if (vB) pBs[s] = f.G + es.gtab + size_t(h0_row(s, iB, jB, N, n1)) * (es.nch * BK);
     }
-    cend[s] = tot;
+    send[s] = nseg;
   }
+  const int tot = (nseg + 1) / 2;
+  const int half = threadIdx.x & 1;
   auto pick = [&](int ch, const double* const* ps) -> const double* {
-    const int s = (ch >= cend[0]) + (ch >= cend[1]) + (ch >= cend[2]);
-    const int lc = ch - (s == 0 ? 0 : s == 1 ? cend[0] : s == 2 ? cend[1] : cend[2]);
+    const int sg = 2 * ch + half;
+    if (sg >= nseg) return nullptr;
+    const int s = (sg >= send[0]) + (sg >= send[1]) + (sg >= send[2]);
+    const int ls = sg - (s == 0 ? 0 : s == 1 ? send[0] : s == 2 ? send[1] : send[2]);
     const double* ptr = s == 0 ? ps[0] : s == 1 ? ps[1] : s == 2 ? ps[2] : ps[3];
-    return ptr ? ptr + lc * BK : nullptr;
+    return ptr ? ptr + ls * 8 : nullptr;
   };
   auto load8 = [&](const double* ptr, double* v) {
     load4_aligned(ptr, v);

@@ -987,7 +987,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         const int c = comp_of[e];
         if (cpos[e] >= 0) {
           es = ExtSide{2, cpos[e], rp[c] / BK, comps[c].r, int(goff[{c, int(is_pre[e])}]), edges[e].b0, edges[e].b1};
-          fl += 2.0 * 64 * rp[c] * npi * npj;
+          fl += 2.0 * double(n1) * n1 * (comps[c].r + 1);  // algorithmic: no padding of K or of the vertex tiles
         } else {
           es.mode = 1;
           es.off = npos[e];
