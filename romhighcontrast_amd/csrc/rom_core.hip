@@ -132,8 +132,35 @@ extern "C" int rom_timer_stop(rom_ctx* c, double* ms) {
   return ROM_OK;
 }
 
+// ---- debugging aid: NaN patterns in the LDS of every CU before a kernel starts ---------------------
+// (ROMHC_POISON_LDS=1: a kernel that reads LDS it has not written picks up whatever the previous workgroup on
+// that CU left there -- harmless zeros-times-finite most of the time, NaN once in a while.  160 KB per workgroup:
+// one workgroup per CU at a time, 4 x the CU count so that every CU gets at least one.)
+__global__ __launch_bounds__(256) void k_poison_lds() {
+  extern __shared__ unsigned long long poison[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 8; i += 256) poison[i] = 0xFFFFFFFFFFFFFFFFull;
+  __syncthreads();
+  if (poison[(threadIdx.x * 977) % (160 * 1024 / 8)] == 0) __builtin_trap();  // keep the stores
+}
+
+static void poison_lds(hipStream_t st) {
+  static bool ready = false;
+  if (!ready) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    ready = true;
+  }
+  k_poison_lds<<<1024, 256, 160 * 1024, st>>>();
+  const hipError_t e = hipGetLastError();
+  static bool told = false;
+  if (!told) {
+    fprintf(stderr, "romhc: ROMHC_POISON_LDS: poison kernel launch: %s\n", hipGetErrorString(e));
+    told = true;
+  }
+}
+
 // ---- per-kernel profiling ----------------------------------------------------------------------
 ProfScope::ProfScope(rom_ctx* c, const char* name, double flops, double bytes) : ctx(c) {
+  if (getenv("ROMHC_POISON_LDS")) poison_lds(c->prof_stream ? c->prof_stream : c->stream);
   if (!c->profile) return;
   int id = -1;
   for (size_t i = 0; i < c->prof_names.size(); ++i)
