@@ -95,7 +95,16 @@ __global__ void k_factor_panel(FemDev f, const double* __restrict__ a, int j, in
 __global__ void k_backsolve(FemDev f);
 __global__ void k_edge_transform(FemDev f, int Mc);
 __global__ void k_extend(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, const int* __restrict__ blocks, int pw_log2);
+// Descriptors of up to X128_BLOCKS blocks for one k_extend128 launch, passed BY VALUE: kernel arguments are read
+// with scalar loads in one batch, whereas f.lr_blocks[z] -> f.sides[b] -> fields compiled into a chain of 14
+// dependent vector loads (each with its own s_waitcnt vmcnt(0)) at the head of every workgroup.
+constexpr int X128_BLOCKS = 16;
+struct X128Args {
+  int blocks[X128_BLOCKS];
+  BlockSide sides[X128_BLOCKS];
+};
+
 template <bool FLAT>
-__global__ void k_extend128(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, int with_expand);
+__global__ void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, int with_expand);
 __global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0);
 __global__ void k_assemble_stencil(FemDev f, const double* __restrict__ a, int M, double* __restrict__ diag, double* __restrict__ east, double* __restrict__ north);

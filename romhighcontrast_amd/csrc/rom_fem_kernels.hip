@@ -1065,6 +1065,25 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
     }
 }
 
+#ifdef ROMHC_STAMPS
+// cycle stamps of k_extend128 (debug build only: make EXTRA=-DROMHC_STAMPS, tools/gpu_stamps.py): [workgroup][5],
+// written by thread 0.  (In this build hipcc if-converts the stagger below and EVERY workgroup sleeps: subtract
+// 2 x 127 x 64 cycles from the first interval.)
+__device__ unsigned long long g_stamps[8192 * 5];
+#define STAMP(i)                                                                                               \
+  do {                                                                                                         \
+    if (threadIdx.x == 0) {                                                                                    \
+      const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                    \
+      if (lin_ < 8192u) g_stamps[lin_ * 5 + (i)] = __builtin_readcyclecounter();                               \
+    }                                                                                                          \
+  } while (0)
+extern "C" int rom_debug_stamps(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), size_t(n) * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#else
+#define STAMP(i)
+#endif
+
 // The same extension for blocks whose sides are all compressed, with 128 x 128 workgroup tiles (128 systems x
 // one mesh row of up to 128 interior vertices; every wave a 64 x 64 quadrant = 4 x 4 MFMA accumulators): K is
 // only sum(rank + 1) ~ 64, so a 64 x 64 tile spends most of its life in its prologue and epilogue; four times
@@ -1076,7 +1095,7 @@ constexpr int X128_STAGE = 128 * LDK;
 // one mesh row -- no padding when n1 is not close to a multiple of 128 (n1 = 170: 226 tiles per block instead of
 // 340); a pair of adjacent vertices may then straddle two mesh rows and is stored as two 8-byte halves.
 template <bool FLAT>
-__global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __restrict__ a, int Mc,
+__global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc,
                                                       double* __restrict__ U, long long row0, int with_expand) {
   __shared__ __align__(16) double lds[4 * X128_STAGE];  // {A,B} x 2 buffers
   __shared__ double scs[128];                            // h^2 / a_b of the workgroup's systems
@@ -1094,6 +1113,7 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
     return;
   }
   const int bz = blockIdx.z;
+  STAMP(0);
   {
     // Two workgroups share a CU; started together they run in lockstep (both loading / multiplying, then both in
     // the epilogue).  The second half of the first round starts one MFMA phase late (about 64 cycles per MFMA)
@@ -1103,9 +1123,9 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
     if (lin >= 256u && lin < 512u)
       for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);  // 2 x 127 x 64 cycles
   }
-  const int b = f.lr_blocks[bz];
+  const int b = xa.blocks[bz];
   const int p = b / f.ncb, q = b % f.ncb;
-  const BlockSide& sd = f.sides[b];
+  const BlockSide sd = xa.sides[bz];  // by value and read without branches below: one batch of scalar loads
   const int iv = blockIdx.x / nct + 1;           // mesh row (1-based interior index)       (!FLAT)
   const int jv0 = 128 * (blockIdx.x % nct) + 1;  // first vertex of the tile                (!FLAT)
   const int vt0 = 128 * blockIdx.x;              // first vertex of the tile, block-local   (FLAT)
@@ -1117,9 +1137,10 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
   const int iB = FLAT ? (vt0 + srow) / n1 + 1 : iv;
   const int jB = FLAT ? (vt0 + srow) % n1 + 1 : jv0 + srow;
   const bool vB = FLAT ? vt0 + srow < nvert : jB <= n1;
+  double my_sc = 0.0;  // h^2 / a_b of system threadIdx.x: requested now, parked in LDS after the k loop
   if (threadIdx.x < 128) {
     const int m = blockIdx.y * 128 + threadIdx.x;
-    scs[threadIdx.x] = m < Mc ? f.y[size_t(m) * f.nGp + f.sblk0 + b] : 0.0;  // h^2 / a_b (visible after the first barrier below)
+    if (m < Mc) my_sc = f.y[size_t(m) * f.nGp + f.sblk0 + b];
   }
   // K runs over the sides' rank + 1 coefficients in segments of 8 (a thread stages one segment per chunk): the
   // tables are padded to 16 per side, but only ceil((rank + 1) / 8) segments of a side hold anything -- the second
@@ -1132,12 +1153,12 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const ExtSide es = sd.s[s];
-    pAs[s] = pBs[s] = nullptr;
-    if (es.mode == 2) {
-      nseg += min(2 * es.nch, (es.r + 1 + 7) / 8);
-      if (vA) pAs[s] = f.y + size_t(mA) * f.nGp + es.off;
-      if (vB) pBs[s] = f.G + es.gtab + size_t(h0_row(s, iB, jB, N, n1)) * (es.nch * BK);
-    }
+    const bool m2 = es.mode == 2;  // (selects, not branches: the descriptor loads of all four sides stay together)
+    nseg += m2 ? min(2 * es.nch, (es.r + 1 + 7) / 8) : 0;
+    const double* pa = f.y + size_t(mA) * f.nGp + es.off;
+    const double* pb = f.G + es.gtab + size_t(h0_row(s, iB, jB, N, n1)) * (es.nch * BK);
+    pAs[s] = m2 && vA ? pa : nullptr;
+    pBs[s] = m2 && vB ? pb : nullptr;
     send[s] = nseg;
   }
   const int tot = (nseg + 1) / 2;
@@ -1183,12 +1204,14 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
       w_own[j] = jj <= n1 ? f.W[(iv - 1) * n1 + (jj - 1)] : 0.0;
     }
   }
+  STAMP(1);
   for (int ch = 0; ch < tot; ++ch) {
     double* sA = lds + (ch & 1) * 2 * X128_STAGE;
     double* sB = sA + X128_STAGE;
     store8(sA, va);
     store8(sB, vb);
     __syncthreads();
+    if (ch == 0) STAMP(2);
     if (ch + 1 < tot) {
       load8(pick(ch + 1, pAs), va);
       load8(pick(ch + 1, pBs), vb);
@@ -1209,7 +1232,9 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
   }
-  if (tot == 0) __syncthreads();  // scs
+  if (threadIdx.x < 128) scs[threadIdx.x] = my_sc;
+  __syncthreads();
+  STAMP(3);
   // epilogue: add the particular solution, swap between lane pairs so that every lane owns two adjacent
   // vertices of one 16-vertex block, 16-byte stores (see k_extend)
   const bool odd = lane & 1;
@@ -1255,9 +1280,10 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, const double* __
         else if (ok0[hp]) dst[off0[hp]] = lo;
       }
     }
+  STAMP(4);
 }
-template __global__ void k_extend128<false>(FemDev, const double*, int, double*, long long, int);
-template __global__ void k_extend128<true>(FemDev, const double*, int, double*, long long, int);
+template __global__ void k_extend128<false>(FemDev, X128Args, const double*, int, double*, long long, int);
+template __global__ void k_extend128<true>(FemDev, X128Args, const double*, int, double*, long long, int);
 
 // interface values that k_expand does not write: cross points and the edges recovered node by node
 __global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0) {

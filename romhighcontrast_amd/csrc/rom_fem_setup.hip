@@ -1019,6 +1019,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     f->n_lr_blocks = int(lr_blocks.size());
     f->n_gen_blocks = int(gen_blocks.size());
     ROM_TRY(upload(&f->d_lr_blocks, lr_blocks));
+    f->lr_blocks_host = lr_blocks;
     ROM_TRY(upload(&f->d_gen_blocks, gen_blocks));
     std::vector<int> eposv;
     for (int e = 0; e < E; ++e)

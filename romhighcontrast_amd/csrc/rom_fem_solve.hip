@@ -192,10 +192,20 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         if (wide) {
           const int mt = (Mc + 127) / 128;
           const int items = (f->n1p / 64) * ((Mc + 63) / 64) * (f->nexp + 1);  // workgroups of the folded expansion
-          const int extra = fold_expand ? (items + mt * f->n_lr_blocks - 1) / (mt * f->n_lr_blocks) : 0;
-          dim3 grid(t128 + extra, mt, f->n_lr_blocks);
-          if (flat) k_extend128<true><<<grid, 256, 0, st>>>(d, am, Mc, U, row, extra);
-          else k_extend128<false><<<grid, 256, 0, st>>>(d, am, Mc, U, row, extra);
+          // block descriptors travel as kernel arguments, X128_BLOCKS per launch; the folded expansion rides in the first
+          for (int z0 = 0; z0 < f->n_lr_blocks; z0 += X128_BLOCKS) {
+            const int nz = std::min(X128_BLOCKS, f->n_lr_blocks - z0);
+            X128Args xa;
+            memset(&xa, 0, sizeof(xa));
+            for (int z = 0; z < nz; ++z) {
+              xa.blocks[z] = f->lr_blocks_host[z0 + z];
+              xa.sides[z] = f->sides[xa.blocks[z]];
+            }
+            const int extra = fold_expand && z0 == 0 ? (items + mt * nz - 1) / (mt * nz) : 0;
+            dim3 grid(t128 + extra, mt, nz);
+            if (flat) k_extend128<true><<<grid, 256, 0, st>>>(d, xa, am, Mc, U, row, extra);
+            else k_extend128<false><<<grid, 256, 0, st>>>(d, xa, am, Mc, U, row, extra);
+          }
         } else {
           dim3 grid(f->n1 * ((f->n1 + 63) / 64), (Mc + 63) / 64, f->n_lr_blocks);
           k_extend<<<grid, 256, 0, st>>>(d, am, Mc, U, row, d.lr_blocks, 6);

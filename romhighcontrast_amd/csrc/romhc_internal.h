@@ -242,6 +242,7 @@ struct rom_fem {
   int nrhs = 0;
   BlockSide* d_sides = nullptr;  // nrb*ncb
   int* d_lr_blocks = nullptr;    // blocks whose sides are all in compressed form (k_extend_lr)
+  std::vector<int> lr_blocks_host;  // the same list on the host (k_extend128 gets its descriptors as kernel arguments)
   int* d_gen_blocks = nullptr;   // the others (k_extend)
   int n_lr_blocks = 0, n_gen_blocks = 0, lr_nch = 0;
   int* d_vmap = nullptr;         // interface position -> global dof (or -1), size nGp

@@ -447,10 +447,11 @@ def test_two_stage_sweep_is_bit_identical(api, blocks, N, M):
 
 
 @pytest.mark.parametrize("blocks,N,M", [((2, 2), 128, 130), ((3, 3), 24, 140), ((2, 3), 40, 200), ((2, 2), 90, 128),
-                                        ((1, 2), 9, 129), ((3, 2), 171, 128)])
+                                        ((1, 2), 9, 129), ((3, 2), 171, 128), ((5, 4), 33, 128)])
 def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
     """The extension into the blocks has three tilings (128 vertices of one mesh row, 128 consecutive vertices of the
-    block, 64 vertices of one mesh row): same products in the same order, so the snapshots must be identical."""
+    block, 64 vertices of one mesh row): same products in the same order, so the snapshots must be identical.
+    (5 x 4 blocks: more than the 16 block descriptors one launch of the 128-tile kernel carries.)"""
     from romhighcontrast_amd import _ffi
     ctx = _ffi.get_context()
     a = 10.0 ** np.random.default_rng(N).uniform(0, 3, size=(M, blocks[0] * blocks[1]))
