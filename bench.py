@@ -287,11 +287,15 @@ def main():
                 "avg_launch_ms": round(d["total_ms"] / d["launches"], 5),
                 "flops_per_launch": d["flops"] / d["launches"],
                 "store_bytes_per_launch": 8.0 * M * blocks[0] * blocks[1] * (N - 1) ** 2 if dom.startswith("extend") else None,
-                "note": "fp64 MFMA (v_mfma_f64_16x16x4_f64) against the spec fp64 matrix rate.  The same launch writes "
-                        "the snapshot rows (store_bytes_per_launch).  MFMAs alone: 0.11-0.13 ms (64 busy cycles per "
-                        "instruction, SQ_VALU_MFMA_BUSY_CYCLES); store stream alone: 0.13-0.18 ms (tools/hbm_write_bw.hip); "
-                        "kernel with its stores disabled: 0.198 ms -- two waves per SIMD leave the MFMA pipe about 60 % busy, "
-                        "see DESIGN.md section 5"}
+                "sustained_mfma_tflops": 49.0,
+                "frac_of_sustained": round(achieved / 49.0, 4),
+                "note": "ALGORITHMIC flops (no padding of K or of the tiles) of the fp64 MFMA kernel (v_mfma_f64_16x16x4_f64) "
+                        "against the spec fp64 matrix rate (64 cycles per instruction).  A register-only loop of that "
+                        "instruction sustains 49 TFLOP/s on this part (one per 100-104 cycles per SIMD; "
+                        "profiles/r01_mfma_f64_peak_microbench_v2.txt): sustained_mfma_tflops / frac_of_sustained.  The same "
+                        "launch writes the snapshot rows (store_bytes_per_launch); store stream alone: 0.13-0.18 ms "
+                        "(tools/hbm_write_bw.hip); kernel with its stores disabled: 0.198 ms; in-kernel cycle stamps and what "
+                        "was tried: DESIGN.md section 5 and section 9"}
     # PMC-measured memory-side traffic of the dominant kernel, if a summary of separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command is committed
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
