@@ -588,6 +588,19 @@ __global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
   for (int i = 0; i < 64; ++i) It[i * 64 + lane] = Ls[i * LDC + lane];
 }
 
+#ifdef ROMHC_STAMPS
+__device__ unsigned long long g_stamps1[2048 * 6];  // k_solve1: [system][6]
+#define STAMP1(i)                                                                                    \
+  do {                                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < 2048u) g_stamps1[blockIdx.x * 6 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+extern "C" int rom_debug_stamps1(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps1), size_t(n) * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#else
+#define STAMP1(i)
+#endif
+
 // Whole reduced solve of a system whose reduced matrix is ONE tile (e.g. 2x2 blocks at N = 128: 2 x 31
 // compressed unknowns + the cross point), one wave per system, nothing but the solution leaves the CU:
 //   assemble the lower 16x16 blocks in MFMA accumulator layout (term by term, double buffered) ->
@@ -610,6 +623,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   // else hides the latency).  The pairs are sorted by block; a block's sum is kept in four registers and
   // stored to an LDS copy of the blocks when its last pair is done (the target block of a pair is a run-time
   // index, which registers cannot have).
+  STAMP1(0);
   double* Cl = Ls;  // the ten lower blocks during the assembly, [block][g][lane] (Ls is not needed before the Cholesky)
   static_assert(40 * 64 <= 64 * LDC, "block copy must fit in the tile buffer");
   const int l16 = lane & 15, l4 = lane >> 4;
@@ -655,6 +669,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
     }
   }
   __builtin_amdgcn_wave_barrier();
+  STAMP1(1);
   d4_t C[4][4];
   {
     int q = 0;
@@ -693,6 +708,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
         y += (rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5) * rv[x];
       }
   }
+  STAMP1(2);
   // Blocked right-looking Cholesky, 16 panels of 4 columns.  A panel goes through LDS into row-per-lane form
   // (lane r holds its 4 entries), is factorised there with readlane broadcasts -- the forward substitution of y
   // rides along -- and goes back through LDS as the A and B operand of v_mfma_f64_16x16x4_f64 (K = 4 is exactly
@@ -758,6 +774,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   }
   if (bad && lane == 0) atomicOr(f.status, 1);
   __syncthreads();
+  STAMP1(3);
   // back substitution x = L^-T y.  Column `lane` of L is fetched from LDS in one batch (conflict free), then the
   // chain x_j = y_j / L_jj ; y_i -= L_ji x_j (i < j) runs on registers and readlane broadcasts only.
   double lcol[64];
@@ -769,6 +786,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
     if (lane == j) y = xj;
     else if (lane < j) y -= lcol[j] * xj;
   }
+  STAMP1(4);
   ym[lane] = y;
   zs[lane] = y;
   __syncthreads();
@@ -807,6 +825,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
     if (cg.kind == 1 && k < cg.r) continue;  // done above
     ym[cg.cpos + k] = k == cg.r ? 1.0 / (am[cg.b0] + am[cg.b1]) : (k < cg.r ? zs[cg.zpos + k] : 0.0);
   }
+  STAMP1(5);
 }
 
 // Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;

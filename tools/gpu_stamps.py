@@ -25,3 +25,15 @@ for i, nm in enumerate(names):
     print(f"  {nm:32s} mean {d[:, i].mean():8.0f}  median {np.median(d[:, i]):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
 span = t[:, 4].max() - t[:, 0].min()
 print(f"kernel span {span} cycles; sum of lifetimes / (512 slots x span) = {np.sum(t[:,4]-t[:,0]) / (512.0 * span):.2f}")
+
+# ---- k_solve1 ----
+if hasattr(lib, "rom_debug_stamps1"):
+    n1 = 1024 * 6
+    b1 = (C.c_ulonglong * n1)()
+    assert lib.rom_debug_stamps1(b1, n1) == 0
+    t1 = np.frombuffer(b1, dtype=np.uint64).reshape(-1, 6).astype(np.int64)
+    t1 = t1[t1[:, 5] > t1[:, 0]]
+    d1 = np.diff(t1, axis=1)
+    print(f"k_solve1: {len(t1)} systems; lifetime mean {np.mean(t1[:,5]-t1[:,0]):.0f} cycles; first start -> last end {t1[:,5].max()-t1[:,0].min()} cycles")
+    for i, nm in enumerate(["assembly", "rhs", "Cholesky", "back substitution", "coefficient blocks"]):
+        print(f"  {nm:20s} mean {d1[:, i].mean():8.0f}  median {np.median(d1[:, i]):8.0f}  p90 {np.percentile(d1[:, i], 90):8.0f}")
