@@ -446,6 +446,34 @@ def test_two_stage_sweep_is_bit_identical(api, blocks, N, M):
     assert np.array_equal(U2.download(shape=(M + 2, fem.dim))[2:], ref)
 
 
+@pytest.mark.parametrize("name", ["b22", "b33", "b44"])
+def test_repeated_sweeps_are_bit_identical(name):
+    """Same parameters, fresh FE spaces, other work in between: the snapshots must not move by a bit (no atomics,
+    no dependence on what a buffer, a workspace or the LDS held before)."""
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    z = load_golden("g4_contrast.npz")
+    blocks, N = tuple(int(x) for x in z[f"{name}_blocks"]), int(z[f"{name}_N"])
+    a = np.asarray(z[f"{name}_a"], dtype=np.float64).reshape(len(z[f"{name}_a"]), -1)
+    M = len(a)
+    ref = None
+    for rep in range(8):
+        if rep % 4 == 0:
+            fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)
+            other = _ffi.Fem(ctx, 2, 2, 16 + rep)  # a different geometry churns allocator, caches and LDS
+            Uo = ctx.alloc(8 * other.dim)
+            other.solve_batch(ctx.upload(np.full((8, 4), 2.0)), 8, Uo)
+        U = ctx.alloc(M * fem.dim)
+        U.fill(float("nan"))
+        fem.solve_batch(ctx.upload(a), M, U)
+        out = U.download(shape=(M, fem.dim))
+        assert not np.isnan(out).any()
+        if ref is None:
+            ref = out
+        else:
+            assert np.array_equal(out, ref), rep
+
+
 @pytest.mark.parametrize("blocks,N,M", [((2, 2), 128, 130), ((3, 3), 24, 140), ((2, 3), 40, 200), ((2, 2), 90, 128),
                                         ((1, 2), 9, 129), ((3, 2), 171, 128), ((5, 4), 33, 128)])
 def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
