@@ -140,3 +140,17 @@ def test_parameter_sampler_matches_reference():
     assert np.array_equal(a, z["s2_a"]) and np.array_equal(ahc, z["s2_ahc"])
     assert np.array_equal(get_full_a(np.array([[2.0, 3.0]]), (2, 2), [[(0, 0)], [(1, 1)]]),
                           np.array([[[2.0, 1.0], [1.0, 3.0]]]))
+
+
+def test_bench_cpu_baselines_run_on_a_small_case():
+    """bench.py's two CPU figures (oracle path on one core / on a process pool) on a tiny geometry:
+    they must run without a GPU, report what they used, and the pool must not lose or duplicate parameters."""
+    import bench
+    blocks, N, M = (2, 2), 8, 24
+    a = 10.0 ** np.random.default_rng(0).uniform(0, 2, size=(M,) + blocks)
+    one = bench.cpu_baseline(blocks, N, a, budget_s=0.2)
+    assert one["cores"] == 1 and one["kind"] == "port" and one["value"] > 0 and one["unit"] == "solves/s"
+    pool = bench.cpu_baseline_pool(blocks, N, a, per_worker=2)
+    assert pool["kind"] == "port" and pool["value"] > 0 and 1 <= pool["cores"] <= 16
+    n_done = int(pool["sample"].split(" of the ")[0])
+    assert n_done == min(M, pool["cores"] * 2)
