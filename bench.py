@@ -137,7 +137,13 @@ def main():
         args.gpus = world
 
     pool_baseline = None
-    if world == 1 and not args.no_cpu_baseline:
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if world == 1 and not args.no_cpu_baseline and under_profiler:
+        # the profiler's preloaded library has initialised the GPU already: no fork()ing process pool in that case
+        pool_baseline = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port",
+                         "sample": "skipped: running under rocprofv3 (the pool forks, which must precede GPU initialisation)"}
+    elif world == 1 and not args.no_cpu_baseline:
         # all-cores CPU figure first: it forks, which must happen before anything touches the GPU
         a0 = 10.0 ** np.random.default_rng(20240807).uniform(0, 2, size=(args.M,) + tuple(args.blocks))
         pool_baseline = cpu_baseline_pool(tuple(args.blocks), args.N, a0)
