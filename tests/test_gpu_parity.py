@@ -420,6 +420,47 @@ def test_full_size_c4_properties(api):
     assert rb.basis.shape == (6, dim)
 
 
+def test_full_size_c5_properties(api):
+    """BASELINE config C5 geometry ((4,4)/N=256: 1024 x 1024 cells, dim 1 046 529), too large for the oracle to
+    sweep: size-independent properties instead -- the residual through the independent stencil kernel, homogeneity
+    u(c a) = u(a) / c, the unit-coefficient solution's symmetry under the square's reflections, POD of the block
+    from rows and from its factored form."""
+    SM, RB = api
+    from romhighcontrast_amd import _ffi, factored
+    sm = SM.SolutionsManagerFEM((4, 4), 256)
+    ctx, fem, dim = sm._ctx, sm._fem, sm.vspace_dim
+    assert dim == 1023 * 1023
+    M = 130  # (>= 128: the wide extension tiles)
+    a = 10.0 ** np.random.default_rng(20240807).uniform(0, 3, size=(M, 4, 4))
+    a[0] = 1.0
+    a[1] = 7.0 * a[2]
+    Ud = sm.generate_solutions_device(a)
+    Y = ctx.alloc(dim)
+    for m in (0, 2, 64, M - 1):
+        row = _ffi.Buffer(ctx, dim).copy_from(Ud.buf, dim, 0, m * dim)
+        fem.stencil_apply(row, 1, Y, a_one=a[m].ravel())
+        res = Y.download(dim) - sm.B_total
+        u = row.download(dim)
+        assert np.abs(res).max() < 1e-11 * np.abs(u).max() * 4 * a[m].max()
+    u0 = Ud.buf.download(dim, offset=0).reshape(1023, 1023)
+    assert np.abs(u0 - u0[::-1, :]).max() < 1e-12 * u0.max() and np.abs(u0 - u0.T).max() < 1e-12 * u0.max()
+    u1, u2 = Ud.buf.download(dim, offset=dim), Ud.buf.download(dim, offset=2 * dim)
+    assert np.abs(7.0 * u1 - u2).max() < 1e-12 * np.abs(u2).max()
+    h1 = sm.H10norm(Ud)
+    assert np.all(h1 > 0) and abs(h1[2] / h1[1] - 7.0) < 1e-11
+    # POD of the block: rows vs interface vectors
+    n = 8
+    Yf = ctx.alloc(M * fem.reduced_stride)
+    fem.solve_reduced(ctx.upload(a.reshape(M, -1)), M, Yf)
+    ctx.solve_status()
+    fs = factored.FactoredSnapshots(sm, Yf, M)
+    modes_f, sig_f = factored.pod_modes_factored(fs, n)
+    X = ctx.alloc(M * dim).copy_from(Ud.buf, M * dim)
+    modes_r, sig_r = RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), n)
+    np.testing.assert_allclose(sig_f, sig_r, rtol=1e-8)
+    assert np.abs(np.abs(np.sum(modes_f * modes_r, axis=1)) - 1.0).max() < 1e-8
+
+
 @pytest.mark.parametrize("blocks,N,M", [((2, 2), 128, 200), ((3, 3), 20, 70), ((1, 2), 6, 5), ((2, 2), 16, 130), ((1, 1), 8, 3)])
 def test_two_stage_sweep_is_bit_identical(api, blocks, N, M):
     """rom_solve_reduced_async + rom_expand_batch_async (the factored form that travels between GPUs) must
