@@ -411,6 +411,19 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blocks, N, a_loc)
         out["cpu_baseline_all_cores"] = pool_baseline
+        # POD on the host: numpy.linalg.svd(X - mean) on a subsample of the same block that fits a few
+        # seconds, LAPACK threads as configured on the box; same F_pod accounting (symmetric half) for its size
+        Ms = min(M, 192)
+        Xs = U_loc.download(Ms * dim, shape=(Ms, dim))
+        t0 = time.perf_counter()
+        Xc = Xs - Xs.mean(axis=0)
+        sv = np.linalg.svd(Xc, full_matrices=False)[1]
+        dts = time.perf_counter() - t0
+        fs_ = float(Ms) * (Ms + 1) * dim + 2.0 * min(50, Ms) * Ms * dim + 10.0 * Ms ** 3
+        out["pod_cpu_baseline"] = {"gflops": round(fs_ / dts * 1e-9, 1), "seconds": round(dts, 3), "M": Ms, "dim": dim,
+                                   "sigma_1": float(sv[0]), "kind": "reference call",
+                                   "sample": f"numpy.linalg.svd of the centred first {Ms} snapshots (the SVD inside "
+                                             f"sklearn PCA, src/lib/ReducedBasis.py:196), all LAPACK threads of the host"}
     if comm:
         ctx.comm_destroy()
         sweep.cleanup_rendezvous(rank)
