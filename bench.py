@@ -37,6 +37,17 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X spec fp64 matrix peak; t
 HBM_PEAK_GBS = 8000.0
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(blocks, N, a, budget_s=15.0):
     """The oracle's restatement of the reference's method='lsqsparse' path (stencil -> CSC ->
     scipy.sparse.linalg.spsolve, src/lib/SolutionsManagers.py:31) on one host core (the reference
@@ -52,7 +63,7 @@ def cpu_baseline(blocks, N, a, budget_s=15.0):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "port",
             "sample": f"first {n} of the {len(a)} C2 parameters, oracle stencil->CSC->scipy spsolve (SuperLU), "
-                      f"{dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+                      f"{dt:.1f} s on 1 of {os.cpu_count()} host cores ({_cpu_model()})"}
 
 
 def _pool_init():
