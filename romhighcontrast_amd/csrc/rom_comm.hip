@@ -179,16 +179,14 @@ extern "C" int rom_comm_allreduce_host(rom_ctx* ctx, double* vals, int n, int op
   ROM_CHECK(ctx->comm, "rom_comm_allreduce_host: communicator not initialised (rom_comm_init)");
   if (n == 0) return ROM_OK;
   double* d = nullptr;
-  ROM_HIP(hipMalloc(&d, n * sizeof(double)));
+  ROM_TRY(rom_ctx_scratch(ctx, size_t(n), &d));
   ROM_HIP(hipMemcpyAsync(d, vals, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   int r = g_rccl.AllReduce(d, d, n, NCCL_FLOAT64, op == 1 ? NCCL_MAX : NCCL_SUM, (nccl_comm_t)ctx->comm, ctx->stream);
   if (r != 0) {
-    hipFree(d);
     rom_set_error("ncclAllReduce failed: %s", g_rccl.GetErrorString(r));
     return ROM_ERR_COMM;
   }
   ROM_HIP(hipMemcpyAsync(vals, d, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ROM_HIP(hipStreamSynchronize(ctx->stream));
-  hipFree(d);
   return ROM_OK;
 }

@@ -237,8 +237,13 @@ extern "C" int rom_profile_query(rom_ctx* c, int idx, char* name, size_t cap, do
 // Device buffers come from a small caching allocator: the host-side drivers (greedy, POD) create and
 // drop many temporaries per iteration, and hipMalloc / hipFree are slow and synchronise the device.
 // A freed block goes back to a per-size free list and is handed to the next request of the same
-// rounded size; because every kernel of the library is enqueued on the context's in-order stream, a
-// recycled block cannot be overwritten before earlier work that used it has finished.
+// rounded size.  Reuse rule: the next user of a recycled block enqueues on the context's in-order compute
+// stream, so the block is safe once everything that touched it is ordered before the compute stream's tail:
+//   * kernels of the library run on the compute stream itself, or on the sub-batch streams of a sweep, which
+//     rom_solve_batch joins back into the compute stream before it returns;
+//   * collectives run on the communication stream and are NOT joined by themselves: rom_buf_free therefore
+//     makes the compute stream wait for the communication stream's tail (one event, no host wait) whenever a
+//     communicator exists, before the block becomes available again.
 static size_t round_bytes(size_t bytes) {
   if (bytes < 4096) return 4096;
   if (bytes < (size_t(1) << 20)) return (bytes + 4095) / 4096 * 4096;
@@ -281,6 +286,10 @@ extern "C" int rom_buf_free(rom_buf* b) {
   if (!b) return ROM_OK;
   rom_ctx* c = b->ctx;
   const size_t bytes = round_bytes((b->n ? b->n : 1) * sizeof(double));
+  if (c->comm_stream) {  // an in-flight collective may still read or write the block (see the reuse rule above)
+    hipEventRecord(c->ev_comm, c->comm_stream);
+    hipStreamWaitEvent(c->stream, c->ev_comm, 0);
+  }
   if (c->cached_bytes + bytes <= c->cache_limit) {
     c->free_blocks[bytes].push_back(b->p);
     c->cached_bytes += bytes;

@@ -70,16 +70,24 @@ static int ensure_workspace(rom_fem* f, int Mc) {
   if (f->d_yhat) hipFree(f->d_yhat);
   f->d_L = f->d_invL = f->d_y = f->d_yhat = nullptr;
   f->ws_M = 0;
-  ROM_HIP(hipMalloc(&f->d_L, std::max<size_t>(size_t(Mc) * f->nslots * 4096, 1) * sizeof(double)));
-  ROM_HIP(hipMalloc(&f->d_invL, std::max<size_t>(size_t(Mc) * f->T * 4096, 1) * sizeof(double)));
-  ROM_HIP(hipMalloc(&f->d_y, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
-  // zeroed once: padding slots are read (against zero table entries) before anything writes them
-  ROM_HIP(hipMemset(f->d_y, 0, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
-  ROM_HIP(hipMalloc(&f->d_yhat, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
+  const size_t nL = std::max<size_t>(size_t(Mc) * f->nslots * 4096, 1) * sizeof(double);
+  const size_t nI = std::max<size_t>(size_t(Mc) * f->T * 4096, 1) * sizeof(double);
+  const size_t nY = std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double);
+  ROM_HIP(hipMalloc(&f->d_L, nL));
+  ROM_HIP(hipMalloc(&f->d_invL, nI));
+  ROM_HIP(hipMalloc(&f->d_y, nY));
+  ROM_HIP(hipMalloc(&f->d_yhat, nY));
+  // Zeroed once: padding slots of d_y are read (against zero table entries) before anything writes them, and a
+  // fresh hipMalloc block may hold another process's NaN bits.  The fill goes on the context's compute stream:
+  // that stream and the sub-batch streams forked from it are hipStreamNonBlocking, so a null-stream hipMemset
+  // is NOT ordered before the kernels that read the buffer.
+  rom_ctx* ctx = f->ctx;
+  ROM_HIP(hipMemsetAsync(f->d_y, 0, nY, ctx->stream));
+  ROM_HIP(hipMemsetAsync(f->d_yhat, 0, nY, ctx->stream));
   if (getenv("ROMHC_POISON_WS")) {  // debugging aid: NaN patterns in everything a kernel must write before it reads
-    ROM_HIP(hipMemset(f->d_L, 0xFF, std::max<size_t>(size_t(Mc) * f->nslots * 4096, 1) * sizeof(double)));
-    ROM_HIP(hipMemset(f->d_invL, 0xFF, std::max<size_t>(size_t(Mc) * f->T * 4096, 1) * sizeof(double)));
-    ROM_HIP(hipMemset(f->d_yhat, 0xFF, std::max<size_t>(size_t(Mc) * f->nGp, 1) * sizeof(double)));
+    ROM_HIP(hipMemsetAsync(f->d_L, 0xFF, nL, ctx->stream));
+    ROM_HIP(hipMemsetAsync(f->d_invL, 0xFF, nI, ctx->stream));
+    ROM_HIP(hipMemsetAsync(f->d_yhat, 0xFF, nY, ctx->stream));
   }
   f->ws_M = Mc;
   return ROM_OK;

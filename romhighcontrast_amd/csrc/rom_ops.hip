@@ -608,17 +608,23 @@ extern "C" int rom_l2norm(rom_ctx* ctx, rom_buf* U, int64_t row0, int K, int64_t
 }
 
 // ============================================================================================
-// batched reduced SPD solves (n <= 88): one workgroup per system, matrix resident in LDS
+// batched reduced SPD solves: one workgroup per system.  The n x n matrix lives in LDS while it fits (n <= 140 with
+// the 160 KB of a gfx950 CU opted in; n <= 88 inside the default 64 KB), otherwise in a per-system slab of global
+// memory (L2 resident: 200 x 200 doubles = 320 KB per system) -- the reference's galerkin() takes any n
+// (src/lib/SolutionsManagers.py:17-40).  Same elimination order either way.
 // ============================================================================================
+constexpr int REDUCED_LDS_DEFAULT = 64 * 1024, REDUCED_LDS_MAX = 160 * 1024;
+
 __global__ __launch_bounds__(256) void k_reduced_solve(int n, int kb, const double* __restrict__ Ahat,
                                                        const double* __restrict__ w, const double* __restrict__ rhs,
-                                                       int rhs_per_system, double* __restrict__ cout, int* status) {
-  extern __shared__ __align__(16) double sm[];  // n*(n+1) matrix + n rhs + n diag
+                                                       int rhs_per_system, double* __restrict__ cout, int* status,
+                                                       double* gws) {
+  extern __shared__ __align__(16) double sm[];  // [n*(n+1) matrix, if it lives here] + n rhs + n diag
   const int ld = n + 1;
-  double* Am = sm;
-  double* b = sm + size_t(n) * ld;
-  double* sd = b + n;
   const int m = blockIdx.x, t = threadIdx.x;
+  double* Am = gws ? gws + size_t(m) * n * ld : sm;
+  double* b = gws ? sm : sm + size_t(n) * ld;
+  double* sd = b + n;
   // A = sum_b w[m,b] Ahat[b]   (the reference's einsum('pqij,pq->ij') on the reduced tensor)
   for (int idx = t; idx < n * n; idx += 256) {
     int r = idx / n, c = idx % n;
@@ -669,18 +675,34 @@ __global__ __launch_bounds__(256) void k_reduced_solve(int n, int kb, const doub
 extern "C" int rom_reduced_solve_batch(rom_ctx* ctx, int n, int kb, int M, rom_buf* Ahat, rom_buf* w, rom_buf* rhs,
                                        int rhs_per_system, rom_buf* c_out) {
   ROM_CHECK(ctx && Ahat && w && rhs && c_out, "rom_reduced_solve_batch: null argument");
-  ROM_CHECK(n >= 1 && n <= 88, "rom_reduced_solve_batch: reduced dimension %d outside [1, 88]", n);
+  ROM_CHECK(n >= 1 && n <= 4096, "rom_reduced_solve_batch: reduced dimension %d outside [1, 4096]", n);
   ROM_CHECK(kb >= 1 && M >= 0, "rom_reduced_solve_batch: bad sizes");
   ROM_CHECK(Ahat->n >= size_t(kb) * n * n && w->n >= size_t(M) * kb && c_out->n >= size_t(M) * n &&
                 rhs->n >= (rhs_per_system ? size_t(M) * n : size_t(n)),
             "rom_reduced_solve_batch: buffer too small");
   if (M == 0) return ROM_OK;
   ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
-  size_t lds = (size_t(n) * (n + 1) + 2 * n) * sizeof(double);
-  {
-    ROM_PROF(ctx, "reduced_solve", M * (double(n) * n * n / 3 + 2.0 * kb * n * n), 8.0 * M * (kb + 2.0 * n));
-    k_reduced_solve<<<M, 256, lds, ctx->stream>>>(n, kb, Ahat->p, w->p, rhs->p, rhs_per_system, c_out->p,
-                                                  ctx->d_status);
+  const size_t mat = size_t(n) * (n + 1) * sizeof(double), vecs = 2 * size_t(n) * sizeof(double);
+  const bool in_lds = mat + vecs <= size_t(REDUCED_LDS_MAX);
+  const size_t lds = in_lds ? mat + vecs : vecs;
+  if (lds > size_t(REDUCED_LDS_DEFAULT)) {
+    static bool opted_in = false;  // (per process; the attribute is a property of the loaded kernel)
+    if (!opted_in) {
+      ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reduced_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  REDUCED_LDS_MAX));
+      opted_in = true;
+    }
+  }
+  // matrices beyond the LDS: slabs of the scratch block, as many systems per launch as 1 GiB of it holds
+  const int per_launch = in_lds ? M : int(std::max<size_t>(1, std::min<size_t>(size_t(M), (size_t(1) << 30) / mat)));
+  double* gws = nullptr;
+  if (!in_lds) ROM_TRY(rom_ctx_scratch(ctx, size_t(per_launch) * n * (n + 1), &gws));
+  for (int m0 = 0; m0 < M; m0 += per_launch) {
+    const int Mc = std::min(per_launch, M - m0);
+    ROM_PROF(ctx, "reduced_solve", Mc * (double(n) * n * n / 3 + 2.0 * kb * n * n), 8.0 * Mc * (kb + 2.0 * n));
+    k_reduced_solve<<<Mc, 256, lds, ctx->stream>>>(n, kb, Ahat->p, w->p + size_t(m0) * kb,
+                                                   rhs->p + (rhs_per_system ? size_t(m0) * n : 0), rhs_per_system,
+                                                   c_out->p + size_t(m0) * n, ctx->d_status, gws);
   }
   ROM_HIP(hipGetLastError());
   int status = 0;
@@ -852,12 +874,14 @@ extern "C" int rom_evaluate_points(rom_fem* f, rom_buf* U, int64_t row0, int K, 
     ROM_CHECK(ix_host[p] >= 0 && ix_host[p] <= f->nc && iy_host[p] >= 0 && iy_host[p] <= f->nr,
               "rom_evaluate_points: point %d outside the domain", p);
   rom_ctx* ctx = f->ctx;
-  int *d_i = nullptr;
-  double* d_t = nullptr;
-  double* d_out = nullptr;
-  ROM_HIP(hipMalloc(&d_i, 2 * size_t(npts) * sizeof(int)));
-  ROM_HIP(hipMalloc(&d_t, 2 * size_t(npts) * sizeof(double)));
-  ROM_HIP(hipMalloc(&d_out, size_t(K) * npts * sizeof(double)));
+  // one carve-up of the context's scratch block (the experiment loop calls this once per basis size: no
+  // hipMalloc / hipFree per call): [ix | iy] as ints, [tx | ty], out
+  const size_t n_idx = (2 * size_t(npts) * sizeof(int) + sizeof(double) - 1) / sizeof(double);
+  double* scratch = nullptr;
+  ROM_TRY(rom_ctx_scratch(ctx, n_idx + 2 * size_t(npts) + size_t(K) * npts, &scratch));
+  int* d_i = reinterpret_cast<int*>(scratch);
+  double* d_t = scratch + n_idx;
+  double* d_out = d_t + 2 * size_t(npts);
   ROM_HIP(hipMemcpyAsync(d_i, ix_host, npts * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   ROM_HIP(hipMemcpyAsync(d_i + npts, iy_host, npts * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   ROM_HIP(hipMemcpyAsync(d_t, tx_host, npts * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -869,9 +893,6 @@ extern "C" int rom_evaluate_points(rom_fem* f, rom_buf* U, int64_t row0, int K, 
   }
   ROM_HIP(hipGetLastError());
   ROM_HIP(hipMemcpyAsync(out_host, d_out, size_t(K) * npts * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  ROM_HIP(hipStreamSynchronize(ctx->stream));
-  hipFree(d_i);
-  hipFree(d_t);
-  hipFree(d_out);
+  ROM_HIP(hipStreamSynchronize(ctx->stream));  // the caller's host arrays are free again; so is the scratch block
   return ROM_OK;
 }

@@ -267,8 +267,14 @@ def greedy_factored(fs: FactoredSnapshots, a2train, n: int, galerkin: bool, h1no
     Ahat = np.zeros((fem.kblk, 0, 0))
     a_dev = ctx.upload(a2train)
     for it in range(n):
-        if it == 0:
-            rel = np.ones(M)                     # empty basis: every relative error is exactly 1 (:129)
+        if Q.shape[0] == 0:
+            # empty basis: the approximation is zero and the error of snapshot i is ||u_i|| / h1norm_i (:129).  With
+            # the snapshots' own norms as h1norm (what experiment() passes) the reference gets exactly 1.0 for every i
+            # and argmax takes index 0; the norms formed here in energy coordinates agree with a caller's stencil norms
+            # to rounding only, so quotients within 1e-10 of 1 are that tie.  Any other normalisation (the documented
+            # default h1norm = 1 included) picks the largest ||u_i|| / h1norm_i, as the reference does.
+            rel = ctx.l2norm(Xi, 0, M, kp) / h1norm
+            rel = np.where(np.abs(rel - 1.0) <= 1e-10, 1.0, rel)
         elif not galerkin:
             rel = ctx.l2norm(R, 0, M, kp) / h1norm
         else:

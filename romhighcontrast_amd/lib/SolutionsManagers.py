@@ -20,7 +20,7 @@ import numpy as np
 
 from .. import _ffi
 
-__all__ = ["galerkin", "SolutionsManager", "SolutionsManagerFEM", "DeviceArray", "h1_error"]
+__all__ = ["galerkin", "SolutionsManager", "SolutionsManagerFEM", "DeviceArray"]
 
 _DENSE_LIMIT_BYTES = 2 << 30  # largest A_preassembled we are willing to materialise on the host
 
@@ -55,11 +55,6 @@ def _as_device(ctx: _ffi.Context, x, dim: int) -> DeviceArray:
     return DeviceArray(ctx.upload(arr), arr.shape[0], dim)
 
 
-def h1_error(v: List[np.ndarray]):
-    """(:13-14) -- dead code in the reference, kept for name parity (host, NumPy)."""
-    return np.sqrt(np.mean(np.sum(np.power(np.gradient(v, axis=(1, 2)), 2), axis=0), axis=(1, 2)))
-
-
 def _check_method(method: str):
     # the reference raises at solve time (:39); 'lsq' (LAPACK posv) and 'lsqsparse' (SuperLU) are
     # both exact direct solves of the same SPD system and map to the one GPU direct solver.
@@ -70,16 +65,14 @@ def _check_method(method: str):
 def galerkin(a, B_total, A_preassembled, method="lsq"):
     """``galerkin`` (:17-40) for *small dense* tensors: ``(sum_pq a_pq A_pq) x = B``.
 
-    Runs on the GPU as one reduced SPD solve (n <= 88).  The full-space solve does not go through
-    a dense tensor in this build: use ``SolutionsManagerFEM.generate_solutions``.
+    Runs on the GPU as one reduced SPD solve (any n the dense tensor allows; the matrix is LDS resident up to
+    n = 140).  The full-space solve does not go through a dense tensor in this build: use
+    ``SolutionsManagerFEM.generate_solutions``.
     """
     _check_method(method)
     A_preassembled = np.asarray(A_preassembled, dtype=np.float64)
     n = A_preassembled.shape[-1]
     kb = int(np.prod(A_preassembled.shape[:-2]))
-    if n > 88:
-        raise Exception("galerkin(): dense tensors beyond n=88 are not supported by the GPU build; "
-                        "use SolutionsManagerFEM.generate_solutions for the full space.")
     ctx = _ffi.get_context()
     Ahat = ctx.upload(A_preassembled.reshape(kb, n, n))
     w = ctx.upload(np.asarray(a, dtype=np.float64).reshape(1, kb))

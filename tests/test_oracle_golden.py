@@ -158,3 +158,34 @@ def test_error_strings():
         ro.solve_one(g, np.ones((2, 2)), ro.load_vector(g), "ridge2")
     with pytest.raises(Exception, match="Not implemented greedy for"):
         ro.greedy_build(g, 1, np.zeros((2, g.dim)), np.ones((2, 2, 2)), 1, greedy_for="x")
+
+
+def test_state_and_parameter_estimation_vs_reference_records():
+    """state_estimation (src/lib/ReducedBasis.py:65-70) and EstimatorInv / EstimatorLinear
+    (src/lib/Estimators.py:24-37) of the product's host mirror against the error records the reference's
+    experiment() produced (fixture g8), with the reference's own snapshots and bases as inputs and the oracle's point
+    evaluation standing in for the device kernel (CPU test).  Same inputs, same LAPACK call: agreement to rounding."""
+    from romhighcontrast_amd.experiments import sample_parameters
+    from romhighcontrast_amd.lib.Estimators import EstimatorInv, EstimatorLinear
+    z = load_golden("g8_experiment.npz")
+    a, _ = sample_parameters((2, 2), [[(0, 0), (1, 1)], [(0, 1)]], 2, 30, 7)   # seeds NumPy's global RNG like the reference
+    assert np.array_equal(a, z["a"])
+    pts = np.random.uniform(size=(12, 2))                                      # (HighContrast.py:155)
+    g = ro.Geometry((2, 2), 6)
+    U, h1 = z["solutions"], z["h1"]
+    meas = ro.evaluate_solutions(g, pts, U)
+    for key in ("Random_infty", "Random", "Greedy_H1_0", "Greedy_galerkin"):
+        basis = z["basis_" + key]
+        idx = [int(np.argmin(np.abs(U - b).max(axis=1))) for b in basis]     # every basis row is a snapshot
+        assert all(np.array_equal(U[i], b) for i, b in zip(idx, basis))
+        ab = a[idx]
+        for n in range(1, 5):
+            E = ro.evaluate_solutions(g, pts, basis[:n])
+            c, *_ = np.linalg.lstsq(E.T, meas.T, rcond=-1)
+            got = {"state_estimation": ro.H10norm(g, c.T @ basis[:n] - U) / h1,
+                   "parameter_estimation_inverse": np.abs(1 - np.array(EstimatorInv(ab[:n]).estimate_parameter(c)) / a),
+                   "parameter_estimation_linear": np.abs(1 - np.array(EstimatorLinear(ab[:n]).estimate_parameter(c)) / a)}
+            for f, v in got.items():
+                ref = z[f"err_{key}_{n}_{f}"]
+                assert v.shape == ref.shape
+                assert np.abs(v - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (key, n, f)
