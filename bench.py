@@ -1,29 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- snapshot-sweep throughput of the HIP hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5]
 
-One "step" = one pass of the hot path over one batch: rom_solve_batch of the BASELINE config C2
-workload (2x2 blocks, N=128 -> 256x256 cells, dim 65 025, 1024-parameter sweep, seeded
-10**U(0,2) coefficients) with the parameters already resident in HBM and the (M, dim) fp64
-snapshot block left in HBM.  With N > 1 (one process per GPU, started by torch.distributed.run)
-every rank solves its own 1024-parameter shard (weak scaling: N=8 is config C3, 8192 parameters)
-and the shards are exchanged with one RCCL all-gather per step, inside the timed region; the
-all-gather of step k runs on a communication stream and overlaps the solves of step k+1 (double
-buffered), the region ends when the last all-gather has landed.
+One "step" = one pass of the hot path over one batch: rom_solve_batch of the workload's parameter sweep with the
+parameters already resident in HBM and the (M, dim) fp64 snapshot block left in HBM.  Workloads:
 
-The timed region is bracketed by a barrier + stream synchronisation on both sides (RCCL all-reduce
-for N > 1), the reported time is the max over ranks, and rank 0 prints ONE JSON line.
+    c2 (default)  2x2 blocks, N=128 -> 256x256 cells, dim 65 025, 1024 parameters, a = 10**U(0,2)   [BASELINE configs[1]]
+    c4            3x3 blocks, N=171 -> 513x513 cells, dim 262 144, 1024-parameter training set, contrast 1e8,
+                  + greedy reduced basis to n=50 (both modes)                                         [configs[3]]
+    c5            4x4 blocks, N=256 -> 1024x1024 cells, dim 1 046 529, 4096 parameters, a = 10**U(0,3),
+                  + POD of the 4096-snapshot block                                                     [configs[4]]
 
-Host side is plain Python + ctypes (no torch): the rendezvous for the RCCL unique id goes through
-a launch-scoped file (romhighcontrast_amd/sweep.py).
+With N > 1 (one process per GPU) every rank solves its own M-parameter shard (weak scaling: c2 at N=8 is config C3,
+8192 parameters) and the shards are exchanged with one RCCL all-gather per step, inside the timed region; the
+all-gather of step k runs on a communication stream and overlaps the solves of step k+1 (double buffered), the
+region ends when the last all-gather has landed.
+
+Launch: `python bench.py --gpus N` with no launcher environment starts the N ranks itself (fresh child processes
+with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; the parent never touches the GPU and never exec()s); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the ranks are the launcher's.  Either
+way rank 0 prints ONE JSON line.
+
+The timed region (exactly K steps) is bracketed by a barrier + stream synchronisation on both sides (RCCL
+all-reduce for N > 1) and the reported time is the max over ranks.  It is repeated `--repeats` times (default 5):
+`value` / `ms_per_step` are those of the MEDIAN region, `repeats` lists all of them.
+
+Host side is plain Python + ctypes (no torch): the rendezvous for the RCCL unique id goes through a launch-scoped
+file (romhighcontrast_amd/sweep.py).
 """
 import argparse
 import contextlib
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
+import uuid
 
 import numpy as np
 
@@ -35,8 +50,90 @@ sys.path.insert(0, ROOT)
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X spec fp64 matrix peak; the instruction itself sustains 48.8
 HBM_PEAK_GBS = 8000.0
+SEED = 20240807                 # seeds and generator (PCG64 via default_rng) are part of the contract
+
+CONFIGS = {
+    "c2": dict(blocks=(2, 2), N=128, M=1024, label="C2", pool_per_worker=40, cpu_budget_s=15.0),
+    "c4": dict(blocks=(3, 3), N=171, M=1024, label="C4", pool_per_worker=3, cpu_budget_s=15.0),
+    "c5": dict(blocks=(4, 4), N=256, M=4096, label="C5", pool_per_worker=1, cpu_budget_s=20.0),
+}
 
 
+def workload_parameters(config: str, blocks, M_total: int) -> np.ndarray:
+    """The synthetic sweep of SURVEY.md 8(d) for `config`, (M_total, nrb, ncb)."""
+    rng = np.random.default_rng(SEED)
+    if config == "c4":
+        # row 0 = all ones; rows 1..k = ones with block j at 1e8 (the "limit solutions" the reference seeds its training
+        # sets with, src/experiments/HighContrast.py:108,113); row k+1 = all 1e8; the rest 10**U(0,8)
+        k = blocks[0] * blocks[1]
+        a = np.ones((M_total,) + tuple(blocks))
+        for j in range(min(k, M_total - 1)):
+            a[1 + j].flat[j] = 1e8
+        if M_total > k + 1:
+            a[k + 1] = 1e8
+        if M_total > k + 2:
+            a[k + 2:] = 10.0 ** rng.uniform(0, 8, size=(M_total - k - 2,) + tuple(blocks))
+        return a
+    hi = 3 if config == "c5" else 2
+    return 10.0 ** rng.uniform(0, hi, size=(M_total,) + tuple(blocks))
+
+
+# =====================================================================================================================
+# launcher: `python bench.py --gpus N` without a launcher environment starts its own ranks
+# =====================================================================================================================
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv, child=None, poll_s: float = 0.05) -> int:
+    """Start `n` fresh child processes (one rank per GPU) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment and wait for them.  The parent must not have touched the GPU (it has not: nothing of libromhc is
+    loaded here) and never exec()s.  Rank 0 inherits stdout (the one JSON line); the other ranks' stdout goes to
+    stderr.  If a rank fails, the remaining ranks -- exactly the PIDs started here -- are terminated and its exit
+    code is returned; 0 only if every rank exited 0."""
+    cmd = list(child) if child is not None else [sys.executable, os.path.abspath(__file__)]
+    port, launch_id = _free_port(), uuid.uuid4().hex
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ROMHC_LAUNCH_ID=launch_id,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = dict(enumerate(procs))
+    while live and rc == 0:
+        for r, p in list(live.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del live[r]
+            if code != 0:
+                print(f"bench.py launcher: rank {r} (pid {p.pid}) exited with {code}; stopping the other ranks",
+                      file=sys.stderr)
+                rc = code if code > 0 else 1
+                break
+        if live and rc == 0:
+            time.sleep(poll_s)
+    for p in live.values():  # only after a failure: stop the ranks we started (by PID)
+        with contextlib.suppress(ProcessLookupError):
+            p.send_signal(signal.SIGTERM)
+    t_end = time.time() + 10.0
+    for p in live.values():
+        try:
+            p.wait(timeout=max(0.1, t_end - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    return rc
+
+
+# =====================================================================================================================
+# CPU baselines (the oracle's restatement of the reference path; test infrastructure used as the checker only)
+# =====================================================================================================================
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -48,7 +145,7 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def cpu_baseline(blocks, N, a, budget_s=15.0):
+def cpu_baseline(blocks, N, a, budget_s=15.0, label="C2", min_solves=4):
     """The oracle's restatement of the reference's method='lsqsparse' path (stencil -> CSC ->
     scipy.sparse.linalg.spsolve, src/lib/SolutionsManagers.py:31) on one host core (the reference
     default num_cores=1), over a bounded sample of the same sweep."""
@@ -57,12 +154,12 @@ def cpu_baseline(blocks, N, a, budget_s=15.0):
     B = ro.load_vector(g)
     t0 = time.perf_counter()
     n = 0
-    while n < len(a) and (time.perf_counter() - t0 < budget_s or n < 4):
+    while n < len(a) and (time.perf_counter() - t0 < budget_s or n < min_solves):
         ro.solve_one(g, a[n], B, "lsqsparse")
         n += 1
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} of the {len(a)} C2 parameters, oracle stencil->CSC->scipy spsolve (SuperLU), "
+            "sample": f"first {n} of the {len(a)} {label} parameters, oracle stencil->CSC->scipy spsolve (SuperLU), "
                       f"{dt:.1f} s on 1 of {os.cpu_count()} host cores ({_cpu_model()})"}
 
 
@@ -84,7 +181,7 @@ def _pool_solve(args):
     return len(rows)
 
 
-def cpu_baseline_pool(blocks, N, a, per_worker=40):
+def cpu_baseline_pool(blocks, N, a, per_worker=40, label="C2"):
     """The same CPU path with the reference's num_cores > 1 semantics (a process pool over the parameters,
     src/lib/SolutionsManagers.py:51,64-68) on this job's share of the host cores.  Runs BEFORE the GPU is
     initialised: the pool forks."""
@@ -103,7 +200,7 @@ def cpu_baseline_pool(blocks, N, a, per_worker=40):
         pool.map(_pool_solve, chunks, chunksize=1)
         dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of the {len(a)} C2 parameters over a pool of {cores} processes (one BLAS thread each), same "
+            "sample": f"{n} of the {len(a)} {label} parameters over a pool of {cores} processes (one BLAS thread each), same "
                       f"oracle path, {dt:.1f} s; host has {os.cpu_count()} cores, {share} usable by this job"}
 
 
@@ -121,31 +218,75 @@ def stdout_to_stderr():
         os.close(saved)
 
 
+def pick_device(local_rank: int, local_world: int, ndev: int) -> int:
+    """One process per GPU.  Every GPU of the node visible -> device LOCAL_RANK; a launcher that pinned one GPU per
+    process (HIP_/ROCR_/CUDA_VISIBLE_DEVICES) -> device 0.  More ranks than visible GPUs otherwise is refused: two ranks
+    on one device make RCCL fail with 'invalid usage' (ROMHC_FORCE_DEVICE overrides for launch rehearsals only)."""
+    if "ROMHC_FORCE_DEVICE" in os.environ:
+        return int(os.environ["ROMHC_FORCE_DEVICE"])
+    if ndev >= local_world:
+        return local_rank
+    # ranks started by launch_ranks() inherit the parent's device visibility unchanged: a visibility variable there
+    # means "this job has that many GPUs", never "one GPU per process"
+    pinned = "ROMHC_LAUNCH_ID" not in os.environ and any(
+        os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if ndev == 1 and pinned:
+        return 0
+    raise SystemExit(f"bench.py: {local_world} ranks on this node but only {ndev} GPU(s) visible: one process per GPU is "
+                     "required (RCCL refuses two ranks on one device)")
+
+
+def pod_accounting(M, dim, r):
+    """Flops of a POD by the Gram route that are USEFUL work (SURVEY 8d without its 10 M^3 'eigh' term, which the
+    subspace iteration never executes): the symmetric half of ONE Gram matrix + the lift of r modes."""
+    return float(M) * (M + 1) * dim + 2.0 * r * M * dim
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--M", type=int, default=1024, help="parameters per GPU per step")
-    ap.add_argument("--N", type=int, default=128, help="cells per block per dimension")
-    ap.add_argument("--blocks", type=int, nargs=2, default=[2, 2])
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the K-step timed region is run (median reported)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--M", type=int, default=None, help="parameters per GPU per step (default: the config's)")
+    ap.add_argument("--N", type=int, default=None, help="cells per block per dimension (default: the config's)")
+    ap.add_argument("--blocks", type=int, nargs=2, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pod", action="store_true")
-    ap.add_argument("--no-pod-c3", action="store_true", help="skip the POD of the 8192-snapshot C3 block")
+    ap.add_argument("--no-extras", "--no-pod", dest="no_extras", action="store_true",
+                    help="only the sweep line: no POD / greedy / API-rate legs")
+    ap.add_argument("--no-pod-c3", action="store_true", help="c2: skip the POD of the 8192-snapshot C3 block")
     ap.add_argument("--force-comm", action="store_true",
                     help="rehearsal: run the N>1 code path (RCCL communicator, all-gather of the interface vectors, "
                          "expansion of the gathered block) with one rank")
     ap.add_argument("--replicate", action="store_true",
-                    help="N>1: also expand the gathered factored block into snapshot rows on every rank")
+                    help="N>1: also expand the gathered factored block into snapshot rows on every rank (the literal "
+                         "(M/G, dim) row block of SURVEY 8e, replicated)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher.  Nothing below this line has run: no GPU call yet.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); using {world}", file=sys.stderr)
         args.gpus = world
+
+    cfg = CONFIGS[args.config]
+    blocks = tuple(args.blocks) if args.blocks else cfg["blocks"]
+    N = args.N or cfg["N"]
+    M = args.M or cfg["M"]
+    custom = (blocks, N, M) != (cfg["blocks"], cfg["N"], cfg["M"])
+    label = cfg["label"] if not custom else f"custom({args.config})"
+    if label == "C2" and world > 1:
+        label = "C3" if world == 8 else f"C2 x {world} GPUs (C3 at 8)"
+
+    a_all = workload_parameters(args.config, blocks, world * M)
+    a_loc = a_all[rank * M:(rank + 1) * M]
 
     pool_baseline = None
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or \
@@ -156,43 +297,37 @@ def main():
                          "sample": "skipped: running under rocprofv3 (the pool forks, which must precede GPU initialisation)"}
     elif world == 1 and not args.no_cpu_baseline:
         # all-cores CPU figure first: it forks, which must happen before anything touches the GPU
-        a0 = 10.0 ** np.random.default_rng(20240807).uniform(0, 2, size=(args.M,) + tuple(args.blocks))
-        pool_baseline = cpu_baseline_pool(tuple(args.blocks), args.N, a0)
+        pool_baseline = cpu_baseline_pool(blocks, N, a_loc, per_worker=cfg["pool_per_worker"], label=label)
 
     from romhighcontrast_amd import _ffi, sweep
     from romhighcontrast_amd.lib.SolutionsManagers import DeviceArray, SolutionsManagerFEM
-    from romhighcontrast_amd.lib.ReducedBasis import pod_modes
 
-    # one process per GPU: device = LOCAL_RANK (ROMHC_FORCE_DEVICE only for rehearsing the launch
-    # path on a box with fewer GPUs than ranks)
     import ctypes
     ndev = ctypes.c_int(0)
     _ffi.check(_ffi.load_library().rom_device_count(ctypes.byref(ndev)))
-    # normally every GPU of the node is visible and LOCAL_RANK picks one; if the launcher pinned one
-    # GPU per process (HIP_VISIBLE_DEVICES) only device 0 exists
-    dev = int(os.environ.get("ROMHC_FORCE_DEVICE", local_rank % max(ndev.value, 1)))
+    dev = pick_device(local_rank, local_world, ndev.value)
     ctx = _ffi.get_context(dev)
-    blocks, N, M = tuple(args.blocks), args.N, args.M
+    ctx.synchronize()
+    t_setup = time.perf_counter()
     sm = SolutionsManagerFEM(blocks, N, device=dev)
+    ctx.synchronize()
+    setup_s = time.perf_counter() - t_setup  # rom_fem_create: parameter-independent tables of the FE space
     fem, dim = sm._fem, sm.vspace_dim
 
     comm = world > 1 or args.force_comm
+    rccl_ranks = 1
     if comm:
         with stdout_to_stderr():
             uid = sweep.exchange_unique_id(rank, ctx.comm_unique_id)
             ctx.comm_init(uid, rank, world)
-            ctx.allreduce_host([0.0], "sum")  # first collective: connection set-up, banner
+            rccl_ranks = int(round(float(ctx.allreduce_host([1.0], "sum")[0])))  # first collective: set-up, banner
+        assert rccl_ranks == world, f"RCCL sees {rccl_ranks} ranks, the launcher started {world}"
 
     def barrier():
         ctx.synchronize()
         if comm:
             ctx.allreduce_host([0.0], "sum")
 
-    # synthetic sweep of SURVEY.md 8(d): seeded, all blocks free, contrast <= 1e2; rank r owns rows
-    # [r*M, (r+1)*M) of the (world*M)-parameter sweep
-    rng = np.random.default_rng(20240807)
-    a_all = 10.0 ** rng.uniform(0, 2, size=(world * M,) + blocks)
-    a_loc = a_all[rank * M:(rank + 1) * M]
     a_dev = ctx.upload(a_loc.reshape(M, -1))
     U_loc = ctx.alloc(M * dim)
     # N > 1: what is exchanged is the factored form of the shard -- the interface vectors (fem.reduced_stride
@@ -234,22 +369,29 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    barrier()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    for _ in range(args.steps):
-        step()
-    drain()  # the timed region ends when the last all-gather has landed
-    ev_ms = ctx.timer_stop()
-    ctx.synchronize()
-    wall = time.perf_counter() - t0
-    if comm:
-        wall = float(ctx.allreduce_host([wall], "max")[0])
-    barrier()
+    walls, evs = [], []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        for _ in range(args.steps):
+            step()
+        drain()  # the timed region ends when the last all-gather has landed
+        ev_ms = ctx.timer_stop()
+        ctx.synchronize()
+        w = time.perf_counter() - t0
+        if comm:
+            w = float(ctx.allreduce_host([w], "max")[0])
+        barrier()
+        walls.append(w)
+        evs.append(ev_ms)
+    order = np.argsort(walls)
+    med = int(order[len(order) // 2])
+    wall, ev_ms = walls[med], evs[med]
 
-    # second pass of the same K steps with every kernel launch bracketed by a HIP-event pair on its
+    # one more pass of the same K steps with every kernel launch bracketed by a HIP-event pair on its
     # launch stream (the per-kernel durations behind `roofline` / `kernels`).  Kept out of the timed
-    # region above: ~70 event records per step cost ~8 % at 3 ms per step.
+    # regions above: ~70 event records per step cost ~8 % at 3 ms per step.
     ctx.profile_reset()
     ctx.profile(True)
     tp = time.perf_counter()
@@ -299,47 +441,62 @@ def main():
     dom = max((k for k in prof if k != "rccl_allgather"), key=lambda k: prof[k]["total_ms"])
     d = prof[dom]
     achieved = d["flops"] / d["total_ms"] * 1e-9  # algorithmic flops of the launches / their event time
+    nblk = blocks[0] * blocks[1]
     roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP64_MATRIX_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP64_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_ms": round(d["total_ms"] / d["launches"], 5),
                 "flops_per_launch": d["flops"] / d["launches"],
-                "store_bytes_per_launch": 8.0 * M * blocks[0] * blocks[1] * (N - 1) ** 2 if dom.startswith("extend") else None,
+                "store_bytes_per_launch": 8.0 * M * nblk * (N - 1) ** 2 if dom.startswith("extend") else None,
                 "sustained_mfma_tflops": 49.0,
                 "frac_of_sustained": round(achieved / 49.0, 4),
                 "note": "ALGORITHMIC flops (no padding of K or of the tiles) of the fp64 MFMA kernel (v_mfma_f64_16x16x4_f64) "
                         "against the spec fp64 matrix rate (64 cycles per instruction).  A register-only loop of that "
                         "instruction sustains 49 TFLOP/s on this part (one per 100-104 cycles per SIMD; "
                         "profiles/r01_mfma_f64_peak_microbench_v2.txt): sustained_mfma_tflops / frac_of_sustained.  The same "
-                        "launch writes the snapshot rows (store_bytes_per_launch); store stream alone: 0.13-0.18 ms "
-                        "(tools/hbm_write_bw.hip); kernel with its stores disabled: 0.198 ms; in-kernel cycle stamps and what "
-                        "was tried: DESIGN.md section 5 and section 9"}
+                        "launch writes the snapshot rows (store_bytes_per_launch); DESIGN.md section 5"}
     # PMC-measured memory-side traffic of the dominant kernel, if a summary of separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command is committed
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    kname = {"factor_panel": "k_factor_panel", "diag_update": "k_diag_update", "extend": "k_extend",
-             "extend_lr": "k_extend128" if N - 1 >= 96 and M >= 128 else "k_extend", "solve1": "k_solve1",
-             "diag_potrf": "k_diag_potrf", "diag_inverse": "k_diag_inverse", "backsolve": "k_backsolve"}.get(dom)
-    if os.path.exists(pmc_path) and (blocks, N, M) == ((2, 2), 128, 1024):
-        pmc = json.load(open(pmc_path))["kernels"].get(kname)
-        if pmc:
-            roofline["traffic"] = pmc["traffic_bytes_per_launch"]
-            roofline["traffic_note"] = ("bytes per launch from profiles/r01_pmc_traffic.json: rocprofv3 --pmc "
-                                        "FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes; includes "
-                                        "Infinity-Cache hits")
+    for pmc_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        pmc_path = os.path.join(ROOT, "profiles", pmc_name)
+        if os.path.exists(pmc_path) and (blocks, N, M) == ((2, 2), 128, 1024):
+            allk = json.load(open(pmc_path))["kernels"]
+            pmc = next((v for k, v in allk.items() if dom.startswith("extend") and k.startswith("k_extend")), None) \
+                if dom.startswith("extend") else allk.get("k_" + dom)
+            if pmc:
+                roofline["traffic"] = pmc["traffic_bytes_per_launch"]
+                roofline["traffic_note"] = (f"bytes per launch from profiles/{pmc_name}: rocprofv3 --pmc FETCH_SIZE (x2, "
+                                            "gfx950) + WRITE_SIZE, separate passes; includes Infinity-Cache hits")
+                break
+    ms_all = [w / args.steps * 1e3 for w in walls]
     out = {
         "metric": "snapshot_solves_per_sec", "value": round(value, 1), "unit": "solves/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"C{2 if world == 1 else 3}: {blocks[0]}x{blocks[1]} blocks, N={N} "
+        "config": {"workload": f"{label}: {blocks[0]}x{blocks[1]} blocks, N={N} "
                                f"({blocks[0] * N}x{blocks[1] * N} cells, dim {dim}), {M}-parameter sweep per GPU "
-                               f"({world * M} total), a=10**U(0,2) seed 20240807"
-                               + ((", RCCL all-gather of the snapshot block in factored form (interface vectors) each "
-                                   "step" + (" + expansion of the whole block on every rank" if args.replicate else
-                                             "; rows of the own shard materialised")) if world > 1 else ""),
-                   "blocks_geometry": list(blocks), "N": N, "dim": dim, "M_per_gpu": M, "M_total": world * M,
-                   "parallelism": f"sweep sharded over {world} GPU(s)"},
+                               f"({world * M} total), SURVEY 8d parameters (seed {SEED})"
+                               + ((", RCCL all-gather each step of the snapshot block in FACTORED form: the interface "
+                                   f"vectors, {stride} doubles = {stride * 8} B per system, {M * stride * 8 / 1e6:.2f} MB sent per "
+                                   "rank" + (" + expansion of the whole block into rows on every rank (the literal 8e row "
+                                             "block, replicated)" if args.replicate else
+                                             "; rows of the own shard materialised, any other row reproducible bit for bit "
+                                             "from the gathered vectors")) if comm else ""),
+                   "config": args.config, "blocks_geometry": list(blocks), "N": N, "dim": dim, "M_per_gpu": M,
+                   "M_total": world * M, "parallelism": f"sweep sharded over {world} GPU(s)"},
+        "repeats": {"regions": len(walls), "ms_per_step": [round(x, 4) for x in ms_all], "min_ms_per_step": round(min(ms_all), 4),
+                    "median_ms_per_step": round(ms_all[med], 4), "max_ms_per_step": round(max(ms_all), 4),
+                    "note": "each region = exactly `steps` steps between barriers; value / ms_per_step are the median region's"},
         "event_ms_per_step": round(ev_ms / args.steps, 4),
         "profiled_pass_ms_per_step": round(wall_prof / args.steps * 1e3, 4),
+        "rccl_ranks": rccl_ranks if comm else 0,
+        "exchange": ({"what": "interface vectors (factored snapshot block)", "doubles_per_system": stride,
+                      "sent_bytes_per_rank_per_step": M * stride * 8, "received_bytes_per_rank_per_step": world * M * stride * 8,
+                      "row_block_bytes_per_rank": M * dim * 8, "replicated_rows": bool(args.replicate)} if comm else None),
+        "setup": {"setup_s": round(setup_s, 4),
+                  "solves_per_sec_incl_setup_one_sweep": round(M / (setup_s + wall / args.steps), 1),
+                  "note": "setup_s = SolutionsManagerFEM(...) = rom_fem_create (parameter-independent tables, once per FE "
+                          "space); NOT in `value` (SURVEY 8d: inputs resident in HBM); the second figure is what a caller "
+                          "pays for ONE sweep on a fresh FE space"},
         "algorithm": {"flops_per_solve": work["flops_own"], "hbm_bytes_per_solve": work["bytes_own"],
                       "canonical_banded_flops_per_solve": work["flops_banded"],
                       "canonical_banded_bytes_per_solve": work["bytes_banded"],
@@ -347,98 +504,199 @@ def main():
         "roofline": roofline, "kernels": kernels,
     }
 
-    if world == 1 and not args.no_pod:
-        # secondary figure of the metric: POD-SVD GF/s on the snapshot block just produced
-        X = ctx.alloc(M * dim).copy_from(U_loc, M * dim)
-        r = 50
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        comps, sig = pod_modes(ctx, DeviceArray(X, M, dim), r, center=True)
-        ctx.synchronize()
-        dt = time.perf_counter() - t0
-        X.copy_from(U_loc, M * dim)          # second, warm run (first one pays one-off kernel loads)
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        comps, sig = pod_modes(ctx, DeviceArray(X, M, dim), r, center=True)
-        ctx.synchronize()
-        dt = min(dt, time.perf_counter() - t0)
-        # F_pod = Gram + lift + eigh; only the lower half of the Gram matrix is computed -> M (M+1) D
-        f_pod = float(M) * (M + 1) * dim + 2.0 * r * M * dim + 10.0 * M ** 3
-        passes = getattr(pod_modes, "last_gram_passes", 1)
-        out["pod"] = {"gflops": round(f_pod / dt * 1e-9, 1), "seconds": round(dt, 4), "M": M, "dim": dim, "modes": r,
-                      "F_pod": f_pod, "sigma_1": float(sig[0]), "resolved_modes": int((sig > 0).sum()),
-                      "gram_passes": passes,
-                      "executed_gram_tflops": round(passes * float(M) * (M + 1) * dim / dt * 1e-12, 2),
-                      "note": "centre + Gram on MFMA (lower tiles only) + device subspace iteration + lift, with one "
-                              "deflation pass (a second Gram) for the modes below the Gram noise floor; F_pod = "
-                              "M (M+1) D + 2 r M D + 10 M^3 (SURVEY 8d, symmetric half, ONE Gram) over the wall time incl. "
-                              "the download of the r modes; executed_gram_tflops counts the Gram flops actually done"}
-        if fem.expansion_is_linear:
-            # the same figure on the block held in factored form (interface vectors; no row is read)
-            from romhighcontrast_amd import factored
-            Yf = ctx.alloc(M * fem.reduced_stride)
-            fem.solve_reduced(a_dev, M, Yf)
-            ctx.solve_status()
-            fs = factored.FactoredSnapshots(sm, Yf, M)
-            dtf = 1e9
-            for _ in range(2):
-                ctx.synchronize()
-                t0 = time.perf_counter()
-                comps_f, sig_f = factored.pod_modes_factored(fs, r)
-                ctx.synchronize()
-                dtf = min(dtf, time.perf_counter() - t0)
-            out["pod_factored"] = {"gflops": round(f_pod / dtf * 1e-9, 1), "seconds": round(dtf, 4), "modes": r,
-                                   "sigma_1_rel_diff": float(abs(sig_f[0] / sig[0] - 1)),
-                                   "note": "POD of the same block from its interface vectors (U = Y B^T, Gram = Y (B^T B) Y^T, "
-                                           "romhighcontrast_amd/factored.py); same F_pod accounting, i.e. the flops of "
-                                           "the row-based algorithm over this algorithm's wall time"}
-        if not args.no_pod_c3:
-            # the POD where the MFMA work dominates the fixed costs: the C3 snapshot block (8192 x 65025, 4.3 GB:
-            # what the 8 GPUs of C3 hold after their all-gather) built and decomposed on this one GPU
-            M3 = 8 * M
-            a3 = 10.0 ** np.random.default_rng(20240807).uniform(0, 2, size=(M3, blocks[0] * blocks[1]))
-            U3 = ctx.alloc(M3 * dim)
-            fem.solve_batch(ctx.upload(a3), M3, U3)
-            X3 = ctx.alloc(M3 * dim)
-            dt3 = 1e9
-            for _ in range(2):
-                X3.copy_from(U3, M3 * dim)
-                ctx.synchronize()
-                t0 = time.perf_counter()
-                comps3, sig3 = pod_modes(ctx, DeviceArray(X3, M3, dim), r, center=True)
-                ctx.synchronize()
-                dt3 = min(dt3, time.perf_counter() - t0)
-            f3 = float(M3) * (M3 + 1) * dim + 2.0 * r * M3 * dim + 10.0 * M3 ** 3
-            passes3 = getattr(pod_modes, "last_gram_passes", 1)
-            out["pod_c3"] = {"gflops": round(f3 / dt3 * 1e-9, 1), "seconds": round(dt3, 4), "M": M3, "dim": dim, "modes": r,
-                             "F_pod": f3, "gflops_without_eigh_term": round((f3 - 10.0 * M3 ** 3) / dt3 * 1e-9, 1),
-                             "gram_passes": passes3,
-                             "executed_gram_tflops": round(passes3 * float(M3) * (M3 + 1) * dim / dt3 * 1e-12, 2),
-                             "sigma_1": float(sig3[0]), "resolved_modes": int((sig3 > 0).sum()),
-                             "note": "same algorithm and accounting on the 8192-snapshot block of config C3, generated "
-                                     "and decomposed on one GPU; gflops_without_eigh_term drops the 10 M^3 of the formula "
-                                     "(the subspace iteration does far less than a full eigh)"}
-            del X3, U3
+    if world == 1 and not args.no_extras:
+        extras_api_rate(out, sm, a_loc, M, dim)
+        if args.config == "c2":
+            extras_pod_c2(out, args, ctx, sm, fem, a_dev, U_loc, M, dim, blocks)
+        elif args.config == "c4":
+            extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim)
+        elif args.config == "c5":
+            extras_pod_c5(out, ctx, sm, fem, a_dev, U_loc, M, dim)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(blocks, N, a_loc)
+        out["cpu_baseline"] = cpu_baseline(blocks, N, a_loc, budget_s=cfg["cpu_budget_s"], label=label,
+                                           min_solves=2 if args.config == "c5" else 4)
         out["cpu_baseline_all_cores"] = pool_baseline
-        # POD on the host: numpy.linalg.svd(X - mean) on a subsample of the same block that fits a few
-        # seconds, LAPACK threads as configured on the box; same F_pod accounting (symmetric half) for its size
-        Ms = min(M, 192)
-        Xs = U_loc.download(Ms * dim, shape=(Ms, dim))
-        t0 = time.perf_counter()
-        Xc = Xs - Xs.mean(axis=0)
-        sv = np.linalg.svd(Xc, full_matrices=False)[1]
-        dts = time.perf_counter() - t0
-        fs_ = float(Ms) * (Ms + 1) * dim + 2.0 * min(50, Ms) * Ms * dim + 10.0 * Ms ** 3
-        out["pod_cpu_baseline"] = {"gflops": round(fs_ / dts * 1e-9, 1), "seconds": round(dts, 3), "M": Ms, "dim": dim,
-                                   "sigma_1": float(sv[0]), "kind": "reference call",
-                                   "sample": f"numpy.linalg.svd of the centred first {Ms} snapshots (the SVD inside "
-                                             f"sklearn PCA, src/lib/ReducedBasis.py:196), all LAPACK threads of the host"}
+        if args.config == "c2":
+            # POD on the host: numpy.linalg.svd(X - mean) on a subsample of the same block that fits a few
+            # seconds, LAPACK threads as configured on the box; same useful-flop accounting for its size
+            Ms = min(M, 192)
+            Xs = U_loc.download(Ms * dim, shape=(Ms, dim))
+            t0 = time.perf_counter()
+            Xc = Xs - Xs.mean(axis=0)
+            sv = np.linalg.svd(Xc, full_matrices=False)[1]
+            dts = time.perf_counter() - t0
+            out["pod_cpu_baseline"] = {"gflops": round(pod_accounting(Ms, dim, min(50, Ms)) / dts * 1e-9, 1),
+                                       "seconds": round(dts, 3), "M": Ms, "dim": dim,
+                                       "sigma_1": float(sv[0]), "kind": "reference call",
+                                       "sample": f"numpy.linalg.svd of the centred first {Ms} snapshots (the SVD inside "
+                                                 f"sklearn PCA, src/lib/ReducedBasis.py:196), all LAPACK threads of the host"}
     if comm:
         ctx.comm_destroy()
         sweep.cleanup_rendezvous(rank)
     print(json.dumps(out))
+
+
+# =====================================================================================================================
+# secondary legs (one GPU, after the timed sweep)
+# =====================================================================================================================
+def _timed(ctx, f, reps=2):
+    best, res = 1e30, None
+    for _ in range(reps):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        res = f()
+        ctx.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return res, best
+
+
+def extras_api_rate(out, sm, a_loc, M, dim):
+    """What a caller of the reference API sees: sm.generate_solutions(a) returns host rows (M, dim), so upload, sweep
+    and the PCIe copy of the block are part of the call.  The first calls land in pageable memory; from the third
+    request of a size on, libromhc's page-locked pool is used (_ffi._pinned_array)."""
+    if M * dim * 8 > 8e9:  # a C5-size block through PCIe four times is not worth the bench time
+        Ms = max(1, int(8e9 // (dim * 8)))
+    else:
+        Ms = M
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        U = sm.generate_solutions(a_loc[:Ms])
+        times.append(time.perf_counter() - t0)
+        del U
+    out["api"] = {"call": "sm.generate_solutions(a) -> host ndarray", "rows": Ms, "bytes": Ms * dim * 8,
+                  "seconds": [round(t, 4) for t in times],
+                  "solves_per_sec_pageable": round(Ms / min(times[:2]), 1),
+                  "solves_per_sec_pinned": round(Ms / min(times[2:]), 1),
+                  "note": "PCIe-inclusive rates of the reference-shaped API (never `value`): calls 1-2 copy into fresh pageable "
+                          "memory, calls 3+ into a page-locked block of libromhc's pool"}
+
+
+def extras_pod_c2(out, args, ctx, sm, fem, a_dev, U_loc, M, dim, blocks):
+    from romhighcontrast_amd.lib.ReducedBasis import pod_modes
+    from romhighcontrast_amd.lib.SolutionsManagers import DeviceArray
+    r = 50
+    X = ctx.alloc(M * dim)
+
+    def run_rows(Xbuf, src, Mx):
+        Xbuf.copy_from(src, Mx * dim)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        res = pod_modes(ctx, DeviceArray(Xbuf, Mx, dim), r, center=True)
+        ctx.synchronize()
+        return res, time.perf_counter() - t0
+
+    def pod_record(Mx, dt, sig, info):
+        useful = pod_accounting(Mx, dim, r)
+        rec = {"gflops": round(useful / dt * 1e-9, 1), "seconds": round(dt, 4), "M": Mx, "dim": dim, "modes": r,
+               "useful_flops": useful, "sigma_1": float(sig[0]), "resolved_modes": int((sig > 0).sum()),
+               "gflops_survey_formula_with_10M3": round((useful + 10.0 * Mx ** 3) / dt * 1e-9, 1)}
+        rec.update(info)
+        return rec
+
+    (_, sig), dt = run_rows(X, U_loc, M)
+    (_, sig), dt2 = run_rows(X, U_loc, M)   # second, warm run (first one pays one-off kernel loads)
+    dt = min(dt, dt2)
+    out["pod"] = pod_record(M, dt, sig, dict(getattr(pod_modes, "last_info", {}),
+                            note="gflops = USEFUL flops (symmetric half of ONE Gram matrix + lift of r modes, no eigh term) over "
+                                 "the wall time of pod_modes incl. the download of the r modes; executed flops in `executed_*`"))
+    if fem.expansion_is_linear:
+        # the same POD on the block held in factored form (interface vectors; no row is read)
+        from romhighcontrast_amd import factored
+        Yf = ctx.alloc(M * fem.reduced_stride)
+        fem.solve_reduced(a_dev, M, Yf)
+        ctx.solve_status()
+        fs = factored.FactoredSnapshots(sm, Yf, M)
+        (_, sig_f), dtf = _timed(ctx, lambda: factored.pod_modes_factored(fs, r))
+        info = dict(getattr(factored.pod_modes_factored, "last_info", {}))
+        out["pod_factored"] = {"seconds": round(dtf, 4), "modes": r, "M": M,
+                               "sigma_1_rel_diff": float(abs(sig_f[0] / sig[0] - 1)),
+                               "resolved_modes": int((sig_f > 0).sum()),
+                               "row_equivalent_gflops": round(pod_accounting(M, dim, r) / dtf * 1e-9, 1), **info,
+                               "note": "POD of the same block from its interface vectors (U = Y B^T; romhighcontrast_amd/"
+                                       "factored.py); row_equivalent_gflops = useful flops of the ROW algorithm over this "
+                                       "algorithm's time (a speed-up statement, not an MFMA rate)"}
+    if not args.no_pod_c3:
+        # the POD where the MFMA work dominates the fixed costs: the C3 snapshot block (8192 x 65025, 4.3 GB:
+        # what the 8 GPUs of C3 hold after their all-gather) built and decomposed on this one GPU
+        M3 = 8 * M
+        a3 = workload_parameters("c2", blocks, M3).reshape(M3, -1)
+        U3 = ctx.alloc(M3 * dim)
+        fem.solve_batch(ctx.upload(a3), M3, U3)
+        X3 = ctx.alloc(M3 * dim)
+        (_, sig3), dt3 = run_rows(X3, U3, M3)
+        (_, sig3), dt3b = run_rows(X3, U3, M3)
+        dt3 = min(dt3, dt3b)
+        out["pod_c3"] = pod_record(M3, dt3, sig3, dict(getattr(pod_modes, "last_info", {}),
+                                   note="same algorithm and accounting on the 8192-snapshot block of config C3, generated and "
+                                        "decomposed on one GPU"))
+        del X3, U3
+
+
+def extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim):
+    """C4: greedy reduced basis to n=50 on the 1024-parameter training set, both modes (src/lib/ReducedBasis.py:112-139),
+    on snapshot rows (what a caller of the reference API has) and on the factored block."""
+    from romhighcontrast_amd.lib import ReducedBasis as RB
+    from romhighcontrast_amd.lib.SolutionsManagers import DeviceArray
+    n = 50
+    Ud = DeviceArray(U_loc, M, dim)
+    h1, t_h1 = _timed(ctx, lambda: sm.H10norm(Ud))
+    rec = {"n": n, "M": M, "h10norm_ms": round(t_h1 * 1e3, 3), "h10norm_gbs": round(8.0 * M * dim / t_h1 * 1e-9, 1)}
+    picks = {}
+    for tag, mode in (("h10", RB.GREEDY_FOR_H10), ("galerkin", RB.GREEDY_FOR_GALERKIN)):
+        rb, t = _timed(ctx, lambda: RB.ReducedBasisGreedy(mode).build(n, sm, Ud, a_loc, h1), reps=1)
+        picks[tag] = rb.picks
+        e = np.array(rb.max_errors)
+        # algorithmic work of the row build (SURVEY 8d): per iteration at basis size m two GEMMs 2 m D M + norms 12 M D
+        fl = sum(4.0 * m * dim * M + 12.0 * M * dim for m in range(n))
+        rec[f"rows_{tag}"] = {"seconds": round(t, 4), "tflops_algorithmic": round(fl / t * 1e-12, 2),
+                              "max_rel_error_at_n": {str(k): float(e[k - 1]) for k in (1, 2, 5, 10, 20, 30, 40, 50) if k <= n},
+                              "first_picks": rb.picks[:10]}
+    if fem.expansion_is_linear:
+        from romhighcontrast_amd import factored
+        Yf = ctx.alloc(M * fem.reduced_stride)
+        fem.solve_reduced(a_dev, M, Yf)
+        ctx.solve_status()
+        fs = factored.FactoredSnapshots(sm, Yf, M)
+        _, t_e = _timed(ctx, lambda: fs.map.energy_coordinates(), reps=1)
+        rec["energy_coordinates_once_s"] = round(t_e, 3)
+        for tag, mode in (("h10", RB.GREEDY_FOR_H10), ("galerkin", RB.GREEDY_FOR_GALERKIN)):
+            rb, t = _timed(ctx, lambda: RB.ReducedBasisGreedy(mode).build(n, sm, fs, a_loc, h1), reps=1)
+            rec[f"factored_{tag}"] = {"seconds": round(t, 4),
+                                      "picks_equal_to_rows": int(sum(p == q for p, q in zip(rb.picks, picks[tag]))),
+                                      "last_max_rel_error": float(rb.max_errors[-1])}
+    out["greedy"] = rec
+
+
+def extras_pod_c5(out, ctx, sm, fem, a_dev, U_loc, M, dim):
+    """C5: POD of the 4096 x 1 046 529 block (src/lib/ReducedBasis.py:189-200), rows and factored."""
+    from romhighcontrast_amd.lib.ReducedBasis import pod_modes
+    from romhighcontrast_amd.lib.SolutionsManagers import DeviceArray
+    r = 50
+    X = ctx.alloc(M * dim)
+    X.copy_from(U_loc, M * dim)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    _, sig = pod_modes(ctx, DeviceArray(X, M, dim), r, center=True)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    useful = pod_accounting(M, dim, r)
+    out["pod"] = {"gflops": round(useful / dt * 1e-9, 1), "seconds": round(dt, 4), "M": M, "dim": dim, "modes": r,
+                  "useful_flops": useful, "sigma_1": float(sig[0]), "resolved_modes": int((sig > 0).sum()),
+                  **getattr(pod_modes, "last_info", {}),
+                  "note": "gflops = useful flops (symmetric half of ONE Gram + lift, no eigh term) over the wall time of pod_modes"}
+    del X
+    if fem.expansion_is_linear:
+        from romhighcontrast_amd import factored
+        Yf = ctx.alloc(M * fem.reduced_stride)
+        fem.solve_reduced(a_dev, M, Yf)
+        ctx.solve_status()
+        fs = factored.FactoredSnapshots(sm, Yf, M)
+        (_, sig_f), dtf = _timed(ctx, lambda: factored.pod_modes_factored(fs, r))
+        out["pod_factored"] = {"seconds": round(dtf, 4), "modes": r, "M": M,
+                               "sigma_rel_diff_max": float(np.abs(sig_f[sig > 1e-6 * sig[0]] / sig[sig > 1e-6 * sig[0]] - 1).max()),
+                               "row_equivalent_gflops": round(useful / dtf * 1e-9, 1),
+                               **getattr(factored.pod_modes_factored, "last_info", {})}
 
 
 if __name__ == "__main__":

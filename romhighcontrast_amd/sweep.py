@@ -60,8 +60,10 @@ def _launcher_start_time() -> str:
 
 
 def rendezvous_path() -> str:
+    # ROMHC_LAUNCH_ID: set by bench.py's own launcher (launch_ranks); TORCHELASTIC_RUN_ID: by torch.distributed.run
     tag = "_".join([os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
-                    os.environ.get("TORCHELASTIC_RUN_ID", "none"), str(os.getppid()), _launcher_start_time()])
+                    os.environ.get("ROMHC_LAUNCH_ID", os.environ.get("TORCHELASTIC_RUN_ID", "none")),
+                    str(os.getppid()), _launcher_start_time()])
     return os.path.join(tempfile.gettempdir(), f"romhc_rdzv_{tag}.bin")
 
 

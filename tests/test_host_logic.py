@@ -154,3 +154,83 @@ def test_bench_cpu_baselines_run_on_a_small_case():
     assert pool["kind"] == "port" and pool["value"] > 0 and 1 <= pool["cores"] <= 16
     n_done = int(pool["sample"].split(" of the ")[0])
     assert n_done == min(M, pool["cores"] * 2)
+
+
+_STUB_RANK = r'''
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                      "ROMHC_LAUNCH_ID", "HSA_ENABLE_IPC_MODE_LEGACY")}
+rec["argv"] = sys.argv[1:]
+open(os.path.join(os.environ["STUB_DIR"], f"rank{rank}.json"), "w").write(json.dumps(rec))
+if os.environ.get("STUB_FAIL_RANK") == str(rank):
+    sys.exit(7)
+if os.environ.get("STUB_FAIL_RANK") is not None:
+    time.sleep(60)   # the surviving ranks would hang in a collective: the launcher must stop them
+print(json.dumps({"n_gpus": world}) if rank == 0 else f"noise from rank {rank}")
+'''
+
+
+def test_bench_launcher_starts_one_rank_per_gpu(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` without a launcher environment starts N fresh ranks itself (before anything touches
+    the GPU): distinct RANK / LOCAL_RANK, one MASTER_PORT and launch id, only rank 0 on stdout, the first failing rank's
+    exit code returned and the other ranks stopped."""
+    import json
+    import time
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(_STUB_RANK)
+    env = dict(os.environ, STUB_DIR=str(tmp_path), PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    code = ("import sys, bench; sys.exit(bench.launch_ranks(3, ['--gpus', '3', '--steps', '2'], "
+            f"child=[sys.executable, {str(stub)!r}]))")
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert json.loads(p.stdout.strip()) == {"n_gpus": 3}           # ONE line on stdout: rank 0's
+    assert "noise from rank 1" in p.stderr and "noise from rank 2" in p.stderr
+    recs = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(3)]
+    assert [r["RANK"] for r in recs] == ["0", "1", "2"] and [r["LOCAL_RANK"] for r in recs] == ["0", "1", "2"]
+    assert {r["WORLD_SIZE"] for r in recs} == {"3"} and {r["LOCAL_WORLD_SIZE"] for r in recs} == {"3"}
+    assert len({r["MASTER_PORT"] for r in recs}) == 1 and len({r["ROMHC_LAUNCH_ID"] for r in recs}) == 1
+    assert {r["MASTER_ADDR"] for r in recs} == {"127.0.0.1"} and {r["HSA_ENABLE_IPC_MODE_LEGACY"] for r in recs} == {"0"}
+    assert recs[0]["argv"] == ["--gpus", "3", "--steps", "2"]
+    # the launcher itself never loads libromhc (no GPU initialisation in the parent)
+    code2 = ("import sys, bench; rc = bench.launch_ranks(2, [], child=[sys.executable, " + repr(str(stub)) + "]); "
+             "assert not any('libromhc' in l for l in open('/proc/self/maps')); sys.exit(rc)")
+    assert subprocess.run([sys.executable, "-c", code2], env=env, cwd=ROOT, capture_output=True, timeout=120).returncode == 0
+    # a failing rank: its exit code comes back and the sleeping ranks are stopped long before their 60 s
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], env=dict(env, STUB_FAIL_RANK="1"), cwd=ROOT, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 7 and time.time() - t0 < 30
+    assert "rank 1" in p.stderr
+
+
+def test_bench_refuses_more_ranks_than_gpus(monkeypatch):
+    import bench
+    for k in ("ROMHC_FORCE_DEVICE", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROMHC_LAUNCH_ID"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.pick_device(3, 8, 8) == 3
+    with pytest.raises(SystemExit, match="one process per GPU"):
+        bench.pick_device(1, 2, 1)                     # two ranks, one visible GPU: no modulo
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5")     # a launcher that pinned one GPU per process
+    assert bench.pick_device(5, 8, 1) == 0
+    monkeypatch.setenv("ROMHC_LAUNCH_ID", "x")         # bench.py's own launcher never pins: the job HAS one GPU
+    with pytest.raises(SystemExit, match="one process per GPU"):
+        bench.pick_device(1, 2, 1)
+    monkeypatch.setenv("ROMHC_FORCE_DEVICE", "0")
+    assert bench.pick_device(1, 2, 1) == 0
+
+
+def test_bench_workloads_follow_survey_8d():
+    import bench
+    a = bench.workload_parameters("c2", (2, 2), 1024)
+    assert np.array_equal(a, 10.0 ** np.random.default_rng(20240807).uniform(0, 2, size=(1024, 2, 2)))
+    a8 = bench.workload_parameters("c2", (2, 2), 8192)   # C3: rank r owns rows [1024 r, 1024 (r+1))
+    assert a8.shape == (8192, 2, 2) and a8.min() >= 1 and a8.max() <= 100
+    c4 = bench.workload_parameters("c4", (3, 3), 1024)
+    assert np.all(c4[0] == 1) and all(c4[1 + j].flat[j] == 1e8 and (c4[1 + j] == 1).sum() == 8 for j in range(9))
+    assert np.all(c4[10] == 1e8) and c4[11:].min() >= 1 and c4[11:].max() <= 1e8
+    assert np.array_equal(c4[11:], 10.0 ** np.random.default_rng(20240807).uniform(0, 8, size=(1013, 3, 3)))
+    c5 = bench.workload_parameters("c5", (4, 4), 4096)
+    assert c5.shape == (4096, 4, 4) and c5.max() <= 1000
