@@ -428,59 +428,125 @@ def test_full_size_c2_properties(api):
     np.testing.assert_allclose(sm.H10norm(Ud)[idx], ro.H10norm(g, Ug), rtol=1e-12)
 
 
-def test_full_size_c4_properties(api):
-    """BASELINE config C4 geometry ((3,3)/N=171: 512 x 512 unknowns, contrast up to 1e8): residual through the
-    independent stencil kernel, one row against SuperLU, norms, and a short greedy on the device block."""
+def _oracle_rows(args):
+    """(worker of a spawned process pool: SuperLU solves of the oracle, ~1 s each at 512 x 512)"""
+    blocks, N, rows = args
+    g = ro.Geometry(blocks, N)
+    B = ro.load_vector(g)
+    return np.stack([ro.solve_one(g, a, B, "lsqsparse") for a in rows])
+
+
+def oracle_sweep_parallel(blocks, N, a, workers=8):
+    """The oracle's generate_solutions over a pool of FRESH processes (spawn: this process has initialised the GPU,
+    it must not fork)."""
+    import multiprocessing as mp
+    workers = max(1, min(workers, len(a)))
+    chunks = [(blocks, N, a[i::workers]) for i in range(workers)]
+    with mp.get_context("spawn").Pool(workers) as pool:
+        parts = pool.map(_oracle_rows, chunks)
+    out = np.empty((len(a), parts[0].shape[1]))
+    for i, part in enumerate(parts):
+        out[i::workers] = part
+    return out
+
+
+def test_full_size_c4_workload(api):
+    """BASELINE config C4 at its stated workload ((3,3)/N=171: 512 x 512 unknowns, contrast up to 1e8, the 1024-row
+    training set of SURVEY 8d, greedy reduced basis to n = 50, src/lib/ReducedBasis.py:112-139):
+      * residual of sampled rows through the independent stencil kernel; the first 64 rows (which hold the limit
+        solutions) against the SuperLU oracle;
+      * greedy to n = 50 in both modes on snapshot rows and on the factored block: identical picks, equal error curves;
+      * the greedy on the 64-row subsample against the ORACLE's greedy on the oracle's own snapshots (the oracle is
+        ~1 s per solve here, so it is the oracle that is subsampled, not the GPU): same picks while the errors are
+        above roundoff, error curves within 1e-8."""
     SM, RB = api
-    from romhighcontrast_amd import _ffi
-    sm = SM.SolutionsManagerFEM((3, 3), 171)
+    import bench
+    from romhighcontrast_amd import _ffi, factored
+    blocks, N, M, n = (3, 3), 171, 1024, 50
+    sm = SM.SolutionsManagerFEM(blocks, N)
     ctx, fem, dim = sm._ctx, sm._fem, sm.vspace_dim
     assert dim == 262144
-    M = 48
-    rng = np.random.default_rng(20240807)
-    a = np.ones((M, 3, 3))
-    for jb in range(9):
-        a[1 + jb].flat[jb] = 1e8          # the "limit solutions" the reference seeds its training sets with
-    a[10] = 1e8
-    a[11:] = 10.0 ** rng.uniform(0, 8, size=(M - 11, 3, 3))
+    a = bench.workload_parameters("c4", blocks, M)
+    assert np.all(a[0] == 1) and np.all(a[10] == 1e8) and a[11:].max() <= 1e8
     Ud = sm.generate_solutions_device(a)
     Y = ctx.alloc(dim)
-    for m in (0, 3, 10, M - 1):
+    for m in (0, 3, 10, 500, M - 1):
         row = _ffi.Buffer(ctx, dim).copy_from(Ud.buf, dim, 0, m * dim)
         fem.stencil_apply(row, 1, Y, a_one=a[m].ravel())
         res = Y.download(dim) - sm.B_total
         u = row.download(dim)
         assert np.abs(res).max() < 1e-11 * np.abs(u).max() * 4 * a[m].max()
-    g = ro.Geometry((3, 3), 171)
-    m = M - 1
-    uo = ro.solve_one(g, a[m], ro.load_vector(g), "lsqsparse")
-    ug = Ud.buf.download(dim, offset=m * dim)
-    assert relh10(g, ug[None], uo[None]).max() < SNAP_TOL
+    g = ro.Geometry(blocks, N)
+    Ms = 64
+    Uo = oracle_sweep_parallel(blocks, N, a[:Ms])
+    Ug = Ud.buf.download(Ms * dim, shape=(Ms, dim))
+    # A block that touches no Dirichlet side and dominates all its neighbours "floats": its plateau level is fixed by
+    # fluxes that are 1e-8 of the matrix entries (row 5: the centre block at 1e8 among ones, kappa(A) ~ 1e13), and two
+    # backward-stable direct solvers agree on it to ~kappa * eps only (the reference's lsq / lsqsparse pair disagrees
+    # by 8.5e-6 on the same construction at N = 11, fixture g4).  Those rows get 1e-3, every other row 1e-11.
+    centre = a[:Ms, 1, 1]
+    others = np.delete(a[:Ms].reshape(Ms, 9), 4, axis=1).max(axis=1)
+    floating = centre >= 1e4 * others
+    assert floating[5] and floating.sum() <= 3
+    err = relh10(g, Ug, Uo)
+    assert err[~floating].max() < SNAP_TOL and err[floating].max() < 1e-3, (err[~floating].max(), err[floating])
     h1 = sm.H10norm(Ud)
-    np.testing.assert_allclose(h1[m], ro.H10norm(g, ug[None])[0], rtol=1e-12)
-    rb = RB.ReducedBasisGreedy(RB.GREEDY_FOR_H10).build(6, sm, Ud, a, h1)
-    assert rb.picks[0] == 0 and rb.max_errors[0] == 1.0
-    assert all(e2 <= e1 * (1 + 1e-12) for e1, e2 in zip(rb.max_errors, rb.max_errors[1:]))  # greedy errors decrease
-    assert rb.basis.shape == (6, dim)
+    h1o = ro.H10norm(g, Uo)
+    np.testing.assert_allclose(h1[:Ms][~floating], h1o[~floating], rtol=1e-11)
+    # greedy n = 50 on the full training set: rows vs factored block
+    Yf = ctx.alloc(M * fem.reduced_stride)
+    fem.solve_reduced(ctx.upload(a.reshape(M, -1)), M, Yf)
+    ctx.solve_status()
+    fs = factored.FactoredSnapshots(sm, Yf, M)
+    np.testing.assert_allclose(factored.h10norm_factored(fs), h1, rtol=1e-10)
+    for mode in (RB.GREEDY_FOR_H10, RB.GREEDY_FOR_GALERKIN):
+        rb_r = RB.ReducedBasisGreedy(mode).build(n, sm, Ud, a, h1)
+        rb_f = RB.ReducedBasisGreedy(mode).build(n, sm, fs, a, h1)
+        assert rb_r.picks[0] == 0 and rb_r.max_errors[0] == 1.0 and len(rb_r.picks) == n
+        er, ef = np.array(rb_r.max_errors), np.array(rb_f.max_errors)
+        # picks are compared while the selection is not a coin toss between near-equal errors (relative gap of the two
+        # error curves); the curves themselves agree throughout
+        assert np.abs(er - ef).max() < 1e-7 * np.maximum(er, 1e-3).max(), (mode, np.abs(er - ef).max())
+        same = [p == q for p, q in zip(rb_r.picks, rb_f.picks)]
+        assert sum(same) >= n - 2, (mode, rb_r.picks, rb_f.picks)
+        # the worst-case error decays (nine free blocks at contrast 1e8: slowly); the H^1_0 projection error never grows
+        # (the Galerkin solution is not the best approximation in this norm: its curve may go up a little)
+        assert er[-1] < 0.2 * er[1], (mode, er)
+        if mode == RB.GREEDY_FOR_H10:
+            assert all(e2 <= e1 * (1 + 1e-9) for e1, e2 in zip(er, er[1:])), (mode, er)
+        assert rb_r.basis.shape == (n, dim)
+    # greedy on the 64-row subsample: GPU vs the oracle end to end
+    ns = 8
+    sub = SM.DeviceArray(_ffi.Buffer(ctx, Ms * dim).copy_from(Ud.buf, Ms * dim), Ms, dim)
+    for mode, omode in ((RB.GREEDY_FOR_H10, ro.GREEDY_FOR_H10), (RB.GREEDY_FOR_GALERKIN, ro.GREEDY_FOR_GALERKIN)):
+        rb = RB.ReducedBasisGreedy(mode).build(ns, sm, sub, a[:Ms], h1[:Ms])
+        _, _, picks_o, errs_o = ro.greedy_build(g, ns, Uo, a[:Ms], h1o, greedy_for=omode, method="lsqsparse",
+                                                return_errors=True)
+        errs_o = np.array(errs_o)
+        ok = errs_o > 1e-9
+        assert [p for p, k in zip(rb.picks, ok) if k] == [p for p, k in zip(picks_o, ok) if k], (mode, rb.picks, picks_o)
+        assert np.abs(np.array(rb.max_errors) - errs_o).max() < 1e-8, (mode, rb.max_errors, errs_o.tolist())
 
 
-def test_full_size_c5_properties(api):
-    """BASELINE config C5 geometry ((4,4)/N=256: 1024 x 1024 cells, dim 1 046 529), too large for the oracle to
-    sweep: size-independent properties instead -- the residual through the independent stencil kernel, homogeneity
-    u(c a) = u(a) / c, the unit-coefficient solution's symmetry under the square's reflections, POD of the block
-    from rows and from its factored form."""
+def test_full_size_c5_workload(api):
+    """BASELINE config C5 at its stated workload ((4,4)/N=256: 1024 x 1024 cells, dim 1 046 529, 4096-parameter sweep =
+    a 34.3 GB snapshot block, POD to 50 modes, src/lib/ReducedBasis.py:189-200).  The oracle cannot sweep this
+    (25 s per solve), so: residual through the independent stencil kernel, homogeneity u(c a) = u(a) / c, the
+    unit-coefficient solution's symmetry, two rows against SuperLU; POD singular values of the full block from rows
+    against the factored form, and -- on a 256-row subsample -- against numpy.linalg.svd of the downloaded rows."""
     SM, RB = api
+    import bench
     from romhighcontrast_amd import _ffi, factored
-    sm = SM.SolutionsManagerFEM((4, 4), 256)
+    blocks, N, M, r = (4, 4), 256, 4096, 50
+    sm = SM.SolutionsManagerFEM(blocks, N)
     ctx, fem, dim = sm._ctx, sm._fem, sm.vspace_dim
     assert dim == 1023 * 1023
-    M = 130  # (>= 128: the wide extension tiles)
-    a = 10.0 ** np.random.default_rng(20240807).uniform(0, 3, size=(M, 4, 4))
+    a = bench.workload_parameters("c5", blocks, M)
     a[0] = 1.0
     a[1] = 7.0 * a[2]
     Ud = sm.generate_solutions_device(a)
     Y = ctx.alloc(dim)
-    for m in (0, 2, 64, M - 1):
+    for m in (0, 2, 2048, M - 1):
         row = _ffi.Buffer(ctx, dim).copy_from(Ud.buf, dim, 0, m * dim)
         fem.stencil_apply(row, 1, Y, a_one=a[m].ravel())
         res = Y.download(dim) - sm.B_total
@@ -490,19 +556,36 @@ def test_full_size_c5_properties(api):
     assert np.abs(u0 - u0[::-1, :]).max() < 1e-12 * u0.max() and np.abs(u0 - u0.T).max() < 1e-12 * u0.max()
     u1, u2 = Ud.buf.download(dim, offset=dim), Ud.buf.download(dim, offset=2 * dim)
     assert np.abs(7.0 * u1 - u2).max() < 1e-12 * np.abs(u2).max()
+    g = ro.Geometry(blocks, N)
+    idx = [5, M - 1]
+    Uo = oracle_sweep_parallel(blocks, N, a[idx], workers=2)
+    Ug = np.stack([Ud.buf.download(dim, offset=i * dim) for i in idx])
+    assert relh10(g, Ug, Uo).max() < SNAP_TOL
     h1 = sm.H10norm(Ud)
     assert np.all(h1 > 0) and abs(h1[2] / h1[1] - 7.0) < 1e-11
-    # POD of the block: rows vs interface vectors
-    n = 8
+    np.testing.assert_allclose(h1[idx], ro.H10norm(g, Ug), rtol=1e-11)
+    # POD of the full block: rows vs interface vectors
     Yf = ctx.alloc(M * fem.reduced_stride)
     fem.solve_reduced(ctx.upload(a.reshape(M, -1)), M, Yf)
     ctx.solve_status()
     fs = factored.FactoredSnapshots(sm, Yf, M)
-    modes_f, sig_f = factored.pod_modes_factored(fs, n)
+    modes_f, sig_f = factored.pod_modes_factored(fs, r)
     X = ctx.alloc(M * dim).copy_from(Ud.buf, M * dim)
-    modes_r, sig_r = RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), n)
-    np.testing.assert_allclose(sig_f, sig_r, rtol=1e-8)
-    assert np.abs(np.abs(np.sum(modes_f * modes_r, axis=1)) - 1.0).max() < 1e-8
+    modes_r, sig_r = RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), r)
+    del X
+    big = sig_r > 1e-6 * sig_r[0]
+    assert big.sum() >= 20
+    np.testing.assert_allclose(sig_f[big], sig_r[big], rtol=1e-7)
+    assert np.abs(np.abs(np.sum(modes_f[big] * modes_r[big], axis=1)) - 1.0).max() < 1e-6
+    assert np.abs(modes_r[big] @ modes_r[big].T - np.eye(int(big.sum()))).max() < 1e-9
+    # a 256-row subsample against LAPACK on the host (the SVD inside sklearn's PCA, src/lib/ReducedBasis.py:196)
+    Ms = 256
+    Xs = Ud.buf.download(Ms * dim, shape=(Ms, dim))
+    sv = np.linalg.svd(Xs - Xs.mean(axis=0), full_matrices=False)[1]
+    Xd = ctx.alloc(Ms * dim).copy_from(Ud.buf, Ms * dim)
+    _, sig_s = RB.pod_modes(ctx, SM.DeviceArray(Xd, Ms, dim), 30)
+    keep = sv[:30] > 1e-7 * sv[0]
+    np.testing.assert_allclose(sig_s[keep], sv[:30][keep], rtol=1e-7)
 
 
 @pytest.mark.parametrize("blocks,N,M", [((2, 2), 128, 200), ((3, 3), 20, 70), ((1, 2), 6, 5), ((2, 2), 16, 130), ((1, 1), 8, 3)])
