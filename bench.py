@@ -592,6 +592,8 @@ def extras_pod_c2(out, args, ctx, sm, fem, a_dev, U_loc, M, dim, blocks):
                "useful_flops": useful, "sigma_1": float(sig[0]), "resolved_modes": int((sig > 0).sum()),
                "gflops_survey_formula_with_10M3": round((useful + 10.0 * Mx ** 3) / dt * 1e-9, 1)}
         rec.update(info)
+        if "executed_flops" in info:
+            rec["executed_gflops"] = round(info["executed_flops"] / dt * 1e-9, 1)
         return rec
 
     (_, sig), dt = run_rows(X, U_loc, M)

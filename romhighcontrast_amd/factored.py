@@ -106,6 +106,26 @@ class ExpansionMap:
         self._energy = (E, np.array(Mb), beta)
         return self._energy
 
+    def l2_coordinates(self):
+        """(E, Einv): with zeta = y E (k' numbers per snapshot) the EUCLIDEAN inner product of two snapshot rows is the
+        Euclidean inner product of their zeta (E = V Lambda^(1/2) from S = B^T B = V Lambda V^T, directions below 1e-15 of
+        the largest eigenvalue dropped), and a direction r in zeta coordinates is the snapshot-space vector B (Einv r) with
+        Einv = V Lambda^(-1/2): B Einv has orthonormal columns.  The POD of a factored block is therefore the POD of the
+        small (M, k') matrix Y E.  Built once per FE space (host eigh of a Kc x Kc matrix, equilibrated like
+        energy_coordinates)."""
+        if getattr(self, "_l2", None) is not None:
+            return self._l2
+        K = self.Kc
+        S = self.S.download(K * K, shape=(K, K))
+        S = (S + S.T) / 2
+        d = np.sqrt(np.maximum(np.diag(S), 0.0))
+        d[d == 0] = 1.0
+        lam, V = np.linalg.eigh(S / np.outer(d, d))
+        keep = lam > 1e-15 * lam[-1]
+        lam, V = lam[keep][::-1], V[:, keep][:, ::-1]
+        self._l2 = ((V * np.sqrt(lam)) * d[:, None], (V / np.sqrt(lam)) / d[:, None])
+        return self._l2
+
     def _a_dummy(self, M):
         if M not in self._ones:
             self._ones = {M: self.ctx.upload(np.ones((M, self.fem.kblk)))}
@@ -170,67 +190,44 @@ class FactoredSnapshots:
         return G
 
 
-def pod_modes_factored(fs: FactoredSnapshots, n: int, center=True, passes=2):
-    """Leading ``n`` POD modes / singular values of the snapshot block ``fs`` without ever forming it:
-    the same algorithm as ``lib.ReducedBasis.pod_modes`` (Gram -> leading eigenpairs by subspace iteration
-    on the device -> lift, repeated on the deflated block because the Gram matrix squares the condition
-    number), carried out on the interface vectors in the S inner product.  Cost O(M^2 K + n K dim) instead of
-    O(M^2 dim).  Returns (modes (n, dim) NumPy, singular values); rows follow scikit-learn's
-    ``svd_flip(u_based_decision=False)`` sign convention (the PCA call at src/lib/ReducedBasis.py:196)."""
-    from .lib.ReducedBasis import _top_eigenpairs_device
+def pod_modes_factored(fs: FactoredSnapshots, n: int, center=True):
+    """Leading ``n`` POD modes / singular values of the snapshot block ``fs`` without ever forming it.
+
+    With U = Y B^T and S = B^T B = E E^T (``ExpansionMap.l2_coordinates``) the rows of Z = Y E (M x k', k' <= a few
+    hundred) have the same Euclidean geometry as the snapshot rows, so the POD of the block IS the POD of Z: the same
+    routine as for rows (``lib.ReducedBasis.pod_modes``: Gram matrix on MFMA, deflation + sketches for the small modes,
+    Rayleigh-Ritz) runs on a matrix dim / k' times narrower, and a mode r in zeta coordinates is expanded as
+    B (Einv r).  Cost O(M^2 k' + n K dim) instead of O(M^2 dim).  Returns (modes (n, dim) NumPy, singular values); rows
+    follow scikit-learn's ``svd_flip(u_based_decision=False)`` sign convention (the PCA call at
+    src/lib/ReducedBasis.py:196)."""
+    from .lib.ReducedBasis import pod_modes
+    from .lib.SolutionsManagers import DeviceArray
     em, M, K = fs.map, fs.M, fs.map.Kc
     ctx, dim = em.ctx, em.dim
+    E, Einv = em.l2_coordinates()
+    kp = E.shape[1]
     n = min(n, M, dim)
     Yc = ctx.alloc(M * K).copy_from(fs.Yc, M * K)
     if center:
-        ctx.center_rows(Yc, M, K, ctx.alloc(K))
-    S_host = em.S.download(K * K, shape=(K, K))
-    Wm = np.zeros((0, K))  # modes found so far, as interface vectors (S-orthonormal)
+        ctx.center_rows(Yc, M, K, ctx.alloc(K))  # the expansion is linear: the mean row is the expansion of the mean vector
+    Z = ctx.alloc(max(M * kp, 1))
+    ctx.gemm_nn(M, kp, K, Yc, 0, K, ctx.upload(E), 0, kp, Z, 0, kp)
+    nz = min(n, kp)
+    modes_z, sig_z = pod_modes(ctx, DeviceArray(Z, M, kp), nz, center=False)
+    info = dict(pod_modes.last_info)
     sig = np.zeros(n)
-    found = 0
-    T = ctx.alloc(M * K)
-    for p in range(passes):
-        if found >= n:
-            break
-        ctx.gemm_nt(M, K, K, Yc, 0, K, em.S, 0, K, T, 0, K)  # T = Yc S
-        G = ctx.alloc(M * M)
-        ctx.gemm_nt(M, M, K, T, 0, K, Yc, 0, K, G, 0, M)     # G = Yc S Yc^T
-        lam, W = _top_eigenpairs_device(ctx, G, M, n - found)
-        lam = np.maximum(lam, 0.0)
-        floor = lam[0] * 1e-13 if lam[0] > 0 else 0.0
-        take = 0
-        while found + take < n and take < len(lam) and lam[take] > floor:
-            take += 1
-        if take == 0:
-            break
-        s = np.sqrt(lam[:take])
-        sig[found:found + take] = s
-        ctx.rows_scale(W.buf, take, M, np.where(s > 0, 1.0 / np.where(s > 0, s, 1.0), 0.0))
-        Wnew = ctx.alloc(take * K)
-        ctx.gemm_nn(take, K, M, W.buf, 0, M, Yc, 0, K, Wnew, 0, K)  # S^-1 W^T Yc : new modes in Y space
-        Wall = np.vstack((Wm, Wnew.download(take * K, shape=(take, K))))
-        # re-orthonormalise all modes in the S inner product (small: (found+take) x K on the host)
-        for _ in range(2):
-            Gm = Wall @ S_host @ Wall.T
-            L = np.linalg.cholesky((Gm + Gm.T) / 2)
-            Wall = np.linalg.solve(L, Wall)
-        Wm = Wall
-        found += take
-        if found < n and p < passes - 1:
-            # deflate in Y space: Yc <- Yc - (Yc S Wm^T) Wm
-            Wd = ctx.upload(Wm)
-            C = ctx.alloc(M * found)
-            ctx.gemm_nt(M, K, K, Yc, 0, K, em.S, 0, K, T, 0, K)
-            ctx.gemm_nt(M, found, K, T, 0, K, Wd, 0, K, C, 0, found)
-            ctx.gemm_nn(M, K, found, C, 0, found, Wd, 0, K, Yc, 0, K, alpha=-1.0, beta=1.0)
+    sig[:nz] = sig_z
     if n == 0:
         return np.zeros((0, dim)), sig
+    W = modes_z @ Einv.T                       # (nz, Kc): the modes as interface vectors
     V = ctx.alloc(n * dim)
-    if found < n:
-        V.fill(0.0)  # modes that stay unresolved are returned as zero rows
-    if found:
-        em.expand_compact(ctx.upload(Wm), found, V)
-        ctx.rows_sign_flip(V, found, dim)  # svd_flip(u_based_decision=False)
+    if nz < n:
+        V.fill(0.0)                            # (more modes requested than the snapshot manifold has dimensions)
+    em.expand_compact(ctx.upload(W), nz, V)
+    ctx.rows_sign_flip(V, nz, dim)  # svd_flip(u_based_decision=False)
+    info["executed_flops"] = info.get("executed_flops", 0.0) + 2.0 * M * K * kp + 2.0 * nz * K * dim
+    info.pop("useful_flops", None)
+    pod_modes_factored.last_info = info
     return V.download(n * dim, shape=(n, dim)), sig
 
 

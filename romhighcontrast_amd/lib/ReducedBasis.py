@@ -73,6 +73,33 @@ def _append_orthonormal_row(ctx: _ffi.Context, Q: _ffi.Buffer, k: int, src: _ffi
         Q.fill(0.0, offset=off, n=dim)
 
 
+def _whiten_rows_device(ctx: _ffi.Context, X: DeviceArray, rel_tol=1e-13) -> DeviceArray:
+    """Orthonormal rows spanning the numerical row space of X (which may be rank deficient: sketches of a deflated block
+    are): two rounds of {b x b Gram on MFMA, symmetric eigen-decomposition of that tiny matrix on the host,
+    X <- Lambda^-1/2 Q^T X as a GEMM}, directions whose singular value is below ``rel_tol`` of the largest are dropped in
+    the first round.  Returns r <= b rows.  (CholeskyQR2 with the Cholesky factor replaced by an eigen-decomposition:
+    no breakdown on dependent rows, and no fall-back to the row-by-row Gram-Schmidt, which costs a host round trip per
+    row.)"""
+    b, dim = X.rows, X.dim
+    cur, r = X.buf, b
+    for rnd in range(2):
+        Gb = ctx.alloc(r * r)
+        ctx.gram(r, dim, cur, 0, dim, Gb, 0, r)
+        Gh = Gb.download(r * r, shape=(r, r))
+        lam, Q = np.linalg.eigh(0.5 * (Gh + Gh.T))
+        keep = lam > (rel_tol ** 2 if rnd == 0 else 1e-8) * lam[-1]
+        lam, Q = lam[keep][::-1], Q[:, keep][:, ::-1]
+        rn = int(keep.sum())
+        T = np.ascontiguousarray((Q / np.sqrt(lam)).T)       # (rn, r): rows_new = Lambda^-1/2 Q^T rows
+        nxt = ctx.alloc(max(rn * dim, 1))
+        if rn:
+            ctx.gemm_nn(rn, dim, r, ctx.upload(T), 0, r, cur, 0, dim, nxt, 0, dim)
+        cur, r = nxt, rn
+        if r == 0:
+            break
+    return DeviceArray(cur, r, dim)
+
+
 def _cholqr2_device(ctx: _ffi.Context, X: DeviceArray) -> DeviceArray:
     """Orthonormalise rows that are already well conditioned (kappa << 1e7): CholeskyQR2.
     Two rounds of {b x b Gram on MFMA, Cholesky of that tiny matrix on the host, X <- R^-T X as a GEMM}.
@@ -295,7 +322,7 @@ def _start_block(b: int, M: int, seed: int) -> np.ndarray:
 
 
 def _top_eigenpairs_device(ctx: _ffi.Context, G: _ffi.Buffer, M: int, nev: int, oversample=12, tol=2e-14,
-                           max_iter=30, seed=0):
+                           max_iter=30, seed=0, accept=1e-13):
     """Leading ``nev`` eigenpairs of the symmetric PSD matrix G (M x M, device) by orthogonal
     (subspace) iteration with Rayleigh-Ritz acceleration.  Every M-sized operation is an MFMA GEMM
     on the device (``Z = Y G``, ``H = Z Y^T``, the rotations, the residuals, the re-orthogonalised
@@ -326,7 +353,8 @@ def _top_eigenpairs_device(ctx: _ffi.Context, G: _ffi.Buffer, M: int, nev: int, 
         res = ctx.l2norm(Res, 0, nev, M)
         # pairs whose eigenvalue sits at the fp64 noise floor of G (theta_i < 1e-13 theta_0) cannot be
         # resolved from the Gram matrix at all (pod_modes deflates and retries for those)
-        resolvable = theta[:nev] > 1e-13 * abs(theta[0])
+        # (only the pairs the caller will accept -- theta_i > accept * theta_0 -- have to converge)
+        resolvable = theta[:nev] > accept * abs(theta[0])
         worst = float(res[resolvable].max()) / max(abs(theta[0]), 1e-300) if resolvable.any() else 0.0
         _top_eigenpairs_device.last_iterations = it + 1
         _top_eigenpairs_device.total_iterations = getattr(_top_eigenpairs_device, 'total_iterations', 0) + 1
@@ -350,58 +378,174 @@ def _top_eigenpairs_device(ctx: _ffi.Context, G: _ffi.Buffer, M: int, nev: int, 
     raise AssertionError("unreachable")
 
 
-def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=2):
+def _transpose_device(ctx: _ffi.Context, T: _ffi.Buffer, rows: int, cols: int) -> _ffi.Buffer:
+    """(cols, rows) transpose of the small row-major (rows, cols) matrix T, on the device (an MFMA GEMM against I)."""
+    out = ctx.alloc(rows * cols)
+    ctx.gemm_nt(cols, rows, cols, ctx.upload(np.eye(cols)), 0, cols, T, 0, cols, out, 0, rows)
+    return out
+
+
+def _orthonormalize_against(ctx: _ffi.Context, V: _ffi.Buffer, found: int, take: int, dim: int):
+    """Rows V[found : found + take] <- orthonormal and orthogonal to the orthonormal rows V[0 : found] (block CGS2 against
+    the old rows, CholeskyQR2 among the new ones)."""
+    new_off = found * dim
+    if found:
+        C = ctx.alloc(take * found)
+        for _ in range(2):
+            ctx.gemm_nt(take, found, dim, V, new_off, dim, V, 0, dim, C, 0, found)
+            ctx.gemm_nn(take, dim, found, C, 0, found, V, 0, dim, V, new_off, dim, alpha=-1.0, beta=1.0)
+    tmp = ctx.alloc(take * dim).copy_from(V, take * dim, src_off=new_off)
+    try:
+        Q = _cholqr2_device(ctx, DeviceArray(tmp, take, dim))
+    except np.linalg.LinAlgError:
+        Q = _orthonormalize_device(ctx, DeviceArray(tmp, take, dim))  # (dependent rows: row by row, zero rows for the dependent ones)
+    V.copy_from(Q.buf, take * dim, dst_off=new_off)
+
+
+def _sketched_modes(ctx: _ffi.Context, X: _ffi.Buffer, M: int, dim: int, k: int, oversample=8, power=1, seed=1):
+    """Leading ``k`` right singular vectors / singular values of the (M, dim) block X by a randomised range finder with
+    power iterations: every big operation is a thin GEMM (2 b M dim flops, b = k + oversample) instead of the
+    2 M^2 dim of a Gram matrix.  Used for the DEFLATED remainder of a snapshot block, whose spectrum falls off
+    geometrically (the error of the range finder is (sigma_{b+1} / sigma_k)^(2 power + 1)).  The small factor
+    T = X Q^T (M x b) goes to the host for a LAPACK SVD -- no Gram matrix of it, so nothing is squared here.
+    Returns (V DeviceArray (k', dim) orthonormal rows, sigma (k',)), k' <= k."""
+    b = int(min(M, dim, k + oversample))
+    Om = ctx.upload(_start_block(b, M, seed))
+    Y = ctx.alloc(b * dim)
+    ctx.gemm_nn(b, dim, M, Om, 0, M, X, 0, dim, Y, 0, dim)                       # Y = Omega X
+    flops = 2.0 * b * M * dim
+    for it in range(power + 1):
+        Q = _whiten_rows_device(ctx, DeviceArray(Y, b, dim))                      # (the remainder may have rank < b)
+        b = Q.rows
+        if b == 0:
+            _sketched_modes.last_flops = flops
+            return DeviceArray(ctx.alloc(1), 0, dim), np.zeros(0)
+        T = ctx.alloc(M * b)
+        ctx.gemm_nt(M, b, dim, X, 0, dim, Q.buf, 0, dim, T, 0, b)                 # T = X Q^T   (M, b)
+        flops += 2.0 * b * M * dim + 4.0 * b * b * dim
+        if it == power:
+            break
+        Tt = _transpose_device(ctx, T, M, b)
+        Y = ctx.alloc(b * dim)
+        ctx.gemm_nn(b, dim, M, Tt, 0, M, X, 0, dim, Y, 0, dim)                   # Y = T^T X = Q X^T X
+        flops += 2.0 * b * M * dim
+    # X ~ T Q: the right singular vectors of the small factor rotate Q into the modes
+    Th = T.download(M * b, shape=(M, b))
+    ss, Rt = np.linalg.svd(Th, full_matrices=False)[1:]
+    k = min(k, b)
+    V = ctx.alloc(k * dim)
+    ctx.gemm_nn(k, dim, b, ctx.upload(np.ascontiguousarray(Rt[:k])), 0, b, Q.buf, 0, dim, V, 0, dim)  # modes = R^T Q
+    flops += 2.0 * k * b * dim
+    _sketched_modes.last_flops = flops
+    return DeviceArray(V, k, dim), ss[:k]
+
+
+GRAM_ACCEPT = 1e-10    # eigenvalues of a Gram matrix are taken down to this fraction of its largest one ...
+SKETCH_ACCEPT = 1e-6   # ... singular values of a sketch down to this fraction of its largest one
+NOISE_FLOOR = 1e-13    # modes below this fraction of sigma_1 are fp64 noise of the snapshots themselves
+
+
+def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=6):
     """Leading ``n`` right singular vectors / singular values of the (M, dim) snapshot block.
 
-    MFMA Gram matrix ``G = Xc Xc^T`` (lower tiles + mirror) -> leading eigenpairs of the M x M
-    matrix by subspace iteration on the device -> lift ``V = S^-1 W^T Xc``.  The Gram matrix squares
-    the condition number (modes below ~1e-8 sigma_1 drown in fp64 roundoff), so the modes found are
-    deflated from the block and the procedure is repeated on the remainder (``passes`` times), each
-    pass resolving ~7 more orders of magnitude.  Rows follow scikit-learn's
-    ``svd_flip(u_based_decision=False)`` sign convention (the PCA call at
-    src/lib/ReducedBasis.py:196).  X is overwritten (centred / deflated).
+    Pass 1: MFMA Gram matrix ``G = Xc Xc^T`` (lower tiles + mirror) -> leading eigenpairs of the M x M matrix by
+    subspace iteration on the device -> lift ``V = S^-1 W^T Xc``.  The Gram matrix squares the condition number: its
+    eigenvectors carry an error of ~eps (sigma_1 / sigma_k)^2, so only the modes with lambda_k > 1e-8 lambda_1
+    (sigma_k > 1e-4 sigma_1) are taken from it.  The rest comes from the DEFLATED block (accepted modes projected out
+    of X) -- not through another Gram matrix, which would cost as much as the first, but through a randomised range
+    finder on the remainder (``_sketched_modes``: a handful of thin GEMMs and a LAPACK SVD of an M x b factor), each
+    round reaching 6 orders of magnitude further down, until the request is filled or the spectrum has reached the
+    fp64 noise of the snapshots (1e-13 sigma_1).  A Rayleigh-Ritz step on the collected subspace (SVD of the M x n
+    coefficient matrix X V^T, which the deflations have produced on the way) orders the modes and fixes the singular
+    values.  What is still missing then does not exist in the data; like LAPACK / scikit-learn, which return SOME
+    orthonormal directions there, the basis is completed with orthonormalised random directions (singular value 0),
+    so the rows returned are always orthonormal.
+    Rows follow scikit-learn's ``svd_flip(u_based_decision=False)`` sign convention (the PCA call at
+    src/lib/ReducedBasis.py:196).  X is overwritten (centred / deflated).  ``pod_modes.last_info`` holds the flop
+    accounting of the call (useful = symmetric half of one Gram + lift; executed = what ran).
     """
     M, dim = X.rows, X.dim
     n = min(n, M, dim)
     if center:
         ctx.center_rows(X.buf, M, dim, ctx.alloc(dim))
     V = ctx.alloc(max(n * dim, 1))
-    V.fill(0.0)  # modes that stay unresolved are returned as zero rows
+    B = ctx.alloc(max(M * n, 1))  # coefficients X V^T of the accepted modes, (M, n) row-major, filled batch by batch
     sig = np.zeros(n)
     found = 0
-    for p in range(passes):
-        if found >= n:
-            break
+    executed = 0.0
+    info = {"gram_passes": 0, "sketch_passes": 0, "completed_modes": 0}
+
+    def deflate(lo, take):
+        """coefficients of the modes V[lo:lo+take] into B[:, lo:lo+take], and those modes out of X"""
+        nonlocal executed
+        Y = ctx.alloc(M * take)
+        ctx.gemm_nt(M, take, dim, X.buf, 0, dim, V, lo * dim, dim, Y, 0, take)
+        ctx.gemm_nn(M, dim, take, Y, 0, take, V, lo * dim, dim, X.buf, 0, dim, alpha=-1.0, beta=1.0)
+        # B[:, lo:lo+take] = Y  (strided destination: one small GEMM against the identity)
+        ctx.gemm_nn(M, take, take, Y, 0, take, ctx.upload(np.eye(take)), 0, take, B, lo, n)
+        executed += 4.0 * take * M * dim
+
+    sigma_1 = 0.0
+    if n > 0:
         G = ctx.alloc(M * M)
         ctx.gram(M, dim, X.buf, 0, dim, G, 0, M)
-        pod_modes.last_gram_passes = p + 1
-        lam, W = _top_eigenpairs_device(ctx, G, M, n - found)
+        info["gram_passes"] = 1
+        pod_modes.last_gram_passes = 1
+        executed += float(M) * (M + 1) * dim
+        lam, W = _top_eigenpairs_device(ctx, G, M, n, accept=GRAM_ACCEPT)
+        del G
         lam = np.maximum(lam, 0.0)
-        # modes of this pass: those above the Gram roundoff floor of the current (deflated) block; what is
-        # below it after the last pass is fp64 noise of the snapshot set and is returned as zero rows
-        floor = lam[0] * 1e-13 if lam[0] > 0 else 0.0
-        last_pass = p == passes - 1
+        sigma_1 = float(np.sqrt(lam[0])) if len(lam) else 0.0
         take = 0
-        while found + take < n and take < len(lam) and lam[take] > floor:
+        while take < n and take < len(lam) and lam[take] > GRAM_ACCEPT * lam[0] and lam[take] > 0:
+            take += 1
+        if take:
+            s = np.sqrt(lam[:take])
+            ctx.rows_scale(W.buf, take, M, 1.0 / s)
+            ctx.gemm_nn(take, dim, M, W.buf, 0, M, X.buf, 0, dim, V, 0, dim)   # V = S^-1 W^T Xc
+            executed += 2.0 * take * M * dim
+            _orthonormalize_against(ctx, V, 0, take, dim)
+            deflate(0, take)
+            found = take
+    for p in range(1, passes):
+        if found >= n or found == 0:
+            break
+        Vs, ss = _sketched_modes(ctx, X.buf, M, dim, n - found, seed=p)
+        executed += _sketched_modes.last_flops
+        info["sketch_passes"] += 1
+        take = 0
+        while take < len(ss) and found + take < n and ss[take] > SKETCH_ACCEPT * ss[0] and ss[take] > NOISE_FLOOR * sigma_1:
             take += 1
         if take == 0:
             break
-        s = np.sqrt(lam[:take])
-        sig[found:found + take] = s
-        ctx.rows_scale(W.buf, take, M, np.where(s > 0, 1.0 / np.where(s > 0, s, 1.0), 0.0))
-        ctx.gemm_nn(take, dim, M, W.buf, 0, M, X.buf, 0, dim, V, found * dim, dim)   # V = S^-1 W^T Xc
-        # re-orthonormalise the new modes against all earlier ones (keeps V orthonormal to ~eps)
-        try:
-            Vall = _cholqr2_device(ctx, DeviceArray(V, found + take, dim))
-        except np.linalg.LinAlgError:
-            Vall = _orthonormalize_device(ctx, DeviceArray(V, found + take, dim))
-        V.copy_from(Vall.buf, (found + take) * dim)
+        V.copy_from(Vs.buf, take * dim, dst_off=found * dim)
+        _orthonormalize_against(ctx, V, found, take, dim)
+        deflate(found, take)
         found += take
-        if found < n and not last_pass:
-            # deflate: X <- X - (X V^T) V
-            Y = ctx.alloc(M * found)
-            ctx.gemm_nt(M, found, dim, X.buf, 0, dim, V, 0, dim, Y, 0, found)
-            ctx.gemm_nn(M, dim, found, Y, 0, found, V, 0, dim, X.buf, 0, dim, alpha=-1.0, beta=1.0)
+        if take < len(ss) and ss[take] <= NOISE_FLOOR * sigma_1:
+            break  # the spectrum has reached the noise floor: nothing left to find
+    if found:
+        # Rayleigh-Ritz on the collected subspace: X ~ B V  ->  SVD of B orders / rotates the modes
+        Bh = B.download(M * n, shape=(M, n))[:, :found]
+        s, Rt = np.linalg.svd(Bh, full_matrices=False)[1:]
+        Vr = ctx.alloc(found * dim)
+        ctx.gemm_nn(found, dim, found, ctx.upload(np.ascontiguousarray(Rt)), 0, found, V, 0, dim, Vr, 0, dim)
+        V.copy_from(Vr, found * dim)
+        executed += 2.0 * found * found * dim
+        sig[:found] = s
+    if found < n:
+        # complete the basis: random directions orthonormalised against the modes (CGS2); they carry no variance
+        rest = n - found
+        fill = ctx.upload(np.random.default_rng(found).standard_normal((rest, dim)))
+        V.copy_from(fill, rest * dim, dst_off=found * dim)
+        _orthonormalize_against(ctx, V, found, rest, dim)
+        info["completed_modes"] = rest
+        warning(f"POD: {rest} of the {n} requested modes lie below the fp64 noise floor of the snapshot block "
+                f"(sigma < {NOISE_FLOOR:g} sigma_1); completed with orthonormal directions of zero singular value")
+    info.update(resolved_modes=found, executed_flops=executed,
+                useful_flops=float(M) * (M + 1) * dim + 2.0 * n * M * dim)
+    pod_modes.last_info = info
+    pod_modes.resolved = found
     if n == 0:
         return np.zeros((0, dim)), sig
     ctx.rows_sign_flip(V, n, dim)  # svd_flip(u_based_decision=False)
@@ -428,6 +572,7 @@ class ReducedBasisPCA(BaseReducedBasis):
             pool = fs.take(np.flatnonzero(~has_inf))
             comps, sigma = pod_modes_factored(pool, n)
             self.singular_values_ = sigma
+            self.resolved_modes_ = pod_modes_factored.last_info.get("resolved_modes", n)
             lead = fs.take(lead_idx).rows().numpy() if lead_idx.size else np.empty((0, sm.vspace_dim))
             super().set(basis=np.vstack((lead, comps))[:n], a=np.vstack((a2train[lead_idx], a2train[~has_inf]))[:n])
             return self
@@ -438,6 +583,7 @@ class ReducedBasisPCA(BaseReducedBasis):
         X = _as_device(ctx, np.array(solutions2train, dtype=np.float64), sm.vspace_dim)  # private copy
         comps, sigma = pod_modes(ctx, X, n, center=True)
         self.singular_values_ = sigma
+        self.resolved_modes_ = pod_modes.resolved  # modes above the fp64 noise floor of the block (the rest: see pod_modes)
         super().set(basis=np.vstack((basis, comps))[:n], a=np.vstack((a, a2train))[:n])
         warning("PCA method has not been adapted for inverse parameter estimation, the a coefficients are not correct.")
         return self

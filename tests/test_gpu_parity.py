@@ -280,6 +280,40 @@ def test_pod_subspace_iteration_vs_oracle(api):
     assert np.abs(P1 - P2).max() < 1e-9
 
 
+def test_pod_small_modes_vs_lapack(api):
+    """The modes below the reach of the Gram matrix (sigma < 1e-4 sigma_1: deflation + sketches + Rayleigh-Ritz in
+    pod_modes) against LAPACK's SVD of the same centred rows (the call inside scikit-learn's PCA,
+    src/lib/ReducedBasis.py:196): singular values over ten orders of magnitude, the subspaces of the leading modes,
+    orthonormal rows throughout -- from snapshot rows and from the factored block."""
+    SM, RB = api
+    from romhighcontrast_amd import factored
+    sm = SM.SolutionsManagerFEM((2, 2), 32)
+    ctx, fem, dim = sm._ctx, sm._fem, sm.vspace_dim
+    M, n = 200, 30
+    a = 10.0 ** np.random.default_rng(4).uniform(0, 2, size=(M, 2, 2))
+    Ud = sm.generate_solutions_device(a)
+    Uh = Ud.numpy()
+    _, sv, Vt = np.linalg.svd(Uh - Uh.mean(axis=0), full_matrices=False)
+    X = ctx.alloc(M * dim).copy_from(Ud.buf, M * dim)
+    comps, sig = RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), n)
+    Yf = ctx.alloc(M * fem.reduced_stride)
+    fem.solve_reduced(ctx.upload(a.reshape(M, -1)), M, Yf)
+    ctx.solve_status()
+    comps_f, sig_f = factored.pod_modes_factored(factored.FactoredSnapshots(sm, Yf, M), n)
+    real = sv[:n] > 1e-11 * sv[0]          # what the fp64 snapshots determine
+    assert real.sum() >= 20 and sv[:n][real][-1] < 1e-8 * sv[0]     # (the test does reach far below the Gram floor)
+    for name, c, s_ in (("rows", comps, sig), ("factored", comps_f, sig_f)):
+        np.testing.assert_allclose(s_[real], sv[:n][real], rtol=1e-4, atol=1e-13 * sv[0], err_msg=name)
+        lead = sv[:n] > 1e-6 * sv[0]
+        np.testing.assert_allclose(s_[lead], sv[:n][lead], rtol=1e-9, err_msg=name)
+        assert np.abs(c @ c.T - np.eye(n)).max() < 1e-9, name
+        k = int(real.sum())
+        P1, P2 = c[:k].T @ c[:k], Vt[:k].T @ Vt[:k]                 # projectors onto the span of the determined modes
+        assert np.abs(P1 - P2).max() < 1e-5, (name, np.abs(P1 - P2).max())
+        k = int(lead.sum())
+        assert np.abs(c[:k].T @ c[:k] - Vt[:k].T @ Vt[:k]).max() < 1e-8, name
+
+
 def SolutionsManagerFEM_cached(SM, blocks, N):
     return SM.SolutionsManagerFEM(blocks, N)
 
