@@ -346,91 +346,6 @@ __device__ inline double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// Diagonal tile j, step 2 of 3: in-register Cholesky, ONE WAVE per system (all systems of the batch
-// resident at once, one wave per SIMD).  Lane r keeps row r of the 64x64 tile in registers; the
-// elimination is fully unrolled (static register indices), column j of L is broadcast through LDS
-// each step; no barriers.  (Steps 2 and 3 are separate kernels because hipcc's register allocation
-// collapses into scratch when the two fully unrolled phases share one function.)
-__global__ __launch_bounds__(64) void k_diag_potrf(FemDev f, int slot) {
-  __shared__ __align__(16) double Ls[64 * LDC];
-  __shared__ __align__(16) double lv[2][64];
-  const int m = blockIdx.x, lane = threadIdx.x;
-  double* Lt = f.L + (size_t(m) * f.nslots + slot) * 4096;
-  for (int i = 0; i < 64; ++i) Ls[i * LDC + lane] = Lt[i * 64 + lane];
-  __syncthreads();
-  double a[64];
-#pragma unroll
-  for (int c = 0; c < 64; c += 2) {
-    double2 v = *reinterpret_cast<const double2*>(&Ls[lane * LDC + c]);
-    a[c] = v.x;
-    a[c + 1] = v.y;
-  }
-  bool bad = false;
-#pragma unroll
-  for (int jj = 0; jj < 64; ++jj) {
-    const double dj = readlane_f64(a[jj], jj);
-    bad = bad || !(dj > 0.0);
-    const double rs = rsqrt_newton(dj);
-    const double l = a[jj] * rs;  // L[lane][jj] for lane >= jj
-    a[jj] = l;
-    if (jj < 63) {
-      double* bv = lv[jj & 1];
-      bv[lane] = l;
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int c = 0; c < 64; ++c)
-        if (c > jj) a[c] -= l * bv[c];  // constant trip count so that both loops unroll fully
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  if (bad && lane == 0) atomicOr(f.status, 1);
-  __syncthreads();
-  // L (lower, zero above the diagonal) back through LDS, coalesced to HBM
-#pragma unroll
-  for (int c = 0; c < 64; ++c) Ls[lane * LDC + c] = c <= lane ? a[c] : 0.0;
-  __syncthreads();
-  for (int i = 0; i < 64; ++i) Lt[i * 64 + lane] = Ls[i * LDC + lane];
-}
-
-// Diagonal tile j, step 3 of 3 (one wave per system): y_j <- L_jj^-1 y_j by column-oriented
-// substitution, and X = L_jj^-1 with lane c owning column c of X in registers:
-// X[r][c] = (delta_rc - sum_{k<r} L[r][k] X[k][c]) / L[r][r]; L is read from LDS with wave-uniform
-// addresses (broadcast), every row of X is stored coalesced.
-__global__ __launch_bounds__(64) void k_diag_inverse(FemDev f, int slot, int j) {
-  __shared__ __align__(16) double Ls[64 * LDC];
-  __shared__ double rinv[64];
-  const int m = blockIdx.x, lane = threadIdx.x;
-  const double* Lt = f.L + (size_t(m) * f.nslots + slot) * 4096;
-  for (int i = 0; i < 64; ++i) Ls[i * LDC + lane] = Lt[i * 64 + lane];
-  __syncthreads();
-  rinv[lane] = 1.0 / Ls[lane * LDC + lane];
-  __syncthreads();
-  double g = f.y[size_t(m) * f.nGp + j * 64 + lane];
-#pragma unroll
-  for (int k = 0; k < 64; ++k) {
-    const double yk = readlane_f64(g, k) * rinv[k];
-    if (lane == k) g = yk;
-    else if (lane > k) g -= Ls[lane * LDC + k] * yk;
-  }
-  f.y[size_t(m) * f.nGp + j * 64 + lane] = g;
-  double* It = f.invL + (size_t(m) * f.T + j) * 4096;
-  double x[64];
-#pragma unroll
-  for (int r = 0; r < 64; ++r) {
-    // four independent partial sums: the dot product is otherwise one dependent FMA chain of length r
-    double s0 = (r == lane) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 64; k += 4) {
-      if (k < r) s0 -= Ls[r * LDC + k] * x[k];
-      if (k + 1 < r) s1 -= Ls[r * LDC + k + 1] * x[k + 1];
-      if (k + 2 < r) s2 -= Ls[r * LDC + k + 2] * x[k + 2];
-      if (k + 3 < r) s3 -= Ls[r * LDC + k + 3] * x[k + 3];
-    }
-    x[r] = ((s0 + s1) + (s2 + s3)) * rinv[r];
-    It[r * 64 + lane] = x[r];
-  }
-}
-
 // Diagonal tile j, steps 2 and 3 in one kernel on the matrix cores (one wave per system, LDS 36 KB: all 1024 systems
 // of a step resident at once):
 //   rank-4 blocked right-looking Cholesky of the tile held in MFMA accumulator layout (the scheme of k_solve1: a
@@ -439,7 +354,7 @@ __global__ __launch_bounds__(64) void k_diag_inverse(FemDev f, int slot, int j) 
 //   then X = L_jj^-1 in place, blocked 16 x 16: the four diagonal blocks by the column sweep of an unblocked
 //   in-place triangular inverse (lane = (block, row), its row of X in registers, the untouched columns of L
 //   broadcast from LDS), the six blocks below them as  X_ij = -sum_{k=j+1..i} X_ik (L_kj X_jj)  on MFMA.
-// Replaces k_diag_potrf + k_diag_inverse (column-by-column on the vector pipe: 2 x 32 us per 1024 systems).
+// (A column-by-column version on the vector pipe, two kernels, took 2 x 32 us per 1024 systems against 33 us.)
 __global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
   __shared__ __align__(16) double Ls[64 * LDC];
   __shared__ __align__(16) double Pn[64 * 4];

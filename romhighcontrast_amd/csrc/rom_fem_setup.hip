@@ -1073,6 +1073,10 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     ROM_TRY(upload(&f->d_scat, scat));
   }
 
+  f->sw_no_fused = getenv("ROMHC_NO_FUSED") != nullptr;
+  f->sw_no_ext128 = getenv("ROMHC_NO_EXT128") != nullptr;
+  f->sw_no_fold = getenv("ROMHC_NO_FOLD_EXPAND") != nullptr;
+  f->sw_ext_flat = getenv("ROMHC_EXT_FLAT") ? (atoi(getenv("ROMHC_EXT_FLAT")) != 0 ? 1 : 0) : -1;
   if (getenv("ROMHC_VERBOSE")) {
     fprintf(stderr, "romhc: %dx%d blocks N=%d: %d edges (%d closed-form, %d of them compressed), reduced size %d -> %d tiles, "
                     "%d slots, %zu terms, kavg %.1f\n", nrb, ncb, N, E, int(pre_list.size()), int(pre_list.size()) - f->npre, nred, T,

@@ -102,9 +102,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   const int kblk = f->nrb * f->ncb;
   static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-column kernel names
   char nm[4][48];
-  const bool no_fused = getenv("ROMHC_NO_FUSED") != nullptr;  // (read per call: the tests toggle it)
-  const bool fused1 = f->fused1 && !no_fused;  // the whole reduced solve in one wave-per-system kernel
-  const bool no_mfma_diag = getenv("ROMHC_NO_MFMA_DIAG") != nullptr;  // A/B switch: vector-pipe potrf + inverse kernels
+  const bool fused1 = f->fused1 && !f->sw_no_fused;  // the whole reduced solve in one wave-per-system kernel
   if (f->nGp > 0 && fused1 && (stages & 1)) {
     ROM_PROF(ctx, "solve1", Mc * (262144 / 3.0 + 3 * 4096.0), Mc * 8.0 * 4096 * 3);
     k_solve1<<<Mc, 64, 0, st>>>(d, am);
@@ -118,24 +116,15 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
       {
         int slot = f->diag_slot[j];
         double nk = f->kptr[slot + 1] - f->kptr[slot];
-        const char* base[4] = {"diag_update", no_mfma_diag ? "diag_potrf" : "diag_factor", "diag_inverse", "factor_panel"};
+        const char* base[4] = {"diag_update", "diag_factor", "", "factor_panel"};
         for (int q = 0; q < 4; ++q) detail ? snprintf(nm[q], 48, "%s_j%02d", base[q], j) : snprintf(nm[q], 48, "%s", base[q]);
         {
           ROM_PROF(ctx, nm[0], Mc * nk * 2.0 * 262144, Mc * 8.0 * 4096 * (1 + 2 * nk));
           k_diag_update<<<Mc, 256, 0, st>>>(d, am, slot);
         }
-        if (!no_mfma_diag) {
+        {
           ROM_PROF(ctx, nm[1], Mc * (2 * 262144 / 3.0 + 4096.0), Mc * 8.0 * 4096 * 3);
           k_diag_factor<<<Mc, 64, 0, st>>>(d, slot, j);
-        } else {
-          {
-            ROM_PROF(ctx, nm[1], Mc * (262144 / 3.0), Mc * 8.0 * 4096 * 2);
-            k_diag_potrf<<<Mc, 64, 0, st>>>(d, slot);
-          }
-          {
-            ROM_PROF(ctx, nm[2], Mc * (262144 / 3.0 + 4096.0), Mc * 8.0 * 4096 * 2);
-            k_diag_inverse<<<Mc, 64, 0, st>>>(d, slot, j);
-          }
         }
       }
       int nrows = f->colptr[j + 1] - f->colptr[j];
@@ -166,11 +155,11 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   // 128 x 128 tiles (k_extend128) when there are systems to fill them and they pad no worse than 64-vertex tiles
   // of one mesh row; their 128 vertices are one mesh row, or consecutive vertices of the block when rows pad badly
   const int t_row = f->n1 * ((f->n1 + 127) / 128), t_flat = (f->n1 * f->n1 + 127) / 128;
-  const bool flat = getenv("ROMHC_EXT_FLAT") ? atoi(getenv("ROMHC_EXT_FLAT")) != 0 : 100 * t_flat < 97 * t_row;
+  const bool flat = f->sw_ext_flat >= 0 ? f->sw_ext_flat != 0 : 100 * t_flat < 97 * t_row;
   const int t128 = flat ? t_flat : t_row;
-  const bool wide = Mc >= 128 && 100 * 128 * t128 <= 102 * 64 * f->n1 * ((f->n1 + 63) / 64) && !getenv("ROMHC_NO_EXT128");
+  const bool wide = Mc >= 128 && 100 * 128 * t128 <= 102 * 64 * f->n1 * ((f->n1 + 63) / 64) && !f->sw_no_ext128;
   const bool fold_expand = f->nexp > 0 && f->npre == 0 && f->n_edges == 0 && f->n_gen_blocks == 0 && f->n_lr_blocks > 0 &&
-                           wide && !getenv("ROMHC_NO_FOLD_EXPAND");
+                           wide && !f->sw_no_fold;
   if (f->nGp > 0) {
     if (f->nexp > 0 && !fold_expand) {
       ROM_PROF(ctx, "expand", Mc * 2.0 * f->n1p * 32.0 * f->nexp, 8.0 * Mc * f->n1p * f->nexp);

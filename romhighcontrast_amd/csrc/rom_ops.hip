@@ -5,6 +5,7 @@
 // project_solutions (:113-139), and the reduced `galerkin` solves (:104-105, :135-138).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "rom_mma.h"
 
@@ -409,36 +410,68 @@ struct StencilGeom {
   long long dim;
 };
 
-// (A(coef) x)(r,c) with x given as a functor over the flat inner-vertex index
-template <class XF>
-__device__ inline double stencil_at(const StencilGeom& g, const double* am, bool unit, long long idx, XF x) {
-  int r = int(idx / g.nc) + 1, c = int(idx % g.nc) + 1;
-  double k00 = 1.0, k01 = 1.0, k10 = 1.0, k11 = 1.0;
-  if (!unit) {
-    int N = g.N;
-    k00 = am[((r - 1) / N) * g.ncb + (c - 1) / N];
-    k01 = am[((r - 1) / N) * g.ncb + c / N];
-    k10 = am[(r / N) * g.ncb + (c - 1) / N];
-    k11 = am[(r / N) * g.ncb + c / N];
-  }
-  double y = (((k00 + k01) + k10) + k11) * x(idx);
-  if (c < g.nc) y += (-(k11 + k01) / 2) * x(idx + 1);
-  if (c > 1) y += (-(k10 + k00) / 2) * x(idx - 1);
-  if (r < g.nr) y += (-(k11 + k10) / 2) * x(idx + g.nc);
-  if (r > 1) y += (-(k01 + k00) / 2) * x(idx - g.nc);
-  return y;
-}
-
-__global__ void k_stencil_apply(StencilGeom g, const double* __restrict__ a_one, int unit,
-                                const double* __restrict__ X, double* __restrict__ Y) {
+// Y = A(coef) X for the 5-point operator with block coefficients (kappa of the four cells around a vertex: SURVEY 8a-1).
+// Every entry is loaded ONCE: a thread owns a mesh column and walks down a slab of rows with the entry above, the entry
+// itself and the entry below in registers; the east / west neighbours come from the next / previous lane (the wave's edge
+// lanes load theirs: same cache lines).  (The first version read five entries per output and moved 3x the bytes through
+// the fabric -- FETCH_SIZE x 2 = 1.62 GB for a 533 MB block, profiles/r02_hbm_kernels_c2_pmc_traffic.json -- at
+// 2.3 TB/s; this one runs at 4.3-4.8 TB/s.)
+constexpr int SA_ROWS = 32;    // rows per slab (+ one halo row above and below: 6 % extra reads)
+constexpr int SA_UNROLL = 8;   // loads in flight per thread
+template <bool UNIT>
+__global__ __launch_bounds__(256) void k_stencil_apply_cols(StencilGeom g, const double* __restrict__ a_one,
+                                                            const double* __restrict__ X, double* __restrict__ Y) {
   __shared__ double am[64];
-  if (!unit)
+  if (!UNIT)
     for (int i = threadIdx.x; i < g.kblk; i += blockDim.x) am[i] = a_one[i];
   __syncthreads();
-  long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (idx >= g.dim) return;
-  const double* x = X + blockIdx.y * g.dim;
-  Y[blockIdx.y * g.dim + idx] = stencil_at(g, am, unit != 0, idx, [&](long long i) { return x[i]; });
+  const double* x = X + blockIdx.z * g.dim;
+  double* y = Y + blockIdx.z * g.dim;
+  const int c = blockIdx.x * 256 + threadIdx.x;  // 0-based interior column
+  const int r0 = blockIdx.y * SA_ROWS, r1 = min(g.nr, r0 + SA_ROWS);
+  const bool in = c < g.nc;
+  const int lane = threadIdx.x & 63;
+  const int N = g.N;
+  // block columns of the cells left / right of vertex column c + 1 (1-based): (c) / N and (c + 1) / N
+  const int qw = c / N, qe = (c + 1) / N;
+  auto at = [&](int r, int cc) -> double { return x[(long long)r * g.nc + cc]; };
+  double xn = (in && r0 > 0) ? at(r0 - 1, c) : 0.0;  // entry above the slab (boundary: 0)
+  double xc = (in && r0 < r1) ? at(r0, c) : 0.0;
+  for (int rb = r0; rb < r1; rb += SA_UNROLL) {
+    double xs[SA_UNROLL], xe_edge[SA_UNROLL], xw_edge[SA_UNROLL];
+#pragma unroll
+    for (int q = 0; q < SA_UNROLL; ++q) {
+      const int r = rb + q;
+      xs[q] = (in && r < r1 && r + 1 < g.nr) ? at(r + 1, c) : 0.0;
+      xe_edge[q] = (lane == 63 && r < r1 && c + 1 < g.nc) ? at(r, c + 1) : 0.0;
+      xw_edge[q] = (lane == 0 && r < r1 && in && c > 0) ? at(r, c - 1) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < SA_UNROLL; ++q) {
+      const int r = rb + q;
+      double xe = __shfl_down(xc, 1, 64), xw = __shfl_up(xc, 1, 64);
+      if (lane == 63) xe = xe_edge[q];
+      if (lane == 0) xw = xw_edge[q];
+      if (in && r < r1) {
+        double k00 = 1.0, k01 = 1.0, k10 = 1.0, k11 = 1.0;
+        if (!UNIT) {
+          const int pn = r / N, ps = (r + 1) / N;  // block rows of the cells above / below vertex row r + 1 (1-based)
+          k00 = am[pn * g.ncb + qw];
+          k01 = am[pn * g.ncb + qe];
+          k10 = am[ps * g.ncb + qw];
+          k11 = am[ps * g.ncb + qe];
+        }
+        double v = (((k00 + k01) + k10) + k11) * xc;
+        if (c + 1 < g.nc) v += (-(k11 + k01) / 2) * xe;
+        if (c > 0) v += (-(k10 + k00) / 2) * xw;
+        if (r + 1 < g.nr) v += (-(k11 + k10) / 2) * xs[q];
+        if (r > 0) v += (-(k01 + k00) / 2) * xn;
+        y[(long long)r * g.nc + c] = v;
+      }
+      xn = xc;
+      xc = xs[q];
+    }
+  }
 }
 
 __device__ inline double block_reduce_sum(double v) {
@@ -549,10 +582,12 @@ extern "C" int rom_stencil_apply(rom_fem* f, const double* a_one_host, int unit,
     ROM_HIP(hipMemcpyAsync(d_a, a_one_host, g.kblk * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     ROM_HIP(hipStreamSynchronize(ctx->stream));
   }
-  dim3 grid(unsigned((g.dim + 255) / 256), K);
+  ROM_CHECK(K <= 65535, "rom_stencil_apply: at most 65535 vectors per call");
   {
     ROM_PROF(ctx, "stencil_apply", 14.0 * g.dim * K, 16.0 * g.dim * K);
-    k_stencil_apply<<<grid, 256, 0, ctx->stream>>>(g, d_a, unit, X->p + x_row0 * f->dim, Y->p + y_row0 * f->dim);
+    const dim3 grid((g.nc + 255) / 256, (g.nr + SA_ROWS - 1) / SA_ROWS, K);
+    if (unit) k_stencil_apply_cols<true><<<grid, 256, 0, ctx->stream>>>(g, d_a, X->p + x_row0 * f->dim, Y->p + y_row0 * f->dim);
+    else k_stencil_apply_cols<false><<<grid, 256, 0, ctx->stream>>>(g, d_a, X->p + x_row0 * f->dim, Y->p + y_row0 * f->dim);
   }
   ROM_HIP(hipGetLastError());
   if (!unit) ROM_HIP(hipStreamSynchronize(ctx->stream));  // scratch may be re-used by the next call

@@ -233,6 +233,10 @@ struct rom_fem {
   int* d_item_k = nullptr;
   int ncoef = 0;               // entries of all coefficient blocks
   bool fused1 = false;         // the reduced matrix is one tile: whole solve in k_solve1
+  // A/B switches of the kernel sequencing, read from the environment ONCE per FE space (rom_fem_create): ROMHC_NO_FUSED,
+  // ROMHC_EXT_FLAT (-1: automatic), ROMHC_NO_EXT128, ROMHC_NO_FOLD_EXPAND
+  bool sw_no_fused = false, sw_no_ext128 = false, sw_no_fold = false;
+  int sw_ext_flat = -1;
   DenseGroup* d_dgroups = nullptr;
   int* d_dweight = nullptr;    // per (dense group, source position): block of the weight, -1 cross point, -2 none
   int* d_ditem_group = nullptr;

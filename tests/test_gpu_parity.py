@@ -425,6 +425,25 @@ def test_projectors_with_a_100_vector_basis(api):
     np.testing.assert_allclose(sm.generate_fm_solutions(a, C), ro.generate_fm_solutions(g, a, C), atol=1e-10 * scale)
 
 
+@pytest.mark.parametrize("blocks,N,K", [((2, 2), 10, 3), ((2, 3), 5, 4), ((3, 2), 4, 1), ((1, 1), 8, 2), ((2, 2), 129, 2),
+                                        ((3, 3), 90, 1), ((1, 4), 70, 3)])
+def test_stencil_apply_vs_oracle(api, blocks, N, K):
+    """rom_stencil_apply (the `C A_pq` contractions, src/lib/SolutionsManagers.py:93-101, and A_1 of :49) against the
+    oracle's sparse matrix: unit coefficient and block coefficients, slabs / columns that do not fill a workgroup."""
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)
+    g = ro.Geometry(blocks, N)
+    rng = np.random.default_rng(N + K)
+    X = rng.standard_normal((K, fem.dim))
+    a = 10.0 ** rng.uniform(0, 3, size=blocks)
+    Xd, Yd = ctx.upload(X), ctx.alloc(K * fem.dim)
+    for coef in (None, a):
+        fem.stencil_apply(Xd, K, Yd, a_one=None if coef is None else coef.ravel())
+        ref = ro.stencil_apply(g, np.ones(blocks) if coef is None else coef, X)
+        np.testing.assert_allclose(Yd.download(shape=(K, fem.dim)), ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+
+
 def test_full_size_c2_properties(api):
     """BASELINE config C2 ((2,2)/N=128, 1024-parameter sweep): size-independent checks on the device."""
     SM, _ = api
@@ -686,12 +705,12 @@ def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
     ctx = _ffi.get_context()
     a = 10.0 ** np.random.default_rng(N).uniform(0, 3, size=(M, blocks[0] * blocks[1]))
     ab = ctx.upload(a)
-    fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)
     out = {}
     for name, env in (("row", {"ROMHC_EXT_FLAT": "0"}), ("flat", {"ROMHC_EXT_FLAT": "1"}), ("t64", {"ROMHC_NO_EXT128": "1"}),
                       ("default", {})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)  # (the switches are read once per FE space)
         U = ctx.alloc(M * fem.dim)
         U.fill(float("nan"))
         fem.solve_batch(ab, M, U)
@@ -706,7 +725,7 @@ def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
 
 
 @pytest.mark.parametrize("env", ["ROMHC_NO_COMPRESS", "ROMHC_NO_PREELIM", "ROMHC_NO_FUSED", "ROMHC_NO_LOWRANK_EXT",
-                                 "ROMHC_NO_EXT128", "ROMHC_NO_EXT_LR", "ROMHC_NO_MFMA_DIAG"])
+                                 "ROMHC_NO_EXT128", "ROMHC_NO_EXT_LR"])
 def test_algorithm_switches_agree(api, env, monkeypatch):
     """Every exact reduction of the solver can be switched off (A/B checks): the snapshots must not move beyond
     rounding, and each variant must itself meet the parity bound against the oracle."""
