@@ -39,6 +39,7 @@ extern "C" int rom_init(int device, rom_ctx** out) {
   }
   rom_ctx* c = new rom_ctx();
   c->device = device;
+  c->n_cu = prop.multiProcessorCount;
   ROM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (int i = 0; i < 3; ++i) {
     ROM_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));

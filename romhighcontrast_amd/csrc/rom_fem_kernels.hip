@@ -876,14 +876,7 @@ __global__ __launch_bounds__(256) void k_edge_transform(FemDev f, int Mc) {
     }
 }
 
-// value of the neighbouring lane (lane ^ 1), by DPP quad permutation
-__device__ inline double lane_swap1(double v) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-// two doubles at an address that is only 8-byte aligned (snapshot rows have odd length)
-typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
+// (lane_swap1, double2_u: rom_fem_dev.h)
 
 // Harmonic extension, one batched MFMA GEMM over all blocks:
 //   U_I,b[m,(i,j)] = (h^2/a_b) W[i,j] + sum_{sides s} sum_k c_s[m, k] * Tab_s[pi_s(i,j)][k]
@@ -1000,19 +993,29 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
 }
 
 #ifdef ROMHC_STAMPS
-// cycle stamps of k_extend128 (debug build only: make EXTRA=-DROMHC_STAMPS, tools/gpu_stamps.py): [workgroup][5],
-// written by thread 0.  (In this build hipcc if-converts the stagger below and EVERY workgroup sleeps: subtract
-// 2 x 127 x 64 cycles from the first interval.)
-__device__ unsigned long long g_stamps[8192 * 5];
+// cycle stamps of k_extend128 (debug build only: make EXTRA=-DROMHC_STAMPS, tools/gpu_stamps.py):
+// [workgroup][6] = entry, first loads issued, first barrier passed, k loop done, stores issued, (XCC_ID << 16 | HW_ID);
+// written by thread 0
+__device__ unsigned long long g_stamps[16384 * 6];
 #define STAMP(i)                                                                                               \
   do {                                                                                                         \
     if (threadIdx.x == 0) {                                                                                    \
-      const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                    \
-      if (lin_ < 8192u) g_stamps[lin_ * 5 + (i)] = __builtin_readcyclecounter();                               \
+      const unsigned lin_ = __builtin_amdgcn_readfirstlane(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
+      if (lin_ < 16384u) g_stamps[lin_ * 6 + (i)] = __builtin_readcyclecounter();                              \
+      if ((i) == 0 && lin_ < 16384u) {                                                                         \
+        unsigned hw_, xcc_;                                                                                    \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                      \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                    \
+        g_stamps[lin_ * 6 + 5] = ((unsigned long long)(xcc_ & 0xf) << 16) | (hw_ & 0xffff);                    \
+      }                                                                                                        \
     }                                                                                                          \
   } while (0)
 extern "C" int rom_debug_stamps(unsigned long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), size_t(n) * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int rom_debug_stamps_clear() {
+  static unsigned long long zeros[16384 * 6];
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : 1;
 }
 #else
 #define STAMP(i)
@@ -1053,7 +1056,7 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
     // the epilogue).  The second half of the first round starts one MFMA phase late (about 64 cycles per MFMA)
     // so that the phases of the two interleave: measured 274 -> 245 us at 256x256 / 2x2 / 1024 systems.
     // Placement only affects speed.
-    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * bz);
+    const unsigned lin = __builtin_amdgcn_readfirstlane(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * bz));
     if (lin >= 256u && lin < 512u)
       for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);  // 2 x 127 x 64 cycles
   }

@@ -1030,7 +1030,11 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     // flops of the extension, per system (for the work accounting)
     f->ext_flops = fl + 2.0 * f->n_edges * double(n1p) * n1p;
   }
-  ROM_TRY(upload(&f->d_W, Wd));
+  {
+    std::vector<double> Wz(Wd);  // + a page of zeros: where k_extend_p points the lanes that have nothing to load
+    Wz.resize(Wd.size() + XP_ZERO_PAGE, 0.0);
+    ROM_TRY(upload(&f->d_W, Wz));
+  }
   ROM_TRY(upload(&f->d_g, g_red));
   ROM_TRY(upload(&f->d_vec, vecs));
   ROM_TRY(upload(&f->d_pool, pool));
@@ -1076,6 +1080,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   f->sw_no_fused = getenv("ROMHC_NO_FUSED") != nullptr;
   f->sw_no_ext128 = getenv("ROMHC_NO_EXT128") != nullptr;
   f->sw_no_fold = getenv("ROMHC_NO_FOLD_EXPAND") != nullptr;
+  f->sw_ext_p = getenv("ROMHC_EXT_P") ? atoi(getenv("ROMHC_EXT_P")) : 0;
   f->sw_ext_flat = getenv("ROMHC_EXT_FLAT") ? (atoi(getenv("ROMHC_EXT_FLAT")) != 0 ? 1 : 0) : -1;
   if (getenv("ROMHC_VERBOSE")) {
     fprintf(stderr, "romhc: %dx%d blocks N=%d: %d edges (%d closed-form, %d of them compressed), reduced size %d -> %d tiles, "

@@ -158,8 +158,11 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   const bool flat = f->sw_ext_flat >= 0 ? f->sw_ext_flat != 0 : 100 * t_flat < 97 * t_row;
   const int t128 = flat ? t_flat : t_row;
   const bool wide = Mc >= 128 && 100 * 128 * t128 <= 102 * 64 * f->n1 * ((f->n1 + 63) / 64) && !f->sw_no_ext128;
+  // k_extend_p: one persistent workgroup per CU; its lane offsets are 32-bit
+  const bool persistent = wide && f->sw_ext_p != 0 && size_t(f->dim) * 32 < (size_t(1) << 32) &&
+                          (size_t(Mc) + 128) * f->nGp * 8 < (size_t(1) << 32) && size_t(f->n1) * f->n1 * 64 * BK * 8 < (size_t(1) << 32);
   const bool fold_expand = f->nexp > 0 && f->npre == 0 && f->n_edges == 0 && f->n_gen_blocks == 0 && f->n_lr_blocks > 0 &&
-                           wide && !f->sw_no_fold;
+                           wide && !persistent && !f->sw_no_fold;
   if (f->nGp > 0) {
     if (f->nexp > 0 && !fold_expand) {
       ROM_PROF(ctx, "expand", Mc * 2.0 * f->n1p * 32.0 * f->nexp, 8.0 * Mc * f->n1p * f->nexp);
@@ -197,6 +200,28 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
             for (int z = 0; z < nz; ++z) {
               xa.blocks[z] = f->lr_blocks_host[z0 + z];
               xa.sides[z] = f->sides[xa.blocks[z]];
+            }
+            if (persistent) {
+              static bool lds_set = false;  // (more than 64 KB of dynamic LDS must be asked for once per kernel)
+              if (!lds_set) {
+                ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_p<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(XP_LDS_BYTES)));
+                ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_p<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(XP_LDS_BYTES)));
+#ifdef ROMHC_XP_PROBES
+                ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_p<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(XP_LDS_BYTES)));
+                ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_p<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(XP_LDS_BYTES)));
+                ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_p<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, int(XP_LDS_BYTES)));
+#endif
+                lds_set = true;
+              }
+              const int nwg = 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256);  // two resident workgroups per CU
+              if (flat) k_extend_p<true, 0><<<nwg, 256, XP_LDS_BYTES, st>>>(d, xa, am, Mc, U, row, nz);
+#ifdef ROMHC_XP_PROBES
+              else if (f->sw_ext_p == 2) k_extend_p<false, 1><<<nwg, 256, XP_LDS_BYTES, st>>>(d, xa, am, Mc, U, row, nz);
+              else if (f->sw_ext_p == 3) k_extend_p<false, 2><<<nwg, 256, XP_LDS_BYTES, st>>>(d, xa, am, Mc, U, row, nz);
+              else if (f->sw_ext_p == 17) k_extend_p<false, 16><<<nwg, 256, XP_LDS_BYTES, st>>>(d, xa, am, Mc, U, row, nz);
+#endif
+              else k_extend_p<false, 0><<<nwg, 256, XP_LDS_BYTES, st>>>(d, xa, am, Mc, U, row, nz);
+              continue;
             }
             const int extra = fold_expand && z0 == 0 ? (items + mt * nz - 1) / (mt * nz) : 0;
             dim3 grid(t128 + extra, mt, nz);

@@ -51,6 +51,7 @@ struct ProfRec {
 
 struct rom_ctx {
   int device = 0;
+  int n_cu = 0;  // compute units of the device (grid of the persistent kernels)
   hipStream_t stream = nullptr;
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // sub-batch streams of rom_solve_batch
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -237,6 +238,7 @@ struct rom_fem {
   // ROMHC_EXT_FLAT (-1: automatic), ROMHC_NO_EXT128, ROMHC_NO_FOLD_EXPAND
   bool sw_no_fused = false, sw_no_ext128 = false, sw_no_fold = false;
   int sw_ext_flat = -1;
+  int sw_ext_p = 0;     // ROMHC_EXT_P=1: the persistent extension kernel (k_extend_p, rom_fem_extend_p.hip)
   DenseGroup* d_dgroups = nullptr;
   int* d_dweight = nullptr;    // per (dense group, source position): block of the weight, -1 cross point, -2 none
   int* d_ditem_group = nullptr;

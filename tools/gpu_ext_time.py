@@ -22,18 +22,22 @@ for spec in filter(None, os.environ.get("VARIANTS", "").split(";")):
     variants.append((name, dict(kv.split("=") for kv in envs.split(",") if kv)))
 ref = None
 times = {n: [] for n, _ in variants}
+fems = {}
+for name, env in variants:  # (the switches are read once per FE space: one per variant)
+    for k, v in env.items():
+        os.environ[k] = v
+    fems[name] = _ffi.Fem(ctx, NB, NB, N)
+    for k in env:
+        del os.environ[k]
 for rep in range(reps):
     for name, env in variants:
-        for k, v in env.items():
-            os.environ[k] = v
+        fem = fems[name]
         fem.expand(ab, M, Y, U)  # warm
         ctx.synchronize()
         ctx.timer_start()
         for _ in range(inner):
             fem.expand(ab, M, Y, U)
         times[name].append(ctx.timer_stop() / inner)
-        for k in env:
-            del os.environ[k]
         if rep == 0:
             out = U.download(8 * fem.dim)
             if ref is None:
@@ -45,28 +49,3 @@ for name, _ in variants:
     t = np.array(times[name])
     print(f"{name:24s} min {t.min():.4f} ms  median {np.median(t):.4f} ms  -> {fl / np.median(t) * 1e-9:.2f} TFLOP/s algorithmic")
 
-if os.environ.get("CLOCKS"):
-    import ctypes
-    lib = _ffi.load_library()
-    for name, env in variants:
-        for k, v in env.items():
-            os.environ[k] = v
-        cz = (ctypes.c_int * 2)()
-        if hasattr(lib, "rom_debug_xs_census"):
-            lib.rom_debug_xs_census(cz, 1)
-        for _ in range(30):
-            fem.expand(ab, M, Y, U)
-        ctx.synchronize()
-        if hasattr(lib, "rom_debug_xs_census"):
-            lib.rom_debug_xs_census(cz, 1)
-            print(f"{name:24s} workgroups inside the kernel at once: max {cz[1]} (left over {cz[0]})")
-        for k in env:
-            del os.environ[k]
-        buf = (ctypes.c_ulonglong * (1024 * 4))()
-        if hasattr(lib, "rom_debug_xs_clock") and lib.rom_debug_xs_clock(buf, 1024 * 4) == 0:
-            c = np.array(buf[:]).reshape(1024, 4).astype(np.float64)
-            ok = (c[:, 3] > c[:, 1]) & (c[:, 2] > c[:, 0])
-            ghz = (c[ok, 2] - c[ok, 0]) / (c[ok, 3] - c[ok, 1]) * 0.1
-            us = (c[ok, 3] - c[ok, 1]) / 100.0
-            print(f"{name:24s} in-kernel clock: median {np.median(ghz):.3f} GHz (min {ghz.min():.3f}, max {ghz.max():.3f}); "
-                  f"workgroup lifetime median {np.median(us):.1f} us, max {us.max():.1f} us, min {us.min():.1f} us")
