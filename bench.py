@@ -48,7 +48,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X spec fp64 matrix peak; the instruction itself sustains 48.8
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X spec fp64 matrix peak; a register-only loop sustains 71-73
 HBM_PEAK_GBS = 8000.0
 SEED = 20240807                 # seeds and generator (PCG64 via default_rng) are part of the contract
 
@@ -447,13 +447,16 @@ def main():
                 "avg_launch_ms": round(d["total_ms"] / d["launches"], 5),
                 "flops_per_launch": d["flops"] / d["launches"],
                 "store_bytes_per_launch": 8.0 * M * nblk * (N - 1) ** 2 if dom.startswith("extend") else None,
-                "sustained_mfma_tflops": 49.0,
-                "frac_of_sustained": round(achieved / 49.0, 4),
+                "sustained_mfma_tflops": 72.0,
+                "frac_of_sustained": round(achieved / 72.0, 4),
+                "store_floor_ms": round(8.0 * M * nblk * (N - 1) ** 2 / 6.0e9, 4) if dom.startswith("extend") else None,
                 "note": "ALGORITHMIC flops (no padding of K or of the tiles) of the fp64 MFMA kernel (v_mfma_f64_16x16x4_f64) "
                         "against the spec fp64 matrix rate (64 cycles per instruction).  A register-only loop of that "
-                        "instruction sustains 49 TFLOP/s on this part (one per 100-104 cycles per SIMD; "
-                        "profiles/r01_mfma_f64_peak_microbench_v2.txt): sustained_mfma_tflops / frac_of_sustained.  The same "
-                        "launch writes the snapshot rows (store_bytes_per_launch); DESIGN.md section 5"}
+                        "instruction (16 accumulators per wave) sustains 71-73 TFLOP/s on this part, 60-65 with a 6 TB/s store "
+                        "stream interleaved (profiles/r02_mfma_store_overlap_microbench.txt; round 1's 49 TFLOP/s came from a "
+                        "probe whose loop the compiler had filled with accumulator moves): sustained_mfma_tflops / "
+                        "frac_of_sustained.  The same launch writes the snapshot rows (store_bytes_per_launch; store_floor_ms = "
+                        "that at the 6 TB/s a store-only kernel reaches); DESIGN.md section 5"}
     # PMC-measured memory-side traffic of the dominant kernel, if a summary of separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command is committed
     for pmc_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):

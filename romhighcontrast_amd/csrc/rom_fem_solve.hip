@@ -158,9 +158,13 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   const bool flat = f->sw_ext_flat >= 0 ? f->sw_ext_flat != 0 : 100 * t_flat < 97 * t_row;
   const int t128 = flat ? t_flat : t_row;
   const bool wide = Mc >= 128 && 100 * 128 * t128 <= 102 * 64 * f->n1 * ((f->n1 + 63) / 64) && !f->sw_no_ext128;
-  // k_extend_p: one persistent workgroup per CU; its lane offsets are 32-bit
+#ifdef ROMHC_EXPERIMENTAL
+  // k_extend_p (rom_fem_extend_p.hip): persistent workgroups; its lane offsets are 32-bit
   const bool persistent = wide && f->sw_ext_p != 0 && size_t(f->dim) * 32 < (size_t(1) << 32) &&
                           (size_t(Mc) + 128) * f->nGp * 8 < (size_t(1) << 32) && size_t(f->n1) * f->n1 * 64 * BK * 8 < (size_t(1) << 32);
+#else
+  const bool persistent = false;
+#endif
   const bool fold_expand = f->nexp > 0 && f->npre == 0 && f->n_edges == 0 && f->n_gen_blocks == 0 && f->n_lr_blocks > 0 &&
                            wide && !persistent && !f->sw_no_fold;
   if (f->nGp > 0) {
@@ -201,6 +205,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
               xa.blocks[z] = f->lr_blocks_host[z0 + z];
               xa.sides[z] = f->sides[xa.blocks[z]];
             }
+#ifdef ROMHC_EXPERIMENTAL
             if (persistent) {
               static bool lds_set = false;  // (more than 64 KB of dynamic LDS must be asked for once per kernel)
               if (!lds_set) {
@@ -223,6 +228,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
               else k_extend_p<false, 0><<<nwg, 256, XP_LDS_BYTES, st>>>(d, xa, am, Mc, U, row, nz);
               continue;
             }
+#endif
             const int extra = fold_expand && z0 == 0 ? (items + mt * nz - 1) / (mt * nz) : 0;
             dim3 grid(t128 + extra, mt, nz);
             if (flat) k_extend128<true><<<grid, 256, 0, st>>>(d, xa, am, Mc, U, row, extra);

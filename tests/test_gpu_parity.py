@@ -707,7 +707,7 @@ def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
     ab = ctx.upload(a)
     out = {}
     for name, env in (("row", {"ROMHC_EXT_FLAT": "0"}), ("flat", {"ROMHC_EXT_FLAT": "1"}), ("t64", {"ROMHC_NO_EXT128": "1"}),
-                      ("p", {"ROMHC_EXT_P": "1", "ROMHC_EXT_FLAT": "0"}), ("pflat", {"ROMHC_EXT_P": "1", "ROMHC_EXT_FLAT": "1"}), ("default", {})):
+                      ("default", {})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)  # (the switches are read once per FE space)
@@ -717,7 +717,7 @@ def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
         out[name] = U.download(shape=(M, fem.dim))
         for k in env:
             monkeypatch.delenv(k)
-    for name in ("flat", "t64", "p", "pflat", "default"):
+    for name in ("flat", "t64", "default"):
         assert np.array_equal(out[name], out["row"]), name
     g = ro.Geometry(blocks, N)
     if N <= 40:

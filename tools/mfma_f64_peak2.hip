@@ -1,4 +1,7 @@
 // fp64 MFMA issue-rate probe: accumulators per wave x waves per SIMD, with the in-kernel clock.
+// FLAWED (round 2): hipcc keeps the accumulators of this loop in AGPRs and copies all of them to VGPRs and back in
+// every iteration (128 v_accvgpr moves per 8 MFMAs), so its 49 TFLOP/s is not the rate of the instruction.
+// tools/mfma_store_overlap.hip (16 accumulators in VGPRs, clean loop) measures 71-73 TFLOP/s.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double d4 __attribute__((ext_vector_type(4)));

@@ -1,7 +1,6 @@
 // Do fp64 MFMA work and a store stream overlap on this part, and at which level do they couple?  (dev probe, round 2)
 // The extension kernel multiplies 8.5 GFLOP (padded) and writes 528 MB per C2 step; every structure tried so far ends
-// at 0.23-0.25 ms, between max(0.174 ms of MFMA at the sustained 49 TFLOP/s, 0.12 ms of stores at 4.5 TB/s) and their
-// sum.  This probe runs the two ingredients without any data dependence between them:
+// at 0.23-0.25 ms, about the SUM of its MFMA time (0.12 ms at the 72 TFLOP/s measured here) and its store time.  This probe runs the two ingredients without any data dependence between them:
 //   mfma      every CU: register-only v_mfma_f64_16x16x4_f64 loop (16 independent accumulators)
 //   store     every CU: 16-byte-per-lane stores, a wave instruction writes 1 KB contiguous, consecutive instructions
 //             consecutive KBs

@@ -1,6 +1,6 @@
 // Microbenchmark: the extension product U[m][v] = sum_k Gt[k][v] * y[m][k] on the VECTOR fp64 pipe
 // (v_fma_f64 with the y operand in SGPRs through the scalar cache) instead of v_mfma_f64_16x16x4_f64:
-// tools/mfma_f64_peak* measure 67 TFLOP/s for v_fma_f64 against 49 TFLOP/s for the fp64 MFMA on gfx950.
+// tools/mfma_f64_peak* measure 67 TFLOP/s for v_fma_f64 against 49 TFLOP/s for the fp64 MFMA on gfx950 (round 2: that 49 was an artefact of the probe, the MFMA sustains 71-73).
 // Lanes own VPL adjacent vertices, J systems per wave in registers; no LDS, no barriers.
 // YT: y stored k-major (yT[k][m]) so that one s_load_dwordx16 fetches 8 systems of one k.
 //   hipcc -O3 --offload-arch=gfx950 tools/valu_gemm.hip -o tools/valu_gemm
