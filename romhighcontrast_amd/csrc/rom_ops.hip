@@ -193,11 +193,19 @@ extern "C" int rom_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double
 // snapshot Gram needs once the block no longer fits in the Infinity Cache (C5: 34 GB).
 // 1-D grid over the lower tiles (XCD-balanced) x split-K; partial tiles go to `part`, reduced + mirrored after.
 // ============================================================================================
-constexpr int G128_STAGE = 128 * LDK;  // one operand chunk [128][BK]
+// Main loop (round 2): the K chunks (16 wide) of both operands go from global memory straight into LDS with
+// global_load_lds_dwordx4 (no staging registers, no ds_write; 8 instructions per wave and chunk: 8 rows x 128 bytes
+// each), two 32 KB slots, chunk ch + 1 in flight under the 64 MFMAs per wave of chunk ch; a row's eight 16-byte units
+// are stored at position u ^ ((row >> 1) & 7) (the DMA writes rows back to back: no padding possible), which makes the
+// MFMA fragment reads conflict free; the fragments of k-step j + 1 are read before the MFMAs of step j.  Rows behind
+// the matrix are clamped to its last row (their products are not stored).  The tail of K (at most 15 columns of the
+// last split) goes through registers as before.
+constexpr int G128_SLOT = 2 * 128 * 128;  // bytes: 128 rows of A, 128 rows of B, 16 doubles each
 
-__global__ __launch_bounds__(256) void k_gram128(long long m, long long K, long long kper, const double* __restrict__ A,
-                                                 long long lda, double* __restrict__ part) {
-  __shared__ __align__(16) double lds[4 * G128_STAGE];  // {A,B} x 2 buffers = 73,728 B
+__global__ __launch_bounds__(256, 2) void k_gram128(long long m, long long K, long long kper, const double* __restrict__ A,
+                                                    long long lda, double* __restrict__ part) {
+  __shared__ __align__(16) char lds[2 * G128_SLOT];  // 65,536 B: two workgroups per CU
+  const unsigned lds0 = unsigned(size_t((__attribute__((address_space(3))) char*)lds));
   const long long t = blockIdx.x;
   long long ty = (long long)((sqrt(8.0 * double(t) + 1.0) - 1.0) * 0.5);
   while (ty * (ty + 1) / 2 > t) --ty;
@@ -205,50 +213,95 @@ __global__ __launch_bounds__(256) void k_gram128(long long m, long long K, long 
   const long long tx = t - ty * (ty + 1) / 2;
   const long long r0 = ty * 128, c0 = tx * 128;
   const long long kbeg = blockIdx.z * kper, kend = std::min<long long>(K, kbeg + kper);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
-  // staging: lane -> k (t & 15), thread t handles rows (t >> 4) + 16 x, x = 0..7: one wave-instruction
-  // reads 4 rows x 128 contiguous bytes whatever the alignment of the (odd-length) snapshot rows
-  const int sk = threadIdx.x & 15, sr0 = threadIdx.x >> 4;
-  const double* Ar[8];
-  const double* Br[8];
-#pragma unroll
-  for (int x = 0; x < 8; ++x) {
-    Ar[x] = (r0 + sr0 + 16 * x < m) ? A + (r0 + sr0 + 16 * x) * lda : nullptr;
-    Br[x] = (c0 + sr0 + 16 * x < m) ? A + (c0 + sr0 + 16 * x) * lda : nullptr;
-  }
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = w >> 1, wc = w & 1;
+  const int fr = lane & 15, kq = lane >> 4;
   d4_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-  auto load8 = [&](const double* const* rows, long long k0, double* v) {
-    const long long k = k0 + sk;
+  const int nfull = int((kend - kbeg) / BK), rem = int((kend - kbeg) % BK);
+
+  // ---- fragment addressing: lane (fr, kq) reads row fr (+ 16 i) at k = 4 kki + kq: unit (2 kki + (kq >> 1)) ^ (fr >> 1)
+  unsigned fa[4], fb[4];
 #pragma unroll
-    for (int x = 0; x < 8; ++x) v[x] = (rows[x] && k < kend) ? rows[x][k] : 0.0;
-  };
-  auto store8 = [&](double* sbuf, const double* v) {
-#pragma unroll
-    for (int x = 0; x < 8; ++x) sbuf[(sr0 + 16 * x) * LDK + sk] = v[x];
-  };
-  const int nch = int((kend - kbeg + BK - 1) / BK);
-  double va[8], vb[8];
-  if (nch > 0) {
-    load8(Ar, kbeg, va);
-    load8(Br, kbeg, vb);
+  for (int kki = 0; kki < 4; ++kki) {
+    const unsigned uo = unsigned((((2 * kki) ^ (kq >> 1) ^ (fr >> 1)) << 4) + (kq & 1) * 8);
+    fa[kki] = unsigned((wr * 64 + fr) * 128) + uo;
+    fb[kki] = unsigned(16384 + (wc * 64 + fr) * 128) + uo;
   }
-  const int fr = lane & 15, kq = lane >> 4;
-  for (int ch = 0; ch < nch; ++ch) {
-    double* sA = lds + (ch & 1) * 2 * G128_STAGE;
-    double* sB = sA + G128_STAGE;
-    store8(sA, va);
-    store8(sB, vb);
-    __syncthreads();
-    if (ch + 1 < nch) {
-      load8(Ar, kbeg + (ch + 1) * BK, va);
-      load8(Br, kbeg + (ch + 1) * BK, vb);
+#define G_FRAGS(SLOT_, KKI_, AF_, BF_)                                                                  \
+  do {                                                                                                  \
+    const char* pa_ = lds + (SLOT_) * G128_SLOT + fa[KKI_];                                             \
+    const char* pb_ = lds + (SLOT_) * G128_SLOT + fb[KKI_];                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                  \
+      AF_[i_] = *reinterpret_cast<const double*>(pa_ + i_ * 2048);                                      \
+      BF_[i_] = *reinterpret_cast<const double*>(pb_ + i_ * 2048);                                      \
+    }                                                                                                   \
+  } while (0)
+  // ---- DMA addressing: a wave fetches rows 32 w .. 32 w + 31 of both operands, 8 rows per instruction (q = 0..3):
+  // lane -> row 32 w + 8 q + (lane >> 3), stored unit lane & 7 = logical unit (lane & 7) ^ ((4 (q & 1) + (lane >> 4)) & 7)
+  unsigned voA[4], voB[4];  // lane offsets (bytes) behind the scalar bases A + (r0 | c0) * lda + k
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rl = 32 * w + 8 * q + (lane >> 3);
+    const unsigned u16 = unsigned((((lane & 7) ^ ((4 * (q & 1) + (lane >> 4)) & 7))) * 16);
+    const long long ra = std::min<long long>(rl, m - 1 - r0), rb = std::min<long long>(rl, m - 1 - c0);
+    voA[q] = unsigned(ra * lda * 8) + u16;  // (127 * lda * 8 < 2^32: checked on the host)
+    voB[q] = unsigned(rb * lda * 8) + u16;
+  }
+  const char* sA = reinterpret_cast<const char*>(A + r0 * lda + kbeg);
+  const char* sB = reinterpret_cast<const char*>(A + c0 * lda + kbeg);
+#define G_DMA(LDS_, BASE_, VOFF_)                                                                                   \
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(LDS_)),    \
+               "v"(VOFF_), "s"(BASE_)                                                                               \
+               : "memory")
+#define G_ISSUE(SLOT_)                                                                                              \
+  do {                                                                                                              \
+    const unsigned sl_ = lds0 + unsigned(SLOT_) * G128_SLOT + unsigned(w) * 4096;                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) G_DMA(sl_ + q_ * 1024, sA, voA[q_]);                           \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) G_DMA(sl_ + 16384 + q_ * 1024, sB, voB[q_]);                   \
+    sA += BK * 8;                                                                                                   \
+    sB += BK * 8;                                                                                                   \
+  } while (0)
+  if (nfull > 0) {
+    G_ISSUE(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    double af[2][4], bf[2][4];
+    G_FRAGS(0, 0, af[0], bf[0]);
+    for (int ch = 0; ch < nfull; ++ch) {
+      const int slot = ch & 1;
+      if (ch + 1 < nfull) G_ISSUE(slot ^ 1);  // (everybody left that slot at the barrier behind chunk ch - 1)
+#pragma unroll
+      for (int kki = 0; kki < 4; ++kki) {
+        const int pb = kki & 1;
+        if (kki < 3) G_FRAGS(slot, kki + 1, af[pb ^ 1], bf[pb ^ 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][i], bf[pb][j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // chunk ch + 1 is in LDS for everybody
+      if (ch + 1 < nfull) G_FRAGS(slot ^ 1, 0, af[0], bf[0]);
     }
-    const double* pa = sA + (wr * 64 + fr) * LDK + kq;
-    const double* pb = sB + (wc * 64 + fr) * LDK + kq;
+  }
+#undef G_ISSUE
+#undef G_DMA
+#undef G_FRAGS
+  if (rem > 0) {
+    // the last columns of K, zero padded to one chunk: lane -> k (t & 15), thread t handles rows (t >> 4) + 16 x
+    double* st = reinterpret_cast<double*>(lds);  // [A 128 x LDK | B 128 x LDK] doubles = 36,864 B
+    const int sk = threadIdx.x & 15, sr0 = threadIdx.x >> 4;
+    const long long k = kbeg + (long long)nfull * BK + sk;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const long long ra = r0 + sr0 + 16 * x, rb = c0 + sr0 + 16 * x;
+      st[(sr0 + 16 * x) * LDK + sk] = (ra < m && k < kend) ? A[ra * lda + k] : 0.0;
+      st[128 * LDK + (sr0 + 16 * x) * LDK + sk] = (rb < m && k < kend) ? A[rb * lda + k] : 0.0;
+    }
+    __syncthreads();
+    const double* pa = st + (wr * 64 + fr) * LDK + kq;
+    const double* pb = st + 128 * LDK + (wc * 64 + fr) * LDK + kq;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
       double af[4], bf[4];
@@ -326,7 +379,7 @@ extern "C" int rom_gram(rom_ctx* ctx, int64_t m, int64_t k, rom_buf* A, size_t a
   if (m == 0) return ROM_OK;
   ROM_CHECK(a_off + size_t(m - 1) * lda + k <= A->n, "rom_gram: A out of range");
   ROM_CHECK(c_off + size_t(m - 1) * ldc + m <= C->n, "rom_gram: C out of range");
-  if (m >= 512 && k >= 4096) return launch_gram128(ctx, m, k, A->p + a_off, lda, C->p + c_off, ldc);
+  if (m >= 512 && k >= 4096 && size_t(lda) * 8 * 128 < (size_t(1) << 32)) return launch_gram128(ctx, m, k, A->p + a_off, lda, C->p + c_off, ldc);
   return rom_launch_gemm_nt_ex(ctx, m, m, k, 1.0, A->p + a_off, lda, A->p + a_off, lda, 0.0, C->p + c_off, ldc, "gram",
                                1);
 }
