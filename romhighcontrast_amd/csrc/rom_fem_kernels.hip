@@ -1026,7 +1026,22 @@ extern "C" int rom_debug_stamps_clear() {
 // only sum(rank + 1) ~ 64, so a 64 x 64 tile spends most of its life in its prologue and epilogue; four times
 // the outputs per workgroup amortise them and every LDS fragment feeds four MFMAs instead of two.
 // grid (mesh rows x column tiles, ceil(Mc/128), lr blocks); LDS 74,752 B -> 2 workgroups per CU
-constexpr int X128_STAGE = 128 * LDK;
+// a pointer that is the same in every lane, in scalar registers whatever the compiler thinks of it
+__device__ inline const char* x128_uniform(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
+  return reinterpret_cast<const char*>((unsigned long long)hi << 32 | lo);
+}
+
+// Main loop (round 2, after the Gram kernel): the K chunks of both operands go from global memory straight into
+// LDS with global_load_lds_dwordx4 -- no staging registers, no ds_write, 8 instructions per wave and chunk, chunk
+// ch + 1 in flight under the 64 MFMAs per wave of chunk ch, the fragments of k-step j + 1 read before the MFMAs of step
+// j.  A chunk slot is {A k 0..7 | A k 8..15 | B k 0..7 | B k 8..15}, 128 rows of 64 bytes each; a DMA instruction
+// writes 64 lanes x 16 bytes back to back = 16 rows of ONE half, i.e. of one block side (scalar base + 32-bit lane
+// offset); the four 16-byte units of a row are stored at position u ^ ((row >> 2) & 3), which makes the MFMA fragment
+// reads conflict free.  Rows that do not exist (systems >= Mc, vertices behind the end of the mesh row / the block) are
+// clamped to the last one that does: their products are not stored.
+constexpr int X128_SLOT = 4 * 128 * 64;  // bytes
 
 // FLAT: the 128 vertices of a tile are consecutive in the block's row-major vertex numbering instead of lying in
 // one mesh row -- no padding when n1 is not close to a multiple of 128 (n1 = 170: 226 tiles per block instead of
@@ -1034,8 +1049,9 @@ constexpr int X128_STAGE = 128 * LDK;
 template <bool FLAT>
 __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc,
                                                       double* __restrict__ U, long long row0, int with_expand) {
-  __shared__ __align__(16) double lds[4 * X128_STAGE];  // {A,B} x 2 buffers
-  __shared__ double scs[128];                            // h^2 / a_b of the workgroup's systems
+  __shared__ __align__(16) char lds_bytes[2 * X128_SLOT];  // two chunk slots = 65,536 B: two workgroups per CU
+  __shared__ double scs[128];                               // h^2 / a_b of the workgroup's systems
+  double* const lds = reinterpret_cast<double*>(lds_bytes);
   const int n1 = f.n1, N = f.N;
   const int nct = (n1 + 127) / 128;
   const int nvert = n1 * n1;
@@ -1043,7 +1059,7 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
   if (int(blockIdx.x) >= ntile) {
     // with_expand: the (small) expansion of the edge values rides in `with_expand` extra workgroups per (y, z) cell
     // of this launch -- it depends on nothing here and nothing here depends on it
-    static_assert(STAGE_TOTAL <= 4 * X128_STAGE, "expansion staging must fit");
+    static_assert(STAGE_TOTAL * sizeof(double) <= 2 * X128_SLOT, "expansion staging must fit");
     const int nx = f.n1p / 64, ny = (Mc + 63) / 64;
     const int item = (blockIdx.x - ntile) + with_expand * (blockIdx.y + gridDim.y * blockIdx.z);
     if (item < nx * ny * (f.nexp + 1)) expand_tile(f, Mc, U, row0, lds, item % nx, (item / nx) % ny, item / (nx * ny));
@@ -1066,68 +1082,13 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
   const int iv = blockIdx.x / nct + 1;           // mesh row (1-based interior index)       (!FLAT)
   const int jv0 = 128 * (blockIdx.x % nct) + 1;  // first vertex of the tile                (!FLAT)
   const int vt0 = 128 * blockIdx.x;              // first vertex of the tile, block-local   (FLAT)
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 1, wc = w & 1;
-  // staging: thread t -> row t >> 1, eight consecutive k starting at (t & 1) * 8
-  const int srow = threadIdx.x >> 1, sseg = (threadIdx.x & 1) * 8;
-  const int mA = blockIdx.y * 128 + srow;
-  const bool vA = mA < Mc;
-  const int iB = FLAT ? (vt0 + srow) / n1 + 1 : iv;
-  const int jB = FLAT ? (vt0 + srow) % n1 + 1 : jv0 + srow;
-  const bool vB = FLAT ? vt0 + srow < nvert : jB <= n1;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = w >> 1, wc = w & 1;
+  const int fr = lane & 15, kq = lane >> 4;
   double my_sc = 0.0;  // h^2 / a_b of system threadIdx.x: requested now, parked in LDS after the k loop
   if (threadIdx.x < 128) {
     const int m = blockIdx.y * 128 + threadIdx.x;
     if (m < Mc) my_sc = f.y[size_t(m) * f.nGp + f.sblk0 + b];
   }
-  // K runs over the sides' rank + 1 coefficients in segments of 8 (a thread stages one segment per chunk): the
-  // tables are padded to 16 per side, but only ceil((rank + 1) / 8) segments of a side hold anything -- the second
-  // half of a side's last chunk is handed to the next side (7-17 % fewer MFMAs where rank + 1 is just above a
-  // multiple of 16; products with the zero padding add nothing, so the sums do not change)
-  int send[4];
-  const double* pAs[4];
-  const double* pBs[4];
-  int nseg = 0;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const ExtSide es = sd.s[s];
-    const bool m2 = es.mode == 2;  // (selects, not branches: the descriptor loads of all four sides stay together)
-    nseg += m2 ? min(2 * es.nch, (es.r + 1 + 7) / 8) : 0;
-    const double* pa = f.y + size_t(mA) * f.nGp + es.off;
-    const double* pb = f.G + es.gtab + size_t(h0_row(s, iB, jB, N, n1)) * (es.nch * BK);
-    pAs[s] = m2 && vA ? pa : nullptr;
-    pBs[s] = m2 && vB ? pb : nullptr;
-    send[s] = nseg;
-  }
-  const int tot = (nseg + 1) / 2;
-  const int half = threadIdx.x & 1;
-  auto pick = [&](int ch, const double* const* ps) -> const double* {
-    const int sg = 2 * ch + half;
-    if (sg >= nseg) return nullptr;
-    const int s = (sg >= send[0]) + (sg >= send[1]) + (sg >= send[2]);
-    const int ls = sg - (s == 0 ? 0 : s == 1 ? send[0] : s == 2 ? send[1] : send[2]);
-    const double* ptr = s == 0 ? ps[0] : s == 1 ? ps[1] : s == 2 ? ps[2] : ps[3];
-    return ptr ? ptr + ls * 8 : nullptr;
-  };
-  auto load8 = [&](const double* ptr, double* v) {
-    load4_aligned(ptr, v);
-    load4_aligned(ptr ? ptr + 4 : nullptr, v + 4);
-  };
-  auto store8 = [&](double* sbuf, const double* v) {
-    double2* dst = reinterpret_cast<double2*>(sbuf + srow * LDK + sseg);  // 144-byte rows, 64-byte segments
-#pragma unroll
-    for (int x = 0; x < 4; ++x) dst[x] = double2{v[2 * x], v[2 * x + 1]};
-  };
-  d4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-  double va[8], vb[8];
-  if (tot > 0) {
-    load8(pick(0, pAs), va);
-    load8(pick(0, pBs), vb);
-  }
-  const int fr = lane & 15, kq = lane >> 4;
   // everything the epilogue needs from memory is fetched before the first store: a load after a store would
   // make its s_waitcnt vmcnt wait for the stores as well (one counter, in order)
   double w_own[4];
@@ -1141,34 +1102,140 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
       w_own[j] = jj <= n1 ? f.W[(iv - 1) * n1 + (jj - 1)] : 0.0;
     }
   }
-  STAMP(1);
-  for (int ch = 0; ch < tot; ++ch) {
-    double* sA = lds + (ch & 1) * 2 * X128_STAGE;
-    double* sB = sA + X128_STAGE;
-    store8(sA, va);
-    store8(sB, vb);
-    __syncthreads();
-    if (ch == 0) STAMP(2);
-    if (ch + 1 < tot) {
-      load8(pick(ch + 1, pAs), va);
-      load8(pick(ch + 1, pBs), vb);
-    }
-    const double* pa = sA + (wr * 64 + fr) * LDK + kq;
-    const double* pb = sB + (wc * 64 + fr) * LDK + kq;
+  // K runs over the sides' rank + 1 coefficients in segments of 8: the tables are padded to 16 per side, but only
+  // ceil((rank + 1) / 8) segments of a side hold anything -- the second half of a side's last chunk is handed to the
+  // next side (7-17 % fewer MFMAs where rank + 1 is just above a multiple of 16; products with the zero padding add
+  // nothing, so the sums do not change).  A chunk = two consecutive segments of that walk.
+  const int cnt0 = sd.s[0].mode == 2 ? min(2 * sd.s[0].nch, (sd.s[0].r + 1 + 7) / 8) : 0;
+  const int cnt1 = sd.s[1].mode == 2 ? min(2 * sd.s[1].nch, (sd.s[1].r + 1 + 7) / 8) : 0;
+  const int cnt2 = sd.s[2].mode == 2 ? min(2 * sd.s[2].nch, (sd.s[2].r + 1 + 7) / 8) : 0;
+  const int cnt3 = sd.s[3].mode == 2 ? min(2 * sd.s[3].nch, (sd.s[3].r + 1 + 7) / 8) : 0;
+  const int nseg = cnt0 + cnt1 + cnt2 + cnt3;
+  const int tot = (nseg + 1) / 2;
+  // ---- fragment addressing: lane (fr, kq) reads row fr (+ 16 i) at k = 4 kki + kq: half kki >> 1, unit
+  // (2 (kki & 1) + (kq >> 1)) ^ (fr >> 2), byte (kq & 1) * 8
+  const unsigned fx = unsigned((kq >> 1) ^ (fr >> 2));
+  const unsigned fa0 = unsigned(fr * 64) + (fx << 4) + unsigned(kq & 1) * 8u;
+  const unsigned fa1 = unsigned(fr * 64) + ((fx ^ 2u) << 4) + unsigned(kq & 1) * 8u;
+#define X_FRAGS(SLOT_, KKI_, AF_, BF_)                                                                             \
+  do {                                                                                                             \
+    const char* pf_ = lds_bytes + (SLOT_) * X128_SLOT + (((KKI_)&1) ? fa1 : fa0);                                  \
+    const char* pa_ = pf_ + ((KKI_) >> 1) * 8192 + wr * 4096;                                                      \
+    const char* pb_ = pf_ + 16384 + ((KKI_) >> 1) * 8192 + wc * 4096;                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                             \
+      AF_[i_] = *reinterpret_cast<const double*>(pa_ + i_ * 1024);                                                 \
+      BF_[i_] = *reinterpret_cast<const double*>(pb_ + i_ * 1024);                                                 \
+    }                                                                                                              \
+  } while (0)
+  // ---- DMA addressing: a wave fetches rows 32 w .. 32 w + 31 of both operands, 16 rows of one half per instruction:
+  // lane -> row 32 w + 16 g + (lane >> 2), stored unit lane & 3 = logical unit (lane & 3) ^ ((lane >> 4) & 3)
+  const unsigned lds0 = unsigned(size_t((__attribute__((address_space(3))) char*)lds_bytes));
+  const unsigned du16 = unsigned(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  const unsigned ybytes_row = unsigned(f.nGp) * 8u;
+  const int m0 = blockIdx.y * 128;
+  unsigned voA[2];             // lane offsets behind ybytes + first system + side block
+  int vi[2], vj[2];            // the lanes' vertices (1-based) in the wave's two B row groups
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 4) {
-      double af[4], bf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = pa[i * 16 * LDK + kk];
-        bf[i] = pb[i * 16 * LDK + kk];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+  for (int g = 0; g < 2; ++g) {
+    const int rl = 32 * w + 16 * g + (lane >> 2);
+    voA[g] = unsigned(max(0, min(rl, Mc - 1 - m0))) * ybytes_row + du16;
+    if (FLAT) {
+      const int v = min(vt0 + rl, nvert - 1);
+      vi[g] = v / n1 + 1;
+      vj[g] = v % n1 + 1;
+    } else {
+      vi[g] = iv;
+      vj[g] = min(jv0 + rl, n1);
     }
   }
+  const char* const ybase = reinterpret_cast<const char*>(f.y) + size_t(min(m0, Mc - 1)) * ybytes_row;
+  const char* const gbase = reinterpret_cast<const char*>(f.G);
+  const char* const zbase = reinterpret_cast<const char*>(f.W + size_t(n1) * n1);  // XP_ZERO_PAGE doubles of zeros
+  const unsigned voZ = unsigned(lane) * 16u;
+  // the walk over the segments (uniform): side, segments left in it, its two running pointers; lanes: table rows
+  int c_side = -1, c_left = 0, c_segs = nseg;
+  const char* pA = zbase;
+  const char* pB = zbase;
+  unsigned voB[2] = {0, 0};
+#define X_NEXT_SIDE()                                                                                              \
+  do {                                                                                                             \
+    do {                                                                                                           \
+      ++c_side;                                                                                                    \
+      c_left = c_side == 0 ? cnt0 : c_side == 1 ? cnt1 : c_side == 2 ? cnt2 : cnt3;                                \
+    } while (c_left == 0 && c_side < 3);                                                                           \
+    const int off_ = c_side == 0 ? sd.s[0].off : c_side == 1 ? sd.s[1].off : c_side == 2 ? sd.s[2].off : sd.s[3].off; \
+    const int gtab_ = c_side == 0 ? sd.s[0].gtab : c_side == 1 ? sd.s[1].gtab : c_side == 2 ? sd.s[2].gtab : sd.s[3].gtab; \
+    const int nch_ = c_side == 0 ? sd.s[0].nch : c_side == 1 ? sd.s[1].nch : c_side == 2 ? sd.s[2].nch : sd.s[3].nch; \
+    const int nb_ = nch_ * BK * 8; /* bytes per table row */                                                       \
+    /* row of the side's table = ci i + cj j + k0 (h0_row) */                                                      \
+    const int cm_ = (c_side & 1) ? -n1 : n1, k0_ = (c_side & 1) ? (N - 1) * n1 - 1 : -n1 - 1;                      \
+    const int ci_ = (c_side & 2) ? 1 : cm_, cj_ = (c_side & 2) ? cm_ : 1;                                          \
+    pA = ybase + size_t(off_) * 8;                                                                                 \
+    pB = gbase + size_t(gtab_) * 8;                                                                                \
+    voB[0] = unsigned(ci_ * vi[0] + cj_ * vj[0] + k0_) * unsigned(nb_) + du16;                                     \
+    voB[1] = unsigned(ci_ * vi[1] + cj_ * vj[1] + k0_) * unsigned(nb_) + du16;                                     \
+  } while (0)
+#define X_DMA(LDS_, BASE_, VOFF_)                                                                                  \
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(LDS_)),   \
+               "v"(VOFF_), "s"(x128_uniform(BASE_))                                                                \
+               : "memory")
+  // the 4 loads of the segment under the cursor into half H_ of slot SLOT_, then the cursor moves on
+#define X_ISSUE_HALF(SLOT_, H_)                                                                                    \
+  do {                                                                                                             \
+    const unsigned sb_ = lds0 + unsigned(SLOT_) * X128_SLOT + (H_) * 8192 + unsigned(w) * 2048;                    \
+    if (c_segs > 0) {                                                                                              \
+      X_DMA(sb_, pA, voA[0]);                                                                                      \
+      X_DMA(sb_ + 1024, pA, voA[1]);                                                                               \
+      X_DMA(sb_ + 16384, pB, voB[0]);                                                                              \
+      X_DMA(sb_ + 16384 + 1024, pB, voB[1]);                                                                       \
+      pA += 64;                                                                                                    \
+      pB += 64;                                                                                                    \
+      --c_segs;                                                                                                    \
+      if (--c_left == 0 && c_segs > 0) X_NEXT_SIDE();                                                              \
+    } else { /* zeros: the odd half of the last chunk */                                                           \
+      X_DMA(sb_, zbase, voZ);                                                                                      \
+      X_DMA(sb_ + 1024, zbase, voZ);                                                                               \
+      X_DMA(sb_ + 16384, zbase, voZ);                                                                              \
+      X_DMA(sb_ + 16384 + 1024, zbase, voZ);                                                                       \
+    }                                                                                                              \
+  } while (0)
+  d4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+  STAMP(1);
+  if (tot > 0) {
+    X_NEXT_SIDE();
+    X_ISSUE_HALF(0, 0);
+    X_ISSUE_HALF(0, 1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    STAMP(2);
+    double af[2][4], bf[2][4];
+    X_FRAGS(0, 0, af[0], bf[0]);
+    for (int ch = 0; ch < tot; ++ch) {
+      const int slot = ch & 1;
+      if (ch + 1 < tot) {  // (everybody left that slot at the barrier behind chunk ch - 1)
+        X_ISSUE_HALF(slot ^ 1, 0);
+        X_ISSUE_HALF(slot ^ 1, 1);
+      }
+#pragma unroll
+      for (int kki = 0; kki < 4; ++kki) {
+        const int pb = kki & 1;
+        if (kki < 3) X_FRAGS(slot, kki + 1, af[pb ^ 1], bf[pb ^ 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][i], bf[pb][j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // chunk ch + 1 is in LDS for everybody
+      if (ch + 1 < tot) X_FRAGS(slot ^ 1, 0, af[0], bf[0]);
+    }
+  }
+#undef X_ISSUE_HALF
+#undef X_DMA
+#undef X_NEXT_SIDE
+#undef X_FRAGS
   if (threadIdx.x < 128) scs[threadIdx.x] = my_sc;
   __syncthreads();
   STAMP(3);
