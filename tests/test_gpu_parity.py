@@ -695,6 +695,24 @@ def test_repeated_sweeps_are_bit_identical(name):
             assert np.array_equal(out, ref), rep
 
 
+@pytest.mark.parametrize("M,D", [(512, 4096), (700, 5001), (1025, 4111), (640, 65025)])
+def test_gram_128_tiles_vs_numpy(api, M, D):
+    """rom_gram on its 128 x 128 LDS-DMA path (M >= 512, D >= 4096): ragged last row tile, rows of odd length (8-byte
+    aligned only), a K that is not a multiple of the 16-wide chunk (tail through registers), several K splits."""
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    x = np.random.default_rng(M + D).standard_normal((M, D)) * np.logspace(0, -6, M)[:, None]
+    X, G = ctx.upload(x), ctx.alloc(M * M)
+    G.fill(float("nan"))
+    ctx.gram(M, D, X, 0, D, G, 0, M)
+    g = G.download(shape=(M, M))
+    ref = x @ x.T
+    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+    assert np.isfinite(g).all()
+    assert np.array_equal(g, g.T)
+    assert (np.abs(g - ref) / scale).max() < 1e-13
+
+
 @pytest.mark.parametrize("blocks,N,M", [((2, 2), 128, 130), ((3, 3), 24, 140), ((2, 3), 40, 200), ((2, 2), 90, 128),
                                         ((1, 2), 9, 129), ((3, 2), 171, 128), ((5, 4), 33, 128)])
 def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
