@@ -11,6 +11,9 @@
 #include <set>
 #include <thread>
 
+#include <chrono>
+#include <tuple>
+
 #include "rom_fem_dev.h"
 #include "rom_hostla.h"
 
@@ -279,11 +282,27 @@ extern "C" int rom_fem_destroy(rom_fem* f) {
   return ROM_OK;
 }
 
+// ROMHC_VERBOSE: wall time of the phases of rom_fem_create
+struct PhaseTimer {
+  bool on = getenv("ROMHC_VERBOSE") != nullptr;
+  const char* name = nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void next(const char* n) {
+    const auto t1 = std::chrono::steady_clock::now();
+    if (on && name) fprintf(stderr, "romhc:   [%7.3f s] %s\n", std::chrono::duration<double>(t1 - t0).count(), name);
+    name = n;
+    t0 = t1;
+  }
+};
+#define ROMHC_PHASE(N_) phase_timer.next(N_)
+
 extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** out) {
   ROM_CHECK(ctx && out, "rom_fem_create: null argument");
   ROM_CHECK(nrb >= 1 && ncb >= 1 && N >= 2, "rom_fem_create: need nrb,ncb >= 1 and N >= 2 (got %d,%d,%d)", nrb, ncb, N);
   ROM_CHECK(nrb * ncb <= 64, "rom_fem_create: at most 64 blocks supported (got %d)", nrb * ncb);
   ROM_HIP(hipSetDevice(ctx->device));
+  PhaseTimer phase_timer;
+  ROMHC_PHASE("geometry");
   rom_fem* f = new rom_fem();
   f->ctx = ctx;
   f->nrb = nrb; f->ncb = ncb; f->N = N;
@@ -295,6 +314,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   f->dim = int64_t(f->nr) * f->nc;
   const int n1p = f->n1p;
 
+  ROMHC_PHASE("edges, crosses");
   // ---- edges, crosses ------------------------------------------------------------------------
   std::vector<Edge> edges;
   std::map<std::pair<int, int>, int> hid, vid, xid;
@@ -334,6 +354,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     return -1;
   };
 
+  ROMHC_PHASE("cross <-> edge-end couplings");
   // ---- cross <-> edge-end couplings ----------------------------------------------------------------
   struct XCpl { int cross, edge, node; };  // node: 0-based local node on the edge
   std::vector<XCpl> xc;
@@ -360,6 +381,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     return -1;
   };
 
+  ROMHC_PHASE("edges eliminated in closed form: a maximal set n");
   // ---- edges eliminated in closed form: a maximal set no two of which touch the same block (greedy);
   //      their self-interaction is (a_b0 + a_b1) K with K parameter independent and they do not couple
   //      to each other ------------------------------------------------------------------------------------
@@ -375,6 +397,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   const int npre = int(pre_list.size());
   const int nact = E - npre;
 
+  ROMHC_PHASE("elimination order of the active edges (greedy mi");
   // ---- elimination order of the active edges (greedy minimum degree on the graph: shared block, or
   //      common neighbour of a closed-form edge) ----------------------------------------------------------
   std::vector<int> order, ord_of(E, -1);
@@ -408,6 +431,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     }
   }
 
+  ROMHC_PHASE("unit-block tables in long double, compression of");
   // ---- unit-block tables in long double, compression of the edges --------------------------------------------
   UnitBlock ub(N, E > 0);
   const Mat& Q = ub.Q;
@@ -497,6 +521,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     use_lr[c] = comps[c].r < n1 && rp[c] <= 1.25 * kavg && n1 > 0 && !getenv("ROMHC_NO_LOWRANK_EXT");
   }
 
+  ROMHC_PHASE("layout of the reduced vector: edge groups in eli");
   // ---- layout of the reduced vector: edge groups in elimination order, every cross point right behind
   //      the adjacent active edge that is eliminated last ------------------------------------------------------
   std::vector<int> zpos(E, -1), rk(E, 0), xred(ncross, -1), xhost(ncross, -1);
@@ -550,6 +575,53 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   f->nsc = E + nrb * ncb;
   f->nGp += (f->nsc + BK - 1) / BK * BK;
 
+  // The r x n1 x n1 long-double products W_c^T T (and W_c^T T K^-1) of the next two phases depend only on (edge type c,
+  // table id): the edges of a regular grid ask for the same few again and again (1.2 s of the 1.7 s of a 4x4 / N=256
+  // setup went into recomputing them one after the other).  Collect the distinct ones, compute them on all host
+  // threads, look them up in the loops.
+  std::map<std::tuple<int, int, int>, Mat> wt_cache;  // (edge type, table id, 0: T | 1: T K^-1) -> W^T table
+  {
+    std::vector<std::tuple<int, int, int>> keys;
+    for (int e : order)
+      for (int e2 : adj[e]) {
+        if (is_pre[e2] || e2 <= e) continue;
+        const int blk = shared_block(e, e2);
+        keys.emplace_back(comp_of[e], side_of(blk, e) * 4 + side_of(blk, e2), 0);
+      }
+    for (int i = 0; i < npre; ++i) {
+      const int e = pre_list[i];
+      for (int u : adj[e]) {
+        const int blk = shared_block(e, u);
+        const int id = side_of(blk, u) * 4 + side_of(blk, e);
+        keys.emplace_back(comp_of[u], id, 0);
+        keys.emplace_back(comp_of[u], id, 1);
+        if (cpos[e] >= 0) keys.emplace_back(comp_of[e], side_of(blk, e) * 4 + side_of(blk, u), 0);
+      }
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    // the tables themselves are built lazily: make sure every one that is needed exists (distinct ids concurrently)
+    std::vector<std::pair<int, int>> tabs;
+    for (const auto& [c, id, which] : keys) tabs.emplace_back(id, which);
+    std::sort(tabs.begin(), tabs.end());
+    tabs.erase(std::unique(tabs.begin(), tabs.end()), tabs.end());
+    std::vector<std::pair<int, int>> tab_ids;  // one entry per id (with K^-1 if any key wants it): a build covers both
+    for (const auto& t : tabs) {
+      if (!tab_ids.empty() && tab_ids.back().first == t.first) tab_ids.back().second |= t.second;
+      else tab_ids.push_back(t);
+    }
+    parallel_for(tab_ids.size(), [&](size_t k) {
+      if (tab_ids[k].second) TK(tab_ids[k].first);
+      Tm(tab_ids[k].first);
+    });
+    std::vector<Mat> vals(keys.size());
+    parallel_for(keys.size(), [&](size_t k) {
+      const auto& [c, id, which] = keys[k];
+      vals[k] = hostla::mul_tn(comps[c].W, which ? TK(id) : Tm(id));
+    });
+    for (size_t k = 0; k < keys.size(); ++k) wt_cache.emplace(keys[k], std::move(vals[k]));
+  }
+  ROMHC_PHASE("blocks of the reduced matrix");
   // ---- blocks of the reduced matrix --------------------------------------------------------------------
   std::vector<Small> smalls;
   auto add_small = [&](int rpos, int cpos, const Mat& tab, int kind, std::array<int, 4> b) {
@@ -565,7 +637,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       const int blk = shared_block(e, e2);
       const int id = side_of(blk, e) * 4 + side_of(blk, e2);
       const Comp& c2 = comps[comp_of[e2]];
-      add_small(zpos[e], zpos[e2], hostla::mul(hostla::mul_tn(ce.W, Tm(id)), c2.W), 0, {blk, 0, 0, 0});
+      add_small(zpos[e], zpos[e2], hostla::mul(wt_cache.at({comp_of[e], id, 0}), c2.W), 0, {blk, 0, 0, 0});
     }
   }
   for (auto& c : xc) {
@@ -582,6 +654,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     add_small(xred[x], xred[x], one, 3, {(p - 1) * ncb + (q - 1), (p - 1) * ncb + q, p * ncb + (q - 1), p * ncb + q});
   }
 
+  ROMHC_PHASE("closed-form edges: neighbours, reduced-matrix bl");
   // ---- closed-form edges: neighbours, reduced-matrix blocks, rhs terms, back substitution ---------------------------
   std::vector<double> vecs;  // vector table
   auto push_vec = [&](const std::vector<ld>& v, int padded) {
@@ -625,11 +698,11 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       const int blk = shared_block(e, u);
       const int id = side_of(blk, u) * 4 + side_of(blk, e);
       const Comp& cu = comps[comp_of[u]];
-      Ent en{zpos[u], cu.r, blk, hostla::mul_tn(cu.W, Tm(id)), hostla::mul_tn(cu.W, TK(id))};
+      Ent en{zpos[u], cu.r, blk, wt_cache.at({comp_of[u], id, 0}), wt_cache.at({comp_of[u], id, 1})};
       ents.push_back(std::move(en));
       if (lr_e) {
         // c_e += a_blk * (W_e^T T^(e,u) P_u z_u + W_e^T T^(e,u) p0_u / s_u)
-        const Mat WT = hostla::mul_tn(cpe.W, Tm(side_of(blk, e) * 4 + side_of(blk, u)));  // r_e x n1
+        const Mat& WT = wt_cache.at({comp_of[e], side_of(blk, e) * 4 + side_of(blk, u), 0});  // r_e x n1
         const Mat Mt = hostla::transpose(hostla::mul(WT, cu.P));                           // r_u x r_e
         const int voff = push_vec(hostla::matvec(WT, cu.p0), cpe.r);
         if (!add_cterm(zpos[u], blk, Mt, voff, edges[u].b0, edges[u].b1)) { rom_set_error("internal: more than 8 neighbours of an eliminated edge"); return ROM_ERR_INVALID; }
@@ -688,6 +761,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
   f->npre = int(pre_edges.size());
 
+  ROMHC_PHASE("tile mask + symbolic fill");
   // ---- tile mask + symbolic fill --------------------------------------------------------------------
   std::vector<char> mask(size_t(T) * T, 0);
   auto M_ = [&](int i, int j) -> char& { return mask[size_t(i) * T + j]; };
@@ -733,6 +807,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     flops += (i == j) ? TB * double(TB) * TB / 3.0 : 2.0 * TB * TB * TB;  // potrf | trsm-as-gemm
   }
 
+  ROMHC_PHASE("distribute the blocks over the tiles: one 64x64 ");
   // ---- distribute the blocks over the tiles: one 64x64 table per (tile, coefficient formula) ---------------------
   std::vector<std::vector<TermAcc>> slot_terms(f->nslots);
   for (const Small& s : smalls)
@@ -810,6 +885,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   // no-op padding: term slot COEF_MAX - 1 is never a real term (its weight is 0), block 0 of the first table
   while (int(pairs.size() / 2) < f->npairs + 64) { pairs.push_back(0); pairs.push_back(COEF_MAX - 1); }
 
+  ROMHC_PHASE("block sides, vmap, parameter-independent part of");
   // ---- block sides, vmap, parameter-independent part of the reduced rhs --------------------------------------------
   std::vector<int> vmap(std::max(f->nGp, 1), -1);
   for (int e = 0; e < E; ++e) {
@@ -832,6 +908,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
   for (int x = 0; x < ncross; ++x) g_red[xred[x]] = h2;
 
+  ROMHC_PHASE("expansion tables of the active edges, back subst");
   // ---- expansion tables of the active edges, back substitution tables of the closed-form ones ------------------------
   const size_t tsz = size_t(n1p) * n1p;
   // table variants of a compressed-edge type: 0 = active edge (P, p0), 1 = closed-form edge (K^-1 W, K^-1 g)
@@ -921,6 +998,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     ROM_TRY(upload(&f->d_Bt, Bt));
   }
 
+  ROMHC_PHASE("device tables of the harmonic extension");
   // ---- device tables of the harmonic extension ---------------------------------------------------------------
   std::vector<double> Qp(size_t(n1p) * n1p, 0.0);
   for (int j = 0; j < n1; ++j)
@@ -1082,6 +1160,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   f->sw_no_fold = getenv("ROMHC_NO_FOLD_EXPAND") != nullptr;
   f->sw_ext_p = getenv("ROMHC_EXT_P") ? atoi(getenv("ROMHC_EXT_P")) : 0;
   f->sw_ext_flat = getenv("ROMHC_EXT_FLAT") ? (atoi(getenv("ROMHC_EXT_FLAT")) != 0 ? 1 : 0) : -1;
+  ROMHC_PHASE("end");
   if (getenv("ROMHC_VERBOSE")) {
     fprintf(stderr, "romhc: %dx%d blocks N=%d: %d edges (%d closed-form, %d of them compressed), reduced size %d -> %d tiles, "
                     "%d slots, %zu terms, kavg %.1f\n", nrb, ncb, N, E, int(pre_list.size()), int(pre_list.size()) - f->npre, nred, T,
@@ -1095,6 +1174,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     fprintf(stderr, "romhc:   blocks extended by the 128-tile kernel: %d, general kernel: %d\n", f->n_lr_blocks, f->n_gen_blocks);
   }
 
+  ROMHC_PHASE("work accounting of this algorithm, per snapshot ");
   // ---- work accounting of this algorithm, per snapshot solve ------------------------------------------------
   double exp_flops = 0;
   for (int e : order) exp_flops += 2.0 * n1p * double((rk[e] + BK - 1) / BK * BK);

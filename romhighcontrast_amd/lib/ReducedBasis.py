@@ -536,7 +536,8 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=6):
     if found < n:
         # complete the basis: random directions orthonormalised against the modes (CGS2); they carry no variance
         rest = n - found
-        fill = ctx.upload(np.random.default_rng(found).standard_normal((rest, dim)))
+        # (any linearly independent directions do; uniform float32 draws are 4x cheaper on the host than normal fp64 ones)
+        fill = ctx.upload(np.random.default_rng(found).random((rest, dim), dtype=np.float32).astype(np.float64) - 0.5)
         V.copy_from(fill, rest * dim, dst_off=found * dim)
         _orthonormalize_against(ctx, V, found, rest, dim)
         info["completed_modes"] = rest
