@@ -1239,49 +1239,72 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
   if (threadIdx.x < 128) scs[threadIdx.x] = my_sc;
   __syncthreads();
   STAMP(3);
-  // epilogue: add the particular solution, swap between lane pairs so that every lane owns two adjacent
-  // vertices of one 16-vertex block, 16-byte stores (see k_extend)
+  // epilogue: add the particular solution, swap between lane pairs so that every lane owns two adjacent vertices of
+  // one 16-vertex block, 16-byte stores.  The stores of a wave walk down its 64 systems four rows at a time (rows
+  // 16 i + 4 g + kq, i and g ascending): the lanes' two pointers (hp = 0, 1) advance by a constant, what a lane stores
+  // where (16-byte pair / single first vertex / -- FLAT, a pair straddling two mesh rows -- single second vertex) is
+  // decided once per tile as three lane masks per hp, and the stores are issued under those masks without branches.
   const bool odd = lane & 1;
-  // off0 / off1: positions of the lane's two vertices in a snapshot row (off1 = off0 + 1 unless the pair straddles
-  // two mesh rows, FLAT only)
-  long long off0[2], off1[2];
-  bool ok0[2], ok1[2];
+  char* sp[2];              // where the lane's next store of pair hp goes
+  long long d1[2] = {0, 0};  // (FLAT) second vertex - first vertex, bytes
+  unsigned long long k16[2], k8[2], k8b[2];
+  {
+    char* const rowp = reinterpret_cast<char*>(U) + size_t(row0 + m0 + wr * 64 + kq) * size_t(f.dim) * 8;
 #pragma unroll
-  for (int hp = 0; hp < 2; ++hp) {  // pair hp of column blocks: (0,1) and (2,3); even lanes take the first, odd the second
-    const int t = wc * 64 + (2 * hp + (odd ? 1 : 0)) * 16 + fr - (odd ? 1 : 0);  // first of the two vertices, tile-local
-    if (FLAT) {
-      const int v = vt0 + t, i0 = v / n1, j0 = v - i0 * n1;
-      off0[hp] = (long long)(p * N + i0) * f.nc + q * N + j0;
-      off1[hp] = j0 + 1 < n1 ? off0[hp] + 1 : (long long)(p * N + i0 + 1) * f.nc + q * N;
-      ok0[hp] = v < nvert;
-      ok1[hp] = v + 1 < nvert;
-    } else {
-      const int jcol = jv0 + t;  // 1-based
-      off0[hp] = (long long)(p * N + iv - 1) * f.nc + q * N - 1 + jcol;
-      off1[hp] = off0[hp] + 1;
-      ok0[hp] = jcol <= n1;
-      ok1[hp] = jcol + 1 <= n1;
+    for (int hp = 0; hp < 2; ++hp) {  // pair hp of column blocks: (0,1) and (2,3); even lanes take the first, odd the second
+      const int t = wc * 64 + (2 * hp + (odd ? 1 : 0)) * 16 + fr - (odd ? 1 : 0);  // first of the two vertices, tile-local
+      long long off0, off1;
+      bool ok0, ok1;
+      if (FLAT) {
+        const int v = vt0 + t, i0 = v / n1, j0 = v - i0 * n1;
+        off0 = (long long)(p * N + i0) * f.nc + q * N + j0;
+        off1 = j0 + 1 < n1 ? off0 + 1 : (long long)(p * N + i0 + 1) * f.nc + q * N;
+        ok0 = v < nvert;
+        ok1 = v + 1 < nvert;
+      } else {
+        const int jcol = jv0 + t;  // 1-based
+        off0 = (long long)(p * N + iv - 1) * f.nc + q * N - 1 + jcol;
+        off1 = off0 + 1;
+        ok0 = jcol <= n1;
+        ok1 = jcol + 1 <= n1;
+      }
+      const bool straddle = FLAT && off1 != off0 + 1;  // the pair lies in two mesh rows
+      k16[hp] = __builtin_amdgcn_ballot_w64(ok1 && !straddle);
+      k8[hp] = __builtin_amdgcn_ballot_w64(ok0 && (!ok1 || straddle));
+      k8b[hp] = __builtin_amdgcn_ballot_w64(ok1 && straddle);
+      sp[hp] = rowp + off0 * 8;
+      d1[hp] = (off1 - off0) * 8;
     }
   }
+  const long long step = 4ll * f.dim * 8;          // four rows down
+  const bool full = m0 + 128 <= Mc;                // all systems of the tile exist
+  const int mrow = m0 + wr * 64 + kq;              // the lane's first system
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int ml = wr * 64 + i * 16 + kq + 4 * g;
-      const int m = blockIdx.y * 128 + ml;
-      const double sc = scs[ml];
+      const double sc = scs[wr * 64 + i * 16 + kq + 4 * g];
+      unsigned long long in = ~0ull;
+      if (!full) in = __builtin_amdgcn_ballot_w64(mrow + i * 16 + 4 * g < Mc);
 #pragma unroll
       for (int hp = 0; hp < 2; ++hp) {
         const double x0 = acc[i][2 * hp][g] + sc * w_own[2 * hp], x1 = acc[i][2 * hp + 1][g] + sc * w_own[2 * hp + 1];
         const double got = lane_swap1(odd ? x0 : x1);
-        if (m >= Mc) continue;
-        double* dst = U + (row0 + m) * f.dim;
-        const double lo = odd ? got : x0, hi = odd ? x1 : got;
-        if (FLAT && ok1[hp] && off1[hp] != off0[hp] + 1) {
-          dst[off0[hp]] = lo;
-          dst[off1[hp]] = hi;
-        } else if (ok1[hp]) *reinterpret_cast<double2_u*>(dst + off0[hp]) = double2_u{lo, hi};
-        else if (ok0[hp]) dst[off0[hp]] = lo;
+        const double2_u pr = double2_u{odd ? got : x0, odd ? x1 : got};
+        const unsigned long long m16 = k16[hp] & in, m8 = k8[hp] & in, m8b = k8b[hp] & in;
+        unsigned long long sv;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx4 %2, %3, off\n\ts_mov_b64 exec, %0"
+                     : "=&s"(sv)
+                     : "s"(m16), "v"(sp[hp]), "v"(pr));
+        if (m8 != 0)  // (uniform: only the wave that holds the end of a mesh row has such lanes)
+          asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx2 %2, %3, off\n\ts_mov_b64 exec, %0"
+                       : "=&s"(sv)
+                       : "s"(m8), "v"(sp[hp]), "v"(pr.x));
+        if (FLAT && m8b != 0)
+          asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx2 %2, %3, off\n\ts_mov_b64 exec, %0"
+                       : "=&s"(sv)
+                       : "s"(m8b), "v"(sp[hp] + d1[hp]), "v"(pr.y));
+        sp[hp] += step;
       }
     }
   STAMP(4);

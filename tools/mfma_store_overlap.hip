@@ -24,7 +24,7 @@
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
 
-enum { MFMA = 0, STORE, SAME, WAVES, CUS, MFMA_HALF, STORE_HALF, SAME2, SAME2X, SAME2L, SAME2LN, SAME2E, SAME2G, SAME2GN, SAME2D };
+enum { MFMA = 0, STORE, SAME, WAVES, CUS, MFMA_HALF, STORE_HALF, SAME2, SAME2X, SAME2L, SAME2LN, SAME2E, SAME2G, SAME2GN, SAME2D, STORE_8TH };
 
 __device__ int g_data;  // 0: operands within 1e-6 of 1 (few mantissa bits toggle), 1: full mantissas
 __device__ inline double operand(int which) {
@@ -207,6 +207,9 @@ __global__ __launch_bounds__(512) void k_probe(double* U, double* sink, unsigned
     case STORE_HALF:
       if (w < 4 && cu_odd) store_loop(U, slot4, 2 * nstore);
       break;
+    case STORE_8TH:  // one CU in eight stores (its own share only): what ONE CU can push when the memory side is idle
+      if (w < 4 && ((hwid >> 8) & 7) == 0) store_loop(U, slot4, nstore);
+      break;
   }
 }
 
@@ -227,12 +230,12 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const char* names[] = {"mfma", "store", "same", "waves", "cus", "mfma/2", "store/2", "same x2", "same x2'", "x2' + LDS", "x2' LDS only", "x2' exec", "x2' + loads", "x2' loads only", "x2' + DMA"};
+  const char* names[] = {"mfma", "store", "same", "waves", "cus", "mfma/2", "store/2", "same x2", "same x2'", "x2' + LDS", "x2' LDS only", "x2' exec", "x2' + loads", "x2' loads only", "x2' + DMA", "store/8"};
   const double gflop = double(iters) * 16 * 2048 * 4 * ncu * 1e-9, mb = double(nstore) * 1024 * 4 * ncu * 1e-6;
   printf("operands: %s; ", data ? "full mantissas" : "within 1e-6 of 1");
   printf("%.2f GFLOP of fp64 MFMA, %.1f MB of stores per launch, one 256/512-thread workgroup on each of %d CUs\n", gflop, mb, ncu);
   for (int rep = 0; rep < 3; ++rep)
-    for (int mode = 0; mode < 15; ++mode) {
+    for (int mode = 0; mode < 16; ++mode) {
       float best = 1e30f;
       for (int t = 0; t < 5; ++t) {
         CK(hipEventRecord(e0));
@@ -243,7 +246,9 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         best = ms < best ? ms : best;
       }
-      if (rep == 2)
+      if (rep == 2 && mode == STORE_8TH)
+        printf("%-8s %.4f ms   (one CU in eight writes its 2.06 MB: %.1f bytes per cycle and CU at 2.4 GHz)\n", names[mode], best, mb / ncu * 1e6 / (best * 1e-3 * 2.4e9));
+      else if (rep == 2)
         printf("%-8s %.4f ms   (%5.1f TFLOP/s %s, %5.2f TB/s %s)\n", names[mode], best, gflop / best,
                mode == STORE || mode == STORE_HALF ? "-" : "mfma", mb / best * 1e-3, mode == MFMA || mode == MFMA_HALF ? "-" : "stores");
     }
