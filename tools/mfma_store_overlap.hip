@@ -12,6 +12,9 @@
 //             store issued with an exec mask from SGPRs and an empty twin, as k_extend_p does
 //   x2' + loads  same x2' with a 16-byte-per-lane global load (2 MB window, L2) per 8 MFMAs, used 8 k-steps later;
 //             `loads only`: without the stores; `+ DMA`: the loads as global_load_lds_dwordx4
+//   full A-D  x2' + DMA stepwise towards k_extend_p: 2 DMA loads per 8 MFMAs; + operands read from the DMA's LDS region;
+//             + s_barrier every 32 MFMAs; + s_waitcnt vmcnt(6) before it; E: every DMA load gathers 16 rows x 64 B (27 KB apart);
+//             F: ... out of a 32 MB table
 //   mfma/2    only the even CUs multiply (twice their share), the odd ones exit      } the two halves of `cus`
 //   store/2   only the odd CUs store (twice their share), the even ones exit         } run alone
 // One workgroup per CU (grid 256, 128 KB of LDS requested so that no two share a CU).
@@ -24,7 +27,7 @@
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
 
-enum { MFMA = 0, STORE, SAME, WAVES, CUS, MFMA_HALF, STORE_HALF, SAME2, SAME2X, SAME2L, SAME2LN, SAME2E, SAME2G, SAME2GN, SAME2D, STORE_8TH };
+enum { MFMA = 0, STORE, SAME, WAVES, CUS, MFMA_HALF, STORE_HALF, SAME2, SAME2X, SAME2L, SAME2LN, SAME2E, SAME2G, SAME2GN, SAME2D, STORE_8TH, FULL_A, FULL_B, FULL_C, FULL_D, FULL_E, FULL_F };
 
 __device__ int g_data;  // 0: operands within 1e-6 of 1 (few mantissa bits toggle), 1: full mantissas
 __device__ inline double operand(int which) {
@@ -207,6 +210,65 @@ __global__ __launch_bounds__(512) void k_probe(double* U, double* sink, unsigned
     case STORE_HALF:
       if (w < 4 && cu_odd) store_loop(U, slot4, 2 * nstore);
       break;
+    case FULL_A:    // x2' + DMA, stepwise towards the structure of k_extend_p: A = 2 DMA loads per 8 MFMAs
+    case FULL_B:    // B = A + the MFMA operands read from the LDS region the DMA writes (6 ds_read_b64 per 8 MFMAs)
+    case FULL_C:    // C = B + s_barrier every 32 MFMAs (all 8 waves)
+    case FULL_D:    // D = C + s_waitcnt vmcnt(6) before the barrier
+    case FULL_E:    // E = D with every DMA load gathering 16 rows x 64 bytes (row stride 27 KB) instead of 1 KB contiguous
+    case FULL_F: {  // F = E with the rows spread over a 32 MB table (L2 misses) instead of a 2 MB window
+      d4_t acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = d4_t{0.0, 0.0, 0.0, 0.0};
+      for (int i = threadIdx.x; i < 16384; i += 512) lds[i] = operand(i & 1);
+      __syncthreads();
+      const int it2 = iters, ns2 = nstore / 2;
+      double* p = U + ((long long)blockIdx.x * 8 + w) * (long long)ns2 * 128 + (threadIdx.x & 63) * 2;
+      const double* src = U + (1ll << 27) + ((blockIdx.x & 31) * 8 + w) * 8192 + (threadIdx.x & 63) * 2;
+      const bool gather = mode == FULL_E || mode == FULL_F;
+      // gather: lane -> row (lane >> 2), 16-byte unit (lane & 3) of a 64-byte segment; rows 3424 doubles apart
+      const double* gsrc = U + (1ll << 27) + (long long)((threadIdx.x & 63) >> 2) * 3424 + (threadIdx.x & 3) * 2 +
+                           (mode == FULL_F ? (long long)((blockIdx.x * 8 + w) & 255) * 16384 : (long long)(w & 3) * 8);
+      const unsigned ldsb = unsigned(size_t((__attribute__((address_space(3))) char*)lds)) + w * 8192;
+      const double* la = lds + (threadIdx.x & 63) * 9 + w * 1024;
+      int done = 0;
+      double a[4] = {operand(0), operand(1), operand(0), operand(1)}, b[2] = {operand(1), operand(0)};
+      for (int it = 0; it < it2; it += 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double* s0 = gather ? gsrc + ((it + r) & 63) * 8 + (mode == FULL_F ? (long long)((it >> 2) & 63) * 65536 : 0) : src + ((it + r) & 63) * 128;
+          const double* s1 = gather ? s0 + 16 * 3424 : src + ((it + r + 32) & 63) * 128;
+          asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(ldsb + (2 * r) * 1024)), "v"(s0) : "memory");
+          asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(ldsb + (2 * r + 1) * 1024)), "v"(s1) : "memory");
+          if (mode != FULL_A) {
+            const double* q = la + ((it + r) & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = q[i * 640];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = q[4096 + j * 640];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i * 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i * 2 + j], 0, 0, 0);
+          if ((r & 1) && done < ns2) {
+            const unsigned long long m16 = ~0ull;
+            unsigned long long sv;
+            const double2_u pr = double2_u{1.0 * it, 2.0};
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx4 %2, %3, off\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv) : "s"(m16), "v"(p + (long long)done * 128), "v"(pr));
+            ++done;
+          }
+        }
+        if (mode == FULL_C) asm volatile("s_barrier" ::: "memory");
+        if (mode >= FULL_D) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+      if (s == 12345.678) sink[0] = s;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      break;
+    }
     case STORE_8TH:  // one CU in eight stores (its own share only): what ONE CU can push when the memory side is idle
       if (w < 4 && ((hwid >> 8) & 7) == 0) store_loop(U, slot4, nstore);
       break;
@@ -230,12 +292,12 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const char* names[] = {"mfma", "store", "same", "waves", "cus", "mfma/2", "store/2", "same x2", "same x2'", "x2' + LDS", "x2' LDS only", "x2' exec", "x2' + loads", "x2' loads only", "x2' + DMA", "store/8"};
+  const char* names[] = {"mfma", "store", "same", "waves", "cus", "mfma/2", "store/2", "same x2", "same x2'", "x2' + LDS", "x2' LDS only", "x2' exec", "x2' + loads", "x2' loads only", "x2' + DMA", "store/8", "full A", "full B", "full C", "full D", "full E", "full F"};
   const double gflop = double(iters) * 16 * 2048 * 4 * ncu * 1e-9, mb = double(nstore) * 1024 * 4 * ncu * 1e-6;
   printf("operands: %s; ", data ? "full mantissas" : "within 1e-6 of 1");
   printf("%.2f GFLOP of fp64 MFMA, %.1f MB of stores per launch, one 256/512-thread workgroup on each of %d CUs\n", gflop, mb, ncu);
   for (int rep = 0; rep < 3; ++rep)
-    for (int mode = 0; mode < 16; ++mode) {
+    for (int mode = 0; mode < 22; ++mode) {
       float best = 1e30f;
       for (int t = 0; t < 5; ++t) {
         CK(hipEventRecord(e0));
