@@ -157,7 +157,9 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   const int t_row = f->n1 * ((f->n1 + 127) / 128), t_flat = (f->n1 * f->n1 + 127) / 128;
   const bool flat = f->sw_ext_flat >= 0 ? f->sw_ext_flat != 0 : 100 * t_flat < 97 * t_row;
   const int t128 = flat ? t_flat : t_row;
-  const bool wide = Mc >= 128 && 100 * 128 * t128 <= 102 * 64 * f->n1 * ((f->n1 + 63) / 64) && !f->sw_no_ext128;
+  // (k_extend128 addresses its table rows and interface-vector rows with 32-bit lane offsets)
+  const bool fits32 = size_t(f->n1) * f->n1 * 64 * BK * 8 < (size_t(1) << 32) && size_t(128) * f->nGp * 8 < (size_t(1) << 32);
+  const bool wide = Mc >= 128 && fits32 && 100 * 128 * t128 <= 102 * 64 * f->n1 * ((f->n1 + 63) / 64) && !f->sw_no_ext128;
 #ifdef ROMHC_EXPERIMENTAL
   // k_extend_p (rom_fem_extend_p.hip): persistent workgroups; its lane offsets are 32-bit
   const bool persistent = wide && f->sw_ext_p != 0 && size_t(f->dim) * 32 < (size_t(1) << 32) &&
