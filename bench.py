@@ -635,7 +635,22 @@ def extras_pod_c2(out, args, ctx, sm, fem, a_dev, U_loc, M, dim, blocks):
         out["pod_c3"] = pod_record(M3, dt3, sig3, dict(getattr(pod_modes, "last_info", {}),
                                    note="same algorithm and accounting on the 8192-snapshot block of config C3, generated and "
                                         "decomposed on one GPU"))
-        del X3, U3
+        # the POD's dominant kernel against the matrix peak: the Gram matrix of the (already centred / deflated) block
+        G3 = ctx.alloc(M3 * M3)
+        ctx.gram(M3, dim, X3, 0, dim, G3, 0, M3)
+        ctx.synchronize()
+        ts = []
+        for _ in range(3):
+            ctx.timer_start()
+            ctx.gram(M3, dim, X3, 0, dim, G3, 0, M3)
+            ts.append(ctx.timer_stop())
+        tg = float(np.median(ts))
+        nt = (M3 + 127) // 128
+        fl_exec = nt * (nt + 1) / 2 * 2.0 * 128 * 128 * dim
+        out["pod_c3"]["gram_kernel"] = {"ms": round(tg, 3), "achieved": round(fl_exec / tg * 1e-9, 2), "peak": FP64_MATRIX_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": round(fl_exec / tg * 1e-9 / FP64_MATRIX_PEAK_TFLOPS, 4),
+                                        "bound": "mfma", "note": "k_gram128 + finish (HIP events, median of 3), flops of the lower 128 x 128 tiles it computes"}
+        del X3, U3, G3
 
 
 def extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim):
