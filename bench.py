@@ -459,9 +459,12 @@ def main():
                         "that at the 6 TB/s a store-only kernel reaches); DESIGN.md section 5"}
     # PMC-measured memory-side traffic of the dominant kernel, if a summary of separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command is committed
-    for pmc_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    cfg_sizes = {"c2": ((2, 2), 128, 1024), "c4": ((3, 3), 171, 1024), "c5": ((4, 4), 256, 4096)}
+    pmc_files = {"c2": ("r02_pmc_traffic.json", "r01_pmc_traffic.json"), "c4": ("r02_pmc_traffic_c4.json",),
+                 "c5": ("r02_pmc_traffic_c5.json",)}
+    for pmc_name in pmc_files.get(args.config, ()):
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-        if os.path.exists(pmc_path) and (blocks, N, M) == ((2, 2), 128, 1024):
+        if os.path.exists(pmc_path) and (blocks, N, M) == cfg_sizes[args.config]:
             allk = json.load(open(pmc_path))["kernels"]
             pmc = next((v for k, v in allk.items() if dom.startswith("extend") and k.startswith("k_extend")), None) \
                 if dom.startswith("extend") else allk.get("k_" + dom)

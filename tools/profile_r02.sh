@@ -29,5 +29,14 @@ for cfg in c2 c4; do
   done
   python3 $R/tools/pmc_summary.py $O/hbm_kernels_${cfg}_FETCH_SIZE.csv $O/hbm_kernels_${cfg}_WRITE_SIZE.csv $O/hbm_kernels_${cfg}_pmc_traffic.json > /dev/null
 done
+# PMC traffic of the C4 / C5 sweeps (read by `bench.py --config c4|c5` as roofline.traffic)
+for cfg in c4 c5; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pc_$c -- python3 $R/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pc_${cfg}_$c.err
+    find $O/pc_$c -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $O/bench_${cfg}_$c.csv
+    rm -rf $O/pc_$c
+  done
+  python3 $R/tools/pmc_summary.py $O/bench_${cfg}_FETCH_SIZE.csv $O/bench_${cfg}_WRITE_SIZE.csv $O/pmc_traffic_$cfg.json > /dev/null
+done
 rm -f $O/*.err
 ls -la $O
