@@ -1236,6 +1236,14 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
 #undef X_DMA
 #undef X_NEXT_SIDE
 #undef X_FRAGS
+#ifndef ROMHC_EPI_PRIO
+#define ROMHC_EPI_PRIO 3
+#endif
+  // The epilogue runs at raised wave priority: while one workgroup of a CU stores and the other multiplies, neither
+  // makes full progress (tools/mfma_store_overlap.hip, `waves`); letting the stores go first shortens that phase
+  // (C2: 0.234 -> 0.220 ms; the other way round, priority to the k loop: 0.243 ms; priority to the prologue as
+  // well: 0.237 ms; profiles/r02_extend128_wave_priority_ab.txt).
+  __builtin_amdgcn_s_setprio(ROMHC_EPI_PRIO);
   if (threadIdx.x < 128) scs[threadIdx.x] = my_sc;
   __syncthreads();
   STAMP(3);
