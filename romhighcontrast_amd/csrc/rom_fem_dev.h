@@ -102,7 +102,7 @@ struct X128Args {
   BlockSide sides[X128_BLOCKS];
 };
 
-template <bool FLAT>
+template <bool FLAT, int NW>
 __global__ void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, int with_expand);
 // value of the neighbouring lane (lane ^ 1), by DPP quad permutation
 __device__ inline double lane_swap1(double v) {

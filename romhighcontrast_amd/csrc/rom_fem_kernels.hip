@@ -218,7 +218,7 @@ __device__ inline void expand_tile(const FemDev& f, int Mc, double* __restrict__
                                    int bx, int by, int bz) {
   if (bz == f.nexp) {
     if (bx != 0) return;
-    for (int idx = threadIdx.x; idx < 64 * f.nscat; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < 64 * f.nscat; idx += 256) {  // (four waves, whatever the launch has)
       const int m = by * 64 + idx / f.nscat, v = f.scat[idx % f.nscat];
       if (m < Mc) U[(row0 + m) * f.dim + f.vmap[v]] = f.y[size_t(m) * f.nGp + v];
     }
@@ -305,19 +305,14 @@ __global__ __launch_bounds__(256) void k_back_pre(FemDev f, const double* __rest
 // Diagonal tile j, step 1 of 3 (MFMA): C = S_jj - sum_k L_jk L_jk^T, written to the tile's L slot.
 // Only the lower triangle is consumed by the factorisation: the wave owning the upper-right
 // quadrant skips its MFMAs.
-__global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __restrict__ a, int slot) {
-  // 36.9 KB: four workgroups per CU, i.e. all 1024 systems of a C2 step resident in one round
-  __shared__ __align__(16) double lds[STAGE_TOTAL];
-  __shared__ int kp[2 * KP_MAX];
-  __shared__ double coef[COEF_MAX];
+__device__ inline void diag_update_body(const FemDev& f, const double* __restrict__ am, int m, int slot, double* lds, int* kp,
+                                        double* coef) {
   double* stB = lds;
   double* stA = lds + 2 * STAGE_DOUBLES;
   double* Cb = lds;  // the C tile aliases the whole staging area (used after the k-loop only)
   static_assert(TILE_DOUBLES <= STAGE_TOTAL, "C tile must fit in the staging area");
-  const int m = blockIdx.x;
   const WavePos wp;
   const TileDesc& d = f.desc[slot];
-  const double* am = a + size_t(m) * f.kblk;
   double* Lm = f.L + size_t(m) * f.nslots * 4096;
   STile st;
   s_tile_load(st, d, f, am, coef);  // table reads fly under the MFMAs below
@@ -328,6 +323,13 @@ __global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __r
   tile_from_acc(Cb, acc, st, wp);
   double* Lout = Lm + size_t(slot) * 4096;
   for (int idx = threadIdx.x; idx < 4096; idx += 256) Lout[idx] = Cb[(idx >> 6) * LDC + (idx & 63)];
+}
+__global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __restrict__ a, int slot) {
+  // 36.9 KB: four workgroups per CU, i.e. all 1024 systems of a C2 step resident in one round
+  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  __shared__ int kp[2 * KP_MAX];
+  __shared__ double coef[COEF_MAX];
+  diag_update_body(f, a + size_t(blockIdx.x) * f.kblk, blockIdx.x, slot, lds, kp, coef);
 }
 
 // 1/sqrt(d) for a positive normal d: hardware seed (v_rsq_f64, ~2^-26 relative error) + two Newton
@@ -355,11 +357,9 @@ __device__ inline double readlane_f64(double v, int lane) {
 //   in-place triangular inverse (lane = (block, row), its row of X in registers, the untouched columns of L
 //   broadcast from LDS), the six blocks below them as  X_ij = -sum_{k=j+1..i} X_ik (L_kj X_jj)  on MFMA.
 // (A column-by-column version on the vector pipe, two kernels, took 2 x 32 us per 1024 systems against 33 us.)
-__global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
-  __shared__ __align__(16) double Ls[64 * LDC];
-  __shared__ __align__(16) double Pn[64 * 4];
-  __shared__ double rinv[64];
-  const int m = blockIdx.x, lane = threadIdx.x;
+// (one wave; Ls: 64 * LDC, Pn: 256, rinv: 64 doubles of LDS; the only synchronisation is between the lanes of the wave)
+__device__ inline void diag_factor_body(const FemDev& f, int m, int slot, int j, double* Ls, double* Pn, double* rinv) {
+  const int lane = threadIdx.x & 63;
   const int l16 = lane & 15, l4 = lane >> 4;
   double* Lt = f.L + (size_t(m) * f.nslots + slot) * 4096;
   // the lower blocks of the (symmetric) tile in accumulator layout; only its lower triangle is valid in memory
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
   if (bad && lane == 0) atomicOr(f.status, 1);
   f.y[size_t(m) * f.nGp + j * 64 + lane] = y;
   rinv[lane] = myrs;  // 1 / L[lane][lane]
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   // L (lower, zero above the diagonal) to HBM, coalesced
   for (int i = 0; i < 64; ++i) Lt[i * 64 + lane] = Ls[i * LDC + lane];
   // ---- X = L^-1 in place ----
@@ -498,9 +498,14 @@ __global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
       for (int g = 0; g < 4; ++g) Ls[(16 * ib + 4 * g + l4) * LDC + 16 * jb + l16] = X[ib][g];
     __builtin_amdgcn_wave_barrier();
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   double* It = f.invL + (size_t(m) * f.T + j) * 4096;
   for (int i = 0; i < 64; ++i) It[i * 64 + lane] = Ls[i * LDC + lane];
+}
+constexpr int DIAGF_LDS_DOUBLES = 64 * LDC + 64 * 4 + 64;
+__global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
+  __shared__ __align__(16) double lds[DIAGF_LDS_DOUBLES];
+  diag_factor_body(f, blockIdx.x, slot, j, lds, lds + 64 * LDC, lds + 64 * LDC + 256);
 }
 
 #ifdef ROMHC_STAMPS
@@ -746,36 +751,15 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
 // Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;
 // y_i -= L_ij y_j.  invL_jj is lower triangular: the waves owning output columns 0..31 only need
 // k < 32 of the second product.
-__global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc) {
-  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];
-  __shared__ int kp[2 * KP_MAX];
-  __shared__ double yj[64];
-  __shared__ double coef[COEF_MAX];
+__device__ inline void panel_body(const FemDev& f, const double* __restrict__ am, int m, int j, int ent, double* lds, int* kp,
+                                  double* yj, double* coef) {
   double* stB = lds;
   double* stA = lds + 2 * STAGE_DOUBLES;
   double* Cb = lds + 2 * STAGE_DOUBLES;
-  // XCD-aware mapping: block ids are dealt round-robin to the 8 XCDs (each with its own L2); all row
-  // tiles of one system are given ids of the same residue mod 8 so that the L_jk / invL_jj tiles they
-  // share are served by one L2.  (Placement only affects speed, never correctness.)
-  const int nrows = f.colptr[j + 1] - f.colptr[j];
-  int m, row;
-  {
-    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-    const int full = (Mc >> 3) << 3;  // systems covered by complete groups of 8
-    m = xcd + 8 * (idx / nrows);
-    row = idx % nrows;
-    if (m >= full) {  // ragged tail (Mc % 8 systems): plain order
-      const int tb = b - full * nrows;
-      m = full + tb / nrows;
-      row = tb % nrows;
-    }
-  }
-  const int ent = f.colptr[j] + row;
   const int slot = f.colrow[ent];
   const int ti = f.colti[ent];
   const WavePos wp;
   const TileDesc& d = f.desc[slot];
-  const double* am = a + size_t(m) * f.kblk;
   double* Lm = f.L + size_t(m) * f.nslots * 4096;
   const int t = threadIdx.x;
   STile st;
@@ -811,6 +795,31 @@ __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __
     for (int k = 0; k < 64; ++k) s += Cb[t * LDC + k] * yj[k];
     f.y[size_t(m) * f.nGp + ti * 64 + t] -= s;
   }
+}
+
+// XCD-aware mapping of (system, row of the column) for `nrows` row tiles per system: block ids are dealt round-robin
+// to the 8 XCDs (each with its own L2); all row tiles of one system are given ids of the same residue mod 8 so that
+// the L_jk / invL_jj tiles they share are served by one L2.  (Placement only affects speed, never correctness.)
+__device__ inline void panel_block(int b, int nrows, int Mc, int& m, int& row) {
+  const int xcd = b & 7, idx = b >> 3;
+  const int full = (Mc >> 3) << 3;  // systems covered by complete groups of 8
+  m = xcd + 8 * (idx / nrows);
+  row = idx % nrows;
+  if (m >= full) {  // ragged tail (Mc % 8 systems): plain order
+    const int tb = b - full * nrows;
+    m = full + tb / nrows;
+    row = tb % nrows;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc) {
+  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];
+  __shared__ int kp[2 * KP_MAX];
+  __shared__ double yj[64];
+  __shared__ double coef[COEF_MAX];
+  int m, row;
+  panel_block(blockIdx.x, f.colptr[j + 1] - f.colptr[j], Mc, m, row);
+  panel_body(f, a + size_t(m) * f.kblk, m, j, f.colptr[j] + row, lds, kp, yj, coef);
 }
 
 // x = L^{-T} y, one workgroup per system, x kept in LDS, written back over y
@@ -1020,6 +1029,23 @@ extern "C" int rom_debug_stamps_clear() {
 #else
 #define STAMP(i)
 #endif
+// -DROMHC_STAMPS_WAIT (with ROMHC_STAMPS): column 1 of a workgroup's stamps holds, instead of a time, the cycles its
+// wave 0 spent in the k loop's `s_waitcnt vmcnt(0); s_barrier` (how far the loop is bound by the latency of its loads)
+#if defined(ROMHC_STAMPS) && defined(ROMHC_STAMPS_WAIT)
+#define WAIT_BEGIN() const unsigned long long wt0_ = __builtin_readcyclecounter()
+#define WAIT_END() wait_cycles += __builtin_readcyclecounter() - wt0_
+#define WAIT_STORE()                                                                                            \
+  do {                                                                                                         \
+    if (threadIdx.x == 0) {                                                                                    \
+      const unsigned lin_ = __builtin_amdgcn_readfirstlane(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
+      if (lin_ < 16384u) g_stamps[lin_ * 6 + 1] = wait_cycles;                                                 \
+    }                                                                                                          \
+  } while (0)
+#else
+#define WAIT_BEGIN()
+#define WAIT_END()
+#define WAIT_STORE()
+#endif
 
 // The same extension for blocks whose sides are all compressed, with 128 x 128 workgroup tiles (128 systems x
 // one mesh row of up to 128 interior vertices; every wave a 64 x 64 quadrant = 4 x 4 MFMA accumulators): K is
@@ -1031,6 +1057,11 @@ __device__ inline const char* x128_uniform(const char* p) {
   const unsigned long long v = reinterpret_cast<unsigned long long>(p);
   const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
   return reinterpret_cast<const char*>((unsigned long long)hi << 32 | lo);
+}
+
+__device__ inline unsigned long long x128_uniform(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
+  return (unsigned long long)hi << 32 | lo;
 }
 
 // Main loop (round 2, after the Gram kernel): the K chunks of both operands go from global memory straight into
@@ -1046,8 +1077,8 @@ constexpr int X128_SLOT = 4 * 128 * 64;  // bytes
 // FLAT: the 128 vertices of a tile are consecutive in the block's row-major vertex numbering instead of lying in
 // one mesh row -- no padding when n1 is not close to a multiple of 128 (n1 = 170: 226 tiles per block instead of
 // 340); a pair of adjacent vertices may then straddle two mesh rows and is stored as two 8-byte halves.
-template <bool FLAT>
-__global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc,
+template <bool FLAT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc,
                                                       double* __restrict__ U, long long row0, int with_expand) {
   __shared__ __align__(16) char lds_bytes[2 * X128_SLOT];  // two chunk slots = 65,536 B: two workgroups per CU
   __shared__ double scs[128];                               // h^2 / a_b of the workgroup's systems
@@ -1062,6 +1093,7 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
     static_assert(STAGE_TOTAL * sizeof(double) <= 2 * X128_SLOT, "expansion staging must fit");
     const int nx = f.n1p / 64, ny = (Mc + 63) / 64;
     const int item = (blockIdx.x - ntile) + with_expand * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (NW > 4 && threadIdx.x >= 256) return;  // (the expansion is written for four waves)
     if (item < nx * ny * (f.nexp + 1)) expand_tile(f, Mc, U, row0, lds, item % nx, (item / nx) % ny, item / (nx * ny));
     return;
   }
@@ -1082,7 +1114,8 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
   const int iv = blockIdx.x / nct + 1;           // mesh row (1-based interior index)       (!FLAT)
   const int jv0 = 128 * (blockIdx.x % nct) + 1;  // first vertex of the tile                (!FLAT)
   const int vt0 = 128 * blockIdx.x;              // first vertex of the tile, block-local   (FLAT)
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = w >> 1, wc = w & 1;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = NW == 8 ? w >> 2 : w >> 1, wc = NW == 8 ? w & 3 : w & 1;
+  constexpr int NJ = 16 / NW;   // 16-vertex column blocks per wave: 4 (wave tile 64 x 64) or 2 (64 x 32)
   const int fr = lane & 15, kq = lane >> 4;
   double my_sc = 0.0;  // h^2 / a_b of system threadIdx.x: requested now, parked in LDS after the k loop
   if (threadIdx.x < 128) {
@@ -1091,14 +1124,14 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
   }
   // everything the epilogue needs from memory is fetched before the first store: a load after a store would
   // make its s_waitcnt vmcnt wait for the stores as well (one counter, in order)
-  double w_own[4];
+  double w_own[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     if (FLAT) {
-      const int v = vt0 + wc * 64 + j * 16 + fr;
+      const int v = vt0 + wc * (16 * NJ) + j * 16 + fr;
       w_own[j] = v < nvert ? f.W[v] : 0.0;
     } else {
-      const int jj = jv0 + wc * 64 + j * 16 + fr;  // 1-based
+      const int jj = jv0 + wc * (16 * NJ) + j * 16 + fr;  // 1-based
       w_own[j] = jj <= n1 ? f.W[(iv - 1) * n1 + (jj - 1)] : 0.0;
     }
   }
@@ -1121,11 +1154,9 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
   do {                                                                                                             \
     const char* pf_ = lds_bytes + (SLOT_) * X128_SLOT + (((KKI_)&1) ? fa1 : fa0);                                  \
     const char* pa_ = pf_ + ((KKI_) >> 1) * 8192 + wr * 4096;                                                      \
-    const char* pb_ = pf_ + 16384 + ((KKI_) >> 1) * 8192 + wc * 4096;                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                             \
-      AF_[i_] = *reinterpret_cast<const double*>(pa_ + i_ * 1024);                                                 \
-      BF_[i_] = *reinterpret_cast<const double*>(pb_ + i_ * 1024);                                                 \
-    }                                                                                                              \
+    const char* pb_ = pf_ + 16384 + ((KKI_) >> 1) * 8192 + wc * (1024 * NJ);                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) AF_[i_] = *reinterpret_cast<const double*>(pa_ + i_ * 1024);  \
+    _Pragma("unroll") for (int i_ = 0; i_ < NJ; ++i_) BF_[i_] = *reinterpret_cast<const double*>(pb_ + i_ * 1024); \
   } while (0)
   // ---- DMA addressing: a wave fetches rows 32 w .. 32 w + 31 of both operands, 16 rows of one half per instruction:
   // lane -> row 32 w + 16 g + (lane >> 2), stored unit lane & 3 = logical unit (lane & 3) ^ ((lane >> 4) & 3)
@@ -1137,7 +1168,7 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
   int vi[2], vj[2];            // the lanes' vertices (1-based) in the wave's two B row groups
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
-    const int rl = 32 * w + 16 * g + (lane >> 2);
+    const int rl = 32 * (w & 3) + 16 * g + (lane >> 2);
     voA[g] = unsigned(max(0, min(rl, Mc - 1 - m0))) * ybytes_row + du16;
     if (FLAT) {
       const int v = min(vt0 + rl, nvert - 1);
@@ -1180,44 +1211,47 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
                "v"(VOFF_), "s"(x128_uniform(BASE_))                                                                \
                : "memory")
   // the 4 loads of the segment under the cursor into half H_ of slot SLOT_, then the cursor moves on
-#define X_ISSUE_HALF(SLOT_, H_)                                                                                    \
+#define X_ISSUE_HALF(SLOT_, H_, MINE_)                                                                             \
   do {                                                                                                             \
-    const unsigned sb_ = lds0 + unsigned(SLOT_) * X128_SLOT + (H_) * 8192 + unsigned(w) * 2048;                    \
+    const unsigned sb_ = lds0 + unsigned(SLOT_) * X128_SLOT + (H_) * 8192 + unsigned(w & 3) * 2048;                \
     if (c_segs > 0) {                                                                                              \
-      X_DMA(sb_, pA, voA[0]);                                                                                      \
-      X_DMA(sb_ + 1024, pA, voA[1]);                                                                               \
-      X_DMA(sb_ + 16384, pB, voB[0]);                                                                              \
-      X_DMA(sb_ + 16384 + 1024, pB, voB[1]);                                                                       \
+      if (MINE_) {                                                                                                 \
+        X_DMA(sb_, pA, voA[0]);                                                                                    \
+        X_DMA(sb_ + 1024, pA, voA[1]);                                                                             \
+        X_DMA(sb_ + 16384, pB, voB[0]);                                                                            \
+        X_DMA(sb_ + 16384 + 1024, pB, voB[1]);                                                                     \
+      }                                                                                                            \
       pA += 64;                                                                                                    \
       pB += 64;                                                                                                    \
       --c_segs;                                                                                                    \
       if (--c_left == 0 && c_segs > 0) X_NEXT_SIDE();                                                              \
-    } else { /* zeros: the odd half of the last chunk */                                                           \
+    } else if (MINE_) { /* zeros: the odd half of the last chunk */                                                \
       X_DMA(sb_, zbase, voZ);                                                                                      \
       X_DMA(sb_ + 1024, zbase, voZ);                                                                               \
       X_DMA(sb_ + 16384, zbase, voZ);                                                                              \
       X_DMA(sb_ + 16384 + 1024, zbase, voZ);                                                                       \
     }                                                                                                              \
   } while (0)
-  d4_t acc[4][4];
+  [[maybe_unused]] unsigned long long wait_cycles = 0;
+  d4_t acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-  STAMP(1);
+    for (int j = 0; j < NJ; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
   if (tot > 0) {
     X_NEXT_SIDE();
-    X_ISSUE_HALF(0, 0);
-    X_ISSUE_HALF(0, 1);
+    X_ISSUE_HALF(0, 0, NW == 4 || w < 4);
+    X_ISSUE_HALF(0, 1, NW == 4 || w < 4);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     STAMP(2);
-    double af[2][4], bf[2][4];
+    double af[2][4], bf[2][NJ];
     X_FRAGS(0, 0, af[0], bf[0]);
     for (int ch = 0; ch < tot; ++ch) {
       const int slot = ch & 1;
       if (ch + 1 < tot) {  // (everybody left that slot at the barrier behind chunk ch - 1)
-        X_ISSUE_HALF(slot ^ 1, 0);
-        X_ISSUE_HALF(slot ^ 1, 1);
+        const bool mine = NW == 4 || (w >> 2) == ((ch + 1) & 1);
+        X_ISSUE_HALF(slot ^ 1, 0, mine);
+        X_ISSUE_HALF(slot ^ 1, 1, mine);
       }
 #pragma unroll
       for (int kki = 0; kki < 4; ++kki) {
@@ -1226,9 +1260,13 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][i], bf[pb][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][i], bf[pb][j], acc[i][j], 0, 0, 0);
       }
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // chunk ch + 1 is in LDS for everybody
+      {
+        WAIT_BEGIN();
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // chunk ch + 1 is in LDS for everybody
+        WAIT_END();
+      }
       if (ch + 1 < tot) X_FRAGS(slot ^ 1, 0, af[0], bf[0]);
     }
   }
@@ -1243,6 +1281,7 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
   // makes full progress (tools/mfma_store_overlap.hip, `waves`); letting the stores go first shortens that phase
   // (C2: 0.234 -> 0.220 ms; the other way round, priority to the k loop: 0.243 ms; priority to the prologue as
   // well: 0.237 ms; profiles/r02_extend128_wave_priority_ab.txt).
+  WAIT_STORE();
   __builtin_amdgcn_s_setprio(ROMHC_EPI_PRIO);
   if (threadIdx.x < 128) scs[threadIdx.x] = my_sc;
   __syncthreads();
@@ -1253,14 +1292,15 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
   // where (16-byte pair / single first vertex / -- FLAT, a pair straddling two mesh rows -- single second vertex) is
   // decided once per tile as three lane masks per hp, and the stores are issued under those masks without branches.
   const bool odd = lane & 1;
-  char* sp[2];              // where the lane's next store of pair hp goes
-  long long d1[2] = {0, 0};  // (FLAT) second vertex - first vertex, bytes
-  unsigned long long k16[2], k8[2], k8b[2];
+  constexpr int NHP = NJ / 2;
+  char* sp[NHP];            // where the lane's next store of pair hp goes
+  long long d1[NHP] = {};  // (FLAT) second vertex - first vertex, bytes
+  unsigned long long k16[NHP], k8[NHP], k8b[NHP];
   {
     char* const rowp = reinterpret_cast<char*>(U) + size_t(row0 + m0 + wr * 64 + kq) * size_t(f.dim) * 8;
 #pragma unroll
-    for (int hp = 0; hp < 2; ++hp) {  // pair hp of column blocks: (0,1) and (2,3); even lanes take the first, odd the second
-      const int t = wc * 64 + (2 * hp + (odd ? 1 : 0)) * 16 + fr - (odd ? 1 : 0);  // first of the two vertices, tile-local
+    for (int hp = 0; hp < NHP; ++hp) {  // pair hp of column blocks: (0,1) and (2,3); even lanes take the first, odd the second
+      const int t = wc * (16 * NJ) + (2 * hp + (odd ? 1 : 0)) * 16 + fr - (odd ? 1 : 0);  // first of the two vertices, tile-local
       long long off0, off1;
       bool ok0, ok1;
       if (FLAT) {
@@ -1295,11 +1335,11 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
       unsigned long long in = ~0ull;
       if (!full) in = __builtin_amdgcn_ballot_w64(mrow + i * 16 + 4 * g < Mc);
 #pragma unroll
-      for (int hp = 0; hp < 2; ++hp) {
+      for (int hp = 0; hp < NHP; ++hp) {
         const double x0 = acc[i][2 * hp][g] + sc * w_own[2 * hp], x1 = acc[i][2 * hp + 1][g] + sc * w_own[2 * hp + 1];
         const double got = lane_swap1(odd ? x0 : x1);
         const double2_u pr = double2_u{odd ? got : x0, odd ? x1 : got};
-        const unsigned long long m16 = k16[hp] & in, m8 = k8[hp] & in, m8b = k8b[hp] & in;
+        const unsigned long long m16 = x128_uniform(k16[hp] & in), m8 = x128_uniform(k8[hp] & in), m8b = x128_uniform(k8b[hp] & in);
         unsigned long long sv;
         asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx4 %2, %3, off\n\ts_mov_b64 exec, %0"
                      : "=&s"(sv)
@@ -1317,8 +1357,10 @@ __global__ __launch_bounds__(256, 2) void k_extend128(FemDev f, X128Args xa, con
     }
   STAMP(4);
 }
-template __global__ void k_extend128<false>(FemDev, X128Args, const double*, int, double*, long long, int);
-template __global__ void k_extend128<true>(FemDev, X128Args, const double*, int, double*, long long, int);
+template __global__ void k_extend128<false, 4>(FemDev, X128Args, const double*, int, double*, long long, int);
+template __global__ void k_extend128<true, 4>(FemDev, X128Args, const double*, int, double*, long long, int);
+template __global__ void k_extend128<false, 8>(FemDev, X128Args, const double*, int, double*, long long, int);
+template __global__ void k_extend128<true, 8>(FemDev, X128Args, const double*, int, double*, long long, int);
 
 // interface values that k_expand does not write: cross points and the edges recovered node by node
 __global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0) {

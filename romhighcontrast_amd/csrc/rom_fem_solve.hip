@@ -233,8 +233,18 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
 #endif
             const int extra = fold_expand && z0 == 0 ? (items + mt * nz - 1) / (mt * nz) : 0;
             dim3 grid(t128 + extra, mt, nz);
-            if (flat) k_extend128<true><<<grid, 256, 0, st>>>(d, xa, am, Mc, U, row, extra);
-            else k_extend128<false><<<grid, 256, 0, st>>>(d, xa, am, Mc, U, row, extra);
+#ifdef ROMHC_STAMPS  // (timeline builds: ROMHC_EXT_LDS_PAD = unused dynamic LDS per workgroup, to run one workgroup per CU)
+            static const size_t pad = getenv("ROMHC_EXT_LDS_PAD") ? size_t(atoi(getenv("ROMHC_EXT_LDS_PAD"))) : 0;
+#else
+            constexpr size_t pad = 0;
+#endif
+            if (f->sw_ext_w8) {
+              if (flat) k_extend128<true, 8><<<grid, 512, pad, st>>>(d, xa, am, Mc, U, row, extra);
+              else k_extend128<false, 8><<<grid, 512, pad, st>>>(d, xa, am, Mc, U, row, extra);
+            } else {
+              if (flat) k_extend128<true, 4><<<grid, 256, pad, st>>>(d, xa, am, Mc, U, row, extra);
+              else k_extend128<false, 4><<<grid, 256, pad, st>>>(d, xa, am, Mc, U, row, extra);
+            }
           }
         } else {
           dim3 grid(f->n1 * ((f->n1 + 63) / 64), (Mc + 63) / 64, f->n_lr_blocks);

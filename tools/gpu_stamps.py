@@ -30,12 +30,20 @@ t = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 6).astype(np.int64)
 t = t[(t[:, 4] > t[:, 0]) & (t[:, 0] > 0)]
 hw = t[:, 5]
 cu = ((hw >> 16) & 0xf) * 4096 + ((hw >> 13) & 7) * 256 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xf)  # xcc, se, sh, cu
+waitcol = os.environ.get("WAITCOL")  # library built with -DROMHC_STAMPS_WAIT: column 1 = cycles in the k loop's waits
+if waitcol:
+    wait = t[:, 1].copy()
+    t[:, 1] = t[:, 0]
 d = np.diff(t[:, :5], axis=1)
 names = ["entry -> first loads issued", "-> first barrier passed", "-> k loop done", "-> stores issued (end)"]
 life = t[:, 4] - t[:, 0]
 print(f"{len(t)} workgroups on {len(np.unique(cu))} CUs, launch {ms * 1e3:.1f} us; lifetime mean {life.mean():.0f} cycles, median {np.median(life):.0f}")
 for i, nm in enumerate(names):
     print(f"  {nm:32s} mean {d[:, i].mean():8.0f}  median {np.median(d[:, i]):8.0f}  p10 {np.percentile(d[:, i], 10):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
+if waitcol:
+    kl = t[:, 3] - t[:, 2]
+    print(f"  k loop {kl.mean():.0f} cycles, of which wave 0 waits for loads + barrier: mean {wait.mean():.0f}  median {np.median(wait):.0f}  "
+          f"p10 {np.percentile(wait, 10):.0f}  p90 {np.percentile(wait, 90):.0f}  ({wait.sum() / kl.sum():.2f} of the k loop)")
 # per-CU timelines: how much of a CU's span has 0 / 1 / >= 2 workgroups inside the k loop, and the gap between a
 # workgroup's last stamp and the entry of the workgroup that takes its place
 kcover = np.zeros(4)

@@ -27,7 +27,7 @@
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
 
-enum { MFMA = 0, STORE, SAME, WAVES, CUS, MFMA_HALF, STORE_HALF, SAME2, SAME2X, SAME2L, SAME2LN, SAME2E, SAME2G, SAME2GN, SAME2D, STORE_8TH, FULL_A, FULL_B, FULL_C, FULL_D, FULL_E, FULL_F };
+enum { MFMA = 0, STORE, SAME, WAVES, CUS, MFMA_HALF, STORE_HALF, SAME2, SAME2X, SAME2L, SAME2LN, SAME2E, SAME2G, SAME2GN, SAME2D, STORE_8TH, FULL_A, FULL_B, FULL_C, FULL_D, FULL_E, FULL_F, WAVES_PS, WAVES_PM, WAVES_SW, WAVES_SWP, WAVES_NV, WAVES_NVP };
 
 __device__ int g_data;  // 0: operands within 1e-6 of 1 (few mantissa bits toggle), 1: full mantissas
 __device__ inline double operand(int which) {
@@ -39,10 +39,12 @@ __device__ inline void mfma_loop(int iters, double* sink) {
   d4_t acc[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = d4_t{0.0, 0.0, 0.0, 0.0};
+  const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
   }
+  if (threadIdx.x == 0 && blockIdx.x == 7) sink[1] = double(__builtin_readcyclecounter() - t0) / (16.0 * iters);  // counter ticks per MFMA
   double s = 0.0;
 #pragma unroll
   for (int j = 0; j < 16; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
@@ -198,6 +200,31 @@ __global__ __launch_bounds__(512) void k_probe(double* U, double* sink, unsigned
       if (w < 4) mfma_loop(iters, sink);
       else store_loop(U, slot4, nstore);
       break;
+    case WAVES_PS:  // ... the storing waves at raised priority
+      if (w < 4) mfma_loop(iters, sink);
+      else { __builtin_amdgcn_s_setprio(3); store_loop(U, slot4, nstore); }
+      break;
+    case WAVES_PM:  // ... the multiplying waves at raised priority
+      if (w < 4) { __builtin_amdgcn_s_setprio(3); mfma_loop(iters, sink); }
+      else store_loop(U, slot4, nstore);
+      break;
+    case WAVES_SW:   // roles swapped: waves 0-3 (the older ones) store
+    case WAVES_SWP:  // ... and the multiplying waves at raised priority
+      if (w >= 4) { if (mode == WAVES_SWP) __builtin_amdgcn_s_setprio(3); mfma_loop(iters, sink); }
+      else store_loop(U, slot4, nstore);
+      break;
+    case WAVES_NV:   // stores with immediate offsets: one address update per four stores (little VALU work)
+    case WAVES_NVP:  // ... at raised priority
+      if (w < 4) mfma_loop(iters, sink);
+      else {
+        if (mode == WAVES_NVP) __builtin_amdgcn_s_setprio(3);
+        double* p = U + slot4 * (long long)nstore * 128 + (threadIdx.x & 63) * 2;
+        const double2_u v = double2_u{1.0, 2.0};
+        for (int i = 0; i < nstore; i += 4, p += 512)
+          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %1, off offset:1024\n\t"
+                       "global_store_dwordx4 %0, %1, off offset:2048\n\tglobal_store_dwordx4 %0, %1, off offset:3072" ::"v"(p), "v"(v) : "memory");
+      }
+      break;
     case CUS:
       if (w < 4) {
         if (cu_odd) store_loop(U, slot4, 2 * nstore);
@@ -292,12 +319,12 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const char* names[] = {"mfma", "store", "same", "waves", "cus", "mfma/2", "store/2", "same x2", "same x2'", "x2' + LDS", "x2' LDS only", "x2' exec", "x2' + loads", "x2' loads only", "x2' + DMA", "store/8", "full A", "full B", "full C", "full D", "full E", "full F"};
+  const char* names[] = {"mfma", "store", "same", "waves", "cus", "mfma/2", "store/2", "same x2", "same x2'", "x2' + LDS", "x2' LDS only", "x2' exec", "x2' + loads", "x2' loads only", "x2' + DMA", "store/8", "full A", "full B", "full C", "full D", "full E", "full F", "waves, store prio", "waves, mfma prio", "waves swapped", "swapped, mfma prio", "waves, imm stores", "imm stores, prio"};
   const double gflop = double(iters) * 16 * 2048 * 4 * ncu * 1e-9, mb = double(nstore) * 1024 * 4 * ncu * 1e-6;
   printf("operands: %s; ", data ? "full mantissas" : "within 1e-6 of 1");
   printf("%.2f GFLOP of fp64 MFMA, %.1f MB of stores per launch, one 256/512-thread workgroup on each of %d CUs\n", gflop, mb, ncu);
   for (int rep = 0; rep < 3; ++rep)
-    for (int mode = 0; mode < 22; ++mode) {
+    for (int mode = 0; mode < 28; ++mode) {
       float best = 1e30f;
       for (int t = 0; t < 5; ++t) {
         CK(hipEventRecord(e0));
@@ -311,9 +338,22 @@ int main(int argc, char** argv) {
       if (rep == 2 && mode == STORE_8TH)
         printf("%-8s %.4f ms   (one CU in eight writes its 2.06 MB: %.1f bytes per cycle and CU at 2.4 GHz)\n", names[mode], best, mb / ncu * 1e6 / (best * 1e-3 * 2.4e9));
       else if (rep == 2)
-        printf("%-8s %.4f ms   (%5.1f TFLOP/s %s, %5.2f TB/s %s)\n", names[mode], best, gflop / best,
+        printf("%-20s %.4f ms   (%5.1f TFLOP/s %s, %5.2f TB/s %s)\n", names[mode], best, gflop / best,
                mode == STORE || mode == STORE_HALF ? "-" : "mfma", mb / best * 1e-3, mode == MFMA || mode == MFMA_HALF ? "-" : "stores");
     }
+  CK(hipMemset(sink, 0, 64));
+  CK(hipEventRecord(e0));
+  k_probe<<<ncu, 512, 128 * 1024>>>(U, sink, nullptr, MFMA, iters, nstore);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  {
+    float ms;
+    double hs[2];
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(hs, sink, 16, hipMemcpyDeviceToHost));
+    printf("mfma alone: %.2f ticks of the cycle counter (s_memtime) per MFMA in one wave; the launch took %.1f us = %.1f ns per MFMA of a wave\n",
+           hs[1], ms * 1e3, ms * 1e6 / (16.0 * iters));
+  }
   unsigned h[2];
   CK(hipMemcpy(h, cnt, 8, hipMemcpyDeviceToHost));
   printf("workgroups on CUs with even / odd CU_ID: %u / %u\n", h[0], h[1]);
