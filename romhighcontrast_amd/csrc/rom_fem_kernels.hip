@@ -138,6 +138,116 @@ __device__ inline void accumulate_klist(const FemDev& f, int slot, const double*
   }
 }
 
+// a pointer that is the same in every lane, in scalar registers whatever the compiler thinks of it
+__device__ inline const char* x128_uniform(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
+  return reinterpret_cast<const char*>((unsigned long long)hi << 32 | lo);
+}
+__device__ inline unsigned long long x128_uniform(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
+  return (unsigned long long)hi << 32 | lo;
+}
+
+// The same sum with the operand chunks going from global memory straight into LDS (global_load_lds_dwordx4, the main
+// loop of k_gram128 / k_extend128 at 64 x 64): no staging registers, no ds_write.  A chunk = 16 k of both tiles =
+// {A 64 rows x 128 B | B 64 rows x 128 B}; one DMA instruction writes 64 lanes x 16 B back to back = 8 rows, the eight
+// 16-byte units of a row stored at position u ^ ((row >> 1) & 7) (conflict-free fragment reads without padding); wave w
+// fetches rows 16 w .. 16 w + 15 of both operands (4 instructions per chunk).  Three slots: chunks ch + 1 and ch + 2 are
+// in flight under the 16 MFMAs per wave of chunk ch, one barrier per chunk behind a counted s_waitcnt (vmcnt retires in
+// order: at most the 4 loads of the younger chunk may still be out).  The k order per accumulator is that of
+// accumulate_klist: same bits.  `lds`: TD_LDS_BYTES; ends with a barrier (the area may be reused right after).
+constexpr int TD_SLOT = 2 * 64 * 128;     // bytes
+constexpr int TD_LDS_BYTES = 3 * TD_SLOT;  // 49,152
+template <class FP>
+__device__ inline void accumulate_klist_dma(const FemDev& f, int slot, const double* Lm, FP active, Acc& acc, char* lds,
+                                            const WavePos& wp) {
+  const int e0 = f.kptr[slot], np = f.kptr[slot + 1] - e0;
+  const int n = 4 * np;  // chunks
+  if (n <= 0) return;
+  const int lane = wp.lane, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, kq = lane >> 4;
+  const unsigned lds0 = unsigned(size_t((__attribute__((address_space(3))) char*)lds));
+  // fragment addressing: lane (fr, kq) reads row fr (+ 16 i) at k = 4 kki + kq: unit (2 kki + (kq >> 1)) ^ (fr >> 1)
+  unsigned fa[4], fb[4];
+#pragma unroll
+  for (int kki = 0; kki < 4; ++kki) {
+    const unsigned uo = unsigned((((2 * kki) ^ (kq >> 1) ^ (fr >> 1)) << 4) + (kq & 1) * 8);
+    fa[kki] = unsigned((wp.wr * 32 + fr) * 128) + uo;
+    fb[kki] = unsigned(8192 + (wp.wc * 32 + fr) * 128) + uo;
+  }
+  // DMA addressing: lane -> row 16 w + 8 q + (lane >> 3) of the tile (512-byte rows), stored unit lane & 7 = logical
+  // unit (lane & 7) ^ ((4 q + (lane >> 4)) & 7)
+  unsigned vo[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    vo[q] = unsigned((16 * w + 8 * q + (lane >> 3)) * 512) + unsigned(((lane & 7) ^ ((4 * q + (lane >> 4)) & 7)) * 16);
+  // the k-list: lane l holds pair l of the current batch of 64
+  int ida = 0, idb = 0;
+  auto load_pairs = [&](int p0) {
+    const int p = min(p0 + lane, np - 1);
+    ida = f.kpair[2 * (e0 + p)];
+    idb = f.kpair[2 * (e0 + p) + 1];
+  };
+  load_pairs(0);
+  const char* const Lb = reinterpret_cast<const char*>(Lm);
+  auto dma = [](unsigned lds_addr, const char* base, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff),
+                 "s"(x128_uniform(base))
+                 : "memory");
+  };
+  auto issue = [&](int ch, unsigned slot_off) {
+    const int p = ch >> 2, c = ch & 3;
+    if (c == 0 && (p & 63) == 0 && p > 0) load_pairs(p);
+    const int ia = __builtin_amdgcn_readlane(ida, p & 63), ib = __builtin_amdgcn_readlane(idb, p & 63);
+    const char* ba = Lb + size_t(ia) * 32768 + c * 128;
+    const char* bb = Lb + size_t(ib) * 32768 + c * 128;
+    const unsigned sl = lds0 + slot_off + unsigned(w) * 2048;
+    dma(sl, ba, vo[0]);
+    dma(sl + 1024, ba, vo[1]);
+    dma(sl + 8192, bb, vo[0]);
+    dma(sl + 8192 + 1024, bb, vo[1]);
+  };
+  unsigned s_cur = 0, s_nxt = TD_SLOT, s_far = 2 * TD_SLOT;  // slots of chunks ch, ch + 1, ch + 2
+  issue(0, s_cur);
+  if (n > 1) issue(1, s_nxt);
+  for (int ch = 0; ch < n; ++ch) {
+    // chunk ch has landed for everybody, and everybody has left the slot of chunk ch - 1 (= that of chunk ch + 2)
+    if (ch + 1 < n) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ch + 2 < n) issue(ch + 2, s_far);
+    if (active(ch)) {
+      const char* sp = lds + s_cur;
+      double af[2][2], bf[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[0][i] = *reinterpret_cast<const double*>(sp + fa[0] + i * 2048);
+        bf[0][i] = *reinterpret_cast<const double*>(sp + fb[0] + i * 2048);
+      }
+#pragma unroll
+      for (int kki = 0; kki < 4; ++kki) {
+        const int pb = kki & 1;
+        if (kki < 3) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            af[pb ^ 1][i] = *reinterpret_cast<const double*>(sp + fa[kki + 1] + i * 2048);
+            bf[pb ^ 1][i] = *reinterpret_cast<const double*>(sp + fb[kki + 1] + i * 2048);
+          }
+        }
+        acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][0], bf[pb][0], acc.c[0][0], 0, 0, 0);
+        acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][0], bf[pb][1], acc.c[0][1], 0, 0, 0);
+        acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][1], bf[pb][0], acc.c[1][0], 0, 0, 0);
+        acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][1], bf[pb][1], acc.c[1][1], 0, 0, 0);
+      }
+    }
+    const unsigned t = s_cur;
+    s_cur = s_nxt;
+    s_nxt = s_far;
+    s_far = t;
+  }
+  __syncthreads();
+}
+
 // ============================================================================================
 // factorisation kernels
 // ============================================================================================
@@ -305,6 +415,7 @@ __global__ __launch_bounds__(256) void k_back_pre(FemDev f, const double* __rest
 // Diagonal tile j, step 1 of 3 (MFMA): C = S_jj - sum_k L_jk L_jk^T, written to the tile's L slot.
 // Only the lower triangle is consumed by the factorisation: the wave owning the upper-right
 // quadrant skips its MFMAs.
+template <bool DMA>
 __device__ inline void diag_update_body(const FemDev& f, const double* __restrict__ am, int m, int slot, double* lds, int* kp,
                                         double* coef) {
   double* stB = lds;
@@ -319,18 +430,23 @@ __device__ inline void diag_update_body(const FemDev& f, const double* __restric
   Acc acc;
   acc_zero(acc);
   const bool lower = !(wp.wr == 0 && wp.wc == 1);
-  accumulate_klist(f, slot, Lm, kp, [&](int) { return lower; }, acc, stA, stB, wp);
+  if (DMA) accumulate_klist_dma(f, slot, Lm, [&](int) { return lower; }, acc, reinterpret_cast<char*>(lds), wp);
+  else accumulate_klist(f, slot, Lm, kp, [&](int) { return lower; }, acc, stA, stB, wp);
   tile_from_acc(Cb, acc, st, wp);
   double* Lout = Lm + size_t(slot) * 4096;
   for (int idx = threadIdx.x; idx < 4096; idx += 256) Lout[idx] = Cb[(idx >> 6) * LDC + (idx & 63)];
 }
+template <bool DMA>
 __global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __restrict__ a, int slot) {
-  // 36.9 KB: four workgroups per CU, i.e. all 1024 systems of a C2 step resident in one round
-  __shared__ __align__(16) double lds[STAGE_TOTAL];
+  // 36.9 KB: four workgroups per CU (register-staged loop); 48 KB: three (LDS-DMA loop)
+  __shared__ __align__(16) double lds[DMA ? TD_LDS_BYTES / 8 : STAGE_TOTAL];
   __shared__ int kp[2 * KP_MAX];
   __shared__ double coef[COEF_MAX];
-  diag_update_body(f, a + size_t(blockIdx.x) * f.kblk, blockIdx.x, slot, lds, kp, coef);
+  static_assert(STAGE_TOTAL * 8 <= TD_LDS_BYTES, "the tile fits in either");
+  diag_update_body<DMA>(f, a + size_t(blockIdx.x) * f.kblk, blockIdx.x, slot, lds, kp, coef);
 }
+template __global__ void k_diag_update<false>(FemDev, const double*, int);
+template __global__ void k_diag_update<true>(FemDev, const double*, int);
 
 // 1/sqrt(d) for a positive normal d: hardware seed (v_rsq_f64, ~2^-26 relative error) + two Newton
 // steps -> within 1-2 ulp; a fraction of the dependent-instruction chain of 1.0 / sqrt(d).
@@ -751,6 +867,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
 // Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;
 // y_i -= L_ij y_j.  invL_jj is lower triangular: the waves owning output columns 0..31 only need
 // k < 32 of the second product.
+template <bool DMA>
 __device__ inline void panel_body(const FemDev& f, const double* __restrict__ am, int m, int j, int ent, double* lds, int* kp,
                                   double* yj, double* coef) {
   double* stB = lds;
@@ -767,7 +884,9 @@ __device__ inline void panel_body(const FemDev& f, const double* __restrict__ am
   if (t < 64) yj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
   Acc acc;
   acc_zero(acc);
-  accumulate_klist(f, slot, Lm, kp, [](int) { return true; }, acc, stA, stB, wp);
+  static_assert(TD_LDS_BYTES <= FACT_LDS_DOUBLES * 8, "the DMA slots alias the staging area and the C tile");
+  if (DMA) accumulate_klist_dma(f, slot, Lm, [](int) { return true; }, acc, reinterpret_cast<char*>(lds), wp);
+  else accumulate_klist(f, slot, Lm, kp, [](int) { return true; }, acc, stA, stB, wp);
   tile_from_acc(Cb, acc, st, wp);
 
   // X = C * invL_jj^T
@@ -812,6 +931,7 @@ __device__ inline void panel_block(int b, int nrows, int Mc, int& m, int& row) {
   }
 }
 
+template <bool DMA>
 __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc) {
   __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];
   __shared__ int kp[2 * KP_MAX];
@@ -819,8 +939,10 @@ __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __
   __shared__ double coef[COEF_MAX];
   int m, row;
   panel_block(blockIdx.x, f.colptr[j + 1] - f.colptr[j], Mc, m, row);
-  panel_body(f, a + size_t(m) * f.kblk, m, j, f.colptr[j] + row, lds, kp, yj, coef);
+  panel_body<DMA>(f, a + size_t(m) * f.kblk, m, j, f.colptr[j] + row, lds, kp, yj, coef);
 }
+template __global__ void k_factor_panel<false>(FemDev, const double*, int, int);
+template __global__ void k_factor_panel<true>(FemDev, const double*, int, int);
 
 // x = L^{-T} y, one workgroup per system, x kept in LDS, written back over y
 __global__ __launch_bounds__(256) void k_backsolve(FemDev f) {
@@ -1051,18 +1173,7 @@ extern "C" int rom_debug_stamps_clear() {
 // one mesh row of up to 128 interior vertices; every wave a 64 x 64 quadrant = 4 x 4 MFMA accumulators): K is
 // only sum(rank + 1) ~ 64, so a 64 x 64 tile spends most of its life in its prologue and epilogue; four times
 // the outputs per workgroup amortise them and every LDS fragment feeds four MFMAs instead of two.
-// grid (mesh rows x column tiles, ceil(Mc/128), lr blocks); LDS 74,752 B -> 2 workgroups per CU
-// a pointer that is the same in every lane, in scalar registers whatever the compiler thinks of it
-__device__ inline const char* x128_uniform(const char* p) {
-  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
-  return reinterpret_cast<const char*>((unsigned long long)hi << 32 | lo);
-}
-
-__device__ inline unsigned long long x128_uniform(unsigned long long v) {
-  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
-  return (unsigned long long)hi << 32 | lo;
-}
+// grid (mesh rows x column tiles, ceil(Mc/128), lr blocks); LDS 66,560 B -> 2 workgroups per CU
 
 // Main loop (round 2, after the Gram kernel): the K chunks of both operands go from global memory straight into
 // LDS with global_load_lds_dwordx4 -- no staging registers, no ds_write, 8 instructions per wave and chunk, chunk

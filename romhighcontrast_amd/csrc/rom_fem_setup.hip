@@ -1159,6 +1159,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   f->sw_no_ext128 = getenv("ROMHC_NO_EXT128") != nullptr;
   f->sw_no_fold = getenv("ROMHC_NO_FOLD_EXPAND") != nullptr;
   f->sw_ext_w8 = getenv("ROMHC_EXT_W4") == nullptr;
+  f->sw_no_tile_dma = getenv("ROMHC_NO_TILE_DMA") != nullptr;
   f->sw_ext_p = getenv("ROMHC_EXT_P") ? atoi(getenv("ROMHC_EXT_P")) : 0;
   f->sw_ext_flat = getenv("ROMHC_EXT_FLAT") ? (atoi(getenv("ROMHC_EXT_FLAT")) != 0 ? 1 : 0) : -1;
   ROMHC_PHASE("end");
@@ -1173,6 +1174,30 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
               use_lr[c] ? "from the reduced unknowns" : "sine modes");
     }
     fprintf(stderr, "romhc:   blocks extended by the 128-tile kernel: %d, general kernel: %d\n", f->n_lr_blocks, f->n_gen_blocks);
+    {  // how sparse the term tables are: non-zero 16 x 16 blocks, bounding rectangles
+      size_t nzb = 0, rect = 0, rows16 = 0;
+      for (size_t t = 0; t < terms.size(); ++t) {
+        const double* tb = pool.data() + size_t(terms[t].tab) * 4096;
+        rect += size_t(terms[t].r_hi - terms[t].r_lo) * size_t(terms[t].c_hi - terms[t].c_lo);
+        for (int ib = 0; ib < 4; ++ib)
+          for (int jb = 0; jb < 4; ++jb) {
+            bool nz = false;
+            for (int i = 0; i < 16 && !nz; ++i)
+              for (int j = 0; j < 16; ++j)
+                if (tb[(16 * ib + i) * 64 + 16 * jb + j] != 0.0) { nz = true; break; }
+            nzb += nz;
+          }
+        for (int r = 0; r < 64; ++r)
+          for (int sg = 0; sg < 4; ++sg) {
+            bool nz = false;
+            for (int j = 0; j < 16; ++j) nz = nz || tb[r * 64 + 16 * sg + j] != 0.0;
+            rows16 += nz;
+          }
+      }
+      fprintf(stderr, "romhc:   term tables: %zu tables, %zu non-zero 16x16 blocks of %zu (%.2f), bounding rectangles cover %.2f, non-zero 1x16 strips %.2f\n",
+              terms.size(), nzb, terms.size() * 16, double(nzb) / (terms.size() * 16), double(rect) / (terms.size() * 4096.0),
+              double(rows16) / (terms.size() * 256.0));
+    }
   }
 
   ROMHC_PHASE("work accounting of this algorithm, per snapshot ");

@@ -120,7 +120,8 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         for (int q = 0; q < 4; ++q) detail ? snprintf(nm[q], 48, "%s_j%02d", base[q], j) : snprintf(nm[q], 48, "%s", base[q]);
         {
           ROM_PROF(ctx, nm[0], Mc * nk * 2.0 * 262144, Mc * 8.0 * 4096 * (1 + 2 * nk));
-          k_diag_update<<<Mc, 256, 0, st>>>(d, am, slot);
+          if (f->sw_no_tile_dma) k_diag_update<false><<<Mc, 256, 0, st>>>(d, am, slot);
+          else k_diag_update<true><<<Mc, 256, 0, st>>>(d, am, slot);
         }
         {
           ROM_PROF(ctx, nm[1], Mc * (2 * 262144 / 3.0 + 4096.0), Mc * 8.0 * 4096 * 3);
@@ -132,7 +133,8 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         double nk = 0;
         for (int e = f->colptr[j]; e < f->colptr[j + 1]; ++e) nk += f->kptr[f->colrow[e] + 1] - f->kptr[f->colrow[e]];
         ROM_PROF(ctx, nm[3], Mc * (nk + nrows) * 2.0 * 262144, Mc * 8.0 * 4096 * (2 * nk + 2 * nrows));
-        k_factor_panel<<<nrows * Mc, 256, 0, st>>>(d, am, j, Mc);
+        if (f->sw_no_tile_dma) k_factor_panel<false><<<nrows * Mc, 256, 0, st>>>(d, am, j, Mc);
+        else k_factor_panel<true><<<nrows * Mc, 256, 0, st>>>(d, am, j, Mc);
       }
     }
     if (f->T > 0) {
