@@ -86,11 +86,11 @@ __global__ void k_rhs(FemDev f, const double* __restrict__ a);
 __global__ void k_coef(FemDev f, const double* __restrict__ a);
 __global__ void k_expand(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0);
 __global__ void k_back_pre(FemDev f, const double* __restrict__ a, int Mc);
-template <bool DMA>
-__global__ void k_diag_update(FemDev f, const double* __restrict__ a, int slot);
+template <bool DMA, int NS>
+__global__ void k_diag_update(FemDev f, const double* __restrict__ a, int slot, int Mc);
 __global__ void k_diag_factor(FemDev f, int slot, int j);
 __global__ void k_solve1(FemDev f, const double* __restrict__ a);
-template <bool DMA>
+template <bool DMA, int NS>
 __global__ void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc);
 __global__ void k_backsolve(FemDev f);
 __global__ void k_edge_transform(FemDev f, int Mc);

@@ -69,33 +69,50 @@ struct STile {
 };
 
 
-__device__ inline void s_tile_load(STile& st, const TileDesc& d, const FemDev& f, const double* __restrict__ am,
-                                   double* coef) {
+// NS systems (consecutive rows of `a`) are assembled from ONE pass over the tables: the assembly costs what it reads
+// (profiles/r02_tile_cholesky_probes.txt), and the tables are the same for every system.  coef: NS * COEF_MAX doubles.
+template <int NS>
+__device__ inline void s_tile_load(STile (&st)[NS], const TileDesc& d, const FemDev& f, const double* __restrict__ am0,
+                                   int nsys, double* coef) {
   const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
 #pragma unroll
-  for (int x = 0; x < 16; ++x) st.v[x] = 0.0;
+  for (int q = 0; q < NS; ++q)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) st[q].v[x] = 0.0;
   for (int tb = d.t0; tb < d.t1; tb += COEF_MAX) {
     const int nt = min(COEF_MAX, d.t1 - tb);
     __syncthreads();
-    if (int(threadIdx.x) < nt) coef[threadIdx.x] = term_coef(f.terms[tb + threadIdx.x], am);
+    if (int(threadIdx.x) < nt) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+        coef[q * COEF_MAX + threadIdx.x] = term_coef(f.terms[tb + threadIdx.x], am0 + size_t(q < nsys ? q : 0) * f.kblk);
+    }
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
       const GenTerm& g = f.terms[tb + t];
       if (r < g.r_lo || r >= g.r_hi || c0 >= g.c_hi || c0 + 16 <= g.c_lo) continue;
-      const double cf = coef[t];
       const double2* src = reinterpret_cast<const double2*>(f.pool + size_t(g.tab) * 4096 + r * 64 + c0);
+      double cf[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) cf[q] = coef[q * COEF_MAX + t];
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
         const double2 w = src[x];  // tables are zero outside their rectangle: no masks needed
-        st.v[2 * x] += cf * w.x;
-        st.v[2 * x + 1] += cf * w.y;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          st[q].v[2 * x] += cf[q] * w.x;
+          st[q].v[2 * x + 1] += cf[q] * w.y;
+        }
       }
     }
   }
   if (d.diag && r >= d.ndr) {
 #pragma unroll
-    for (int x = 0; x < 16; ++x) st.v[x] = (c0 + x == r) ? 1.0 : 0.0;  // padding unknowns: identity
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) st[q].v[x] = (c0 + x == r) ? 1.0 : 0.0;  // padding unknowns: identity
   }
+  __syncthreads();  // (`coef` may alias memory the caller writes next)
 }
 
 // C(LDS tile) = S_tile - acc
@@ -415,38 +432,46 @@ __global__ __launch_bounds__(256) void k_back_pre(FemDev f, const double* __rest
 // Diagonal tile j, step 1 of 3 (MFMA): C = S_jj - sum_k L_jk L_jk^T, written to the tile's L slot.
 // Only the lower triangle is consumed by the factorisation: the wave owning the upper-right
 // quadrant skips its MFMAs.
-template <bool DMA>
-__device__ inline void diag_update_body(const FemDev& f, const double* __restrict__ am, int m, int slot, double* lds, int* kp,
-                                        double* coef) {
+template <bool DMA, int NS>
+__device__ inline void diag_update_body(const FemDev& f, const double* __restrict__ am0, int m0, int nsys, int slot, double* lds,
+                                        int* kp, double* coef) {
   double* stB = lds;
   double* stA = lds + 2 * STAGE_DOUBLES;
   double* Cb = lds;  // the C tile aliases the whole staging area (used after the k-loop only)
   static_assert(TILE_DOUBLES <= STAGE_TOTAL, "C tile must fit in the staging area");
   const WavePos wp;
   const TileDesc& d = f.desc[slot];
-  double* Lm = f.L + size_t(m) * f.nslots * 4096;
-  STile st;
-  s_tile_load(st, d, f, am, coef);  // table reads fly under the MFMAs below
-  Acc acc;
-  acc_zero(acc);
+  STile st[NS];
+  s_tile_load<NS>(st, d, f, am0, nsys, coef);  // (the values wait in registers)
   const bool lower = !(wp.wr == 0 && wp.wc == 1);
-  if (DMA) accumulate_klist_dma(f, slot, Lm, [&](int) { return lower; }, acc, reinterpret_cast<char*>(lds), wp);
-  else accumulate_klist(f, slot, Lm, kp, [&](int) { return lower; }, acc, stA, stB, wp);
-  tile_from_acc(Cb, acc, st, wp);
-  double* Lout = Lm + size_t(slot) * 4096;
-  for (int idx = threadIdx.x; idx < 4096; idx += 256) Lout[idx] = Cb[(idx >> 6) * LDC + (idx & 63)];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    if (q >= nsys) break;
+    double* Lm = f.L + size_t(m0 + q) * f.nslots * 4096;
+    Acc acc;
+    acc_zero(acc);
+    if (q > 0) __syncthreads();  // (the copy-out of the previous system reads the tile)
+    if (DMA) accumulate_klist_dma(f, slot, Lm, [&](int) { return lower; }, acc, reinterpret_cast<char*>(lds), wp);
+    else accumulate_klist(f, slot, Lm, kp, [&](int) { return lower; }, acc, stA, stB, wp);
+    tile_from_acc(Cb, acc, st[q], wp);
+    double* Lout = Lm + size_t(slot) * 4096;
+    for (int idx = threadIdx.x; idx < 4096; idx += 256) Lout[idx] = Cb[(idx >> 6) * LDC + (idx & 63)];
+  }
 }
-template <bool DMA>
-__global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __restrict__ a, int slot) {
+// NS = 2: two systems per workgroup (one pass over the term tables for both)
+template <bool DMA, int NS>
+__global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __restrict__ a, int slot, int Mc) {
   // 36.9 KB: four workgroups per CU (register-staged loop); 48 KB: three (LDS-DMA loop)
   __shared__ __align__(16) double lds[DMA ? TD_LDS_BYTES / 8 : STAGE_TOTAL];
   __shared__ int kp[2 * KP_MAX];
-  __shared__ double coef[COEF_MAX];
+  __shared__ double coef[NS * COEF_MAX];
   static_assert(STAGE_TOTAL * 8 <= TD_LDS_BYTES, "the tile fits in either");
-  diag_update_body<DMA>(f, a + size_t(blockIdx.x) * f.kblk, blockIdx.x, slot, lds, kp, coef);
+  const int m0 = blockIdx.x * NS;
+  diag_update_body<DMA, NS>(f, a + size_t(m0) * f.kblk, m0, min(NS, Mc - m0), slot, lds, kp, coef);
 }
-template __global__ void k_diag_update<false>(FemDev, const double*, int);
-template __global__ void k_diag_update<true>(FemDev, const double*, int);
+template __global__ void k_diag_update<false, 1>(FemDev, const double*, int, int);
+template __global__ void k_diag_update<true, 1>(FemDev, const double*, int, int);
+template __global__ void k_diag_update<true, 2>(FemDev, const double*, int, int);
 
 // 1/sqrt(d) for a positive normal d: hardware seed (v_rsq_f64, ~2^-26 relative error) + two Newton
 // steps -> within 1-2 ulp; a fraction of the dependent-instruction chain of 1.0 / sqrt(d).
@@ -867,9 +892,9 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
 // Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;
 // y_i -= L_ij y_j.  invL_jj is lower triangular: the waves owning output columns 0..31 only need
 // k < 32 of the second product.
-template <bool DMA>
-__device__ inline void panel_body(const FemDev& f, const double* __restrict__ am, int m, int j, int ent, double* lds, int* kp,
-                                  double* yj, double* coef) {
+template <bool DMA, int NS>
+__device__ inline void panel_body(const FemDev& f, const double* __restrict__ am0, int m0, int nsys, int j, int ent, double* lds,
+                                  int* kp, double* yj, double* coef) {
   double* stB = lds;
   double* stA = lds + 2 * STAGE_DOUBLES;
   double* Cb = lds + 2 * STAGE_DOUBLES;
@@ -877,42 +902,48 @@ __device__ inline void panel_body(const FemDev& f, const double* __restrict__ am
   const int ti = f.colti[ent];
   const WavePos wp;
   const TileDesc& d = f.desc[slot];
-  double* Lm = f.L + size_t(m) * f.nslots * 4096;
   const int t = threadIdx.x;
-  STile st;
-  s_tile_load(st, d, f, am, coef);
-  if (t < 64) yj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
-  Acc acc;
-  acc_zero(acc);
+  STile st[NS];
+  s_tile_load<NS>(st, d, f, am0, nsys, coef);
   static_assert(TD_LDS_BYTES <= FACT_LDS_DOUBLES * 8, "the DMA slots alias the staging area and the C tile");
-  if (DMA) accumulate_klist_dma(f, slot, Lm, [](int) { return true; }, acc, reinterpret_cast<char*>(lds), wp);
-  else accumulate_klist(f, slot, Lm, kp, [](int) { return true; }, acc, stA, stB, wp);
-  tile_from_acc(Cb, acc, st, wp);
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    if (q >= nsys) break;
+    const int m = m0 + q;
+    double* Lm = f.L + size_t(m) * f.nslots * 4096;
+    if (q > 0) __syncthreads();  // (the rhs update of the previous system reads the tile and yj)
+    if (t < 64) yj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
+    Acc acc;
+    acc_zero(acc);
+    if (DMA) accumulate_klist_dma(f, slot, Lm, [](int) { return true; }, acc, reinterpret_cast<char*>(lds), wp);
+    else accumulate_klist(f, slot, Lm, kp, [](int) { return true; }, acc, stA, stB, wp);
+    tile_from_acc(Cb, acc, st[q], wp);
 
-  // X = C * invL_jj^T
-  acc_zero(acc);
-  const double* I = f.invL + (size_t(m) * f.T + j) * 4096 + stage_row() * 64 + stage_seg();
-  const int kmax = (wp.wc + 1) * 32;  // invL[c][k] = 0 for k > c
-  gemm_loop_Atile(Cb, 4, [&](int ch, double* v) { load4_aligned(I + ch * BK, v); },
-                  [&](int ch) { return ch * BK < kmax; }, acc, stB, wp);
+    // X = C * invL_jj^T
+    acc_zero(acc);
+    const double* I = f.invL + (size_t(m) * f.T + j) * 4096 + stage_row() * 64 + stage_seg();
+    const int kmax = (wp.wc + 1) * 32;  // invL[c][k] = 0 for k > c
+    gemm_loop_Atile(Cb, 4, [&](int ch, double* v) { load4_aligned(I + ch * BK, v); },
+                    [&](int ch) { return ch * BK < kmax; }, acc, stB, wp);
 
-  double* Lout = Lm + size_t(slot) * 4096;
+    double* Lout = Lm + size_t(slot) * 4096;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
+      for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        int r = acc_row(wp, i, g), c = acc_col(wp, jb);
-        double v = acc.c[i][jb][g];
-        Lout[r * 64 + c] = v;
-        Cb[r * LDC + c] = v;
-      }
-  __syncthreads();
-  if (t < 64) {
-    double s = 0.0;
-    for (int k = 0; k < 64; ++k) s += Cb[t * LDC + k] * yj[k];
-    f.y[size_t(m) * f.nGp + ti * 64 + t] -= s;
+        for (int g = 0; g < 4; ++g) {
+          int r = acc_row(wp, i, g), c = acc_col(wp, jb);
+          double v = acc.c[i][jb][g];
+          Lout[r * 64 + c] = v;
+          Cb[r * LDC + c] = v;
+        }
+    __syncthreads();
+    if (t < 64) {
+      double sum = 0.0;
+      for (int k = 0; k < 64; ++k) sum += Cb[t * LDC + k] * yj[k];
+      f.y[size_t(m) * f.nGp + ti * 64 + t] -= sum;
+    }
   }
 }
 
@@ -931,18 +962,21 @@ __device__ inline void panel_block(int b, int nrows, int Mc, int& m, int& row) {
   }
 }
 
-template <bool DMA>
+// (NS = 2, a workgroup doing its row tile for two systems with one pass over the term tables, pays in the diagonal
+// update -- 20 % -- but not here: C4 0.69 ms either way, C5 7 % slower; profiles/r02_tile_cholesky_probes.txt)
+template <bool DMA, int NS>
 __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc) {
-  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];
+  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];  // (+ kp + yj = 53,248 B: the most that leaves three workgroups per CU)
   __shared__ int kp[2 * KP_MAX];
   __shared__ double yj[64];
-  __shared__ double coef[COEF_MAX];
-  int m, row;
-  panel_block(blockIdx.x, f.colptr[j + 1] - f.colptr[j], Mc, m, row);
-  panel_body<DMA>(f, a + size_t(m) * f.kblk, m, j, f.colptr[j] + row, lds, kp, yj, coef);
+  double* coef = lds;  // NS * COEF_MAX term weights: only the assembly reads them, before the k loop writes the area
+  int mp, row;
+  panel_block(blockIdx.x, f.colptr[j + 1] - f.colptr[j], (Mc + NS - 1) / NS, mp, row);
+  const int m0 = mp * NS;
+  panel_body<DMA, NS>(f, a + size_t(m0) * f.kblk, m0, min(NS, Mc - m0), j, f.colptr[j] + row, lds, kp, yj, coef);
 }
-template __global__ void k_factor_panel<false>(FemDev, const double*, int, int);
-template __global__ void k_factor_panel<true>(FemDev, const double*, int, int);
+template __global__ void k_factor_panel<false, 1>(FemDev, const double*, int, int);
+template __global__ void k_factor_panel<true, 1>(FemDev, const double*, int, int);
 
 // x = L^{-T} y, one workgroup per system, x kept in LDS, written back over y
 __global__ __launch_bounds__(256) void k_backsolve(FemDev f) {

@@ -238,6 +238,7 @@ struct rom_fem {
   // ROMHC_EXT_FLAT (-1: automatic), ROMHC_NO_EXT128, ROMHC_NO_FOLD_EXPAND
   bool sw_no_fused = false, sw_no_ext128 = false, sw_no_fold = false;
   int sw_ext_flat = -1;
+  bool sw_no_tile_pairs = false;  // ROMHC_NO_TILE_PAIRS: tile Cholesky with one system per workgroup
   bool sw_no_tile_dma = false;  // ROMHC_NO_TILE_DMA: tile Cholesky with the register-staged k loop
   bool sw_ext_w8 = true;   // k_extend128 with eight waves per workgroup (64 x 32 wave tiles); ROMHC_EXT_W4: four (64 x 64)
   int sw_ext_p = 0;     // ROMHC_EXT_P=1: the persistent extension kernel (k_extend_p, rom_fem_extend_p.hip)

@@ -745,7 +745,7 @@ def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
 
 
 @pytest.mark.parametrize("env", ["ROMHC_NO_COMPRESS", "ROMHC_NO_PREELIM", "ROMHC_NO_FUSED", "ROMHC_NO_LOWRANK_EXT",
-                                 "ROMHC_NO_EXT128", "ROMHC_NO_EXT_LR", "ROMHC_NO_TILE_DMA"])
+                                 "ROMHC_NO_EXT128", "ROMHC_NO_EXT_LR", "ROMHC_NO_TILE_DMA", "ROMHC_NO_TILE_PAIRS"])
 def test_algorithm_switches_agree(api, env, monkeypatch):
     """Every exact reduction of the solver can be switched off (A/B checks): the snapshots must not move beyond
     rounding, and each variant must itself meet the parity bound against the oracle."""
