@@ -508,6 +508,9 @@ def main():
                       "canonical_banded_bytes_per_solve": work["bytes_banded"],
                       "canonical_banded_equiv_gbs": round(value * work["bytes_banded"] * 1e-9, 1)},
         "roofline": roofline, "kernels": kernels,
+        "kernels_note": "per-kernel HIP-event times of one extra pass of the same K steps with the sweep on ONE stream "
+                        "(rom_profile_enable); the timed regions behind `value` run C4 / C5 as two concurrent sub-batches "
+                        "(ROMHC_STREAMS; C2 is one batch either way), so `ms_per_step` can be below the sum of `kernels`",
     }
 
     if world == 1 and not args.no_extras:

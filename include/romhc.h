@@ -59,7 +59,10 @@ int rom_timer_start(rom_ctx* ctx);
 int rom_timer_stop(rom_ctx* ctx, double* elapsed_ms);
 
 /* per-kernel HIP-event profiling: when enabled every kernel launch of the library is
- * bracketed by an event pair on the launch stream; rom_profile_query sums them by name. */
+ * bracketed by an event pair on the launch stream; rom_profile_query sums them by name.
+ * While it is enabled rom_solve_batch* keeps a sweep on ONE stream (otherwise geometries whose
+ * reduced solve is the tile Cholesky run as two concurrent sub-batches, ROMHC_STREAMS), so
+ * that a bracket times its kernel alone. */
 int rom_profile_enable(rom_ctx* ctx, int on);
 int rom_profile_reset(rom_ctx* ctx);
 int rom_profile_count(rom_ctx* ctx, int* n_kernels);

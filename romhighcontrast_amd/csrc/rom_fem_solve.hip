@@ -291,7 +291,9 @@ static int solve_batch_impl(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t r
   ROM_CHECK(lds_back <= 60 * 1024, "rom_solve_batch: interface too large for the LDS-resident back substitution");
   // Sub-batches run on separate HIP streams: the wave-per-system diagonal kernels are latency bound
   // (one wave per SIMD), the MFMA kernels of another sub-batch fill the chip meanwhile.
-  const int nsub = std::max(1, std::min(ctx->n_streams, (M + 255) / 256));
+  // (under per-kernel profiling the sweep stays on one stream: an event bracket then times its kernel alone)
+  const int want = ctx->profile ? 1 : ctx->n_streams > 0 ? ctx->n_streams : (f->fused1 && !f->sw_no_fused ? 1 : 2);
+  const int nsub = std::max(1, std::min(want, (M + 255) / 256));
   ROM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
   for (int s = 1; s < nsub; ++s) ROM_HIP(hipStreamWaitEvent(ctx->aux[s - 1], ctx->ev_fork, 0));
   for (int m0 = 0; m0 < M; m0 += Mc_max) {

@@ -771,6 +771,33 @@ def test_algorithm_switches_agree(api, env, monkeypatch):
             assert relh10(g, alt[:4], ro.generate_solutions(g, a[:4].reshape((4,) + blocks))).max() < SNAP_TOL
 
 
+def test_sub_batch_streams_agree(api, monkeypatch):
+    """A sweep over a geometry whose reduced solve is the tile Cholesky runs as two concurrent sub-batches on
+    separate HIP streams (disjoint workspaces and rows): same rows as one batch on one stream (ROMHC_STREAMS=1, read
+    when the context is created), and as four sub-batches."""
+    from romhighcontrast_amd import _ffi
+    blocks, N, M = (3, 3), 24, 700
+    a = 10.0 ** np.random.default_rng(5).uniform(0, 3, size=(M, 9))
+    out = {}
+    for name, streams in (("default", None), ("one", "1"), ("four", "4")):
+        if streams is None:
+            monkeypatch.delenv("ROMHC_STREAMS", raising=False)
+            ctx = _ffi.get_context()
+        else:
+            monkeypatch.setenv("ROMHC_STREAMS", streams)
+            ctx = _ffi.Context(0)  # (a second context on the device: its own streams and workspace)
+        fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)
+        U = ctx.alloc(M * fem.dim)
+        U.fill(float("nan"))
+        fem.solve_batch(ctx.upload(a), M, U)
+        out[name] = U.download(shape=(M, fem.dim))
+    monkeypatch.delenv("ROMHC_STREAMS", raising=False)
+    assert np.array_equal(out["one"], out["default"])
+    assert np.array_equal(out["four"], out["default"])
+    g = ro.Geometry(blocks, N)
+    assert relh10(g, out["default"][-3:], ro.generate_solutions(g, a[-3:].reshape((3,) + blocks))).max() < SNAP_TOL
+
+
 def test_factored_snapshot_block(api):
     """U = Y B^T: rows, Gram matrix and POD of a sweep formed from the interface vectors alone must agree with
     the same quantities formed from the materialised snapshot rows."""
