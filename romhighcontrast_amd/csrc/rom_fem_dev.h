@@ -86,11 +86,11 @@ __global__ void k_rhs(FemDev f, const double* __restrict__ a);
 __global__ void k_coef(FemDev f, const double* __restrict__ a);
 __global__ void k_expand(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0);
 __global__ void k_back_pre(FemDev f, const double* __restrict__ a, int Mc);
-template <bool DMA, int NS>
+template <int NS>
 __global__ void k_diag_update(FemDev f, const double* __restrict__ a, int slot, int Mc);
 __global__ void k_diag_factor(FemDev f, int slot, int j);
 __global__ void k_solve1(FemDev f, const double* __restrict__ a);
-template <bool DMA, int NS>
+template <int NS>
 __global__ void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc);
 __global__ void k_backsolve(FemDev f);
 __global__ void k_edge_transform(FemDev f, int Mc);
@@ -104,7 +104,7 @@ struct X128Args {
   BlockSide sides[X128_BLOCKS];
 };
 
-template <bool FLAT, int NW>
+template <bool FLAT>
 __global__ void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, int with_expand);
 // value of the neighbouring lane (lane ^ 1), by DPP quad permutation
 __device__ inline double lane_swap1(double v) {

@@ -134,27 +134,8 @@ __device__ inline void tile_from_acc(double* Cb, const Acc& acc, const STile& st
 
 // LDS carve-up of the factor kernels: B staging (2 buffers) | union { A staging (2 buffers), C tile }
 constexpr int FACT_LDS_DOUBLES = 2 * STAGE_DOUBLES + TILE_DOUBLES;  // 6528 doubles = 52,224 B -> 3 WG / CU
-constexpr int KP_MAX = 64;                                            // k-pairs cached in LDS per pass
 
-// acc += sum over the k-list of `slot` of L[slotA] * L[slotB]^T, one merged pipelined loop
-template <class FP>
-__device__ inline void accumulate_klist(const FemDev& f, int slot, const double* Lm, int* kp, FP active, Acc& acc,
-                                        double* stA, double* stB, const WavePos& wp) {
-  const int e0 = f.kptr[slot], e1 = f.kptr[slot + 1];
-  const int srow = stage_row(), sseg = stage_seg();
-  for (int eb = e0; eb < e1; eb += KP_MAX) {
-    const int np = min(KP_MAX, e1 - eb);
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * np; i += blockDim.x) kp[i] = f.kpair[2 * eb + i];
-    __syncthreads();
-    const double* base = Lm + srow * 64 + sseg;
-    gemm_loop2(
-        4 * np, [&](int ch, double* v) { load4_aligned(base + size_t(kp[2 * (ch >> 2)]) * 4096 + (ch & 3) * BK, v); },
-        [&](int ch, double* v) { load4_aligned(base + size_t(kp[2 * (ch >> 2) + 1]) * 4096 + (ch & 3) * BK, v); },
-        active, acc, stA, stB, wp);
-  }
-}
-
+// acc += sum over the k-list of `slot` of L[slotA] * L[slotB]^T
 // a pointer that is the same in every lane, in scalar registers whatever the compiler thinks of it
 __device__ inline const char* x128_uniform(const char* p) {
   const unsigned long long v = reinterpret_cast<unsigned long long>(p);
@@ -166,14 +147,15 @@ __device__ inline unsigned long long x128_uniform(unsigned long long v) {
   return (unsigned long long)hi << 32 | lo;
 }
 
-// The same sum with the operand chunks going from global memory straight into LDS (global_load_lds_dwordx4, the main
-// loop of k_gram128 / k_extend128 at 64 x 64): no staging registers, no ds_write.  A chunk = 16 k of both tiles =
+// The operand chunks go from global memory straight into LDS (global_load_lds_dwordx4, the main loop of k_gram128 /
+// k_extend128 at 64 x 64): no staging registers, no ds_write (the register-staged loop of round 1 gave the same bits;
+// equal at C4, 2-3 % slower at C5).  A chunk = 16 k of both tiles =
 // {A 64 rows x 128 B | B 64 rows x 128 B}; one DMA instruction writes 64 lanes x 16 B back to back = 8 rows, the eight
 // 16-byte units of a row stored at position u ^ ((row >> 1) & 7) (conflict-free fragment reads without padding); wave w
 // fetches rows 16 w .. 16 w + 15 of both operands (4 instructions per chunk).  Three slots: chunks ch + 1 and ch + 2 are
 // in flight under the 16 MFMAs per wave of chunk ch, one barrier per chunk behind a counted s_waitcnt (vmcnt retires in
-// order: at most the 4 loads of the younger chunk may still be out).  The k order per accumulator is that of
-// accumulate_klist: same bits.  `lds`: TD_LDS_BYTES; ends with a barrier (the area may be reused right after).
+// order: at most the 4 loads of the younger chunk may still be out).  `lds`: TD_LDS_BYTES; ends with a barrier (the
+// area may be reused right after).
 constexpr int TD_SLOT = 2 * 64 * 128;     // bytes
 constexpr int TD_LDS_BYTES = 3 * TD_SLOT;  // 49,152
 template <class FP>
@@ -432,11 +414,9 @@ __global__ __launch_bounds__(256) void k_back_pre(FemDev f, const double* __rest
 // Diagonal tile j, step 1 of 3 (MFMA): C = S_jj - sum_k L_jk L_jk^T, written to the tile's L slot.
 // Only the lower triangle is consumed by the factorisation: the wave owning the upper-right
 // quadrant skips its MFMAs.
-template <bool DMA, int NS>
+template <int NS>
 __device__ inline void diag_update_body(const FemDev& f, const double* __restrict__ am0, int m0, int nsys, int slot, double* lds,
-                                        int* kp, double* coef) {
-  double* stB = lds;
-  double* stA = lds + 2 * STAGE_DOUBLES;
+                                        double* coef) {
   double* Cb = lds;  // the C tile aliases the whole staging area (used after the k-loop only)
   static_assert(TILE_DOUBLES <= STAGE_TOTAL, "C tile must fit in the staging area");
   const WavePos wp;
@@ -451,27 +431,23 @@ __device__ inline void diag_update_body(const FemDev& f, const double* __restric
     Acc acc;
     acc_zero(acc);
     if (q > 0) __syncthreads();  // (the copy-out of the previous system reads the tile)
-    if (DMA) accumulate_klist_dma(f, slot, Lm, [&](int) { return lower; }, acc, reinterpret_cast<char*>(lds), wp);
-    else accumulate_klist(f, slot, Lm, kp, [&](int) { return lower; }, acc, stA, stB, wp);
+    accumulate_klist_dma(f, slot, Lm, [&](int) { return lower; }, acc, reinterpret_cast<char*>(lds), wp);
     tile_from_acc(Cb, acc, st[q], wp);
     double* Lout = Lm + size_t(slot) * 4096;
     for (int idx = threadIdx.x; idx < 4096; idx += 256) Lout[idx] = Cb[(idx >> 6) * LDC + (idx & 63)];
   }
 }
 // NS = 2: two systems per workgroup (one pass over the term tables for both)
-template <bool DMA, int NS>
+template <int NS>
 __global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __restrict__ a, int slot, int Mc) {
-  // 36.9 KB: four workgroups per CU (register-staged loop); 48 KB: three (LDS-DMA loop)
-  __shared__ __align__(16) double lds[DMA ? TD_LDS_BYTES / 8 : STAGE_TOTAL];
-  __shared__ int kp[2 * KP_MAX];
+  __shared__ __align__(16) double lds[TD_LDS_BYTES / 8];  // 48 KB: three workgroups per CU
   __shared__ double coef[NS * COEF_MAX];
-  static_assert(STAGE_TOTAL * 8 <= TD_LDS_BYTES, "the tile fits in either");
+  static_assert(STAGE_TOTAL * 8 <= TD_LDS_BYTES, "the tile fits");
   const int m0 = blockIdx.x * NS;
-  diag_update_body<DMA, NS>(f, a + size_t(m0) * f.kblk, m0, min(NS, Mc - m0), slot, lds, kp, coef);
+  diag_update_body<NS>(f, a + size_t(m0) * f.kblk, m0, min(NS, Mc - m0), slot, lds, coef);
 }
-template __global__ void k_diag_update<false, 1>(FemDev, const double*, int, int);
-template __global__ void k_diag_update<true, 1>(FemDev, const double*, int, int);
-template __global__ void k_diag_update<true, 2>(FemDev, const double*, int, int);
+template __global__ void k_diag_update<1>(FemDev, const double*, int, int);
+template __global__ void k_diag_update<2>(FemDev, const double*, int, int);
 
 // 1/sqrt(d) for a positive normal d: hardware seed (v_rsq_f64, ~2^-26 relative error) + two Newton
 // steps -> within 1-2 ulp; a fraction of the dependent-instruction chain of 1.0 / sqrt(d).
@@ -892,11 +868,10 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
 // Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;
 // y_i -= L_ij y_j.  invL_jj is lower triangular: the waves owning output columns 0..31 only need
 // k < 32 of the second product.
-template <bool DMA, int NS>
+template <int NS>
 __device__ inline void panel_body(const FemDev& f, const double* __restrict__ am0, int m0, int nsys, int j, int ent, double* lds,
-                                  int* kp, double* yj, double* coef) {
+                                  double* yj, double* coef) {
   double* stB = lds;
-  double* stA = lds + 2 * STAGE_DOUBLES;
   double* Cb = lds + 2 * STAGE_DOUBLES;
   const int slot = f.colrow[ent];
   const int ti = f.colti[ent];
@@ -915,8 +890,7 @@ __device__ inline void panel_body(const FemDev& f, const double* __restrict__ am
     if (t < 64) yj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
     Acc acc;
     acc_zero(acc);
-    if (DMA) accumulate_klist_dma(f, slot, Lm, [](int) { return true; }, acc, reinterpret_cast<char*>(lds), wp);
-    else accumulate_klist(f, slot, Lm, kp, [](int) { return true; }, acc, stA, stB, wp);
+    accumulate_klist_dma(f, slot, Lm, [](int) { return true; }, acc, reinterpret_cast<char*>(lds), wp);
     tile_from_acc(Cb, acc, st[q], wp);
 
     // X = C * invL_jj^T
@@ -964,19 +938,17 @@ __device__ inline void panel_block(int b, int nrows, int Mc, int& m, int& row) {
 
 // (NS = 2, a workgroup doing its row tile for two systems with one pass over the term tables, pays in the diagonal
 // update -- 20 % -- but not here: C4 0.69 ms either way, C5 7 % slower; profiles/r02_tile_cholesky_probes.txt)
-template <bool DMA, int NS>
+template <int NS>
 __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc) {
-  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];  // (+ kp + yj = 53,248 B: the most that leaves three workgroups per CU)
-  __shared__ int kp[2 * KP_MAX];
+  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];  // (+ yj = 52,736 B: three workgroups per CU)
   __shared__ double yj[64];
   double* coef = lds;  // NS * COEF_MAX term weights: only the assembly reads them, before the k loop writes the area
   int mp, row;
   panel_block(blockIdx.x, f.colptr[j + 1] - f.colptr[j], (Mc + NS - 1) / NS, mp, row);
   const int m0 = mp * NS;
-  panel_body<DMA, NS>(f, a + size_t(m0) * f.kblk, m0, min(NS, Mc - m0), j, f.colptr[j] + row, lds, kp, yj, coef);
+  panel_body<NS>(f, a + size_t(m0) * f.kblk, m0, min(NS, Mc - m0), j, f.colptr[j] + row, lds, yj, coef);
 }
-template __global__ void k_factor_panel<false, 1>(FemDev, const double*, int, int);
-template __global__ void k_factor_panel<true, 1>(FemDev, const double*, int, int);
+template __global__ void k_factor_panel<1>(FemDev, const double*, int, int);
 
 // x = L^{-T} y, one workgroup per system, x kept in LDS, written back over y
 __global__ __launch_bounds__(256) void k_backsolve(FemDev f) {
@@ -1204,14 +1176,18 @@ extern "C" int rom_debug_stamps_clear() {
 #endif
 
 // The same extension for blocks whose sides are all compressed, with 128 x 128 workgroup tiles (128 systems x
-// one mesh row of up to 128 interior vertices; every wave a 64 x 64 quadrant = 4 x 4 MFMA accumulators): K is
-// only sum(rank + 1) ~ 64, so a 64 x 64 tile spends most of its life in its prologue and epilogue; four times
-// the outputs per workgroup amortise them and every LDS fragment feeds four MFMAs instead of two.
+// one mesh row of up to 128 interior vertices): K is only sum(rank + 1) ~ 64, so a 64 x 64 tile spends most of its
+// life in its prologue and epilogue; four times the outputs per workgroup amortise them.  Eight waves, 2 x 4 wave
+// tiles of 64 systems x 32 vertices = 4 x 2 MFMA accumulators (106 VGPRs): two waves of the workgroup on every
+// SIMD, and the two halves of the workgroup take turns fetching the chunks -- a wave held up at the issue of its
+// loads (a fifth of the launch goes there while the neighbour workgroup's stores fill the CU's memory pipeline,
+// profiles/r02_extend128_kloop_probes.txt) leaves the MFMA pipe to its twin.  (Four waves of 64 x 64 with 184 VGPRs,
+// the shape of round 1: +1 % at C2, +3.5 % at C4.)
 // grid (mesh rows x column tiles, ceil(Mc/128), lr blocks); LDS 66,560 B -> 2 workgroups per CU
 
 // Main loop (round 2, after the Gram kernel): the K chunks of both operands go from global memory straight into
-// LDS with global_load_lds_dwordx4 -- no staging registers, no ds_write, 8 instructions per wave and chunk, chunk
-// ch + 1 in flight under the 64 MFMAs per wave of chunk ch, the fragments of k-step j + 1 read before the MFMAs of step
+// LDS with global_load_lds_dwordx4 -- no staging registers, no ds_write, 8 instructions per fetching wave and chunk, chunk
+// ch + 1 in flight under the 32 MFMAs per wave of chunk ch, the fragments of k-step j + 1 read before the MFMAs of step
 // j.  A chunk slot is {A k 0..7 | A k 8..15 | B k 0..7 | B k 8..15}, 128 rows of 64 bytes each; a DMA instruction
 // writes 64 lanes x 16 bytes back to back = 16 rows of ONE half, i.e. of one block side (scalar base + 32-bit lane
 // offset); the four 16-byte units of a row are stored at position u ^ ((row >> 2) & 3), which makes the MFMA fragment
@@ -1222,8 +1198,8 @@ constexpr int X128_SLOT = 4 * 128 * 64;  // bytes
 // FLAT: the 128 vertices of a tile are consecutive in the block's row-major vertex numbering instead of lying in
 // one mesh row -- no padding when n1 is not close to a multiple of 128 (n1 = 170: 226 tiles per block instead of
 // 340); a pair of adjacent vertices may then straddle two mesh rows and is stored as two 8-byte halves.
-template <bool FLAT, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc,
+template <bool FLAT>
+__global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc,
                                                       double* __restrict__ U, long long row0, int with_expand) {
   __shared__ __align__(16) char lds_bytes[2 * X128_SLOT];  // two chunk slots = 65,536 B: two workgroups per CU
   __shared__ double scs[128];                               // h^2 / a_b of the workgroup's systems
@@ -1238,7 +1214,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_extend128(FemDev f, X128Args xa,
     static_assert(STAGE_TOTAL * sizeof(double) <= 2 * X128_SLOT, "expansion staging must fit");
     const int nx = f.n1p / 64, ny = (Mc + 63) / 64;
     const int item = (blockIdx.x - ntile) + with_expand * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (NW > 4 && threadIdx.x >= 256) return;  // (the expansion is written for four waves)
+    if (threadIdx.x >= 256) return;  // (the expansion is written for four waves)
     if (item < nx * ny * (f.nexp + 1)) expand_tile(f, Mc, U, row0, lds, item % nx, (item / nx) % ny, item / (nx * ny));
     return;
   }
@@ -1259,8 +1235,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_extend128(FemDev f, X128Args xa,
   const int iv = blockIdx.x / nct + 1;           // mesh row (1-based interior index)       (!FLAT)
   const int jv0 = 128 * (blockIdx.x % nct) + 1;  // first vertex of the tile                (!FLAT)
   const int vt0 = 128 * blockIdx.x;              // first vertex of the tile, block-local   (FLAT)
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = NW == 8 ? w >> 2 : w >> 1, wc = NW == 8 ? w & 3 : w & 1;
-  constexpr int NJ = 16 / NW;   // 16-vertex column blocks per wave: 4 (wave tile 64 x 64) or 2 (64 x 32)
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = w >> 2, wc = w & 3;
+  constexpr int NJ = 2;  // 16-vertex column blocks per wave (wave tile 64 x 32)
   const int fr = lane & 15, kq = lane >> 4;
   double my_sc = 0.0;  // h^2 / a_b of system threadIdx.x: requested now, parked in LDS after the k loop
   if (threadIdx.x < 128) {
@@ -1303,8 +1279,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_extend128(FemDev f, X128Args xa,
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) AF_[i_] = *reinterpret_cast<const double*>(pa_ + i_ * 1024);  \
     _Pragma("unroll") for (int i_ = 0; i_ < NJ; ++i_) BF_[i_] = *reinterpret_cast<const double*>(pb_ + i_ * 1024); \
   } while (0)
-  // ---- DMA addressing: a wave fetches rows 32 w .. 32 w + 31 of both operands, 16 rows of one half per instruction:
-  // lane -> row 32 w + 16 g + (lane >> 2), stored unit lane & 3 = logical unit (lane & 3) ^ ((lane >> 4) & 3)
+  // ---- DMA addressing: wave w of the fetching half takes rows 32 (w & 3) .. + 31 of both operands, 16 rows of one half
+  // per instruction: lane -> row 32 (w & 3) + 16 g + (lane >> 2), stored unit lane & 3 = logical unit (lane & 3) ^ ((lane >> 4) & 3)
   const unsigned lds0 = unsigned(size_t((__attribute__((address_space(3))) char*)lds_bytes));
   const unsigned du16 = unsigned(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
   const unsigned ybytes_row = unsigned(f.nGp) * 8u;
@@ -1385,8 +1361,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_extend128(FemDev f, X128Args xa,
     for (int j = 0; j < NJ; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
   if (tot > 0) {
     X_NEXT_SIDE();
-    X_ISSUE_HALF(0, 0, NW == 4 || w < 4);
-    X_ISSUE_HALF(0, 1, NW == 4 || w < 4);
+    X_ISSUE_HALF(0, 0, w < 4);
+    X_ISSUE_HALF(0, 1, w < 4);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     STAMP(2);
     double af[2][4], bf[2][NJ];
@@ -1394,7 +1370,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_extend128(FemDev f, X128Args xa,
     for (int ch = 0; ch < tot; ++ch) {
       const int slot = ch & 1;
       if (ch + 1 < tot) {  // (everybody left that slot at the barrier behind chunk ch - 1)
-        const bool mine = NW == 4 || (w >> 2) == ((ch + 1) & 1);
+        const bool mine = (w >> 2) == ((ch + 1) & 1);
         X_ISSUE_HALF(slot ^ 1, 0, mine);
         X_ISSUE_HALF(slot ^ 1, 1, mine);
       }
@@ -1433,9 +1409,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_extend128(FemDev f, X128Args xa,
   STAMP(3);
   // epilogue: add the particular solution, swap between lane pairs so that every lane owns two adjacent vertices of
   // one 16-vertex block, 16-byte stores.  The stores of a wave walk down its 64 systems four rows at a time (rows
-  // 16 i + 4 g + kq, i and g ascending): the lanes' two pointers (hp = 0, 1) advance by a constant, what a lane stores
+  // 16 i + 4 g + kq, i and g ascending): the lane's pointer advances by a constant, what a lane stores
   // where (16-byte pair / single first vertex / -- FLAT, a pair straddling two mesh rows -- single second vertex) is
-  // decided once per tile as three lane masks per hp, and the stores are issued under those masks without branches.
+  // decided once per tile as three lane masks, and the stores are issued under those masks without branches.
   const bool odd = lane & 1;
   constexpr int NHP = NJ / 2;
   char* sp[NHP];            // where the lane's next store of pair hp goes
@@ -1502,10 +1478,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_extend128(FemDev f, X128Args xa,
     }
   STAMP(4);
 }
-template __global__ void k_extend128<false, 4>(FemDev, X128Args, const double*, int, double*, long long, int);
-template __global__ void k_extend128<true, 4>(FemDev, X128Args, const double*, int, double*, long long, int);
-template __global__ void k_extend128<false, 8>(FemDev, X128Args, const double*, int, double*, long long, int);
-template __global__ void k_extend128<true, 8>(FemDev, X128Args, const double*, int, double*, long long, int);
+template __global__ void k_extend128<false>(FemDev, X128Args, const double*, int, double*, long long, int);
+template __global__ void k_extend128<true>(FemDev, X128Args, const double*, int, double*, long long, int);
 
 // interface values that k_expand does not write: cross points and the edges recovered node by node
 __global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0) {

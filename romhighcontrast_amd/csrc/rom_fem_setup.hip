@@ -1158,8 +1158,6 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   f->sw_no_fused = getenv("ROMHC_NO_FUSED") != nullptr;
   f->sw_no_ext128 = getenv("ROMHC_NO_EXT128") != nullptr;
   f->sw_no_fold = getenv("ROMHC_NO_FOLD_EXPAND") != nullptr;
-  f->sw_ext_w8 = getenv("ROMHC_EXT_W4") == nullptr;
-  f->sw_no_tile_dma = getenv("ROMHC_NO_TILE_DMA") != nullptr;
   f->sw_no_tile_pairs = getenv("ROMHC_NO_TILE_PAIRS") != nullptr;
   f->sw_ext_p = getenv("ROMHC_EXT_P") ? atoi(getenv("ROMHC_EXT_P")) : 0;
   f->sw_ext_flat = getenv("ROMHC_EXT_FLAT") ? (atoi(getenv("ROMHC_EXT_FLAT")) != 0 ? 1 : 0) : -1;

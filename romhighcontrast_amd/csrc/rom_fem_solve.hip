@@ -120,10 +120,9 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         for (int q = 0; q < 4; ++q) detail ? snprintf(nm[q], 48, "%s_j%02d", base[q], j) : snprintf(nm[q], 48, "%s", base[q]);
         {
           ROM_PROF(ctx, nm[0], Mc * nk * 2.0 * 262144, Mc * 8.0 * 4096 * (1 + 2 * nk));
-          if (f->sw_no_tile_dma) k_diag_update<false, 1><<<Mc, 256, 0, st>>>(d, am, slot, Mc);
           // (two systems per workgroup share one pass over the term tables: -20 % at 1024 systems, nothing at 4096)
-          else if (f->sw_no_tile_pairs || Mc > 2048) k_diag_update<true, 1><<<Mc, 256, 0, st>>>(d, am, slot, Mc);
-          else k_diag_update<true, 2><<<(Mc + 1) / 2, 256, 0, st>>>(d, am, slot, Mc);
+          if (f->sw_no_tile_pairs || Mc > 2048) k_diag_update<1><<<Mc, 256, 0, st>>>(d, am, slot, Mc);
+          else k_diag_update<2><<<(Mc + 1) / 2, 256, 0, st>>>(d, am, slot, Mc);
         }
         {
           ROM_PROF(ctx, nm[1], Mc * (2 * 262144 / 3.0 + 4096.0), Mc * 8.0 * 4096 * 3);
@@ -135,8 +134,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
         double nk = 0;
         for (int e = f->colptr[j]; e < f->colptr[j + 1]; ++e) nk += f->kptr[f->colrow[e] + 1] - f->kptr[f->colrow[e]];
         ROM_PROF(ctx, nm[3], Mc * (nk + nrows) * 2.0 * 262144, Mc * 8.0 * 4096 * (2 * nk + 2 * nrows));
-        if (f->sw_no_tile_dma) k_factor_panel<false, 1><<<nrows * Mc, 256, 0, st>>>(d, am, j, Mc);
-        else k_factor_panel<true, 1><<<nrows * Mc, 256, 0, st>>>(d, am, j, Mc);
+        k_factor_panel<1><<<nrows * Mc, 256, 0, st>>>(d, am, j, Mc);
       }
     }
     if (f->T > 0) {
@@ -242,13 +240,8 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
 #else
             constexpr size_t pad = 0;
 #endif
-            if (f->sw_ext_w8) {
-              if (flat) k_extend128<true, 8><<<grid, 512, pad, st>>>(d, xa, am, Mc, U, row, extra);
-              else k_extend128<false, 8><<<grid, 512, pad, st>>>(d, xa, am, Mc, U, row, extra);
-            } else {
-              if (flat) k_extend128<true, 4><<<grid, 256, pad, st>>>(d, xa, am, Mc, U, row, extra);
-              else k_extend128<false, 4><<<grid, 256, pad, st>>>(d, xa, am, Mc, U, row, extra);
-            }
+            if (flat) k_extend128<true><<<grid, 512, pad, st>>>(d, xa, am, Mc, U, row, extra);
+            else k_extend128<false><<<grid, 512, pad, st>>>(d, xa, am, Mc, U, row, extra);
           }
         } else {
           dim3 grid(f->n1 * ((f->n1 + 63) / 64), (Mc + 63) / 64, f->n_lr_blocks);

@@ -242,8 +242,6 @@ struct rom_fem {
   bool sw_no_fused = false, sw_no_ext128 = false, sw_no_fold = false;
   int sw_ext_flat = -1;
   bool sw_no_tile_pairs = false;  // ROMHC_NO_TILE_PAIRS: tile Cholesky with one system per workgroup
-  bool sw_no_tile_dma = false;  // ROMHC_NO_TILE_DMA: tile Cholesky with the register-staged k loop
-  bool sw_ext_w8 = true;   // k_extend128 with eight waves per workgroup (64 x 32 wave tiles); ROMHC_EXT_W4: four (64 x 64)
   int sw_ext_p = 0;     // ROMHC_EXT_P=1: the persistent extension kernel (k_extend_p, rom_fem_extend_p.hip)
   DenseGroup* d_dgroups = nullptr;
   int* d_dweight = nullptr;    // per (dense group, source position): block of the weight, -1 cross point, -2 none

@@ -717,8 +717,7 @@ def test_gram_128_tiles_vs_numpy(api, M, D):
                                         ((1, 2), 9, 129), ((3, 2), 171, 128), ((5, 4), 33, 128)])
 def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
     """The extension into the blocks has three tilings (128 vertices of one mesh row, 128 consecutive vertices of the
-    block, 64 vertices of one mesh row) and the 128-vertex ones two workgroup shapes (eight waves of 64 x 32, four of
-    64 x 64): same products in the same order, so the snapshots must be identical.
+    block, 64 vertices of one mesh row): same products in the same order, so the snapshots must be identical.
     (5 x 4 blocks: more than the 16 block descriptors one launch of the 128-tile kernel carries.)"""
     from romhighcontrast_amd import _ffi
     ctx = _ffi.get_context()
@@ -726,7 +725,6 @@ def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
     ab = ctx.upload(a)
     out = {}
     for name, env in (("row", {"ROMHC_EXT_FLAT": "0"}), ("flat", {"ROMHC_EXT_FLAT": "1"}), ("t64", {"ROMHC_NO_EXT128": "1"}),
-                      ("w4", {"ROMHC_EXT_W4": "1"}), ("w4flat", {"ROMHC_EXT_W4": "1", "ROMHC_EXT_FLAT": "1"}),
                       ("default", {})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -737,7 +735,7 @@ def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
         out[name] = U.download(shape=(M, fem.dim))
         for k in env:
             monkeypatch.delenv(k)
-    for name in ("flat", "t64", "w4", "w4flat", "default"):
+    for name in ("flat", "t64", "default"):
         assert np.array_equal(out[name], out["row"]), name
     g = ro.Geometry(blocks, N)
     if N <= 40:
@@ -745,7 +743,7 @@ def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
 
 
 @pytest.mark.parametrize("env", ["ROMHC_NO_COMPRESS", "ROMHC_NO_PREELIM", "ROMHC_NO_FUSED", "ROMHC_NO_LOWRANK_EXT",
-                                 "ROMHC_NO_EXT128", "ROMHC_NO_EXT_LR", "ROMHC_NO_TILE_DMA", "ROMHC_NO_TILE_PAIRS"])
+                                 "ROMHC_NO_EXT128", "ROMHC_NO_EXT_LR", "ROMHC_NO_TILE_PAIRS"])
 def test_algorithm_switches_agree(api, env, monkeypatch):
     """Every exact reduction of the solver can be switched off (A/B checks): the snapshots must not move beyond
     rounding, and each variant must itself meet the parity bound against the oracle."""
