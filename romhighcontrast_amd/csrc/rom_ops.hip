@@ -152,7 +152,11 @@ int rom_launch_gemm_nt_ex(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double 
   dim3 grid(unsigned((n + 63) / 64), unsigned((m + 63) / 64), unsigned(splits));
   if (lower_only) grid = dim3(unsigned(tiles), 1, unsigned(splits));
   {
-    ROM_PROF(ctx, prof_name, (lower_only ? 1.0 : 2.0) * m * n * k + (lower_only ? 64.0 * n * k : 0.0),
+    static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-shape names in the profile records
+    char nm[64];
+    detail ? snprintf(nm, sizeof nm, "%s_%lldx%lldx%lld_s%d", prof_name, (long long)m, (long long)n, (long long)k, splits)
+           : snprintf(nm, sizeof nm, "%s", prof_name);
+    ROM_PROF(ctx, nm, (lower_only ? 1.0 : 2.0) * m * n * k + (lower_only ? 64.0 * n * k : 0.0),
              8.0 * (double(m) * k + double(n) * k + double(m) * n));
     if (aligned)
       k_gemm_nt<true><<<grid, 256, 0, ctx->stream>>>(m, n, k, kper, alpha, A, lda, B, ldb, beta, C, ldc, part, lower_only);
@@ -447,7 +451,10 @@ extern "C" int rom_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double
   ROM_CHECK(c_off + size_t(m - 1) * ldc + n <= C->n, "rom_gemm_nn: C out of range");
   dim3 grid(unsigned((n + 63) / 64), unsigned((m + 63) / 64));
   {
-    ROM_PROF(ctx, "gemm_nn", 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(m) * n));
+    static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-shape names in the profile records
+    char nm[64];
+    detail ? snprintf(nm, sizeof nm, "gemm_nn_%lldx%lldx%lld", (long long)m, (long long)n, (long long)k) : snprintf(nm, sizeof nm, "gemm_nn");
+    ROM_PROF(ctx, nm, 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(m) * n));
     k_gemm_nn<<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A->p + a_off, lda, B->p + b_off, ldb, beta,
                                              C->p + c_off, ldc);
   }

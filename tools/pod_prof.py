@@ -23,5 +23,5 @@ for rep in range(2):
     rep_ = ctx.profile_report()
 tot = sum(v["total_ms"] for v in rep_.values())
 print(f"wall {dt*1e3:.1f} ms, kernels {tot:.1f} ms, info {RB.pod_modes.last_info}")
-for k, v in sorted(rep_.items(), key=lambda kv: -kv[1]["total_ms"])[:12]:
-    print(f"  {k:18s} {v['total_ms']:8.2f} ms  launches {v['launches']:5d}  {v['flops']/max(v['total_ms'],1e-9)*1e-9:7.2f} TFLOP/s")
+for k, v in sorted(rep_.items(), key=lambda kv: -kv[1]["total_ms"])[:int(os.environ.get("TOP", "12"))]:
+    print(f"  {k:34s} {v['total_ms']:8.2f} ms  launches {v['launches']:5d}  {v['flops']/max(v['total_ms'],1e-9)*1e-9:7.2f} TFLOP/s")
