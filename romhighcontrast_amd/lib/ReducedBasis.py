@@ -461,7 +461,7 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=6):
     orthonormal directions there, the basis is completed with orthonormalised random directions (singular value 0),
     so the rows returned are always orthonormal.
     Rows follow scikit-learn's ``svd_flip(u_based_decision=False)`` sign convention (the PCA call at
-    src/lib/ReducedBasis.py:196).  X is overwritten (centred / deflated).  ``pod_modes.last_info`` holds the flop
+    src/lib/ReducedBasis.py:196).  X is overwritten (centred, and deflated by all accepted modes but the last batch).  ``pod_modes.last_info`` holds the flop
     accounting of the call (useful = symmetric half of one Gram + lift; executed = what ran).
     """
     M, dim = X.rows, X.dim
@@ -475,15 +475,17 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=6):
     executed = 0.0
     info = {"gram_passes": 0, "sketch_passes": 0, "completed_modes": 0}
 
-    def deflate(lo, take):
-        """coefficients of the modes V[lo:lo+take] into B[:, lo:lo+take], and those modes out of X"""
+    def deflate(lo, take, last=False):
+        """coefficients of the modes V[lo:lo+take] into B[:, lo:lo+take], and those modes out of X (not when nothing
+        reads X afterwards: ``last``)"""
         nonlocal executed
         Y = ctx.alloc(M * take)
         ctx.gemm_nt(M, take, dim, X.buf, 0, dim, V, lo * dim, dim, Y, 0, take)
-        ctx.gemm_nn(M, dim, take, Y, 0, take, V, lo * dim, dim, X.buf, 0, dim, alpha=-1.0, beta=1.0)
+        if not last:
+            ctx.gemm_nn(M, dim, take, Y, 0, take, V, lo * dim, dim, X.buf, 0, dim, alpha=-1.0, beta=1.0)
         # B[:, lo:lo+take] = Y  (strided destination: one small GEMM against the identity)
         ctx.gemm_nn(M, take, take, Y, 0, take, ctx.upload(np.eye(take)), 0, take, B, lo, n)
-        executed += 4.0 * take * M * dim
+        executed += (2.0 if last else 4.0) * take * M * dim
 
     sigma_1 = 0.0
     if n > 0:
@@ -505,7 +507,7 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=6):
             ctx.gemm_nn(take, dim, M, W.buf, 0, M, X.buf, 0, dim, V, 0, dim)   # V = S^-1 W^T Xc
             executed += 2.0 * take * M * dim
             _orthonormalize_against(ctx, V, 0, take, dim)
-            deflate(0, take)
+            deflate(0, take, last=take >= n or passes <= 1)
             found = take
     for p in range(1, passes):
         if found >= n or found == 0:
@@ -520,9 +522,10 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, passes=6):
             break
         V.copy_from(Vs.buf, take * dim, dst_off=found * dim)
         _orthonormalize_against(ctx, V, found, take, dim)
-        deflate(found, take)
+        at_floor = take < len(ss) and ss[take] <= NOISE_FLOOR * sigma_1
+        deflate(found, take, last=at_floor or found + take >= n or p == passes - 1)
         found += take
-        if take < len(ss) and ss[take] <= NOISE_FLOOR * sigma_1:
+        if at_floor:
             break  # the spectrum has reached the noise floor: nothing left to find
     if found:
         # Rayleigh-Ritz on the collected subspace: X ~ B V  ->  SVD of B orders / rotates the modes
