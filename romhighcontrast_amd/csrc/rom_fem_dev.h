@@ -35,6 +35,8 @@ struct FemDev {
   const int* item_k;
   int ncoef;
   const double* G;     // extension tables of the compressed edges: per table (n1*n1) x (rank+1 padded)
+  const double* Gs;    // segment-major copies: [8-wide K segment][row][8], rows ordered so that the vertices of a mesh
+                       // row are adjacent (sides 2, 3: the transposed table) -- one DMA instruction = 1 KB contiguous
   const double* A0;    // (n1*n1) x n1p : Q[j,mode] rho_mode(i), harmonic extension in the sine basis
   const double* Qp;    // n1p x n1p sine matrix (zero padded)
   const int* kmax;     // [N+1] modes (multiple of 16) that matter at distance d from a side
@@ -81,6 +83,7 @@ __host__ __device__ inline int h0_row(int s, int i, int j, int N, int n1) {
 }
 
 // ---- kernels (rom_fem_kernels.hip) ----------------------------------------------------------------
+__global__ void k_repack_table(const double* __restrict__ G, int ld, int nseg, int n1, int orient, double* __restrict__ Gs);
 __global__ void k_build_A0(double* A0, const double* Qp, const double* rho, int n1, int n1p, int N);
 __global__ void k_rhs(FemDev f, const double* __restrict__ a);
 __global__ void k_coef(FemDev f, const double* __restrict__ a);

@@ -44,6 +44,22 @@ __global__ void k_build_A0(double* A0, const double* Qp, const double* rho, int 
   A0[idx] = (m < n1) ? Qp[size_t(j - 1) * n1p + m] * rho[size_t(m) * (N + 1) + i] : 0.0;
 }
 
+// Segment-major copy of one extension table for k_extend128: Gs[(seg * n1^2 + row') * 8 + kk] = G[row * ld + 8 seg + kk],
+// row = distance-from-the-side * n1 + position-along-it; row' = row for the sides a mesh row runs along (orient 0) and
+// the transposed numbering, position * n1 + distance, for the sides it runs away from (orient 1) -- either way the 128
+// vertices of a tile are adjacent rows, and one global_load_lds_dwordx4 of the kernel (16 rows x 64 bytes) reads one
+// contiguous kilobyte = 8 cache lines instead of pieces of 16 (probe: -6 % at C2, profiles/r02_extend128_kloop_probes.txt)
+__global__ void k_repack_table(const double* __restrict__ G, int ld, int nseg, int n1, int orient, double* __restrict__ Gs) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long hrows = (long long)n1 * n1;
+  if (idx >= (long long)nseg * hrows * 8) return;
+  const int kk = int(idx & 7);
+  const long long rp = (idx >> 3) % hrows, seg = (idx >> 3) / hrows;
+  const long long row = orient ? (rp % n1) * n1 + rp / n1 : rp;
+  const int k = int(seg) * 8 + kk;
+  Gs[idx] = k < ld ? G[row * ld + k] : 0.0;
+}
+
 
 // ============================================================================================
 // reduced-system tile assembly
@@ -1301,7 +1317,8 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
     }
   }
   const char* const ybase = reinterpret_cast<const char*>(f.y) + size_t(min(m0, Mc - 1)) * ybytes_row;
-  const char* const gbase = reinterpret_cast<const char*>(f.G);
+  const char* const gsbase = reinterpret_cast<const char*>(f.Gs);
+  const size_t seg_stride = size_t(n1) * n1 * 64;  // bytes between the K segments of a table
   const char* const zbase = reinterpret_cast<const char*>(f.W + size_t(n1) * n1);  // XP_ZERO_PAGE doubles of zeros
   const unsigned voZ = unsigned(lane) * 16u;
   // the walk over the segments (uniform): side, segments left in it, its two running pointers; lanes: table rows
@@ -1316,16 +1333,15 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
       c_left = c_side == 0 ? cnt0 : c_side == 1 ? cnt1 : c_side == 2 ? cnt2 : cnt3;                                \
     } while (c_left == 0 && c_side < 3);                                                                           \
     const int off_ = c_side == 0 ? sd.s[0].off : c_side == 1 ? sd.s[1].off : c_side == 2 ? sd.s[2].off : sd.s[3].off; \
-    const int gtab_ = c_side == 0 ? sd.s[0].gtab : c_side == 1 ? sd.s[1].gtab : c_side == 2 ? sd.s[2].gtab : sd.s[3].gtab; \
-    const int nch_ = c_side == 0 ? sd.s[0].nch : c_side == 1 ? sd.s[1].nch : c_side == 2 ? sd.s[2].nch : sd.s[3].nch; \
-    const int nb_ = nch_ * BK * 8; /* bytes per table row */                                                       \
-    /* row of the side's table = ci i + cj j + k0 (h0_row) */                                                      \
-    const int cm_ = (c_side & 1) ? -n1 : n1, k0_ = (c_side & 1) ? (N - 1) * n1 - 1 : -n1 - 1;                      \
-    const int ci_ = (c_side & 2) ? 1 : cm_, cj_ = (c_side & 2) ? cm_ : 1;                                          \
+    const int gseg_ = c_side == 0 ? sd.s[0].gseg : c_side == 1 ? sd.s[1].gseg : c_side == 2 ? sd.s[2].gseg : sd.s[3].gseg; \
+    /* row of the side's segment-major table (k_repack_table) = ci i + cj j + k0, i / j the 1-based interior indices: */ \
+    /* side 0: n1 (i - 1) + (j - 1); 1: n1 (n1 - i) + (j - 1); 2: n1 (i - 1) + (j - 1); 3: n1 (i - 1) + (n1 - j)  */     \
+    const int ci_ = c_side == 1 ? -n1 : n1, cj_ = c_side == 3 ? -1 : 1;                                             \
+    const int k0_ = c_side == 1 ? n1 * n1 - 1 : c_side == 3 ? -n1 + n1 : -n1 - 1;                                   \
     pA = ybase + size_t(off_) * 8;                                                                                 \
-    pB = gbase + size_t(gtab_) * 8;                                                                                \
-    voB[0] = unsigned(ci_ * vi[0] + cj_ * vj[0] + k0_) * unsigned(nb_) + du16;                                     \
-    voB[1] = unsigned(ci_ * vi[1] + cj_ * vj[1] + k0_) * unsigned(nb_) + du16;                                     \
+    pB = gsbase + size_t(gseg_) * 8;                                                                               \
+    voB[0] = unsigned(ci_ * vi[0] + cj_ * vj[0] + k0_) * 64u + du16;                                               \
+    voB[1] = unsigned(ci_ * vi[1] + cj_ * vj[1] + k0_) * 64u + du16;                                               \
   } while (0)
 #define X_DMA(LDS_, BASE_, VOFF_)                                                                                  \
   asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(LDS_)),   \
@@ -1343,7 +1359,7 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
         X_DMA(sb_ + 16384 + 1024, pB, voB[1]);                                                                     \
       }                                                                                                            \
       pA += 64;                                                                                                    \
-      pB += 64;                                                                                                    \
+      pB += seg_stride; /* the next 8-wide K segment of the table */                                              \
       --c_segs;                                                                                                    \
       if (--c_left == 0 && c_segs > 0) X_NEXT_SIDE();                                                              \
     } else if (MINE_) { /* zeros: the odd half of the last chunk */                                                \

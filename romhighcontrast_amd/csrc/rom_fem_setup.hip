@@ -27,7 +27,7 @@ FemDev make_dev(const rom_fem* f) {
   d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.dgroups = f->d_dgroups; d.dweight = f->d_dweight;
   d.ditem_group = f->d_ditem_group; d.ditem_k = f->d_ditem_k; d.dmat = f->d_dmat; d.ndg = f->ndg; d.ndi = f->ndi; d.T = f->T; d.nslots = f->nslots;
   d.kblk = f->nrb * f->ncb; d.dim = f->dim;
-  d.G = f->d_G; d.A0 = f->d_A0; d.Qp = f->d_Qp; d.kmax = f->d_kmax; d.epos = f->d_epos; d.yhat = f->d_yhat; d.W = f->d_W;
+  d.G = f->d_G; d.Gs = f->d_Gs; d.A0 = f->d_A0; d.Qp = f->d_Qp; d.kmax = f->d_kmax; d.epos = f->d_epos; d.yhat = f->d_yhat; d.W = f->d_W;
   d.g = f->d_g; d.desc = f->d_desc;
   d.kptr = f->d_kptr; d.kpair = f->d_kpair; d.colptr = f->d_colptr; d.colrow = f->d_colrow;
   d.colti = f->d_colti; d.sides = f->d_sides; d.lr_blocks = f->d_lr_blocks; d.n_lr = f->n_lr_blocks; d.gen_blocks = f->d_gen_blocks; d.vmap = f->d_vmap; d.scat = f->d_scat; d.nscat = f->nscat; d.L = f->d_L; d.invL = f->d_invL;
@@ -271,7 +271,7 @@ void put_table(std::vector<double>& pool, size_t idx, int n1p, const Mat& A, boo
 extern "C" int rom_fem_destroy(rom_fem* f) {
   if (!f) return ROM_OK;
   hipStreamSynchronize(f->ctx->stream);
-  void* ptrs[] = {f->d_A0, f->d_G, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
+  void* ptrs[] = {f->d_A0, f->d_G, f->d_Gs, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
                   f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
                   f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred, f->d_groups, f->d_cm,
                   f->d_item_group, f->d_item_k, f->d_pairs, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
@@ -1053,6 +1053,8 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       hipFree(d_B);
     }
     f->sides.resize(nrb * ncb);
+    std::map<std::tuple<int, int, int>, long long> gsoff;  // (type, variant, orientation) -> offset in Gs
+    long long gstotal = 0;
     std::vector<char> need_tr(E, 0);
     double fl = 0;
     const int npj = (n1 + 15) / 16, npi = (n1 + 3) / 4;
@@ -1064,7 +1066,17 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         if (e < 0) continue;
         const int c = comp_of[e];
         if (cpos[e] >= 0) {
-          es = ExtSide{2, cpos[e], rp[c] / BK, comps[c].r, int(goff[{c, int(is_pre[e])}]), edges[e].b0, edges[e].b1};
+          es = ExtSide{2, cpos[e], rp[c] / BK, comps[c].r, int(goff[{c, int(is_pre[e])}]), 0, edges[e].b0, edges[e].b1};
+          // segment-major copy for k_extend128: rows ordered for this side's orientation (one per table and orientation)
+          {
+            const int orient = sdx >= 2 ? 1 : 0;
+            const auto key = std::make_tuple(c, int(is_pre[e]), orient);
+            if (!gsoff.count(key)) {
+              gsoff[key] = gstotal;
+              gstotal += (long long)((comps[c].r + 1 + 7) / 8) * (long long)hrows * 8;
+            }
+            es.gseg = int(gsoff[key]);
+          }
           fl += 2.0 * double(n1) * n1 * (comps[c].r + 1);  // algorithmic: no padding of K or of the vertex tiles
         } else {
           es.mode = 1;
@@ -1107,6 +1119,19 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     ROM_TRY(upload(&f->d_epos, eposv));
     // flops of the extension, per system (for the work accounting)
     f->ext_flops = fl + 2.0 * f->n_edges * double(n1p) * n1p;
+    // the segment-major copies k_extend128 reads
+    ROM_CHECK(gstotal < (1ll << 31), "rom_fem_create: extension tables too large");
+    ROM_HIP(hipMalloc(&f->d_Gs, std::max<size_t>(size_t(gstotal), 1) * sizeof(double)));
+    for (auto& kv : gsoff) {
+      const int c = std::get<0>(kv.first), variant = std::get<1>(kv.first), orient = std::get<2>(kv.first);
+      const int nseg = (comps[c].r + 1 + 7) / 8;
+      const size_t total = size_t(nseg) * hrows * 8;
+      if (total == 0) continue;
+      k_repack_table<<<unsigned((total + 255) / 256), 256, 0, ctx->stream>>>(f->d_G + goff[{c, variant}], rp[c], nseg, n1, orient,
+                                                                              f->d_Gs + kv.second);
+      ROM_HIP(hipGetLastError());
+    }
+    ROM_HIP(hipStreamSynchronize(ctx->stream));
   }
   {
     std::vector<double> Wz(Wd);  // + a page of zeros: where k_extend_p points the lanes that have nothing to load

@@ -126,6 +126,7 @@ struct ExtSide {
   int nch;     // mode 2: K chunks = (rank + 1) rounded up to BK, / BK
   int r;       // mode 2: rank
   int gtab;    // mode 2: offset (doubles) of the (n1*n1) x (nch*BK) table H_0 [P_f, p0_f]
+  int gseg;    // mode 2: offset (doubles) of the segment-major copy of that table in Gs (k_extend128)
   int b0, b1;  // mode 2: blocks of the edge (s_f = a_b0 + a_b1)
 };
 // coefficient block of one closed-form edge on the single-tile path (k_solve1): see the dense product there
@@ -203,6 +204,7 @@ struct rom_fem {
   int nslots;  // nonzero lower tiles
   // device tables
   double* d_G = nullptr;     // extension tables of the compressed edges
+  double* d_Gs = nullptr;    // the same tables, segment-major and with the vertices of a mesh row adjacent (k_extend128)
   double* d_A0 = nullptr;    // (n1*n1) x n1p : Q[j,mode] rho_mode(i) (harmonic extension from side i=0, sine basis)
   double* d_Qp = nullptr;    // n1p x n1p sine matrix
   int* d_kmax = nullptr;     // [N+1]

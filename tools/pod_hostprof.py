@@ -21,4 +21,4 @@ for rep in range(2):
     ctx.synchronize()
     pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(28)
+st.sort_stats(os.environ.get("SORT", "cumulative")).print_stats(int(os.environ.get("TOP", "28")))
