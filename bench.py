@@ -605,9 +605,10 @@ def extras_pod_c2(out, args, ctx, sm, fem, a_dev, U_loc, M, dim, blocks):
             rec["executed_gflops"] = round(info["executed_flops"] / dt * 1e-9, 1)
         return rec
 
-    (_, sig), dt = run_rows(X, U_loc, M)
-    (_, sig), dt2 = run_rows(X, U_loc, M)   # second, warm run (first one pays one-off kernel loads)
-    dt = min(dt, dt2)
+    dt = 1e30
+    for _ in range(4):  # (the first run pays one-off kernel loads; best of the rest)
+        (_, sig), dt2 = run_rows(X, U_loc, M)
+        dt = min(dt, dt2)
     out["pod"] = pod_record(M, dt, sig, dict(getattr(pod_modes, "last_info", {}),
                             note="gflops = USEFUL flops (symmetric half of ONE Gram matrix + lift of r modes, no eigh term) over "
                                  "the wall time of pod_modes incl. the download of the r modes; executed flops in `executed_*`"))
@@ -636,9 +637,11 @@ def extras_pod_c2(out, args, ctx, sm, fem, a_dev, U_loc, M, dim, blocks):
         U3 = ctx.alloc(M3 * dim)
         fem.solve_batch(ctx.upload(a3), M3, U3)
         X3 = ctx.alloc(M3 * dim)
-        (_, sig3), dt3 = run_rows(X3, U3, M3)
-        (_, sig3), dt3b = run_rows(X3, U3, M3)
-        dt3 = min(dt3, dt3b)
+        # (best of 5: the call has ~25 host round trips; its wall time scatters by +-20 % from call to call on one box)
+        dt3 = 1e30
+        for _ in range(5):
+            (_, sig3), dt3b = run_rows(X3, U3, M3)
+            dt3 = min(dt3, dt3b)
         out["pod_c3"] = pod_record(M3, dt3, sig3, dict(getattr(pod_modes, "last_info", {}),
                                    note="same algorithm and accounting on the 8192-snapshot block of config C3, generated and "
                                         "decomposed on one GPU"))
@@ -701,12 +704,14 @@ def extras_pod_c5(out, ctx, sm, fem, a_dev, U_loc, M, dim):
     from romhighcontrast_amd.lib.SolutionsManagers import DeviceArray
     r = 50
     X = ctx.alloc(M * dim)
-    X.copy_from(U_loc, M * dim)
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    _, sig = pod_modes(ctx, DeviceArray(X, M, dim), r, center=True)
-    ctx.synchronize()
-    dt = time.perf_counter() - t0
+    dt = 1e30
+    for _ in range(3):  # (best of 3: the first call pays one-off kernel loads, and the host round trips scatter)
+        X.copy_from(U_loc, M * dim)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        _, sig = pod_modes(ctx, DeviceArray(X, M, dim), r, center=True)
+        ctx.synchronize()
+        dt = min(dt, time.perf_counter() - t0)
     useful = pod_accounting(M, dim, r)
     out["pod"] = {"gflops": round(useful / dt * 1e-9, 1), "seconds": round(dt, 4), "M": M, "dim": dim, "modes": r,
                   "useful_flops": useful, "sigma_1": float(sig[0]), "resolved_modes": int((sig > 0).sum()),

@@ -29,7 +29,10 @@ for cfg in c2 c4; do
   done
   python3 $R/tools/pmc_summary.py $O/hbm_kernels_${cfg}_FETCH_SIZE.csv $O/hbm_kernels_${cfg}_WRITE_SIZE.csv $O/hbm_kernels_${cfg}_pmc_traffic.json > /dev/null
 done
-# PMC traffic of the C4 / C5 sweeps (read by `bench.py --config c4|c5` as roofline.traffic)
+# PMC traffic of the C4 / C5 sweeps (read by `bench.py --config c4|c5` as roofline.traffic); one stream, so that a
+# launch is the whole 1024- / 4096-system sweep as in the bench's per-kernel pass (by default these sweeps run as two
+# concurrent sub-batches)
+export ROMHC_STREAMS=1
 for cfg in c4 c5; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pc_$c -- python3 $R/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pc_${cfg}_$c.err
@@ -38,5 +41,6 @@ for cfg in c4 c5; do
   done
   python3 $R/tools/pmc_summary.py $O/bench_${cfg}_FETCH_SIZE.csv $O/bench_${cfg}_WRITE_SIZE.csv $O/pmc_traffic_$cfg.json > /dev/null
 done
+unset ROMHC_STREAMS
 rm -f $O/*.err
 ls -la $O
