@@ -671,6 +671,60 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   std::vector<std::pair<int, Mat>> bt_extra;  // cross-block tables (index, n1 x ncross)
   int nbt = 0;
   double pre_flops = 0;
+  // the long-double products of every closed-form edge first, one host thread per edge (they read shared tables only);
+  // the bookkeeping below, which appends to the shared lists in a fixed order, then just picks them up
+  struct Ent { int pos, len, blk; Mat X, Y; };  // X: len x n1 coupling to e (without its weight), Y = X K^-1
+  struct PreWork {
+    std::vector<ld> we;              // K^-1 g_e
+    std::vector<Ent> ents;           // neighbours (order of adj[e]), then the cross points on e (order of xc)
+    std::vector<Mat> Mt;             // per neighbour (compressed e only): (W_e^T T P_u)^T
+    std::vector<std::vector<ld>> mtv;  //                                    W_e^T T p0_u
+    Mat Btx;
+    bool has_x = false;
+    std::vector<std::vector<ld>> rhsv;  // per entity: Y g_e
+    std::vector<Mat> R;                 // Y_u X_v^T for v <= u, in the order of the loops below
+  };
+  std::vector<PreWork> prework(npre);
+  parallel_for(size_t(npre), [&](size_t i) {
+    const int e = pre_list[i];
+    const Edge& pe = edges[e];
+    const bool lr_e = cpos[e] >= 0;
+    PreWork& w = prework[i];
+    w.we = hostla::matvec(Kinv, gE[pe.hv]);
+    for (int u : adj[e]) {
+      const int blk = shared_block(e, u);
+      const int id = side_of(blk, u) * 4 + side_of(blk, e);
+      const Comp& cu = comps[comp_of[u]];
+      w.ents.push_back(Ent{zpos[u], cu.r, blk, wt_cache.at({comp_of[u], id, 0}), wt_cache.at({comp_of[u], id, 1})});
+      if (lr_e) {
+        const Mat& WT = wt_cache.at({comp_of[e], side_of(blk, e) * 4 + side_of(blk, u), 0});  // r_e x n1
+        w.Mt.push_back(hostla::transpose(hostla::mul(WT, cu.P)));                            // r_u x r_e
+        w.mtv.push_back(hostla::matvec(WT, cu.p0));
+      }
+    }
+    w.Btx = Mat(n1, std::max(ncross, 1));
+    for (auto& c : xc) {
+      if (c.edge != e) continue;
+      Ent en{xred[c.cross], 1, -1, Mat(1, n1), Mat(1, n1)};
+      en.X(0, c.node) = 1.0L;
+      for (int k = 0; k < n1; ++k) {
+        en.Y(0, k) = Kinv(c.node, k);
+        w.Btx(k, c.cross) = Kinv(k, c.node);
+      }
+      w.ents.push_back(std::move(en));
+      w.has_x = true;
+    }
+    for (size_t u = 0; u < w.ents.size(); ++u) {
+      w.rhsv.push_back(hostla::matvec(w.ents[u].Y, gE[pe.hv]));
+      for (size_t v = 0; v <= u; ++v) {
+        Mat R = hostla::mul_nt(w.ents[u].Y, w.ents[v].X);
+        if (u == v)
+          for (int a = 0; a < R.r; ++a)
+            for (int b = 0; b < a; ++b) R(a, b) = R(b, a) = (R(a, b) + R(b, a)) / 2;
+        w.R.push_back(std::move(R));
+      }
+    }
+  });
   for (int i = 0; i < npre; ++i) {
     const int e = pre_list[i];
     const Edge& pe = edges[e];
@@ -690,21 +744,19 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     P.pos = npos[e];
     P.e0 = pe.b0;
     P.e1 = pe.b1;
-    const std::vector<ld> we = hostla::matvec(Kinv, gE[pe.hv]);
-    P.woff = push_vec(we, n1p);
-    struct Ent { int pos, len, blk; Mat X, Y; };  // X: len x n1 coupling to e (without its weight), Y = X K^-1
-    std::vector<Ent> ents;
+    const PreWork& pw = prework[i];
+    P.woff = push_vec(pw.we, n1p);
+    const std::vector<Ent>& ents = pw.ents;
+    size_t nbi = 0;  // neighbour counter (index into pw.Mt / pw.mtv)
     for (int u : adj[e]) {
       const int blk = shared_block(e, u);
       const int id = side_of(blk, u) * 4 + side_of(blk, e);
       const Comp& cu = comps[comp_of[u]];
-      Ent en{zpos[u], cu.r, blk, wt_cache.at({comp_of[u], id, 0}), wt_cache.at({comp_of[u], id, 1})};
-      ents.push_back(std::move(en));
       if (lr_e) {
         // c_e += a_blk * (W_e^T T^(e,u) P_u z_u + W_e^T T^(e,u) p0_u / s_u)
-        const Mat& WT = wt_cache.at({comp_of[e], side_of(blk, e) * 4 + side_of(blk, u), 0});  // r_e x n1
-        const Mat Mt = hostla::transpose(hostla::mul(WT, cu.P));                           // r_u x r_e
-        const int voff = push_vec(hostla::matvec(WT, cu.p0), cpe.r);
+        const Mat& Mt = pw.Mt[nbi];
+        const int voff = push_vec(pw.mtv[nbi], cpe.r);
+        ++nbi;
         if (!add_cterm(zpos[u], blk, Mt, voff, edges[u].b0, edges[u].b1)) { rom_set_error("internal: more than 8 neighbours of an eliminated edge"); return ROM_ERR_INVALID; }
         pre_flops += 2.0 * cpe.r * double(cu.r);
       } else {
@@ -714,18 +766,10 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         pre_flops += 2.0 * n1p * double(n1p);
       }
     }
-    Mat Btx(n1, std::max(ncross, 1));
-    bool has_x = false;
+    const Mat& Btx = pw.Btx;
+    const bool has_x = pw.has_x;
     for (auto& c : xc) {
       if (c.edge != e) continue;
-      Ent en{xred[c.cross], 1, -1, Mat(1, n1), Mat(1, n1)};
-      en.X(0, c.node) = 1.0L;
-      for (int k = 0; k < n1; ++k) {
-        en.Y(0, k) = Kinv(c.node, k);
-        Btx(k, c.cross) = Kinv(k, c.node);
-      }
-      ents.push_back(std::move(en));
-      has_x = true;
       if (lr_e) {  // c_e += (s_e / 2) W_e[node, :]^T u_x
         Mat Mt(1, cpe.r);
         for (int k = 0; k < cpe.r; ++k) Mt(0, k) = cpe.W(c.node, k);
@@ -739,16 +783,14 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       bt_extra.push_back({nbt++, Btx});
       pre_flops += 2.0 * n1p * double((ncross + BK - 1) / BK * BK);
     }
+    size_t ri = 0;
     for (size_t u = 0; u < ents.size(); ++u) {
       const Ent& eu = ents[u];
-      rhs_terms.push_back(RhsTerm{eu.pos, eu.len, push_vec(hostla::matvec(eu.Y, gE[pe.hv]), eu.len), eu.blk >= 0 ? 0 : 1,
+      rhs_terms.push_back(RhsTerm{eu.pos, eu.len, push_vec(pw.rhsv[u], eu.len), eu.blk >= 0 ? 0 : 1,
                                   std::max(eu.blk, 0), pe.b0, pe.b1});
       for (size_t v = 0; v <= u; ++v) {
         const Ent& ev = ents[v];
-        Mat R = hostla::mul_nt(eu.Y, ev.X);
-        if (u == v)
-          for (int a = 0; a < R.r; ++a)
-            for (int b = 0; b < a; ++b) R(a, b) = R(b, a) = (R(a, b) + R(b, a)) / 2;
+        const Mat& R = pw.R[ri++];
         if (eu.blk >= 0 && ev.blk >= 0)
           add_small(eu.pos, ev.pos, R, 4, {std::min(eu.blk, ev.blk), std::max(eu.blk, ev.blk), pe.b0, pe.b1});
         else if (eu.blk >= 0 || ev.blk >= 0)
@@ -1031,13 +1073,17 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       }
     ROM_CHECK(gtotal < (1ll << 31), "rom_fem_create: extension tables too large");
     ROM_HIP(hipMalloc(&f->d_G, std::max<size_t>(size_t(gtotal), 1) * sizeof(double)));
-    for (auto& kv : goff) {
-      const int c = kv.first.first;
+    // the sine coefficients Q^T [P_c, p0_c] of every table: long-double products, one host thread per table
+    std::vector<std::pair<std::pair<int, int>, long long>> gkeys(goff.begin(), goff.end());
+    std::vector<std::vector<double>> Bhs(gkeys.size());
+    parallel_for(gkeys.size(), [&](size_t gi) {
+      const int c = gkeys[gi].first.first;
       const Comp& cp = comps[c];
-      const Mat& Pm = kv.first.second == 0 ? cp.P : cp.KiW;
-      const std::vector<ld>& pv = kv.first.second == 0 ? cp.p0 : cp.wK;
+      const Mat& Pm = gkeys[gi].first.second == 0 ? cp.P : cp.KiW;
+      const std::vector<ld>& pv = gkeys[gi].first.second == 0 ? cp.p0 : cp.wK;
       Mat Bm = hostla::mul_tn(Pm, Q);  // r x n1
-      std::vector<double> Bh(size_t(rp[c]) * n1p, 0.0);
+      std::vector<double>& Bh = Bhs[gi];
+      Bh.assign(size_t(rp[c]) * n1p, 0.0);
       for (int k = 0; k < cp.r; ++k)
         for (int m = 0; m < n1; ++m) Bh[size_t(k) * n1p + m] = double(Bm(k, m));
       for (int m = 0; m < n1; ++m) {
@@ -1045,6 +1091,11 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         for (int t = 0; t < n1; ++t) sacc += pv[t] * Q(t, m);
         Bh[size_t(cp.r) * n1p + m] = double(sacc);
       }
+    });
+    for (size_t gi = 0; gi < gkeys.size(); ++gi) {
+      const auto& kv = gkeys[gi];
+      const int c = kv.first.first;
+      const std::vector<double>& Bh = Bhs[gi];
       double* d_B = nullptr;
       ROM_TRY(upload(&d_B, Bh));
       ROM_TRY(rom_launch_gemm_nt(ctx, int64_t(hrows), rp[c], n1p, 1.0, f->d_A0, n1p, d_B, n1p, 0.0, f->d_G + kv.second,

@@ -108,8 +108,10 @@ inline bool spd_inverse(const Mat& A, Mat& inv) {
 
 // Orthonormal basis W (n x rank) of the numerical column space of C (n x m): Householder QR with
 // column pivoting, stopped when the largest remaining column norm drops below tol * (the first pivot).
-inline Mat range_basis(Mat C, ld tol) {
-  const int n = C.r, m = C.c;
+inline Mat range_basis(const Mat& C0, ld tol) {
+  // (worked on the transpose: the columns the reflections sweep are then contiguous -- same sums in the same order)
+  Mat C = transpose(C0);
+  const int n = C0.r, m = C0.c;
   const int kmax = std::min(n, m);
   std::vector<std::vector<ld>> refl;  // Householder vectors (unit normalised so that H = I - 2 v v^T)
   ld first = 0;
@@ -118,47 +120,49 @@ inline Mat range_basis(Mat C, ld tol) {
     int piv = -1;
     ld best = 0;
     for (int j = k; j < m; ++j) {
+      const ld* cj = C.row(j);
       ld s = 0;
-      for (int i = k; i < n; ++i) s += C(i, j) * C(i, j);
+      for (int i = k; i < n; ++i) s += cj[i] * cj[i];
       if (piv < 0 || s > best) { piv = j; best = s; }
     }
     best = sqrtl(best);
     if (k == 0) first = best;
     if (!(best > tol * first) || best == 0.0L) break;
-    if (piv != k)
-      for (int i = 0; i < n; ++i) std::swap(C(i, k), C(i, piv));
+    if (piv != k) std::swap_ranges(C.row(k), C.row(k) + n, C.row(piv));
     std::vector<ld> v(n, 0.0L);
     const ld alpha = C(k, k) > 0 ? -best : best;
     ld vn = 0;
     for (int i = k; i < n; ++i) {
-      v[i] = C(i, k) - (i == k ? alpha : 0.0L);
+      v[i] = C(k, i) - (i == k ? alpha : 0.0L);
       vn += v[i] * v[i];
     }
     vn = sqrtl(vn);
     if (vn == 0.0L) break;
     for (int i = k; i < n; ++i) v[i] /= vn;
     for (int j = k; j < m; ++j) {
+      ld* cj = C.row(j);
       ld s = 0;
-      for (int i = k; i < n; ++i) s += v[i] * C(i, j);
+      for (int i = k; i < n; ++i) s += v[i] * cj[i];
       s *= 2;
-      for (int i = k; i < n; ++i) C(i, j) -= s * v[i];
+      for (int i = k; i < n; ++i) cj[i] -= s * v[i];
     }
     refl.push_back(v);
     ++rank;
   }
-  // W = H_0 H_1 ... H_{rank-1} [I_rank; 0]
-  Mat W(n, rank);
-  for (int j = 0; j < rank; ++j) W(j, j) = 1.0L;
+  // W = H_0 H_1 ... H_{rank-1} [I_rank; 0]   (built transposed as well)
+  Mat Wt(rank, n);
+  for (int j = 0; j < rank; ++j) Wt(j, j) = 1.0L;
   for (int k = rank - 1; k >= 0; --k) {
     const std::vector<ld>& v = refl[k];
     for (int j = 0; j < rank; ++j) {
+      ld* wj = Wt.row(j);
       ld s = 0;
-      for (int i = k; i < n; ++i) s += v[i] * W(i, j);
+      for (int i = k; i < n; ++i) s += v[i] * wj[i];
       s *= 2;
-      for (int i = k; i < n; ++i) W(i, j) -= s * v[i];
+      for (int i = k; i < n; ++i) wj[i] -= s * v[i];
     }
   }
-  return W;
+  return transpose(Wt);
 }
 
 inline Mat identity(int n) {
