@@ -126,11 +126,13 @@ struct UnitBlock {
         QK(j, m) = Q(j, m) * kappa[m];
         QKi(j, m) = Q(j, m) / kappa[m];
       }
-    parallel_for(with_edges ? 3 : 1, [&](size_t i) {
-      if (i == 0) Wl = hostla::mul(Q, hostla::mul_nt(Zs, Q));
-      else if (i == 1) Kmat = hostla::mul_nt(QK, Q);
-      else Kinv = hostla::mul_nt(QKi, Q);
-    });
+    // (four n1^3 products, one after the other with their rows spread over the host threads: two of them depend on
+    // each other, so one thread per product would leave the critical path at two products)
+    Wl = hostla::mul_par(Q, hostla::mul_nt_par(Zs, Q));
+    if (with_edges) {
+      Kmat = hostla::mul_nt_par(QK, Q);
+      Kinv = hostla::mul_nt_par(QKi, Q);
+    }
     Wd.resize(size_t(n1) * n1);
     for (size_t i = 0; i < Wd.size(); ++i) Wd[i] = double(Wl.v[i]);
     const ld h2 = 1.0L / ((ld)N * (ld)N);
