@@ -8,7 +8,7 @@ rm -rf $O; mkdir -p $O
 cd $R
 timeout -k 10 400 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_c2_under_rocprof.json 2> $O/stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-extras > $O/bench_c2_under_rocprof.json 2> $O/stats.err
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_c2_kernel_stats.csv
 rm -rf $O/stats
 for c in FETCH_SIZE WRITE_SIZE; do
