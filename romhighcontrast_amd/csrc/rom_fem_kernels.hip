@@ -267,17 +267,50 @@ __device__ inline void accumulate_klist_dma(const FemDev& f, int slot, const dou
 // factorisation kernels
 // ============================================================================================
 // rhs of the reduced system: the parameter-independent part plus the contributions of the closed-form
-// edges.  One workgroup per system; the terms are applied one after another (they overlap).
+// edges.  One workgroup per system; the terms overlap and are summed in their order, entry by entry: a thread owns
+// its entries of y and walks the terms that cover them (one store per entry, no barrier and no read-modify-write
+// of global memory per term: 23 -> 13 us per 1024 systems at C4, 45 -> 22 at C5).
 __global__ __launch_bounds__(256) void k_rhs(FemDev f, const double* __restrict__ a) {
+  __shared__ double coef[256];
   const int m = blockIdx.x;
   const double* am = a + size_t(m) * f.kblk;
   double* y = f.y + size_t(m) * f.nGp;
-  for (int v = threadIdx.x; v < f.nGa; v += blockDim.x) y[v] = f.g[v];
-  for (int t = 0; t < f.nrhs; ++t) {
+  double acc[4];  // entries threadIdx.x + 256 q, q < 4; interfaces of more than 1024 unknowns: the loop at the end
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int v = threadIdx.x + 256 * q;
+    acc[q] = v < f.nGa ? f.g[v] : 0.0;
+  }
+  for (int t0 = 0; t0 < f.nrhs; t0 += 256) {
+    const int nt = min(256, f.nrhs - t0);
     __syncthreads();
-    const RhsTerm& rt = f.rhs[t];
-    const double coef = rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5;
-    for (int i = threadIdx.x; i < rt.len; i += blockDim.x) y[rt.pos + i] += coef * f.vec[rt.voff + i];
+    if (int(threadIdx.x) < nt) {
+      const RhsTerm& rt = f.rhs[t0 + threadIdx.x];
+      coef[threadIdx.x] = rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5;
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      const RhsTerm& rt = f.rhs[t0 + t];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = threadIdx.x + 256 * q - rt.pos;
+        if (i >= 0 && i < rt.len) acc[q] += coef[t] * f.vec[rt.voff + i];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int v = threadIdx.x + 256 * q;
+    if (v < f.nGa) y[v] = acc[q];
+  }
+  for (int v = threadIdx.x + 1024; v < f.nGa; v += 256) {
+    double s = f.g[v];
+    for (int t = 0; t < f.nrhs; ++t) {
+      const RhsTerm& rt = f.rhs[t];
+      const int i = v - rt.pos;
+      if (i >= 0 && i < rt.len) s += (rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5) * f.vec[rt.voff + i];
+    }
+    y[v] = s;
   }
 }
 
@@ -290,7 +323,10 @@ __global__ __launch_bounds__(256) void k_coef(FemDev f, const double* __restrict
   const int m = blockIdx.x;
   const double* am = a + size_t(m) * f.kblk;
   double* y = f.y + size_t(m) * f.nGp;
-  for (int x = threadIdx.x; x < f.ncross; x += blockDim.x) y[f.xb0 + x] = y[f.xred[x]];
+  extern __shared__ double ys[];  // the nGa reduced unknowns of the system (what the coefficient blocks are built from)
+  for (int v = threadIdx.x; v < f.nGa; v += blockDim.x) ys[v] = y[v];
+  __syncthreads();
+  for (int x = threadIdx.x; x < f.ncross; x += blockDim.x) y[f.xb0 + x] = ys[f.xred[x]];
   for (int i = threadIdx.x; i < f.nsc; i += blockDim.x) {
     const int b0 = f.scb[2 * i], b1 = f.scb[2 * i + 1];
     y[f.spos0 + i] = b1 >= 0 ? 1.0 / (am[b0] + am[b1]) : (1.0 / (double(f.N) * double(f.N))) / am[b0];
@@ -304,13 +340,13 @@ __global__ __launch_bounds__(256) void k_coef(FemDev f, const double* __restrict
       out = 1.0 / s;
     } else if (k < cg.r) {
       if (cg.kind == 0) {
-        out = y[cg.zpos + k];
+        out = ys[cg.zpos + k];
       } else {
         double acc = 0.0;
         for (int t = 0; t < cg.nterm; ++t) {
           const CoefTerm& ct = cg.t[t];
           const double* Mt = f.cm + ct.moff + k;
-          const double* src = y + ct.src;
+          const double* src = ys + ct.src;  // (the reduced unknowns: staged in LDS above)
           double dot = 0.0;
 #pragma unroll 16
           for (int j = 0; j < ct.len; ++j) dot += Mt[size_t(j) * cg.r] * src[j];

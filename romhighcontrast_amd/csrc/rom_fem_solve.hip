@@ -143,7 +143,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
     }
     {
       ROM_PROF(ctx, "coef", 0, 8.0 * Mc * f->ncoef);
-      k_coef<<<Mc, 256, 0, st>>>(d, am);
+      k_coef<<<Mc, 256, lds_back, st>>>(d, am);  // (LDS: the nGa reduced unknowns, as in k_backsolve)
     }
   }
   if (!(stages & 2)) {
