@@ -42,5 +42,12 @@ for cfg in c4 c5; do
   python3 $R/tools/pmc_summary.py $O/bench_${cfg}_FETCH_SIZE.csv $O/bench_${cfg}_WRITE_SIZE.csv $O/pmc_traffic_$cfg.json > /dev/null
 done
 unset ROMHC_STREAMS
+# rocprofv3 per-kernel statistics of the C4 / C5 sweeps as they run by default (two concurrent sub-batches: a launch
+# covers half the systems, and kernels of the two halves overlap)
+for cfg in c4 c5; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_$cfg -- python3 $R/bench.py --config $cfg --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_${cfg}_under_rocprof.json 2> $O/st_$cfg.err
+  find $O/st_$cfg -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_${cfg}_kernel_stats.csv
+  rm -rf $O/st_$cfg
+done
 rm -f $O/*.err
 ls -la $O
