@@ -234,3 +234,22 @@ def test_bench_workloads_follow_survey_8d():
     assert np.array_equal(c4[11:], 10.0 ** np.random.default_rng(20240807).uniform(0, 8, size=(1013, 3, 3)))
     c5 = bench.workload_parameters("c5", (4, 4), 4096)
     assert c5.shape == (4096, 4, 4) and c5.max() <= 1000
+
+
+def test_environment_switches_are_documented():
+    """Every ROMHC_* variable the library reads (getenv in csrc/, os.environ in the Python layer) has a row in
+    INTEGRATION.md, and the table names no variable that nothing reads."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "romhighcontrast_amd", "csrc")
+    read = set()
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".h")):
+            read |= set(re.findall(r'getenv\("(ROMHC_[A-Z0-9_]+)"\)', open(os.path.join(csrc, fn)).read()))
+    for rel in ("romhighcontrast_amd/_ffi.py", "romhighcontrast_amd/lib/ReducedBasis.py", "romhighcontrast_amd/sweep.py"):
+        read |= set(re.findall(r'environ(?:\.get)?[\[(]\s*"(ROMHC_[A-Z0-9_]+)"', open(os.path.join(root, rel)).read()))
+    doc = set(re.findall(r"ROMHC_[A-Z0-9_]+", open(os.path.join(root, "INTEGRATION.md")).read()))
+    dev_only = {"ROMHC_EXT_LDS_PAD"}                      # timeline builds (-DROMHC_STAMPS): tools/README.md
+    launcher = {"ROMHC_LAUNCH_ID", "ROMHC_FORCE_DEVICE"}  # set / read by bench.py's launcher, not by the library
+    assert read - dev_only <= doc, sorted(read - dev_only - doc)
+    assert doc - launcher <= read, sorted(doc - launcher - read)
