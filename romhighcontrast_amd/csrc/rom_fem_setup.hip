@@ -194,27 +194,29 @@ struct UnitBlock {
 };
 
 // Compressed form of an edge whose couplings act through the tables `tabs` (ids sr*4+sc) and, if x0 / x1, through
-// its first / last node (cross points): W = orthonormal basis of the union of their ranges (tolerance `ctol` of the
-// first pivot); full rank or !compress: nodal unknowns (W = I).  False if the compressed self block is not SPD.
-bool compress_edge(const UnitBlock& ub, const std::vector<int>& tabs, bool x0, bool x1, int hv, bool compress, ld ctol, Comp& cp) {
+// its first / last node (cross points): W = orthonormal basis of the union of their ranges.
+// Step 1: the nested basis down to `keep` of the first pivot, with the pivot norms (the caller picks the rank).
+void compress_basis(const UnitBlock& ub, const std::vector<int>& tabs, bool x0, bool x1, ld keep, Mat& Wb, std::vector<ld>& pivots) {
   const int n1 = ub.n1;
-  Mat Wb;
-  if (compress) {
-    const int ntab = int(tabs.size());
-    Mat C(n1, ntab * n1 + 2);
-    for (int t = 0; t < ntab; ++t) {
-      const Mat& Tt = ub.Tm_ready(tabs[t]);
-      ld mx = 0;
-      for (ld v : Tt.v) mx = std::max(mx, fabsl(v));
-      if (mx == 0.0L) mx = 1.0L;
-      for (int i = 0; i < n1; ++i)
-        for (int k = 0; k < n1; ++k) C(i, t * n1 + k) = Tt(i, k) / mx;
-    }
-    if (x0) C(0, ntab * n1) = 1.0L;
-    if (x1) C(n1 - 1, ntab * n1 + 1) = 1.0L;
-    Wb = hostla::range_basis(C, ctol);
+  const int ntab = int(tabs.size());
+  Mat C(n1, ntab * n1 + 2);
+  for (int t = 0; t < ntab; ++t) {
+    const Mat& Tt = ub.Tm_ready(tabs[t]);
+    ld mx = 0;
+    for (ld v : Tt.v) mx = std::max(mx, fabsl(v));
+    if (mx == 0.0L) mx = 1.0L;
+    for (int i = 0; i < n1; ++i)
+      for (int k = 0; k < n1; ++k) C(i, t * n1 + k) = Tt(i, k) / mx;
   }
-  if (!compress || Wb.c >= n1) {  // nothing to gain: nodal unknowns
+  if (x0) C(0, ntab * n1) = 1.0L;
+  if (x1) C(n1 - 1, ntab * n1 + 1) = 1.0L;
+  Wb = hostla::range_basis(C, keep, &pivots);
+}
+// Step 2: everything that follows from the first `r` columns of that basis (r >= n1 or !compress: nodal unknowns,
+// W = I).  False if the compressed self block is not SPD.
+bool compress_finish(const UnitBlock& ub, const Mat& Wfull, int r, int hv, bool compress, Comp& cp) {
+  const int n1 = ub.n1;
+  if (!compress || r >= n1) {  // nothing to gain: nodal unknowns
     cp.r = n1;
     cp.W = hostla::identity(n1);
     cp.Kt = ub.Kmat;
@@ -225,7 +227,10 @@ bool compress_edge(const UnitBlock& ub, const std::vector<int>& tabs, bool x0, b
     cp.wK = hostla::matvec(ub.Kinv, ub.gE[hv]);
     return true;
   }
-  cp.r = Wb.c;
+  Mat Wb(n1, r);
+  for (int i = 0; i < n1; ++i)
+    for (int k = 0; k < r; ++k) Wb(i, k) = Wfull(i, k);
+  cp.r = r;
   cp.W = Wb;
   Mat KiW = hostla::mul(ub.Kinv, Wb);
   Mat G = hostla::mul_tn(Wb, KiW);
@@ -445,8 +450,16 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   auto Tm = [&](int id) -> const Mat& { return ub.Tm(id); };
   auto TK = [&](int id) -> const Mat& { return ub.TK(id); };
   const bool compress = !getenv("ROMHC_NO_COMPRESS");
-  ld ctol = 1e-17L;
+  // Numerical rank of an edge's coupling tables.  Directions weaker than `ctol` = 1e-14 of the strongest are dropped
+  // where that removes work: the tables are rounded to fp64 on upload, and against a basis kept down to 1e-17 the
+  // snapshots move by <= 1.2e-14 relative over seven geometries and contrasts up to 1e8 (1e-13: 9e-14; the distance to the
+  // SuperLU oracle, 1e-13..1e-12, does not change in its first three digits) while the reduced system shrinks from 347
+  // to 301 unknowns at C4 (6 -> 5 tile columns) and from 801 to 697 at C5 (13 -> 11): -19 % per step
+  // (profiles/r02_compress_tolerance.txt).  Where it removes nothing -- the weaker directions fit into the padding of the
+  // extension's 8-wide K segments and add no tile column to the reduced matrix (C2) -- they are kept, down to `ckeep`.
+  ld ctol = 1e-14L;
   if (const char* s = getenv("ROMHC_COMPRESS_TOL")) ctol = (ld)atof(s);
+  const ld ckeep = std::min<ld>(ctol, 1e-17L);
   std::map<std::vector<int>, int> sig_id;  // edges with the same surroundings share one compressed form
   std::vector<std::vector<int>> sigs;
   std::vector<int> comp_of(E, -1);
@@ -484,20 +497,34 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     ub.prepare(ids, false);
     ub.prepare(ids_tk, true);
     std::vector<char> ok(sigs.size(), 1);
-    const unsigned nthr = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), unsigned(sigs.size())));
-    std::atomic<size_t> next{0};
-    auto work = [&]() {
-      for (size_t c = next++; c < sigs.size(); c = next++) {
+    std::vector<Mat> Wfull(sigs.size());
+    std::vector<std::vector<ld>> pivots(sigs.size());
+    if (compress)
+      parallel_for(sigs.size(), [&](size_t c) {
         const std::vector<int>& sig = sigs[c];
         const int flags = sig.back() - 100;
-        ok[c] = compress_edge(ub, std::vector<int>(sig.begin() + 1, sig.end() - 1), flags & 1, flags & 2, sig[0], compress,
-                              ctol, comps[c]);
+        compress_basis(ub, std::vector<int>(sig.begin() + 1, sig.end() - 1), flags & 1, flags & 2, ckeep, Wfull[c], pivots[c]);
+      });
+    // the ranks: at `ctol`, or -- if that costs neither a K segment nor a tile column -- up to the end of the last segment
+    std::vector<int> r_drop(sigs.size(), n1), r_use(sigs.size(), n1);
+    if (compress) {
+      std::vector<int> r_fill(sigs.size(), n1);
+      for (size_t c = 0; c < sigs.size(); ++c) {
+        int r = 0;
+        while (r < int(pivots[c].size()) && pivots[c][r] > ctol * pivots[c][0]) ++r;
+        r_drop[c] = r;
+        r_fill[c] = std::min<int>(int(pivots[c].size()), (r + 1 + 7) / 8 * 8 - 1);
       }
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+      auto tiles = [&](const std::vector<int>& rr) {
+        long long nred_ = ncross;
+        for (int e : order) nred_ += std::min(rr[comp_of[e]], n1);
+        return (nred_ + TB - 1) / TB;
+      };
+      r_use = tiles(r_fill) <= tiles(r_drop) ? r_fill : r_drop;
+    }
+    parallel_for(sigs.size(), [&](size_t c) {
+      ok[c] = compress_finish(ub, Wfull[c], r_use[c], sigs[c][0], compress, comps[c]);
+    });
     for (char o : ok)
       if (!o) { rom_set_error("internal: compressed edge block not positive definite"); return ROM_ERR_INVALID; }
   }

@@ -155,7 +155,9 @@ inline bool spd_inverse(const Mat& A, Mat& inv) {
 
 // Orthonormal basis W (n x rank) of the numerical column space of C (n x m): Householder QR with
 // column pivoting, stopped when the largest remaining column norm drops below tol * (the first pivot).
-inline Mat range_basis(const Mat& C0, ld tol) {
+// `pivots` (optional): the norm of the pivot column of every accepted step (the bases are nested: the first r columns
+// of W span the r strongest directions).
+inline Mat range_basis(const Mat& C0, ld tol, std::vector<ld>* pivots = nullptr) {
   // (worked on the transpose: the columns the reflections sweep are then contiguous -- same sums in the same order)
   Mat C = transpose(C0);
   const int n = C0.r, m = C0.c;
@@ -175,6 +177,7 @@ inline Mat range_basis(const Mat& C0, ld tol) {
     best = sqrtl(best);
     if (k == 0) first = best;
     if (!(best > tol * first) || best == 0.0L) break;
+    if (pivots) pivots->push_back(best);
     if (piv != k) std::swap_ranges(C.row(k), C.row(k) + n, C.row(piv));
     std::vector<ld> v(n, 0.0L);
     const ld alpha = C(k, k) > 0 ? -best : best;
