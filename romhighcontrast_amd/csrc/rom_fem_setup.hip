@@ -453,7 +453,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   // Numerical rank of an edge's coupling tables.  Directions weaker than `ctol` = 1e-14 of the strongest are dropped
   // where that removes work: the tables are rounded to fp64 on upload, and against a basis kept down to 1e-17 the
   // snapshots move by <= 1.2e-14 relative over seven geometries and contrasts up to 1e8 (1e-13: 9e-14; the distance to the
-  // SuperLU oracle, 1e-13..1e-12, does not change in its first three digits) while the reduced system shrinks from 347
+  // reference SuperLU solve, 1e-13..1e-12, does not change in its first three digits) while the reduced system shrinks from 347
   // to 301 unknowns at C4 (6 -> 5 tile columns) and from 801 to 697 at C5 (13 -> 11): -19 % per step
   // (profiles/r02_compress_tolerance.txt).  Where it removes nothing -- the weaker directions fit into the padding of the
   // extension's 8-wide K segments and add no tile column to the reduced matrix (C2) -- they are kept, down to `ckeep`.
