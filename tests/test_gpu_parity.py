@@ -769,6 +769,32 @@ def test_algorithm_switches_agree(api, env, monkeypatch):
             assert relh10(g, alt[:4], ro.generate_solutions(g, a[:4].reshape((4,) + blocks))).max() < SNAP_TOL
 
 
+def test_edge_compression_tolerance(api, monkeypatch):
+    """The edge compression stops at 1e-14 of the strongest direction where that removes work (3x3 / N=171: 301 reduced
+    unknowns = 5 tile columns = 15 tiles instead of 347 / 6 / 21 with the basis run down to 1e-17) and keeps the weaker
+    directions where they are free (2x2 / N=128: one tile either way).  The snapshots of the two settings agree to
+    1e-13 (measured 1.2e-14, profiles/r02_compress_tolerance.txt), far inside the parity bound."""
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    monkeypatch.delenv("ROMHC_COMPRESS_TOL", raising=False)
+    assert _ffi.Fem(ctx, 2, 2, 128).n_tiles == 1
+    blocks, N, M = (3, 3), 171, 48
+    a = 10.0 ** np.random.default_rng(3).uniform(-4, 4, size=(M, 9))
+    ab = ctx.upload(a)
+    out = {}
+    for name, tol, tiles in (("default", None, 15), ("1e-17", "1e-17", 21)):
+        if tol:
+            monkeypatch.setenv("ROMHC_COMPRESS_TOL", tol)
+        fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)
+        assert fem.n_tiles == tiles, (name, fem.n_tiles)
+        U = ctx.alloc(M * fem.dim)
+        fem.solve_batch(ab, M, U)
+        out[name] = U.download(shape=(M, fem.dim))
+    monkeypatch.delenv("ROMHC_COMPRESS_TOL", raising=False)
+    d = np.linalg.norm(out["default"] - out["1e-17"], axis=1) / np.linalg.norm(out["1e-17"], axis=1)
+    assert d.max() < 1e-13, d.max()
+
+
 def test_sub_batch_streams_agree(api, monkeypatch):
     """A sweep over a geometry whose reduced solve is the tile Cholesky runs as two concurrent sub-batches on
     separate HIP streams (disjoint workspaces and rows): same rows as one batch on one stream (ROMHC_STREAMS=1, read
