@@ -181,16 +181,17 @@ def _pool_solve(args):
     return len(rows)
 
 
-def cpu_baseline_pool(blocks, N, a, per_worker=40, label="C2"):
+def cpu_baseline_pool(blocks, N, a, per_worker=40, label="C2", max_cores=16):
     """The same CPU path with the reference's num_cores > 1 semantics (a process pool over the parameters,
-    src/lib/SolutionsManagers.py:51,64-68) on this job's share of the host cores.  Runs BEFORE the GPU is
-    initialised: the pool forks."""
+    src/lib/SolutionsManagers.py:51,64-68).  max_cores = 16: a one-GPU job's CPU share on the bench box; None: every
+    core this job may use (Pool(os.cpu_count())).  Runs BEFORE the GPU is initialised: the
+    pool forks."""
     import multiprocessing as mp
     try:
         share = len(os.sched_getaffinity(0))
     except AttributeError:
         share = os.cpu_count() or 1
-    cores = max(1, min(16, share))  # a one-GPU job's CPU share on the bench box
+    cores = max(1, min(max_cores, share) if max_cores else share)
     n = min(len(a), cores * per_worker)
     chunks = [(blocks, N, a[i::cores][: (n + cores - 1) // cores]) for i in range(cores)]
     n = sum(len(c[2]) for c in chunks)
@@ -288,7 +289,7 @@ def main():
     a_all = workload_parameters(args.config, blocks, world * M)
     a_loc = a_all[rank * M:(rank + 1) * M]
 
-    pool_baseline = None
+    pool_baseline = pool_baseline_full = None
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or \
         "rocprof" in os.environ.get("LD_PRELOAD", "")
     if world == 1 and not args.no_cpu_baseline and under_profiler:
@@ -298,6 +299,10 @@ def main():
     elif world == 1 and not args.no_cpu_baseline:
         # all-cores CPU figure first: it forks, which must happen before anything touches the GPU
         pool_baseline = cpu_baseline_pool(blocks, N, a_loc, per_worker=cfg["pool_per_worker"], label=label)
+        # ... and with every core of the host (the contract's Pool(os.cpu_count())); a short sample per worker
+        # (C2 only: 256 workers hold 256 SuperLU factorisations -- 50 MB each at C2, 1.2 GB each at C5)
+        if args.config == "c2" and not custom:
+            pool_baseline_full = cpu_baseline_pool(blocks, N, a_loc, per_worker=5, label=label, max_cores=None)
 
     from romhighcontrast_amd import _ffi, sweep
     from romhighcontrast_amd.lib.SolutionsManagers import DeviceArray, SolutionsManagerFEM
@@ -339,32 +344,28 @@ def main():
     step_no = [0]
     if comm:
         # two buffer pairs: the all-gather of step k (communication stream) overlaps the expansion of step k and
-        # the reduced solves of step k+1 (compute stream)
-        Y_loc = [ctx.alloc(max(M * stride, 1)) for _ in range(2)]
-        Y_all = [ctx.alloc(max(world * M * stride, 1)) for _ in range(2)]
+        # the reduced solves of step k+1 (compute stream).  The loop itself is sweep.run_step -- the function the
+        # 2-rank CPU rehearsal drives (tests/test_host_logic.py).
+        replicate = None
         if args.replicate:
             U_all = ctx.alloc(world * M * dim)
             a_all_dev = ctx.upload(a_all.reshape(world * M, -1))
+            replicate = (a_all_dev, U_all)
+        be = sweep.GpuStepBackend(ctx, fem, a_dev, M, world, U_loc=U_loc, replicate=replicate)
+        Y_all = be.Y_all
 
     def step():
         if not comm:
             fem.solve_batch(a_dev, M, U_loc, wait=False)  # enqueued only: no host round trip per step
             return
-        k = step_no[0] & 1
+        sweep.run_step(be, step_no[0])
         step_no[0] += 1
-        ctx.comm_wait_slot(k)                                    # the all-gather that last read Y_loc[k] is done
-        fem.solve_reduced(a_dev, M, Y_loc[k])                    # this rank's shard: interface vectors ...
-        ctx.allgather_async(Y_loc[k], 0, Y_all[k], 0, M * stride, slot=k)   # ... all-gathered (RCCL over xGMI)
-        if args.replicate:
-            ctx.comm_wait(False)                                 # compute stream waits for the gathered vectors
-            fem.expand(a_all_dev, world * M, Y_all[k], U_all)    # the whole block as rows, on every rank
-        else:
-            fem.expand(a_dev, M, Y_loc[k], U_loc)                # the rows of the own shard, while the vectors travel
 
     def drain():
-        ctx.solve_status()  # waits for the compute stream; raises if any system was not positive definite
         if comm:
-            ctx.comm_wait(True)
+            sweep.drain(be)
+        else:
+            ctx.solve_status()  # waits for the compute stream; raises if any system was not positive definite
 
     for _ in range(args.warmup):
         step()
@@ -521,10 +522,24 @@ def main():
             extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim)
         elif args.config == "c5":
             extras_pod_c5(out, ctx, sm, fem, a_dev, U_loc, M, dim)
+    pod_key = "pod_c3" if "pod_c3" in out else ("pod" if "pod" in out else None)
+    if pod_key:
+        pr = out[pod_key]
+        out["roofline"]["secondary"] = {
+            "metric": "pod_svd_gflops", "kernel": "rom_pod (k_gram128 + subspace iteration + deflation / lift GEMMs)",
+            "bound": "mfma", "achieved": round(pr["gflops"] * 1e-3, 2), "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(pr["gflops"] * 1e-3 / FP64_MATRIX_PEAK_TFLOPS, 4), "seconds": pr["seconds"],
+            "workload": f"{pr['modes']}-mode POD of the {pr['M']} x {pr['dim']} snapshot block "
+                        + ("(config C3's gathered block, generated and decomposed on this GPU)" if pod_key == "pod_c3" else f"({label})"),
+            "note": "USEFUL flops (symmetric half of ONE Gram matrix M(M+1)dim + lift 2 r M dim; no eigh term) over the wall "
+                    "time of ONE rom_pod call incl. the download of the modes; the executed flops and the Gram kernel's own "
+                    "rate are in the `" + pod_key + "` record"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blocks, N, a_loc, budget_s=cfg["cpu_budget_s"], label=label,
                                            min_solves=2 if args.config == "c5" else 4)
         out["cpu_baseline_all_cores"] = pool_baseline
+        if pool_baseline_full is not None:
+            out["cpu_baseline_host_cores"] = pool_baseline_full
         if args.config == "c2":
             # POD on the host: numpy.linalg.svd(X - mean) on a subsample of the same block that fits a few
             # seconds, LAPACK threads as configured on the box; same useful-flop accounting for its size
@@ -619,7 +634,6 @@ def extras_pod_c2(out, args, ctx, sm, fem, a_dev, U_loc, M, dim, blocks):
         fem.solve_reduced(a_dev, M, Yf)
         ctx.solve_status()
         fs = factored.FactoredSnapshots(sm, Yf, M)
-        # (best of 5: a call is ~10 ms of small host LAPACK / allocator work that occasionally takes 80 ms)
         (_, sig_f), dtf = _timed(ctx, lambda: factored.pod_modes_factored(fs, r), reps=5)
         info = dict(getattr(factored.pod_modes_factored, "last_info", {}))
         out["pod_factored"] = {"seconds": round(dtf, 4), "modes": r, "M": M,
@@ -637,7 +651,7 @@ def extras_pod_c2(out, args, ctx, sm, fem, a_dev, U_loc, M, dim, blocks):
         U3 = ctx.alloc(M3 * dim)
         fem.solve_batch(ctx.upload(a3), M3, U3)
         X3 = ctx.alloc(M3 * dim)
-        # (best of 5: the call has ~25 host round trips; its wall time scatters by +-20 % from call to call on one box)
+        # (best of 5 calls)
         dt3 = 1e30
         for _ in range(5):
             (_, sig3), dt3b = run_rows(X3, U3, M3)
@@ -705,7 +719,7 @@ def extras_pod_c5(out, ctx, sm, fem, a_dev, U_loc, M, dim):
     r = 50
     X = ctx.alloc(M * dim)
     dt = 1e30
-    for _ in range(3):  # (best of 3: the first call pays one-off kernel loads, and the host round trips scatter)
+    for _ in range(3):  # (best of 3: the first call pays one-off kernel loads)
         X.copy_from(U_loc, M * dim)
         ctx.synchronize()
         t0 = time.perf_counter()

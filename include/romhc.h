@@ -181,6 +181,47 @@ int rom_rows_sign_flip(rom_ctx* ctx, rom_buf* X, int64_t row0, int rows, int64_t
 int rom_evaluate_points(rom_fem* fem, rom_buf* U, int64_t row0, int K, int npts, const int* ix_host,
                         const int* iy_host, const double* tx_host, const double* ty_host, double* out_host);
 
+/* ---- the basis stage as single calls (rom_project_h10, rom_galerkin_rom, rom_greedy, rom_pod) --------
+ * Each call enqueues all its kernels on the context's stream and waits for it once at its end (status word /
+ * results); small dense problems (Gram matrices of the basis, projected eigenproblems, argmax of the greedy) are solved
+ * on the device.  rom_pod additionally reads a few dozen spectrum values per pass to decide how many modes to accept. */
+/* project_solutions (src/lib/SolutionsManagers.py:108-139): OUT[out_row0+m] = H^1_0-orthogonal projection of
+ * U[u_row0+m] onto the span of the n rows C[c_row0 ...] (any full-rank rows; n = 0: zeros, :109-111).
+ * ROM_ERR_NOT_SPD if C A_1 C^T is not positive definite (dependent rows). */
+int rom_project_h10(rom_fem* fem, rom_buf* U, int64_t u_row0, int M, rom_buf* C, int64_t c_row0, int n, rom_buf* OUT,
+                    int64_t out_row0);
+/* generate_fm_solutions (:88-106): OUT[out_row0+m] = Galerkin reduced-order solution for a[m] (M x nrb*ncb) in the span
+ * of the n rows of C (n = 0: zeros, :89-91) */
+int rom_galerkin_rom(rom_fem* fem, rom_buf* a, int M, rom_buf* C, int64_t c_row0, int n, rom_buf* OUT, int64_t out_row0);
+/* orthonormalize_base (src/lib/ReducedBasis.py:18-21): rows of X -> Euclidean-orthonormal rows of Q spanning the same
+ * nested subspaces (the thin QR at :19 up to the sign of each row; a dependent row becomes zero).  Q may be X. */
+int rom_orthonormalize_rows(rom_ctx* ctx, rom_buf* X, int64_t x_row0, int n, int64_t dim, rom_buf* Q, int64_t q_row0);
+/* ReducedBasisGreedy.build (src/lib/ReducedBasis.py:112-139): strong greedy over the M training snapshots U[u_row0 ...]
+ * in relative H^1_0 error; mode 0 = error of the H^1_0 projection (:122), 1 = error of the Galerkin ROM (:124, needs
+ * the training parameters a, M x nrb*ncb).  h1norm_host: the M normalisations (solutions2train_h1norm, :129).
+ * picks_out[i] = training index chosen in iteration i (first maximum, like np.argmax), max_err_out[i] = its relative
+ * error, i < n.  Iteration 0 has the empty basis: with h1norm = rom_h10norm(U) every error is exactly 1.0 and the
+ * pick is index 0, as in the reference. */
+int rom_greedy(rom_fem* fem, rom_buf* U, int64_t u_row0, int M, rom_buf* a, const double* h1norm_host, int mode, int n,
+               int64_t* picks_out, double* max_err_out);
+/* PCA(n_components = n).fit (src/lib/ReducedBasis.py:196): leading n right singular vectors of the (M, dim) block
+ * X[x_row0 ...] -- OVERWRITTEN (centred when center != 0, deflated) -- into V[v_row0 ...] (n x dim, orthonormal rows,
+ * scikit-learn's svd_flip(u_based_decision=False) signs) and their singular values into sigma_host (n).  MFMA Gram
+ * matrix + subspace iteration for the modes above 1e-5 sigma_1, deflation + randomised range finder below, Rayleigh-
+ * Ritz over the collected modes; modes below 1e-13 sigma_1 do not exist in fp64 data and are completed with
+ * orthonormal directions of singular value 0.  info_host (8 doubles or NULL): resolved modes, completed modes, Gram
+ * passes, sketch passes, executed flops, useful flops (M(M+1)dim + 2 n M dim), subspace iterations, 0. */
+int rom_pod(rom_ctx* ctx, rom_buf* X, int64_t x_row0, int M, int64_t dim, int n, int center, rom_buf* V, int64_t v_row0,
+            double* sigma_host, double* info_host);
+/* rows V[v_row0+found .. +found+rest) <- deterministic pseudo-random directions, orthonormal and orthogonal to the
+ * orthonormal rows V[v_row0 .. +found): how rom_pod completes a request beyond what the data determine */
+int rom_complete_orthonormal(rom_ctx* ctx, rom_buf* V, int64_t v_row0, int found, int rest, int64_t dim);
+/* the device eigen-solver the calls above use for their small symmetric problems (cyclic Jacobi, one workgroup), for
+ * n x n host matrices, n <= 1024: mode 0 T = eigenvector rows (eigenvalues descending in lam_host); 1 T = whitening
+ * transform Lambda^-1/2 Q^T (rows with lambda <= rel_tol lambda_max zero); 2 T = Q Lambda^-1/2 Q^T.  Test hook. */
+int rom_small_eig_host(rom_ctx* ctx, int n, const double* A_host, int mode, double rel_tol, double* lam_host,
+                       double* T_host);
+
 /* ---- multi-GPU: RCCL all-gather of the snapshot block --------------------- */
 /* id_out: 128 bytes (ncclUniqueId).  librccl is dlopen()ed on first use. */
 int rom_comm_unique_id(char* id_out, size_t cap);

@@ -83,6 +83,13 @@ PROTOTYPES = {
     "rom_rows_scale": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp]),
     "rom_rows_sign_flip": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64]),
     "rom_evaluate_points": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "rom_project_h10": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64, C.c_int, _vp, C.c_int64]),
+    "rom_galerkin_rom": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, _vp, C.c_int64]),
+    "rom_orthonormalize_rows": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp, C.c_int64]),
+    "rom_greedy": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rom_pod": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp]),
+    "rom_complete_orthonormal": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int64]),
+    "rom_small_eig_host": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, _vp, _vp]),
     "rom_comm_unique_id": (C.c_int, [C.c_char_p, C.c_size_t]),
     "rom_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),
     "rom_comm_destroy": (C.c_int, [_vp]),
@@ -252,6 +259,30 @@ class Context:
         check(self.lib.rom_l2norm(self.h, U.h, row0, K, dim, out.ctypes.data))
         return out
 
+    # -- basis stage (single C calls) ------------------------------------------------------------
+    def orthonormalize_rows(self, X: "Buffer", n, dim, Q: "Buffer", x_row0=0, q_row0=0):
+        check(self.lib.rom_orthonormalize_rows(self.h, X.h, x_row0, n, dim, Q.h, q_row0))
+
+    def pod(self, X: "Buffer", M, dim, n, V: "Buffer", center=True, x_row0=0, v_row0=0):
+        """rom_pod: X is overwritten.  Returns (sigma (n,), info dict)."""
+        sigma, info = np.zeros(max(n, 1)), np.zeros(8)
+        check(self.lib.rom_pod(self.h, X.h, x_row0, M, dim, n, 1 if center else 0, V.h, v_row0, sigma.ctypes.data,
+                               info.ctypes.data))
+        keys = ("resolved_modes", "completed_modes", "gram_passes", "sketch_passes")
+        d = {k: int(info[i]) for i, k in enumerate(keys)}
+        d.update(executed_flops=float(info[4]), useful_flops=float(info[5]), subspace_iterations=int(info[6]))
+        return sigma[:n], d
+
+    def complete_orthonormal(self, V: "Buffer", found, rest, dim, v_row0=0):
+        check(self.lib.rom_complete_orthonormal(self.h, V.h, v_row0, found, rest, dim))
+
+    def small_eig(self, A, mode=0, rel_tol=0.0):
+        A = _host(A)
+        n = A.shape[0]
+        lam, T = np.empty(n), np.empty((n, n))
+        check(self.lib.rom_small_eig_host(self.h, n, A.ctypes.data, mode, rel_tol, lam.ctypes.data, T.ctypes.data))
+        return lam, T
+
     # -- RCCL ----------------------------------------------------------------------------------
     def comm_unique_id(self) -> bytes:
         buf = C.create_string_buffer(128)
@@ -419,6 +450,21 @@ class Fem:
         check(self.ctx.lib.rom_h10norm(self.h, U.h, u_row0, V.h if V is not None else None, v_row0, K,
                                        out.ctypes.data))
         return out
+
+    def project_h10(self, U: Buffer, M: int, Cb: Buffer | None, n: int, OUT: Buffer, u_row0=0, c_row0=0, out_row0=0):
+        check(self.ctx.lib.rom_project_h10(self.h, U.h, u_row0, M, Cb.h if Cb is not None else None, c_row0, n, OUT.h,
+                                           out_row0))
+
+    def galerkin_rom(self, a: Buffer, M: int, Cb: Buffer | None, n: int, OUT: Buffer, c_row0=0, out_row0=0):
+        check(self.ctx.lib.rom_galerkin_rom(self.h, a.h, M, Cb.h if Cb is not None else None, c_row0, n, OUT.h, out_row0))
+
+    def greedy(self, U: Buffer, M: int, a: Buffer | None, h1norm, galerkin: bool, n: int, u_row0=0):
+        """rom_greedy: (picks list, max relative errors list)."""
+        h1 = _host(np.broadcast_to(np.asarray(h1norm, dtype=np.float64), (M,)))
+        picks, errs = np.zeros(max(n, 1), dtype=np.int64), np.zeros(max(n, 1))
+        check(self.ctx.lib.rom_greedy(self.h, U.h, u_row0, M, a.h if a is not None else None, h1.ctypes.data,
+                                      1 if galerkin else 0, n, picks.ctypes.data, errs.ctypes.data))
+        return [int(p) for p in picks[:n]], [float(e) for e in errs[:n]]
 
     def evaluate_points(self, U: Buffer, K: int, ix, iy, tx, ty, row0=0) -> np.ndarray:
         ix = np.ascontiguousarray(ix, dtype=np.int32)

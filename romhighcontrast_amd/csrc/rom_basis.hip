@@ -1,0 +1,1016 @@
+// The basis stage behind the C-ABI: single-call operations for the projectors, the greedy and the POD.
+//
+// Reference counterparts: project_solutions (src/lib/SolutionsManagers.py:108-139), generate_fm_solutions (:88-106),
+// orthonormalize_base (src/lib/ReducedBasis.py:18-21), ReducedBasisGreedy.build (:112-139), the PCA fit inside
+// ReducedBasisPCA.build (:189-200).  Everything here runs on the device: small dense problems (symmetric eigenproblems
+// of at most a few hundred unknowns, Cholesky-free whitening) are solved by a one-workgroup Jacobi kernel, selections
+// (argmax of the greedy) stay in device memory, norms feed the next kernel through device scalars.  The host sees a
+// status word at the end of a call -- and, in the POD, the handful of spectrum values its acceptance decisions need.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "rom_ops.h"
+
+namespace {
+
+// ---- temporaries from the context's caching allocator ---------------------------------------------------------------
+struct Tmp {
+  rom_buf* b = nullptr;
+  Tmp() = default;
+  Tmp(const Tmp&) = delete;
+  Tmp& operator=(const Tmp&) = delete;
+  ~Tmp() { release(); }
+  void release() {
+    if (b) rom_buf_free(b);
+    b = nullptr;
+  }
+  int get(rom_ctx* ctx, size_t n) {
+    release();
+    return rom_buf_alloc(ctx, std::max<size_t>(n, 1), &b);
+  }
+  double* p() const { return b->p; }
+  operator double*() const { return b->p; }
+};
+
+int read_status(rom_ctx* ctx, const char* who) {
+  int status = 0;
+  ROM_HIP(hipMemcpyAsync(&status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  if (status) {
+    rom_set_error("%s: reduced matrix not positive definite", who);
+    return ROM_ERR_NOT_SPD;
+  }
+  return ROM_OK;
+}
+
+int download(rom_ctx* ctx, const double* d, double* h, size_t n) {
+  if (n == 0) return ROM_OK;
+  ROM_HIP(hipMemcpyAsync(h, d, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  return ROM_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// small elementwise / indexing kernels
+// =====================================================================================================================
+__global__ void kb_fill(double* p, size_t n, double v) {
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) p[i] = v;
+}
+
+static int fill(rom_ctx* ctx, double* p, size_t n, double v) {
+  if (n == 0) return ROM_OK;
+  if (v == 0.0) {
+    ROM_HIP(hipMemsetAsync(p, 0, n * sizeof(double), ctx->stream));
+    return ROM_OK;
+  }
+  kb_fill<<<unsigned(std::min<size_t>((n + 255) / 256, 2048)), 256, 0, ctx->stream>>>(p, n, v);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// counter-based generator (splitmix64 of seed and index): the same numbers whatever the launch shape
+__device__ inline unsigned long long mix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ inline double u01(unsigned long long h) { return (double(h >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
+// gaussian != 0: standard normal (Box-Muller); else uniform in (-0.5, 0.5)
+__global__ void kb_fill_random(double* p, size_t n, unsigned long long seed, int gaussian) {
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    const unsigned long long h1 = mix64(seed * 0xD1342543DE82EF95ull + 2 * i), h2 = mix64(seed * 0xD1342543DE82EF95ull + 2 * i + 1);
+    p[i] = gaussian ? sqrt(-2.0 * log(u01(h1))) * cos(6.283185307179586 * u01(h2)) : u01(h1) - 0.5;
+  }
+}
+
+static int fill_random(rom_ctx* ctx, double* p, size_t n, unsigned long long seed, bool gaussian) {
+  if (n == 0) return ROM_OK;
+  kb_fill_random<<<unsigned(std::min<size_t>((n + 255) / 256, 4096)), 256, 0, ctx->stream>>>(p, n, seed, gaussian ? 1 : 0);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// out[i, :] = x[i, :] + s * f[i] * y[i, :]    (rows x dim; x may be null = 0)
+__global__ void kb_rows_axpy(double* __restrict__ out, const double* __restrict__ x, const double* __restrict__ y,
+                             const double* __restrict__ f, double s, long long dim) {
+  const double a = s * f[blockIdx.y];
+  const long long o = blockIdx.y * dim;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < dim; j += (long long)gridDim.x * blockDim.x)
+    out[o + j] = (x ? x[o + j] : 0.0) + a * y[o + j];
+}
+
+// dst (cols x rows, ld ldd) = transpose of src (rows x cols, ld lds): small matrices only
+__global__ void kb_transpose(double* __restrict__ dst, long long ldd, const double* __restrict__ src, long long lds,
+                             int rows, int cols) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= (long long)rows * cols) return;
+  const int r = int(idx / cols), c = int(idx % cols);
+  dst[c * ldd + r] = src[r * lds + c];
+}
+
+static int transpose(rom_ctx* ctx, double* dst, long long ldd, const double* src, long long lds, int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return ROM_OK;
+  kb_transpose<<<unsigned(((long long)rows * cols + 255) / 256), 256, 0, ctx->stream>>>(dst, ldd, src, lds, rows, cols);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// =====================================================================================================================
+// symmetric eigenproblem of a small matrix: cyclic Jacobi, one workgroup
+// =====================================================================================================================
+// A (n x n, leading dimension lda, symmetrised on entry) = sum_i lam_i q_i q_i^T.  Rotations of a round act on disjoint
+// index pairs (round-robin tournament ordering), so a round is three workgroup-wide phases: angles, row rotations of A
+// and of the accumulated eigenvector rows, column rotations of A.  A rotation is skipped when |a_pq| <= eps sqrt(a_pp a_qq)
+// -- the criterion under which Jacobi computes the small eigenvalues of a graded positive definite matrix to high
+// RELATIVE accuracy (Demmel-Veselic), which is what the whitening of nearly dependent sketches and the Rayleigh-Ritz
+// rounds of the POD rely on.  The matrix and the eigenvector rows live in LDS up to n = SE_LDS_MAX (160 KB opted in),
+// beyond that in a global workspace (gws; L2 resident).
+// Output (mode): eigenvalues descending in lam, and in T (ld ldt)
+//   SE_EIG     rows = eigenvectors q_i^T
+//   SE_WHITEN  row i = q_i^T / sqrt(lam_i) for lam_i > rel_tol * lam_0, zero rows otherwise
+//              (T X has orthonormal rows spanning the numerical row space of X when A = X X^T)
+//   SE_LOWDIN  sum_i q_i q_i^T / sqrt(lam_i) over the same i: the symmetric inverse square root (nearest orthonormal rows)
+enum { SE_EIG = 0, SE_WHITEN = 1, SE_LOWDIN = 2 };
+constexpr int SE_LDS_MAX = 96, SE_MAX = 1024;
+
+__global__ __launch_bounds__(256) void kb_small_eig(int n, const double* __restrict__ A, int lda, double* __restrict__ lam,
+                                                    double* __restrict__ T, int ldt, int mode, double rel_tol,
+                                                    double* __restrict__ gws) {
+  extern __shared__ __align__(16) double sm[];
+  const int t = threadIdx.x, ld = n | 1, ne = n + (n & 1), half = ne / 2;
+  double* As = gws ? gws : sm;
+  double* Vt = As + size_t(n) * ld;
+  double* vec = gws ? sm : Vt + size_t(n) * ld;  // [cs half | sn half | lam n | (int) pp half, qq half, perm n, flag]
+  double* cs = vec;
+  double* sn = vec + half;
+  double* ev = vec + 2 * half;
+  int* pp = reinterpret_cast<int*>(ev + n);
+  int* qq = pp + half;
+  int* perm = qq + half;
+  int* flag = perm + n;
+  for (int idx = t; idx < n * n; idx += 256) {
+    const int r = idx / n, c = idx % n;
+    As[r * ld + c] = 0.5 * (A[size_t(r) * lda + c] + A[size_t(c) * lda + r]);
+    Vt[r * ld + c] = r == c ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const double eps = 1.1e-16;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    if (t == 0) *flag = 0;
+    __syncthreads();
+    for (int r = 0; r < ne - 1; ++r) {
+      if (t < half) {
+        int p = t == 0 ? ne - 1 : (r + t) % (ne - 1), q = t == 0 ? r : (r - t + ne - 1) % (ne - 1);
+        if (p > q) { const int x = p; p = q; q = x; }
+        double c = 1.0, s = 0.0;
+        if (q < n) {
+          const double app = As[p * ld + p], aqq = As[q * ld + q], apq = As[p * ld + q];
+          if (fabs(apq) > eps * sqrt(fabs(app * aqq)) && fabs(apq) > 1e-300) {
+            const double theta = (aqq - app) / (2.0 * apq);
+            const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            c = 1.0 / sqrt(tt * tt + 1.0);
+            s = tt * c;
+            *flag = 1;
+          } else {
+            q = -1;
+          }
+        } else {
+          q = -1;
+        }
+        cs[t] = c;
+        sn[t] = s;
+        pp[t] = p;
+        qq[t] = q;
+      }
+      __syncthreads();
+      // rows p, q of A and of Vt
+      for (int idx = t; idx < half * n; idx += 256) {
+        const int k = idx / n, j = idx % n, q = qq[k];
+        if (q < 0) continue;
+        const int p = pp[k];
+        const double c = cs[k], s = sn[k];
+        const double ap = As[p * ld + j], aq = As[q * ld + j];
+        As[p * ld + j] = c * ap - s * aq;
+        As[q * ld + j] = s * ap + c * aq;
+        const double vp = Vt[p * ld + j], vq = Vt[q * ld + j];
+        Vt[p * ld + j] = c * vp - s * vq;
+        Vt[q * ld + j] = s * vp + c * vq;
+      }
+      __syncthreads();
+      // columns p, q of A
+      for (int idx = t; idx < half * n; idx += 256) {
+        const int k = idx % half, i = idx / half, q = qq[k];
+        if (q < 0) continue;
+        const int p = pp[k];
+        const double c = cs[k], s = sn[k];
+        const double ap = As[i * ld + p], aq = As[i * ld + q];
+        As[i * ld + p] = c * ap - s * aq;
+        As[i * ld + q] = s * ap + c * aq;
+      }
+      __syncthreads();
+    }
+    const int any = *flag;
+    __syncthreads();
+    if (!any) break;
+  }
+  // eigenvalues, descending order (stable: ties by index)
+  for (int i = t; i < n; i += 256) ev[i] = As[i * ld + i];
+  __syncthreads();
+  for (int i = t; i < n; i += 256) {
+    int rank = 0;
+    const double v = ev[i];
+    for (int j = 0; j < n; ++j) rank += (ev[j] > v || (ev[j] == v && j < i)) ? 1 : 0;
+    perm[rank] = i;
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += 256) lam[i] = ev[perm[i]];
+  const double lmax = ev[perm[0]];
+  if (mode == SE_LOWDIN) {
+    for (int idx = t; idx < n * n; idx += 256) {
+      const int r = idx / n, c = idx % n;
+      double s = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double l = ev[i];
+        if (l > rel_tol * lmax && l > 0.0) s += Vt[i * ld + r] * Vt[i * ld + c] / sqrt(l);
+      }
+      T[size_t(r) * ldt + c] = s;
+    }
+  } else {
+    for (int idx = t; idx < n * n; idx += 256) {
+      const int r = idx / n, c = idx % n, src = perm[r];
+      double v = Vt[src * ld + c];
+      if (mode == SE_WHITEN) {
+        const double l = ev[src];
+        v = (l > rel_tol * lmax && l > 0.0) ? v / sqrt(l) : 0.0;
+      }
+      T[size_t(r) * ldt + c] = v;
+    }
+  }
+}
+
+static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, int mode, double rel_tol) {
+  if (n <= 0) return ROM_OK;
+  ROM_CHECK(n <= SE_MAX, "small symmetric eigenproblem: n = %d beyond %d", n, SE_MAX);
+  const int ld = n | 1, half = (n + (n & 1)) / 2;
+  const size_t vec = (2 * size_t(half) + n) * sizeof(double) + (2 * size_t(half) + n + 2) * sizeof(int);
+  double* gws = nullptr;
+  size_t lds = vec + 16;
+  if (n <= SE_LDS_MAX) {
+    lds += 2 * size_t(n) * ld * sizeof(double);
+  } else {
+    ROM_TRY(rom_ctx_scratch(ctx, 2 * size_t(n) * ld, &gws));
+  }
+  if (lds > 64 * 1024 && !ctx->lds_optin_small_eig) {
+    ROM_HIP(hipSetDevice(ctx->device));
+    ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb_small_eig), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ctx->lds_optin_small_eig = true;
+  }
+  {
+    ROM_PROF(ctx, "small_eig", 30.0 * n * n * n, 16.0 * n * n);
+    kb_small_eig<<<1, 256, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gws);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// test / diagnostic entry: eigen-decomposition of a small symmetric matrix given on the host
+extern "C" int rom_small_eig_host(rom_ctx* ctx, int n, const double* A_host, int mode, double rel_tol, double* lam_host,
+                                  double* T_host) {
+  ROM_CHECK(ctx && A_host && lam_host && T_host && n >= 1 && n <= SE_MAX, "rom_small_eig_host: bad arguments");
+  ROM_CHECK(mode >= 0 && mode <= 2, "rom_small_eig_host: mode must be 0, 1 or 2");
+  Tmp A, lam, T;
+  ROM_TRY(A.get(ctx, size_t(n) * n));
+  ROM_TRY(lam.get(ctx, n));
+  ROM_TRY(T.get(ctx, size_t(n) * n));
+  ROM_HIP(hipMemcpyAsync(A.p(), A_host, size_t(n) * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ROM_TRY(small_eig(ctx, n, A, n, lam, T, n, mode, rel_tol));
+  ROM_TRY(download(ctx, lam, lam_host, n));
+  return download(ctx, T, T_host, size_t(n) * n);
+}
+
+// =====================================================================================================================
+// orthonormalisation helpers (rows of a (b, dim) block)
+// =====================================================================================================================
+// X (b x dim) <- T X with T from the b x b Gram matrix X X^T: SE_WHITEN (rank revealing: dependent directions become
+// zero rows) or SE_LOWDIN (rows stay individually close to what they were).  `rounds` repetitions (the second one
+// removes what the squared condition number of the first Gram matrix left).  Y is a scratch block of the same size; the
+// result ends in X.
+static int gram_transform(rom_ctx* ctx, double* X, double* Y, int b, int64_t dim, int mode, double rel_tol, int rounds) {
+  if (b <= 0) return ROM_OK;
+  Tmp G, lam, T;
+  ROM_TRY(G.get(ctx, size_t(b) * b));
+  ROM_TRY(lam.get(ctx, b));
+  ROM_TRY(T.get(ctx, size_t(b) * b));
+  for (int r = 0; r < rounds; ++r) {
+    ROM_TRY(rom_launch_gram(ctx, b, dim, X, dim, G, b));
+    ROM_TRY(small_eig(ctx, b, G, b, lam, T, b, mode, r == 0 ? rel_tol : 1e-8));
+    ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, b, 1.0, T, b, X, dim, 0.0, Y, dim));
+    ROM_HIP(hipMemcpyAsync(X, Y, size_t(b) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return ROM_OK;
+}
+
+// rows V[found : found + take] <- orthonormal and orthogonal to the orthonormal rows V[0 : found]: block Gram-Schmidt
+// against the old rows (twice), symmetric orthonormalisation among the new ones
+static int orthonormalize_against(rom_ctx* ctx, double* V, int found, int take, int64_t dim) {
+  if (take <= 0) return ROM_OK;
+  double* Vn = V + size_t(found) * dim;
+  if (found > 0) {
+    Tmp C;
+    ROM_TRY(C.get(ctx, size_t(take) * found));
+    for (int r = 0; r < 2; ++r) {
+      ROM_TRY(rom_launch_gemm_nt(ctx, take, found, dim, 1.0, Vn, dim, V, dim, 0.0, C, found, "gemm_nt"));
+      ROM_TRY(rom_launch_gemm_nn(ctx, take, dim, found, -1.0, C, found, V, dim, 1.0, Vn, dim));
+    }
+  }
+  Tmp Y;
+  ROM_TRY(Y.get(ctx, size_t(take) * dim));
+  return gram_transform(ctx, Vn, Y, take, dim, SE_LOWDIN, 1e-30, 2);
+}
+
+// kb_cgs_finish: v <- v / ||v||_2 (norm squared given on the device), zero row if the norm underflows
+__global__ void kb_scale_by_inv_norm(double* __restrict__ v, long long dim, const double* __restrict__ nrm2) {
+  const double n2 = *nrm2;
+  const double a = (n2 > 0.0 && sqrt(n2) > 1e-300) ? 1.0 / sqrt(n2) : 0.0;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < dim; j += (long long)gridDim.x * blockDim.x) v[j] *= a;
+}
+
+// orthonormalize_base (src/lib/ReducedBasis.py:18-21): rows of X -> Euclidean-orthonormal rows spanning the same NESTED
+// subspaces (thin QR of X^T up to the sign of each row), by re-orthogonalised classical Gram-Schmidt; every step is a
+// device operation, the norms never leave the device.
+extern "C" int rom_orthonormalize_rows(rom_ctx* ctx, rom_buf* X, int64_t x_row0, int n, int64_t dim, rom_buf* Q, int64_t q_row0) {
+  ROM_CHECK(ctx && X && Q, "rom_orthonormalize_rows: null argument");
+  ROM_CHECK(n >= 0 && dim >= 1 && x_row0 >= 0 && q_row0 >= 0, "rom_orthonormalize_rows: bad sizes");
+  ROM_CHECK(size_t(x_row0 + n) * dim <= X->n && size_t(q_row0 + n) * dim <= Q->n, "rom_orthonormalize_rows: rows out of range");
+  if (n == 0) return ROM_OK;
+  double* q = Q->p + q_row0 * dim;
+  if (q != X->p + x_row0 * dim)
+    ROM_HIP(hipMemcpyAsync(q, X->p + x_row0 * dim, size_t(n) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  Tmp h, nrm;
+  ROM_TRY(h.get(ctx, n));
+  ROM_TRY(nrm.get(ctx, 1));
+  const unsigned grid = unsigned(std::min<int64_t>((dim + 255) / 256, 512));
+  for (int j = 0; j < n; ++j) {
+    double* v = q + size_t(j) * dim;
+    for (int r = 0; r < 2 && j > 0; ++r) {  // "twice is enough"
+      ROM_TRY(rom_launch_gemm_nt(ctx, j, 1, dim, 1.0, q, dim, v, dim, 0.0, h, 1, "gemm_nt"));   // h = Q[:j] v
+      ROM_TRY(rom_launch_gemm_nn(ctx, 1, dim, j, -1.0, h, j, q, dim, 1.0, v, dim));              // v -= h^T Q[:j]
+    }
+    ROM_TRY(rom_launch_l2norm(ctx, v, 1, dim, nrm, false));
+    kb_scale_by_inv_norm<<<grid, 256, 0, ctx->stream>>>(v, dim, nrm);
+    ROM_HIP(hipGetLastError());
+  }
+  return ROM_OK;
+}
+
+// rows V[found : found + rest] <- pseudo-random directions (seeded: deterministic) made orthonormal and orthogonal to the
+// orthonormal rows V[0 : found]: how a mode request beyond what the data determine is completed (LAPACK and scikit-learn
+// return SOME orthonormal directions there too)
+extern "C" int rom_complete_orthonormal(rom_ctx* ctx, rom_buf* V, int64_t v_row0, int found, int rest, int64_t dim) {
+  ROM_CHECK(ctx && V, "rom_complete_orthonormal: null argument");
+  ROM_CHECK(found >= 0 && rest >= 0 && dim >= 1 && v_row0 >= 0 && size_t(v_row0 + found + rest) * dim <= V->n,
+            "rom_complete_orthonormal: bad sizes");
+  ROM_CHECK(int64_t(found) + rest <= dim && rest <= SE_MAX, "rom_complete_orthonormal: more rows than the space has dimensions");
+  if (rest == 0) return ROM_OK;
+  double* v = V->p + v_row0 * dim;
+  ROM_TRY(fill_random(ctx, v + size_t(found) * dim, size_t(rest) * dim, 0xc0de0000ull + unsigned(found), false));
+  return orthonormalize_against(ctx, v, found, rest, dim);
+}
+
+// =====================================================================================================================
+// projectors
+// =====================================================================================================================
+// project_solutions (src/lib/SolutionsManagers.py:108-139): OUT_i = c_i C with (C A_1 C^T) c_i = C A_1 u_i
+extern "C" int rom_project_h10(rom_fem* f, rom_buf* U, int64_t u_row0, int M, rom_buf* C, int64_t c_row0, int n,
+                               rom_buf* OUT, int64_t out_row0) {
+  ROM_CHECK(f && U && OUT && (C || n == 0), "rom_project_h10: null argument");
+  ROM_CHECK(M >= 0 && n >= 0 && u_row0 >= 0 && c_row0 >= 0 && out_row0 >= 0, "rom_project_h10: negative size");
+  ROM_CHECK(n <= 4096, "rom_project_h10: basis of %d vectors (at most 4096)", n);
+  const int64_t dim = f->dim;
+  ROM_CHECK(size_t(u_row0 + M) * dim <= U->n && size_t(out_row0 + M) * dim <= OUT->n && (n == 0 || size_t(c_row0 + n) * dim <= C->n),
+            "rom_project_h10: rows out of range");
+  rom_ctx* ctx = f->ctx;
+  if (M == 0) return ROM_OK;
+  double* out = OUT->p + out_row0 * dim;
+  if (n == 0) return fill(ctx, out, size_t(M) * dim, 0.0);  // (:109-111)
+  const double* u = U->p + u_row0 * dim;
+  const double* c = C->p + c_row0 * dim;
+  Tmp AC, G, R, ones, coef;
+  ROM_TRY(AC.get(ctx, size_t(n) * dim));
+  ROM_TRY(G.get(ctx, size_t(n) * n));
+  ROM_TRY(R.get(ctx, size_t(M) * n));
+  ROM_TRY(ones.get(ctx, M));
+  ROM_TRY(coef.get(ctx, size_t(M) * n));
+  ROM_TRY(rom_launch_stencil_apply(f, nullptr, c, n, AC));                                           // A_1 C^T (:123)
+  ROM_TRY(rom_launch_gemm_nt(ctx, n, n, dim, 1.0, AC, dim, c, dim, 0.0, G, n, "gemm_nt"));            // C A_1 C^T (:136)
+  ROM_TRY(rom_launch_gemm_nt(ctx, M, n, dim, 1.0, u, dim, AC, dim, 0.0, R, n, "gemm_nt"));            // rhs (:113-124)
+  ROM_TRY(fill(ctx, ones, M, 1.0));
+  ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+  ROM_TRY(rom_launch_reduced_solve(ctx, n, n, 1, M, G, ones, R, 1, coef));                            // (:135-138)
+  ROM_TRY(rom_launch_gemm_nn(ctx, M, dim, n, 1.0, coef, n, c, dim, 0.0, out, dim));                   // (:139)
+  return read_status(ctx, "rom_project_h10");
+}
+
+// reduced tensor Ahat[b] = C A_b C^T (k, n, n) and b_hat = C B_total of generate_fm_solutions (:93-103)
+static int reduced_tensor(rom_fem* f, const double* c, int n, double* Ahat, double* bhat) {
+  rom_ctx* ctx = f->ctx;
+  const int k = f->nrb * f->ncb;
+  const int64_t dim = f->dim;
+  Tmp AC, onehot, Bt;
+  ROM_TRY(AC.get(ctx, size_t(n) * dim));
+  ROM_TRY(onehot.get(ctx, size_t(k) * k));
+  ROM_TRY(Bt.get(ctx, dim));
+  std::vector<double> eye(size_t(k) * k, 0.0);
+  for (int b = 0; b < k; ++b) eye[size_t(b) * k + b] = 1.0;
+  ROM_HIP(hipMemcpyAsync(onehot.p(), eye.data(), eye.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));  // (the host vector goes out of scope)
+  for (int b = 0; b < k; ++b) {
+    ROM_TRY(rom_launch_stencil_apply(f, onehot.p() + size_t(b) * k, c, n, AC));
+    ROM_TRY(rom_launch_gemm_nt(ctx, n, n, dim, 1.0, AC, dim, c, dim, 0.0, Ahat + size_t(b) * n * n, n, "gemm_nt"));
+  }
+  ROM_TRY(fill(ctx, Bt, dim, 1.0 / (double(f->N) * f->N)));  // B_total = h^2 (:177-185)
+  return rom_launch_gemm_nt(ctx, n, 1, dim, 1.0, c, dim, Bt, dim, 0.0, bhat, 1, "gemm_nt");
+}
+
+// generate_fm_solutions (:88-106): OUT_m = c_m C with (sum_b a[m,b] C A_b C^T) c_m = C B_total
+extern "C" int rom_galerkin_rom(rom_fem* f, rom_buf* a, int M, rom_buf* C, int64_t c_row0, int n, rom_buf* OUT, int64_t out_row0) {
+  ROM_CHECK(f && a && OUT && (C || n == 0), "rom_galerkin_rom: null argument");
+  ROM_CHECK(M >= 0 && n >= 0 && c_row0 >= 0 && out_row0 >= 0, "rom_galerkin_rom: negative size");
+  ROM_CHECK(n <= 4096, "rom_galerkin_rom: basis of %d vectors (at most 4096)", n);
+  const int64_t dim = f->dim;
+  const int k = f->nrb * f->ncb;
+  ROM_CHECK(size_t(M) * k <= a->n && size_t(out_row0 + M) * dim <= OUT->n && (n == 0 || size_t(c_row0 + n) * dim <= C->n),
+            "rom_galerkin_rom: buffers too small");
+  rom_ctx* ctx = f->ctx;
+  if (M == 0) return ROM_OK;
+  double* out = OUT->p + out_row0 * dim;
+  if (n == 0) return fill(ctx, out, size_t(M) * dim, 0.0);  // (:89-91)
+  const double* c = C->p + c_row0 * dim;
+  Tmp Ahat, bhat, coef;
+  ROM_TRY(Ahat.get(ctx, size_t(k) * n * n));
+  ROM_TRY(bhat.get(ctx, n));
+  ROM_TRY(coef.get(ctx, size_t(M) * n));
+  ROM_TRY(reduced_tensor(f, c, n, Ahat, bhat));
+  ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+  ROM_TRY(rom_launch_reduced_solve(ctx, n, n, k, M, Ahat, a->p, bhat, 0, coef));   // (:104-105)
+  ROM_TRY(rom_launch_gemm_nn(ctx, M, dim, n, 1.0, coef, n, c, dim, 0.0, out, dim));  // (:106)
+  return read_status(ctx, "rom_galerkin_rom");
+}
+
+// =====================================================================================================================
+// strong greedy (src/lib/ReducedBasis.py:112-139)
+// =====================================================================================================================
+// The reference recomputes, in every iteration, the approximation of all M training snapshots in the current basis
+// (H^1_0 projection or Galerkin ROM) and the H^1_0 norm of the differences.  Both depend on the SPAN of the basis only,
+// so the span is carried as an A_1-orthonormal basis W (w_j^T A_1 w_i = delta_ij) and the projection residuals
+//     R_m = u_m - sum_j p_mj w_j ,   p_mj = <u_m, w_j>_{A_1}
+// are kept in HBM and UPDATED by one vector per iteration (modified Gram-Schmidt over the training block):
+//     w   = R_pick / ||R_pick||_A        (the residual of the pick is already orthogonal to W; one re-orthogonalisation)
+//     p_m = R_m . (A_1 w) ,  R_m <- R_m - p_m w ,  ||R_m||_A  (edge form, fused with the update: one read + one write)
+// The Galerkin approximation g_m = sum_j c_mj w_j differs from the projection inside span W only, so by Pythagoras
+//     ||u_m - g_m||_A^2 = ||R_m||_A^2 + sum_j (p_mj - c_mj)^2      (no cancellation: both terms >= 0)
+// with c_m from the reduced systems in the W basis, whose tensor W A_b W^T grows by one row per iteration.
+// Per iteration the training block is read twice and written once, whatever the basis size; the reference's dense
+// contractions are O(n M dim) per iteration.
+
+// err[m] = sqrt(nrm2[m]); rel = err / h1; first maximum -> picks[it], maxerr[it]; one workgroup
+__global__ __launch_bounds__(1024) void kb_greedy_select(int M, const double* __restrict__ err2, const double* __restrict__ extra2,
+                                                         const double* __restrict__ h1, int it, int* __restrict__ picks,
+                                                         double* __restrict__ maxerr) {
+  __shared__ double bv[1024];
+  __shared__ int bi[1024];
+  double best = -1.0;
+  int at = 0;
+  for (int m = threadIdx.x; m < M; m += 1024) {
+    const double e2 = err2[m] + (extra2 ? extra2[m] : 0.0);
+    const double rel = sqrt(e2) / h1[m];
+    if (rel > best) { best = rel; at = m; }  // ascending m per thread: keeps the first maximum
+  }
+  bv[threadIdx.x] = best;
+  bi[threadIdx.x] = at;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (int(threadIdx.x) < s) {
+      const double o = bv[threadIdx.x + s];
+      const int oi = bi[threadIdx.x + s];
+      if (o > bv[threadIdx.x] || (o == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = o; bi[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    picks[it] = bi[0];
+    maxerr[it] = bv[0];
+  }
+}
+
+// w <- R[pick] / ||R[pick]||_A ; a pick whose residual is at roundoff of its snapshot (a duplicate) gives w = 0
+__global__ void kb_take_pick(double* __restrict__ w, const double* __restrict__ R, long long dim, const int* __restrict__ picks,
+                             int it, const double* __restrict__ err2, const double* __restrict__ norm0sq,
+                             int* __restrict__ degenerate) {
+  const int p = picks[it];
+  const double e2 = err2[p];
+  const bool dead = !(e2 > 1e-26 * norm0sq[p]) || !(e2 > 0.0);
+  const double a = dead ? 0.0 : 1.0 / sqrt(e2);
+  if (blockIdx.x == 0 && threadIdx.x == 0) degenerate[it] = dead ? 1 : 0;
+  const double* r = R + (long long)p * dim;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < dim; j += (long long)gridDim.x * blockDim.x) w[j] = a * r[j];
+}
+
+// w <- w / sqrt(nrm2) unless the vector is dead
+__global__ void kb_renormalise(double* __restrict__ w, long long dim, const double* __restrict__ nrm2,
+                               const int* __restrict__ degenerate, int it) {
+  const double n2 = *nrm2;
+  const double a = (degenerate[it] || !(n2 > 0.0)) ? 0.0 : 1.0 / sqrt(n2);
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < dim; j += (long long)gridDim.x * blockDim.x) w[j] *= a;
+}
+
+// Rout[m] = Rin[m] - p[m] w, and partial sums of ||Rout[m]||_A^2 in edge form (the layout of k_h10_partial, rom_ops.hip:
+// a thread owns a mesh column and walks down a slab of rows; every entry is read once, the halo row above the slab and
+// the wave's east neighbour a second time -- which is why the update goes to a second buffer, not in place)
+constexpr int GU_ROWS = 32, GU_UNROLL = 8;
+__global__ __launch_bounds__(256) void kb_greedy_update(StencilGeom g, const double* __restrict__ Rin, double* __restrict__ Rout,
+                                                        const double* __restrict__ w, const double* __restrict__ p, long long ldp,
+                                                        double* __restrict__ partial, int nblk) {
+  __shared__ double red[4];
+  const long long base = blockIdx.z * g.dim;
+  const double* u = Rin + base;
+  double* o = Rout + base;
+  const double pm = p[blockIdx.z * ldp];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * GU_ROWS, r1 = min(g.nr, r0 + GU_ROWS);
+  const bool in = c < g.nc;
+  const int lane = threadIdx.x & 63;
+  auto at = [&](int r, int cc) -> double {
+    const long long i = (long long)r * g.nc + cc;
+    return u[i] - pm * w[i];
+  };
+  double s = 0.0;
+  double north = (in && r0 > 0) ? at(r0 - 1, c) : 0.0;
+  for (int rb = r0; rb < r1; rb += GU_UNROLL) {
+    double x[GU_UNROLL], xl[GU_UNROLL];
+#pragma unroll
+    for (int q = 0; q < GU_UNROLL; ++q) {
+      const int r = rb + q;
+      x[q] = (in && r < r1) ? at(r, c) : 0.0;
+      xl[q] = (lane == 63 && c + 1 < g.nc && r < r1) ? at(r, c + 1) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < GU_UNROLL; ++q) {
+      const int r = rb + q;
+      double east = __shfl_down(x[q], 1, 64);
+      if (lane == 63) east = xl[q];
+      if (in && r < r1) {
+        o[(long long)r * g.nc + c] = x[q];
+        if (c + 1 >= g.nc) east = 0.0;
+        const double dh = x[q] - east, dv = x[q] - north;
+        s += dh * dh + dv * dv;
+        if (c == 0) s += x[q] * x[q];
+        if (r == g.nr - 1) s += x[q] * x[q];
+        north = x[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.z * (long long)nblk + blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void kb_sum_partials(const double* __restrict__ partial, int nblk, double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partial[blockIdx.x * (long long)nblk + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// row / column j of the reduced tensor (k, ld, ld) from col[i, b] = w_i^T A_b w_j (i <= j); a dead vector gets a unit
+// diagonal and zero couplings, which keeps every reduced matrix positive definite and its coefficient at 0
+__global__ void kb_grow_ahat(double* __restrict__ Ahat, int k, int ld, int j, const double* __restrict__ col,
+                             const int* __restrict__ degenerate, int it) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (j + 1) * k) return;
+  const int i = idx / k, b = idx % k;
+  const bool dead = degenerate[it] != 0;
+  const double v = dead ? (i == j ? 1.0 : 0.0) : col[idx];
+  Ahat[(size_t(b) * ld + j) * ld + i] = v;
+  Ahat[(size_t(b) * ld + i) * ld + j] = v;
+}
+
+// extra2[m] = sum_{j < n} (P[m, j] - c[m, j])^2   (P: ld ldp, c: packed n)
+__global__ void kb_galerkin_gap(int M, int n, const double* __restrict__ P, int ldp, const double* __restrict__ c,
+                                double* __restrict__ extra2) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double s = 0.0;
+  for (int j = 0; j < n; ++j) {
+    const double d = P[size_t(m) * ldp + j] - c[size_t(m) * n + j];
+    s += d * d;
+  }
+  extra2[m] = s;
+}
+
+__global__ void kb_ints_to_doubles(const int* __restrict__ src, double* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = double(src[i]);
+}
+
+// mode 0: greedy for the H^1_0 projection error; 1: for the Galerkin error.  h1norm: the normalisation the caller passes
+// as solutions2train_h1norm (M doubles on the host).  picks_out / max_err_out: n entries.
+extern "C" int rom_greedy(rom_fem* f, rom_buf* U, int64_t u_row0, int M, rom_buf* a, const double* h1norm_host, int mode,
+                          int n, int64_t* picks_out, double* max_err_out) {
+  ROM_CHECK(f && U && h1norm_host && (picks_out || n == 0) && (max_err_out || n == 0), "rom_greedy: null argument");
+  ROM_CHECK(mode == 0 || mode == 1, "rom_greedy: mode must be 0 (H10 projection) or 1 (Galerkin)");
+  ROM_CHECK(mode == 0 || a, "rom_greedy: the Galerkin greedy needs the training parameters");
+  ROM_CHECK(M >= 1 && M <= 65535 && n >= 0 && u_row0 >= 0, "rom_greedy: bad sizes (1 <= M <= 65535)");
+  ROM_CHECK(n <= 2048, "rom_greedy: at most 2048 basis vectors");
+  const int64_t dim = f->dim;
+  const int k = f->nrb * f->ncb;
+  ROM_CHECK(size_t(u_row0 + M) * dim <= U->n && (!a || size_t(M) * k <= a->n), "rom_greedy: buffers too small");
+  if (n == 0) return ROM_OK;
+  rom_ctx* ctx = f->ctx;
+  const StencilGeom g = rom_make_geom(f->nrb, f->ncb, f->N);
+  const double* u = U->p + u_row0 * dim;
+  const int nb = std::max(n - 1, 1);  // basis vectors ever built
+  Tmp Ra, Rb, W, AW, P, pcol, err2, norm0, h1, ipick, idead, maxerr, t, nrm, part, Ahat, bhat, cg, extra, ZB, col, onehot, Bt;
+  ROM_TRY(Ra.get(ctx, size_t(M) * dim));
+  ROM_TRY(Rb.get(ctx, size_t(M) * dim));
+  ROM_TRY(W.get(ctx, size_t(nb) * dim));
+  ROM_TRY(AW.get(ctx, size_t(nb) * dim));
+  ROM_TRY(pcol.get(ctx, M));
+  ROM_TRY(err2.get(ctx, M));
+  ROM_TRY(norm0.get(ctx, M));
+  ROM_TRY(h1.get(ctx, M));
+  ROM_TRY(ipick.get(ctx, n));   // n ints (picks) in a block of n doubles
+  ROM_TRY(idead.get(ctx, n));   // n ints (1: the vector built from this pick is dead)
+  ROM_TRY(maxerr.get(ctx, n));
+  ROM_TRY(t.get(ctx, nb));
+  ROM_TRY(nrm.get(ctx, 1));
+  const dim3 ugrid((g.nc + 255) / 256, (g.nr + GU_ROWS - 1) / GU_ROWS, M);
+  const int nblk = int(ugrid.x * ugrid.y);
+  ROM_TRY(part.get(ctx, size_t(M) * nblk));
+  int* d_picks = reinterpret_cast<int*>(ipick.p());
+  int* d_dead = reinterpret_cast<int*>(idead.p());
+  double* d_maxerr = maxerr.p();
+  if (mode == 1) {
+    ROM_TRY(P.get(ctx, size_t(M) * nb));   // projection coefficients p_mj (needed for the Galerkin gap only)
+    ROM_TRY(Ahat.get(ctx, size_t(k) * nb * nb));
+    ROM_TRY(bhat.get(ctx, nb));
+    ROM_TRY(cg.get(ctx, size_t(M) * nb));
+    ROM_TRY(extra.get(ctx, M));
+    ROM_TRY(ZB.get(ctx, size_t(k) * dim));
+    ROM_TRY(col.get(ctx, size_t(nb) * k));
+    ROM_TRY(onehot.get(ctx, size_t(k) * k));
+    ROM_TRY(Bt.get(ctx, dim));
+    ROM_TRY(fill(ctx, Ahat, size_t(k) * nb * nb, 0.0));
+    ROM_TRY(fill(ctx, Bt, dim, 1.0 / (double(f->N) * f->N)));
+    std::vector<double> eye(size_t(k) * k, 0.0);
+    for (int b = 0; b < k; ++b) eye[size_t(b) * k + b] = 1.0;
+    ROM_HIP(hipMemcpyAsync(onehot.p(), eye.data(), eye.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ROM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  ROM_HIP(hipMemcpyAsync(h1.p(), h1norm_host, size_t(M) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));  // the caller's array is free again
+  ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+  ROM_HIP(hipMemsetAsync(ipick.p(), 0, size_t(n) * sizeof(double), ctx->stream));
+  ROM_HIP(hipMemsetAsync(idead.p(), 0, size_t(n) * sizeof(double), ctx->stream));
+  ROM_HIP(hipMemsetAsync(maxerr.p(), 0, size_t(n) * sizeof(double), ctx->stream));
+  // empty basis (:120-129 with basis (0, 0)): the approximation is zero, the error of snapshot m is ||u_m||_A / h1_m --
+  // the same kernel as rom_h10norm, so a caller that passes sm.H10norm(U) gets exactly 1.0 everywhere and index 0
+  ROM_TRY(rom_launch_h10norm(f, u, nullptr, M, norm0, false));
+  ROM_HIP(hipMemcpyAsync(err2.p(), norm0.p(), size_t(M) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  kb_greedy_select<<<1, 1024, 0, ctx->stream>>>(M, err2, nullptr, h1, 0, d_picks, d_maxerr);
+  ROM_HIP(hipGetLastError());
+  const double* Rcur = u;  // residuals of the empty basis are the snapshots themselves (never written)
+  double* bufs[2] = {Ra.p(), Rb.p()};
+  const unsigned vgrid = unsigned(std::min<int64_t>((dim + 255) / 256, 512));
+  for (int it = 1; it < n; ++it) {
+    const int j = it - 1;  // index of the basis vector built from pick it - 1
+    double* wj = W.p() + size_t(j) * dim;
+    double* zj = AW.p() + size_t(j) * dim;
+    kb_take_pick<<<vgrid, 256, 0, ctx->stream>>>(wj, Rcur, dim, d_picks, it - 1, err2, norm0, d_dead);
+    ROM_HIP(hipGetLastError());
+    if (j > 0) {  // one re-orthogonalisation against W in the A_1 inner product, then renormalise
+      ROM_TRY(rom_launch_gemm_nt(ctx, j, 1, dim, 1.0, AW, dim, wj, dim, 0.0, t, 1, "gemm_nt"));
+      ROM_TRY(rom_launch_gemm_nn(ctx, 1, dim, j, -1.0, t, j, W, dim, 1.0, wj, dim));
+      ROM_TRY(rom_launch_h10norm(f, wj, nullptr, 1, nrm, false));
+      kb_renormalise<<<vgrid, 256, 0, ctx->stream>>>(wj, dim, nrm, d_dead, it - 1);
+      ROM_HIP(hipGetLastError());
+    }
+    ROM_TRY(rom_launch_stencil_apply(f, nullptr, wj, 1, zj));                      // z = A_1 w
+    ROM_TRY(rom_launch_rowdot(ctx, Rcur, M, dim, zj, pcol));                        // p_m = R_m . z
+    if (mode == 1) ROM_TRY(transpose(ctx, P.p() + j, nb, pcol, M, 1, M));            // column j of P
+    {
+      ROM_PROF(ctx, "greedy_update", 12.0 * double(M) * dim, 16.0 * double(M) * dim);
+      double* Rnext = bufs[it & 1];
+      kb_greedy_update<<<ugrid, 256, 0, ctx->stream>>>(g, Rcur, Rnext, wj, pcol, 1, part, nblk);
+      kb_sum_partials<<<M, 256, 0, ctx->stream>>>(part, nblk, err2);
+      Rcur = Rnext;
+    }
+    ROM_HIP(hipGetLastError());
+    if (mode == 1) {
+      for (int b = 0; b < k; ++b) ROM_TRY(rom_launch_stencil_apply(f, onehot.p() + size_t(b) * k, wj, 1, ZB.p() + size_t(b) * dim));
+      ROM_TRY(rom_launch_gemm_nt(ctx, j + 1, k, dim, 1.0, W, dim, ZB, dim, 0.0, col, k, "gemm_nt"));  // col[i, b] = w_i . A_b w_j
+      kb_grow_ahat<<<unsigned(((j + 1) * k + 255) / 256), 256, 0, ctx->stream>>>(Ahat, k, nb, j, col, d_dead, it - 1);
+      ROM_HIP(hipGetLastError());
+      ROM_TRY(rom_launch_gemm_nt(ctx, 1, 1, dim, 1.0, wj, dim, Bt, dim, 0.0, bhat.p() + j, 1, "gemm_nt"));  // w_j . B_total
+      ROM_TRY(rom_launch_reduced_solve(ctx, j + 1, nb, k, M, Ahat, a->p, bhat, 0, cg));
+      kb_galerkin_gap<<<unsigned((M + 255) / 256), 256, 0, ctx->stream>>>(M, j + 1, P, nb, cg, extra);
+      ROM_HIP(hipGetLastError());
+    }
+    kb_greedy_select<<<1, 1024, 0, ctx->stream>>>(M, err2, mode == 1 ? extra.p() : nullptr, h1, it, d_picks, d_maxerr);
+    ROM_HIP(hipGetLastError());
+  }
+  // results: picks as doubles through one download
+  Tmp outd;
+  ROM_TRY(outd.get(ctx, 2 * size_t(n)));
+  kb_ints_to_doubles<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(d_picks, outd, n);
+  ROM_HIP(hipMemcpyAsync(outd.p() + n, d_maxerr, size_t(n) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  std::vector<double> host(2 * size_t(n));
+  ROM_TRY(download(ctx, outd, host.data(), host.size()));
+  for (int i = 0; i < n; ++i) {
+    picks_out[i] = int64_t(host[i]);
+    max_err_out[i] = host[n + i];
+  }
+  return read_status(ctx, "rom_greedy");
+}
+
+// =====================================================================================================================
+// POD (the PCA fit of ReducedBasisPCA.build, src/lib/ReducedBasis.py:189-200)
+// =====================================================================================================================
+__global__ void kb_next_block(double* __restrict__ Zs, const double* __restrict__ Zr, const double* __restrict__ Yr,
+                              const double* __restrict__ theta, long long M) {
+  // rows: the rotated power step G y_i / theta_i for the resolvable pairs, the Ritz vector itself at the noise floor
+  const double th = theta[blockIdx.y], t0 = fabs(theta[0]);
+  const bool ok = th > 1e-13 * t0;
+  const double a = ok ? 1.0 / th : 0.0;
+  const long long o = blockIdx.y * M;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < M; j += (long long)gridDim.x * blockDim.x)
+    Zs[o + j] = ok ? a * Zr[o + j] : Yr[o + j];
+}
+
+// out[i] = lam[i] > 0 ? 1 / sqrt(lam[i]) : 0
+__global__ void kb_inv_sqrt(const double* __restrict__ lam, double* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = lam[i] > 0.0 ? 1.0 / sqrt(lam[i]) : 0.0;
+}
+
+namespace {
+
+constexpr double GRAM_ACCEPT = 1e-10;    // eigenvalues of a Gram matrix are taken down to this fraction of its largest one
+constexpr double SKETCH_ACCEPT = 1e-6;   // singular values of a sketch down to this fraction of its largest one
+constexpr double NOISE_FLOOR = 1e-13;    // modes below this fraction of sigma_1 are fp64 noise of the snapshots
+
+struct PodInfo {
+  int gram_passes = 0, sketch_passes = 0, completed = 0, resolved = 0, eig_iterations = 0;
+  double executed = 0.0;
+};
+
+// Leading nev eigenpairs of the symmetric PSD matrix G (M x M) by subspace iteration with Rayleigh-Ritz; the projected
+// b x b problems are solved on the device.  theta_host: nev values; W: (nev, M) rows = eigenvectors.
+int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std::vector<double>& theta_host, PodInfo& info,
+                   int oversample = 12, double tol = 2e-14, int max_iter = 30, double accept = GRAM_ACCEPT) {
+  const int b = std::min(M, nev + oversample);
+  Tmp Y, Z, H, St, lam, Yr, Zr, Res, res, Zs, scr;
+  ROM_TRY(Y.get(ctx, size_t(b) * M));
+  ROM_TRY(Z.get(ctx, size_t(b) * M));
+  ROM_TRY(H.get(ctx, size_t(b) * b));
+  ROM_TRY(St.get(ctx, size_t(b) * b));
+  ROM_TRY(lam.get(ctx, 2 * size_t(b)));
+  ROM_TRY(Yr.get(ctx, size_t(b) * M));
+  ROM_TRY(Zr.get(ctx, size_t(b) * M));
+  ROM_TRY(Res.get(ctx, size_t(b) * M));
+  ROM_TRY(Zs.get(ctx, size_t(b) * M));
+  ROM_TRY(scr.get(ctx, size_t(b) * M));
+  double* d_res = lam.p() + b;
+  ROM_TRY(fill_random(ctx, Y, size_t(b) * M, 0x5eed0000ull + unsigned(b) * 131u + unsigned(M), true));
+  ROM_TRY(gram_transform(ctx, Y, scr, b, M, SE_WHITEN, 1e-30, 2));  // Gaussian rows: kappa ~ 1
+  std::vector<double> th(2 * size_t(b));
+  double best = 1e300;
+  int stall = 0;
+  for (int it = 0; it < max_iter; ++it) {
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, M, 1.0, Y, M, G, M, 0.0, Z, M, "gemm_nt"));   // Z = Y G (G symmetric)
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, b, M, 1.0, Z, M, Y, M, 0.0, H, b, "gemm_nt"));   // H = Y G Y^T
+    ROM_TRY(small_eig(ctx, b, H, b, lam, St, b, SE_EIG, 0.0));                          // rows of St: Ritz rotations
+    ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Y, M, 0.0, Yr, M));            // Ritz vectors
+    info.eig_iterations = it + 1;
+    if (b == M) {  // full space: exact after one Ritz step
+      ROM_TRY(download(ctx, lam, th.data(), b));
+      break;
+    }
+    ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Z, M, 0.0, Zr, M));            // G applied to them
+    kb_rows_axpy<<<dim3(unsigned(std::min((M + 255) / 256, 64)), b), 256, 0, ctx->stream>>>(Res, Zr, Yr, lam, -1.0, M);
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(rom_launch_l2norm(ctx, Res, nev, M, d_res, true));
+    ROM_TRY(download(ctx, lam, th.data(), 2 * size_t(b)));
+    const double t0 = std::max(std::fabs(th[0]), 1e-300);
+    double worst = 0.0;
+    for (int i = 0; i < nev; ++i)
+      if (th[i] > accept * std::fabs(th[0])) worst = std::max(worst, th[b + i] / t0);
+    if (worst < 0.7 * best) { best = worst; stall = 0; } else { ++stall; }
+    if (worst <= tol || stall >= 3 || it == max_iter - 1) break;
+    kb_next_block<<<dim3(unsigned(std::min((M + 255) / 256, 64)), b), 256, 0, ctx->stream>>>(Zs, Zr, Yr, lam, M);
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(gram_transform(ctx, Zs, scr, b, M, SE_WHITEN, 1e-30, 2));
+    ROM_HIP(hipMemcpyAsync(Y.p(), Zs.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  theta_host.assign(th.begin(), th.begin() + nev);
+  ROM_HIP(hipMemcpyAsync(W, Yr.p(), size_t(nev) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return ROM_OK;
+}
+
+// Right singular vectors / singular values of a tall factor given TRANSPOSED, Tt (b x M, ld M): Rayleigh-Ritz rounds on
+// the b x b Gram matrix Tt Tt^T.  The first round rotates the rows towards the singular directions; from then on the
+// Gram matrix is graded and nearly diagonal, where Jacobi resolves the small eigenvalues to high relative accuracy --
+// nothing is lost to the squaring that a single eigen-decomposition of an ungraded Gram matrix would lose.
+// Rt (b x b): accumulated rotation (rows = right singular vectors in the coordinates Tt came in); sig2: b values.
+int tall_svd_rotation(rom_ctx* ctx, double* Tt, int b, int M, double* Rt, double* sig2, int rounds = 3) {
+  Tmp H, St, T2, R2;
+  ROM_TRY(H.get(ctx, size_t(b) * b));
+  ROM_TRY(St.get(ctx, size_t(b) * b));
+  ROM_TRY(T2.get(ctx, size_t(b) * M));
+  ROM_TRY(R2.get(ctx, size_t(b) * b));
+  for (int r = 0; r < rounds; ++r) {
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, b, M, 1.0, Tt, M, Tt, M, 0.0, H, b, "gemm_nt"));
+    ROM_TRY(small_eig(ctx, b, H, b, sig2, St, b, SE_EIG, 0.0));
+    ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Tt, M, 0.0, T2, M));
+    ROM_HIP(hipMemcpyAsync(Tt, T2.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (r == 0) {
+      ROM_HIP(hipMemcpyAsync(Rt, St.p(), size_t(b) * b * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+      ROM_TRY(rom_launch_gemm_nn(ctx, b, b, b, 1.0, St, b, Rt, b, 0.0, R2, b));
+      ROM_HIP(hipMemcpyAsync(Rt, R2.p(), size_t(b) * b * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
+  return ROM_OK;
+}
+
+// Leading k right singular vectors / singular values of the (M, dim) block X by a randomised range finder with one power
+// iteration: thin GEMMs (2 b M dim flops each) instead of the 2 M^2 dim of a Gram matrix.  Used for the DEFLATED
+// remainder of a snapshot block.  Vs: (b, dim) block, its first k rows are the modes; ss_host: b singular values.
+int sketched_modes(rom_ctx* ctx, const double* X, int M, int64_t dim, int k, int seed, double* Vs, std::vector<double>& ss_host,
+                   int& b_out, PodInfo& info, int oversample = 8, int power = 1) {
+  const int b = int(std::min<int64_t>(std::min<int64_t>(M, dim), k + oversample));
+  b_out = b;
+  Tmp Om, Y, scr, Tt, Rt, s2;
+  ROM_TRY(Om.get(ctx, size_t(b) * M));
+  ROM_TRY(Y.get(ctx, size_t(b) * dim));
+  ROM_TRY(scr.get(ctx, size_t(b) * dim));
+  ROM_TRY(Tt.get(ctx, size_t(b) * M));
+  ROM_TRY(Rt.get(ctx, size_t(b) * b));
+  ROM_TRY(s2.get(ctx, b));
+  ROM_TRY(fill_random(ctx, Om, size_t(b) * M, 0xabcd0000ull + unsigned(seed) * 7919u + unsigned(b), true));
+  ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Om, M, X, dim, 0.0, Y, dim));                 // Y = Omega X
+  info.executed += 2.0 * b * M * double(dim);
+  for (int it = 0; it <= power; ++it) {
+    ROM_TRY(gram_transform(ctx, Y, scr, b, dim, SE_WHITEN, 1e-26, 2));                           // Q (rank may drop: zero rows)
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, dim, 1.0, Y, dim, X, dim, 0.0, Tt, M, "gemm_nt"));      // Tt = Q X^T  (b, M)
+    info.executed += 2.0 * b * M * double(dim) + 4.0 * b * b * double(dim);
+    if (it == power) break;
+    ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Tt, M, X, dim, 0.0, scr, dim));               // Q X^T X
+    ROM_HIP(hipMemcpyAsync(Y.p(), scr.p(), size_t(b) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    info.executed += 2.0 * b * M * double(dim);
+  }
+  // X ~ T Q: the right singular vectors of the small factor rotate Q into the modes
+  ROM_TRY(tall_svd_rotation(ctx, Tt, b, M, Rt, s2));
+  ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, b, 1.0, Rt, b, Y, dim, 0.0, Vs, dim));                  // modes = R^T Q
+  info.executed += 2.0 * b * b * double(dim);
+  ss_host.resize(b);
+  ROM_TRY(download(ctx, s2, ss_host.data(), b));
+  for (double& v : ss_host) v = std::sqrt(std::max(v, 0.0));
+  return ROM_OK;
+}
+
+}  // namespace
+
+// Leading n right singular vectors / singular values of the (M, dim) block X (overwritten: centred and deflated).
+// center != 0: subtract the column means first (sklearn PCA.fit).  V: (n, dim) rows = modes, sign convention of
+// sklearn's svd_flip(u_based_decision=False); sigma_host: n singular values (0 for completed modes);
+// info_host (8 doubles, may be null): resolved modes, completed modes, Gram passes, sketch passes, executed flops,
+// useful flops, subspace iterations, 0.
+extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t dim, int n, int center, rom_buf* Vb,
+                       int64_t v_row0, double* sigma_host, double* info_host) {
+  ROM_CHECK(ctx && Xb && Vb && (sigma_host || n == 0), "rom_pod: null argument");
+  ROM_CHECK(M >= 1 && dim >= 1 && n >= 0 && x_row0 >= 0 && v_row0 >= 0, "rom_pod: bad sizes");
+  ROM_CHECK(n <= std::min<int64_t>(M, dim), "rom_pod: %d modes requested from a %d x %lld block", n, M, (long long)dim);
+  ROM_CHECK(n + 12 <= SE_MAX, "rom_pod: at most %d modes", SE_MAX - 12);
+  ROM_CHECK(size_t(x_row0 + M) * dim <= Xb->n && size_t(v_row0 + n) * dim <= Vb->n, "rom_pod: buffers too small");
+  double* X = Xb->p + x_row0 * dim;
+  double* V = Vb->p + v_row0 * dim;
+  PodInfo info;
+  if (center) {
+    Tmp mean;
+    ROM_TRY(mean.get(ctx, dim));
+    ROM_TRY(rom_launch_center_rows(ctx, X, M, dim, mean));
+  }
+  for (int i = 0; i < n; ++i) sigma_host[i] = 0.0;
+  int found = 0;
+  double sigma_1 = 0.0;
+  Tmp Bt;  // coefficients of the accepted modes, (n, M): row j = X v_j
+  ROM_TRY(Bt.get(ctx, size_t(std::max(n, 1)) * M));
+  auto deflate = [&](int lo, int take, bool last) -> int {
+    // coefficients of the modes V[lo : lo + take] into Bt, and those modes out of X (not when nothing reads X afterwards)
+    Tmp Yc;
+    ROM_TRY(Yc.get(ctx, size_t(M) * take));
+    ROM_TRY(rom_launch_gemm_nt(ctx, M, take, dim, 1.0, X, dim, V + size_t(lo) * dim, dim, 0.0, Yc, take, "gemm_nt"));
+    if (!last) ROM_TRY(rom_launch_gemm_nn(ctx, M, dim, take, -1.0, Yc, take, V + size_t(lo) * dim, dim, 1.0, X, dim));
+    ROM_TRY(transpose(ctx, Bt.p() + size_t(lo) * M, M, Yc, take, M, take));
+    info.executed += (last ? 2.0 : 4.0) * take * M * double(dim);
+    return ROM_OK;
+  };
+  const int passes = 6;
+  if (n > 0) {
+    Tmp G, W, fac;
+    ROM_TRY(G.get(ctx, size_t(M) * M));
+    ROM_TRY(W.get(ctx, size_t(n) * M));
+    ROM_TRY(fac.get(ctx, n));
+    ROM_TRY(rom_launch_gram(ctx, M, dim, X, dim, G, M));
+    info.gram_passes = 1;
+    info.executed += double(M) * (M + 1) * double(dim);
+    std::vector<double> lam;
+    ROM_TRY(top_eigenpairs(ctx, G, M, n, W, lam, info));
+    G.release();
+    for (double& v : lam) v = std::max(v, 0.0);
+    sigma_1 = lam.empty() ? 0.0 : std::sqrt(lam[0]);
+    int take = 0;
+    while (take < n && take < int(lam.size()) && lam[take] > GRAM_ACCEPT * lam[0] && lam[take] > 0) ++take;
+    if (take) {
+      std::vector<double> inv(take);
+      for (int i = 0; i < take; ++i) inv[i] = 1.0 / std::sqrt(lam[i]);
+      ROM_HIP(hipMemcpyAsync(fac.p(), inv.data(), size_t(take) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      ROM_HIP(hipStreamSynchronize(ctx->stream));
+      ROM_TRY(rom_launch_rows_scale(ctx, W, take, M, fac));
+      ROM_TRY(rom_launch_gemm_nn(ctx, take, dim, M, 1.0, W, M, X, dim, 0.0, V, dim));   // V = S^-1 W^T Xc
+      info.executed += 2.0 * take * M * double(dim);
+      ROM_TRY(orthonormalize_against(ctx, V, 0, take, dim));
+      ROM_TRY(deflate(0, take, take >= n || passes <= 1));
+      found = take;
+    }
+  }
+  for (int p = 1; p < passes; ++p) {
+    if (found >= n || found == 0) break;
+    Tmp Vs;
+    std::vector<double> ss;
+    int b = 0;
+    const int want = n - found;
+    const int bmax = int(std::min<int64_t>(std::min<int64_t>(M, dim), want + 8));
+    ROM_TRY(Vs.get(ctx, size_t(bmax) * dim));
+    ROM_TRY(sketched_modes(ctx, X, M, dim, want, p, Vs, ss, b, info));
+    info.sketch_passes += 1;
+    int take = 0;
+    while (take < std::min(b, want) && ss[take] > SKETCH_ACCEPT * ss[0] && ss[take] > NOISE_FLOOR * sigma_1) ++take;
+    if (take == 0) break;
+    ROM_HIP(hipMemcpyAsync(V + size_t(found) * dim, Vs.p(), size_t(take) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ROM_TRY(orthonormalize_against(ctx, V, found, take, dim));
+    const bool at_floor = take < b && ss[take] <= NOISE_FLOOR * sigma_1;
+    ROM_TRY(deflate(found, take, at_floor || found + take >= n || p == passes - 1));
+    found += take;
+    if (at_floor) break;  // the spectrum has reached the noise floor: nothing left to find
+  }
+  if (found) {
+    // Rayleigh-Ritz on the collected subspace: X ~ B V  ->  the SVD of B orders / rotates the modes
+    Tmp Rt, s2, Vr;
+    ROM_TRY(Rt.get(ctx, size_t(found) * found));
+    ROM_TRY(s2.get(ctx, found));
+    ROM_TRY(Vr.get(ctx, size_t(found) * dim));
+    ROM_TRY(tall_svd_rotation(ctx, Bt, found, M, Rt, s2));
+    ROM_TRY(rom_launch_gemm_nn(ctx, found, dim, found, 1.0, Rt, found, V, dim, 0.0, Vr, dim));
+    ROM_HIP(hipMemcpyAsync(V, Vr.p(), size_t(found) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    info.executed += 2.0 * found * found * double(dim);
+    std::vector<double> s(found);
+    ROM_TRY(download(ctx, s2, s.data(), found));
+    for (int i = 0; i < found; ++i) sigma_host[i] = std::sqrt(std::max(s[i], 0.0));
+  }
+  if (found < n) {
+    // complete the basis: random directions orthonormalised against the modes; they carry no variance (LAPACK and
+    // scikit-learn return SOME orthonormal directions there too).  Seeded by the count of resolved modes: deterministic.
+    const int rest = n - found;
+    ROM_TRY(rom_complete_orthonormal(ctx, Vb, v_row0, found, rest, dim));
+    info.completed = rest;
+  }
+  info.resolved = found;
+  if (n > 0) ROM_TRY(rom_launch_rows_sign_flip(ctx, V, n, dim));  // svd_flip(u_based_decision=False)
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  if (info_host) {
+    info_host[0] = info.resolved;
+    info_host[1] = info.completed;
+    info_host[2] = info.gram_passes;
+    info_host[3] = info.sketch_passes;
+    info_host[4] = info.executed;
+    info_host[5] = double(M) * (M + 1) * double(dim) + 2.0 * n * M * double(dim);
+    info_host[6] = info.eig_iterations;
+    info_host[7] = 0.0;
+  }
+  return ROM_OK;
+}

@@ -106,6 +106,7 @@ extern "C" int rom_comm_destroy(rom_ctx* ctx) {
       hipEventDestroy(ctx->ev_slot[i]);
       ctx->ev_slot[i] = nullptr;
       ctx->slot_used[i] = false;
+      ctx->slot_joined[i] = true;
     }
     ctx->comm_stream = nullptr;
     ctx->ev_comm = nullptr;
@@ -153,6 +154,11 @@ extern "C" int rom_comm_allgather_async(rom_ctx* ctx, rom_buf* send, size_t send
                             ctx->comm_stream));
   ROM_HIP(hipEventRecord(ctx->ev_slot[slot], ctx->comm_stream));
   ctx->slot_used[slot] = true;
+  ctx->slot_joined[slot] = false;
+  ctx->slot_lo[slot][0] = send->p + send_off;
+  ctx->slot_hi[slot][0] = send->p + send_off + count;
+  ctx->slot_lo[slot][1] = recv->p + recv_off;
+  ctx->slot_hi[slot][1] = recv->p + recv_off + count * size_t(ctx->nranks);
   return ROM_OK;
 }
 
@@ -162,6 +168,7 @@ extern "C" int rom_comm_wait_slot(rom_ctx* ctx, int slot) {
   ROM_CHECK(ctx && slot >= 0 && slot < 2, "rom_comm_wait_slot: bad arguments");
   if (!ctx->comm_stream || !ctx->slot_used[slot]) return ROM_OK;
   ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_slot[slot], 0));
+  ctx->slot_joined[slot] = true;
   return ROM_OK;
 }
 
@@ -170,6 +177,7 @@ extern "C" int rom_comm_wait(rom_ctx* ctx, int host_sync) {
   if (!ctx->comm_stream) return ROM_OK;
   ROM_HIP(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
   ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_comm, 0));
+  ctx->slot_joined[0] = ctx->slot_joined[1] = true;
   if (host_sync) ROM_HIP(hipStreamSynchronize(ctx->comm_stream));
   return ROM_OK;
 }

@@ -243,8 +243,8 @@ extern "C" int rom_profile_query(rom_ctx* c, int idx, char* name, size_t cap, do
 //   * kernels of the library run on the compute stream itself, or on the sub-batch streams of a sweep, which
 //     rom_solve_batch joins back into the compute stream before it returns;
 //   * collectives run on the communication stream and are NOT joined by themselves: rom_buf_free therefore
-//     makes the compute stream wait for the communication stream's tail (one event, no host wait) whenever a
-//     communicator exists, before the block becomes available again.
+//     makes the compute stream wait for the end of an outstanding collective (its slot's event, no host wait)
+//     when -- and only when -- the freed block is one that collective reads or writes.
 static size_t round_bytes(size_t bytes) {
   if (bytes < 4096) return 4096;
   if (bytes < (size_t(1) << 20)) return (bytes + 4095) / 4096 * 4096;
@@ -287,9 +287,21 @@ extern "C" int rom_buf_free(rom_buf* b) {
   if (!b) return ROM_OK;
   rom_ctx* c = b->ctx;
   const size_t bytes = round_bytes((b->n ? b->n : 1) * sizeof(double));
-  if (c->comm_stream) {  // an in-flight collective may still read or write the block (see the reuse rule above)
-    hipEventRecord(c->ev_comm, c->comm_stream);
-    hipStreamWaitEvent(c->stream, c->ev_comm, 0);
+  if (c->comm_stream) {
+    // Only a block that an outstanding collective reads or writes needs the wait (temporaries of the basis stage that
+    // are dropped during a step must not serialise the compute stream behind the all-gather it is meant to overlap):
+    // the compute stream is ordered behind the END of that slot's collective, through the slot's own event.
+    const double* lo = b->p;
+    const double* hi = reinterpret_cast<const double*>(reinterpret_cast<const char*>(b->p) + bytes);
+    for (int s = 0; s < 2; ++s) {
+      if (!c->slot_used[s] || c->slot_joined[s]) continue;
+      bool touches = false;
+      for (int k = 0; k < 2; ++k) touches = touches || (c->slot_lo[s][k] < hi && lo < c->slot_hi[s][k]);
+      if (!touches) continue;
+      ROM_HIP(hipSetDevice(c->device));
+      ROM_HIP(hipStreamWaitEvent(c->stream, c->ev_slot[s], 0));
+      c->slot_joined[s] = true;
+    }
   }
   if (c->cached_bytes + bytes <= c->cache_limit) {
     c->free_blocks[bytes].push_back(b->p);

@@ -118,17 +118,6 @@ __device__ inline double lane_swap1(double v) {
 // two doubles at an address that is only 8-byte aligned (snapshot rows have odd length)
 typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
 
-// k_extend_p (rom_fem_extend_p.hip), per workgroup (two per CU): ring of XP_SLOTS chunk slots
-// {A k 0..7: 64 rows x 64 B | A k 8..15 | B k 0..7: 128 rows x 64 B | B k 8..15}, 16-byte units swizzled,
-// + 4 x {h^2 / a_b of a tile's 64 systems}, 4 x {W at its 128 vertices} + a dump for the loads that fetch nothing
-constexpr int XP_SLOTS = 3;
-constexpr int XP_SLOT_BYTES = 2 * 64 * 64 + 2 * 128 * 64;
-constexpr int XP_SC_OFF = XP_SLOTS * XP_SLOT_BYTES;
-constexpr int XP_W_OFF = XP_SC_OFF + 4 * 512;
-constexpr int XP_DUMP_OFF = XP_W_OFF + 4 * 1024;
-constexpr size_t XP_LDS_BYTES = XP_DUMP_OFF + 1024;  // 80,896 B <= 160 KB / 2
-constexpr int XP_ZERO_PAGE = 256;                    // doubles of zeros behind FemDev::W
-template <bool FLAT, int DBG>
-__global__ void k_extend_p(FemDev f, X128Args xa, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, int nz);
+constexpr int EXT_ZERO_PAGE = 256;  // doubles of zeros behind FemDev::W (target of the lanes of k_extend128 that have nothing to load)
 __global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0);
 __global__ void k_assemble_stencil(FemDev f, const double* __restrict__ a, int M, double* __restrict__ diag, double* __restrict__ east, double* __restrict__ north);

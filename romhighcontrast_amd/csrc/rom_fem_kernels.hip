@@ -677,18 +677,6 @@ __global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
   diag_factor_body(f, blockIdx.x, slot, j, lds, lds + 64 * LDC, lds + 64 * LDC + 256);
 }
 
-#ifdef ROMHC_STAMPS
-__device__ unsigned long long g_stamps1[2048 * 6];  // k_solve1: [system][6]
-#define STAMP1(i)                                                                                    \
-  do {                                                                                               \
-    if (threadIdx.x == 0 && blockIdx.x < 2048u) g_stamps1[blockIdx.x * 6 + (i)] = __builtin_readcyclecounter(); \
-  } while (0)
-extern "C" int rom_debug_stamps1(unsigned long long* out, int n) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps1), size_t(n) * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
-}
-#else
-#define STAMP1(i)
-#endif
 
 // Whole reduced solve of a system whose reduced matrix is ONE tile (e.g. 2x2 blocks at N = 128: 2 x 31
 // compressed unknowns + the cross point), one wave per system, nothing but the solution leaves the CU:
@@ -712,7 +700,6 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   // else hides the latency).  The pairs are sorted by block; a block's sum is kept in four registers and
   // stored to an LDS copy of the blocks when its last pair is done (the target block of a pair is a run-time
   // index, which registers cannot have).
-  STAMP1(0);
   double* Cl = Ls;  // the ten lower blocks during the assembly, [block][g][lane] (Ls is not needed before the Cholesky)
   static_assert(40 * 64 <= 64 * LDC, "block copy must fit in the tile buffer");
   const int l16 = lane & 15, l4 = lane >> 4;
@@ -758,7 +745,6 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
     }
   }
   __builtin_amdgcn_wave_barrier();
-  STAMP1(1);
   d4_t C[4][4];
   {
     int q = 0;
@@ -797,7 +783,6 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
         y += (rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5) * rv[x];
       }
   }
-  STAMP1(2);
   // Blocked right-looking Cholesky, 16 panels of 4 columns.  A panel goes through LDS into row-per-lane form
   // (lane r holds its 4 entries), is factorised there with readlane broadcasts -- the forward substitution of y
   // rides along -- and goes back through LDS as the A and B operand of v_mfma_f64_16x16x4_f64 (K = 4 is exactly
@@ -863,7 +848,6 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   }
   if (bad && lane == 0) atomicOr(f.status, 1);
   __syncthreads();
-  STAMP1(3);
   // back substitution x = L^-T y.  Column `lane` of L is fetched from LDS in one batch (conflict free), then the
   // chain x_j = y_j / L_jj ; y_i -= L_ji x_j (i < j) runs on registers and readlane broadcasts only.
   double lcol[64];
@@ -875,7 +859,6 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
     if (lane == j) y = xj;
     else if (lane < j) y -= lcol[j] * xj;
   }
-  STAMP1(4);
   ym[lane] = y;
   zs[lane] = y;
   __syncthreads();
@@ -914,7 +897,6 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
     if (cg.kind == 1 && k < cg.r) continue;  // done above
     ym[cg.cpos + k] = k == cg.r ? 1.0 / (am[cg.b0] + am[cg.b1]) : (k < cg.r ? zs[cg.zpos + k] : 0.0);
   }
-  STAMP1(5);
 }
 
 // Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;
@@ -1181,51 +1163,6 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
     }
 }
 
-#ifdef ROMHC_STAMPS
-// cycle stamps of k_extend128 (debug build only: make EXTRA=-DROMHC_STAMPS, tools/gpu_stamps.py):
-// [workgroup][6] = entry, first loads issued, first barrier passed, k loop done, stores issued, (XCC_ID << 16 | HW_ID);
-// written by thread 0
-__device__ unsigned long long g_stamps[16384 * 6];
-#define STAMP(i)                                                                                               \
-  do {                                                                                                         \
-    if (threadIdx.x == 0) {                                                                                    \
-      const unsigned lin_ = __builtin_amdgcn_readfirstlane(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
-      if (lin_ < 16384u) g_stamps[lin_ * 6 + (i)] = __builtin_readcyclecounter();                              \
-      if ((i) == 0 && lin_ < 16384u) {                                                                         \
-        unsigned hw_, xcc_;                                                                                    \
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                      \
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                    \
-        g_stamps[lin_ * 6 + 5] = ((unsigned long long)(xcc_ & 0xf) << 16) | (hw_ & 0xffff);                    \
-      }                                                                                                        \
-    }                                                                                                          \
-  } while (0)
-extern "C" int rom_debug_stamps(unsigned long long* out, int n) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), size_t(n) * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
-}
-extern "C" int rom_debug_stamps_clear() {
-  static unsigned long long zeros[16384 * 6];
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : 1;
-}
-#else
-#define STAMP(i)
-#endif
-// -DROMHC_STAMPS_WAIT (with ROMHC_STAMPS): column 1 of a workgroup's stamps holds, instead of a time, the cycles its
-// wave 0 spent in the k loop's `s_waitcnt vmcnt(0); s_barrier` (how far the loop is bound by the latency of its loads)
-#if defined(ROMHC_STAMPS) && defined(ROMHC_STAMPS_WAIT)
-#define WAIT_BEGIN() const unsigned long long wt0_ = __builtin_readcyclecounter()
-#define WAIT_END() wait_cycles += __builtin_readcyclecounter() - wt0_
-#define WAIT_STORE()                                                                                            \
-  do {                                                                                                         \
-    if (threadIdx.x == 0) {                                                                                    \
-      const unsigned lin_ = __builtin_amdgcn_readfirstlane(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
-      if (lin_ < 16384u) g_stamps[lin_ * 6 + 1] = wait_cycles;                                                 \
-    }                                                                                                          \
-  } while (0)
-#else
-#define WAIT_BEGIN()
-#define WAIT_END()
-#define WAIT_STORE()
-#endif
 
 // The same extension for blocks whose sides are all compressed, with 128 x 128 workgroup tiles (128 systems x
 // one mesh row of up to 128 interior vertices): K is only sum(rank + 1) ~ 64, so a 64 x 64 tile spends most of its
@@ -1271,7 +1208,6 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
     return;
   }
   const int bz = blockIdx.z;
-  STAMP(0);
   {
     // Two workgroups share a CU; started together they run in lockstep (both loading / multiplying, then both in
     // the epilogue).  The second half of the first round starts one MFMA phase late (about 64 cycles per MFMA)
@@ -1355,7 +1291,7 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
   const char* const ybase = reinterpret_cast<const char*>(f.y) + size_t(min(m0, Mc - 1)) * ybytes_row;
   const char* const gsbase = reinterpret_cast<const char*>(f.Gs);
   const size_t seg_stride = size_t(n1) * n1 * 64;  // bytes between the K segments of a table
-  const char* const zbase = reinterpret_cast<const char*>(f.W + size_t(n1) * n1);  // XP_ZERO_PAGE doubles of zeros
+  const char* const zbase = reinterpret_cast<const char*>(f.W + size_t(n1) * n1);  // EXT_ZERO_PAGE doubles of zeros
   const unsigned voZ = unsigned(lane) * 16u;
   // the walk over the segments (uniform): side, segments left in it, its two running pointers; lanes: table rows
   int c_side = -1, c_left = 0, c_segs = nseg;
@@ -1405,7 +1341,6 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
       X_DMA(sb_ + 16384 + 1024, zbase, voZ);                                                                       \
     }                                                                                                              \
   } while (0)
-  [[maybe_unused]] unsigned long long wait_cycles = 0;
   d4_t acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1416,7 +1351,6 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
     X_ISSUE_HALF(0, 0, w < 4);
     X_ISSUE_HALF(0, 1, w < 4);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    STAMP(2);
     double af[2][4], bf[2][NJ];
     X_FRAGS(0, 0, af[0], bf[0]);
     for (int ch = 0; ch < tot; ++ch) {
@@ -1436,9 +1370,7 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
           for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][i], bf[pb][j], acc[i][j], 0, 0, 0);
       }
       {
-        WAIT_BEGIN();
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // chunk ch + 1 is in LDS for everybody
-        WAIT_END();
       }
       if (ch + 1 < tot) X_FRAGS(slot ^ 1, 0, af[0], bf[0]);
     }
@@ -1454,11 +1386,9 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
   // makes full progress (tools/mfma_store_overlap.hip, `waves`); letting the stores go first shortens that phase
   // (C2: 0.234 -> 0.220 ms; the other way round, priority to the k loop: 0.243 ms; priority to the prologue as
   // well: 0.237 ms; profiles/r02_extend128_wave_priority_ab.txt).
-  WAIT_STORE();
   __builtin_amdgcn_s_setprio(ROMHC_EPI_PRIO);
   if (threadIdx.x < 128) scs[threadIdx.x] = my_sc;
   __syncthreads();
-  STAMP(3);
   // epilogue: add the particular solution, swap between lane pairs so that every lane owns two adjacent vertices of
   // one 16-vertex block, 16-byte stores.  The stores of a wave walk down its 64 systems four rows at a time (rows
   // 16 i + 4 g + kq, i and g ascending): the lane's pointer advances by a constant, what a lane stores
@@ -1528,7 +1458,6 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
         sp[hp] += step;
       }
     }
-  STAMP(4);
 }
 template __global__ void k_extend128<false>(FemDev, X128Args, const double*, int, double*, long long, int);
 template __global__ void k_extend128<true>(FemDev, X128Args, const double*, int, double*, long long, int);

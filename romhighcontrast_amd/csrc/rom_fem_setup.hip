@@ -255,11 +255,16 @@ struct TermAcc {
   int r_lo, r_hi, c_lo, c_hi;
 };
 
+// Table uploads go through the context's (non-blocking) compute stream, the stream every reader runs on, and wait for
+// it: the host vector may be destroyed on return, and no ordering is left to a null-stream copy being host-synchronous.
 template <class Tp>
-int upload(Tp** dptr, const std::vector<Tp>& h) {
+int upload(hipStream_t st, Tp** dptr, const std::vector<Tp>& h) {
   size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(Tp);
   ROM_HIP(hipMalloc(dptr, bytes));
-  if (!h.empty()) ROM_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice));
+  if (!h.empty()) {
+    ROM_HIP(hipMemcpyAsync(*dptr, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice, st));
+    ROM_HIP(hipStreamSynchronize(st));
+  }
   return ROM_OK;
 }
 
@@ -1052,21 +1057,21 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     if (!ok) f->fused1 = false;
     f->ndg = f->fused1 ? int(dgroups.size()) : 0;
     f->ndi = f->fused1 ? ndi : 0;
-    ROM_TRY(upload(&f->d_dgroups, dgroups));
-    ROM_TRY(upload(&f->d_dweight, dweight));
-    ROM_TRY(upload(&f->d_ditem_group, ditem_group));
-    ROM_TRY(upload(&f->d_ditem_k, ditem_k));
-    ROM_TRY(upload(&f->d_dmat, dmat));
+    ROM_TRY(upload(ctx->stream, &f->d_dgroups, dgroups));
+    ROM_TRY(upload(ctx->stream, &f->d_dweight, dweight));
+    ROM_TRY(upload(ctx->stream, &f->d_ditem_group, ditem_group));
+    ROM_TRY(upload(ctx->stream, &f->d_ditem_k, ditem_k));
+    ROM_TRY(upload(ctx->stream, &f->d_dmat, dmat));
   }
   {
     std::vector<double> Ptab(std::max<size_t>(ptab_list.size() * tsz, 1), 0.0);
     for (size_t t = 0; t < ptab_list.size(); ++t)
       put_table(Ptab, t, n1p, ptab_list[t].second == 0 ? comps[ptab_list[t].first].P : comps[ptab_list[t].first].KiW, false);
-    ROM_TRY(upload(&f->d_P, Ptab));
+    ROM_TRY(upload(ctx->stream, &f->d_P, Ptab));
     std::vector<double> Bt(std::max<size_t>(size_t(nbt) * tsz, 1), 0.0);
     for (auto& kv : bt_of_id) put_table(Bt, kv.second, n1p, TK(kv.first), true);  // (T K^-1)^T: row = node of e
     for (auto& kv : bt_extra) put_table(Bt, kv.first, n1p, kv.second, false);
-    ROM_TRY(upload(&f->d_Bt, Bt));
+    ROM_TRY(upload(ctx->stream, &f->d_Bt, Bt));
   }
 
   ROMHC_PHASE("device tables of the harmonic extension");
@@ -1075,8 +1080,8 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   for (int j = 0; j < n1; ++j)
     for (int m = 0; m < n1; ++m) Qp[size_t(j) * n1p + m] = double(Q(j, m));
   double* d_rho = nullptr;
-  ROM_TRY(upload(&f->d_Qp, Qp));
-  ROM_TRY(upload(&d_rho, rho_d));
+  ROM_TRY(upload(ctx->stream, &f->d_Qp, Qp));
+  ROM_TRY(upload(ctx->stream, &d_rho, rho_d));
   const size_t hrows = size_t(n1) * n1;
   ROM_HIP(hipMalloc(&f->d_A0, std::max<size_t>(hrows * n1p, 1) * sizeof(double)));
   if (hrows > 0) {
@@ -1087,7 +1092,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
   hipFree(d_rho);
   {
-    ROM_TRY(upload(&f->d_kmax, kmax));
+    ROM_TRY(upload(ctx->stream, &f->d_kmax, kmax));
 
     // Representation of every block side in the extension.  A compressed edge enters through its reduced
     // unknowns when that is cheaper than the distance-truncated sine modes: table G_c = H_0 [P_c, p0_c]
@@ -1126,7 +1131,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
       const int c = kv.first.first;
       const std::vector<double>& Bh = Bhs[gi];
       double* d_B = nullptr;
-      ROM_TRY(upload(&d_B, Bh));
+      ROM_TRY(upload(ctx->stream, &d_B, Bh));
       ROM_TRY(rom_launch_gemm_nt(ctx, int64_t(hrows), rp[c], n1p, 1.0, f->d_A0, n1p, d_B, n1p, 0.0, f->d_G + kv.second,
                                  rp[c], "setup_gemm_G"));
       ROM_HIP(hipStreamSynchronize(ctx->stream));
@@ -1188,15 +1193,15 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     }
     f->n_lr_blocks = int(lr_blocks.size());
     f->n_gen_blocks = int(gen_blocks.size());
-    ROM_TRY(upload(&f->d_lr_blocks, lr_blocks));
+    ROM_TRY(upload(ctx->stream, &f->d_lr_blocks, lr_blocks));
     f->lr_blocks_host = lr_blocks;
-    ROM_TRY(upload(&f->d_gen_blocks, gen_blocks));
+    ROM_TRY(upload(ctx->stream, &f->d_gen_blocks, gen_blocks));
     std::vector<int> eposv;
     for (int e = 0; e < E; ++e)
       if (need_tr[e]) eposv.push_back(npos[e]);
     f->n_edges = int(eposv.size());
     if (eposv.empty()) eposv.push_back(0);
-    ROM_TRY(upload(&f->d_epos, eposv));
+    ROM_TRY(upload(ctx->stream, &f->d_epos, eposv));
     // flops of the extension, per system (for the work accounting)
     f->ext_flops = fl + 2.0 * f->n_edges * double(n1p) * n1p;
     // the segment-major copies k_extend128 reads
@@ -1214,38 +1219,38 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     ROM_HIP(hipStreamSynchronize(ctx->stream));
   }
   {
-    std::vector<double> Wz(Wd);  // + a page of zeros: where k_extend_p points the lanes that have nothing to load
-    Wz.resize(Wd.size() + XP_ZERO_PAGE, 0.0);
-    ROM_TRY(upload(&f->d_W, Wz));
+    std::vector<double> Wz(Wd);  // + a page of zeros: where k_extend128 points the lanes that have nothing to load
+    Wz.resize(Wd.size() + EXT_ZERO_PAGE, 0.0);
+    ROM_TRY(upload(ctx->stream, &f->d_W, Wz));
   }
-  ROM_TRY(upload(&f->d_g, g_red));
-  ROM_TRY(upload(&f->d_vec, vecs));
-  ROM_TRY(upload(&f->d_pool, pool));
-  ROM_TRY(upload(&f->d_terms, terms));
-  ROM_TRY(upload(&f->d_pairs, pairs));
+  ROM_TRY(upload(ctx->stream, &f->d_g, g_red));
+  ROM_TRY(upload(ctx->stream, &f->d_vec, vecs));
+  ROM_TRY(upload(ctx->stream, &f->d_pool, pool));
+  ROM_TRY(upload(ctx->stream, &f->d_terms, terms));
+  ROM_TRY(upload(ctx->stream, &f->d_pairs, pairs));
   f->nrhs = int(rhs_terms.size());
-  ROM_TRY(upload(&f->d_rhs, rhs_terms));
-  ROM_TRY(upload(&f->d_pre, pre_edges));
-  ROM_TRY(upload(&f->d_exp, exps));
-  ROM_TRY(upload(&f->d_groups, groups));
-  ROM_TRY(upload(&f->d_cm, cm));
-  ROM_TRY(upload(&f->d_item_group, item_group));
-  ROM_TRY(upload(&f->d_item_k, item_k));
-  ROM_TRY(upload(&f->d_xred, xred));
+  ROM_TRY(upload(ctx->stream, &f->d_rhs, rhs_terms));
+  ROM_TRY(upload(ctx->stream, &f->d_pre, pre_edges));
+  ROM_TRY(upload(ctx->stream, &f->d_exp, exps));
+  ROM_TRY(upload(ctx->stream, &f->d_groups, groups));
+  ROM_TRY(upload(ctx->stream, &f->d_cm, cm));
+  ROM_TRY(upload(ctx->stream, &f->d_item_group, item_group));
+  ROM_TRY(upload(ctx->stream, &f->d_item_k, item_k));
+  ROM_TRY(upload(ctx->stream, &f->d_xred, xred));
   {
     std::vector<int> scb;  // (b0, b1) per scalar: an edge's two blocks, or (block, -1)
     for (int e = 0; e < E; ++e) { scb.push_back(edges[e].b0); scb.push_back(edges[e].b1); }
     for (int b = 0; b < nrb * ncb; ++b) { scb.push_back(b); scb.push_back(-1); }
-    ROM_TRY(upload(&f->d_scb, scb));
+    ROM_TRY(upload(ctx->stream, &f->d_scb, scb));
   }
-  ROM_TRY(upload(&f->d_desc, f->desc));
-  ROM_TRY(upload(&f->d_kptr, f->kptr));
-  ROM_TRY(upload(&f->d_kpair, f->kpair));
-  ROM_TRY(upload(&f->d_colptr, f->colptr));
-  ROM_TRY(upload(&f->d_colrow, f->colrow));
-  ROM_TRY(upload(&f->d_colti, f->colti));
-  ROM_TRY(upload(&f->d_sides, f->sides));
-  ROM_TRY(upload(&f->d_vmap, vmap));
+  ROM_TRY(upload(ctx->stream, &f->d_desc, f->desc));
+  ROM_TRY(upload(ctx->stream, &f->d_kptr, f->kptr));
+  ROM_TRY(upload(ctx->stream, &f->d_kpair, f->kpair));
+  ROM_TRY(upload(ctx->stream, &f->d_colptr, f->colptr));
+  ROM_TRY(upload(ctx->stream, &f->d_colrow, f->colrow));
+  ROM_TRY(upload(ctx->stream, &f->d_colti, f->colti));
+  ROM_TRY(upload(ctx->stream, &f->d_sides, f->sides));
+  ROM_TRY(upload(ctx->stream, &f->d_vmap, vmap));
   {
     std::vector<char> expanded(E, 0);
     for (int e : order) expanded[e] = 1;
@@ -1257,14 +1262,13 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         for (int t = 0; t < n1; ++t) scat.push_back(npos[e] + t);
     for (int x = 0; x < ncross; ++x) scat.push_back(f->xb0 + x);
     f->nscat = int(scat.size());
-    ROM_TRY(upload(&f->d_scat, scat));
+    ROM_TRY(upload(ctx->stream, &f->d_scat, scat));
   }
 
   f->sw_no_fused = getenv("ROMHC_NO_FUSED") != nullptr;
   f->sw_no_ext128 = getenv("ROMHC_NO_EXT128") != nullptr;
   f->sw_no_fold = getenv("ROMHC_NO_FOLD_EXPAND") != nullptr;
   f->sw_no_tile_pairs = getenv("ROMHC_NO_TILE_PAIRS") != nullptr;
-  f->sw_ext_p = getenv("ROMHC_EXT_P") ? atoi(getenv("ROMHC_EXT_P")) : 0;
   f->sw_ext_flat = getenv("ROMHC_EXT_FLAT") ? (atoi(getenv("ROMHC_EXT_FLAT")) != 0 ? 1 : 0) : -1;
   ROMHC_PHASE("end");
   if (getenv("ROMHC_VERBOSE")) {

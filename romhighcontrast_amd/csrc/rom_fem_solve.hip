@@ -162,15 +162,8 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   // (k_extend128 addresses its table rows and interface-vector rows with 32-bit lane offsets)
   const bool fits32 = size_t(f->n1) * f->n1 * 64 * BK * 8 < (size_t(1) << 32) && size_t(128) * f->nGp * 8 < (size_t(1) << 32);
   const bool wide = Mc >= 128 && fits32 && 100 * 128 * t128 <= 102 * 64 * f->n1 * ((f->n1 + 63) / 64) && !f->sw_no_ext128;
-#ifdef ROMHC_EXPERIMENTAL
-  // k_extend_p (rom_fem_extend_p.hip): persistent workgroups; its lane offsets are 32-bit
-  const bool persistent = wide && f->sw_ext_p != 0 && size_t(f->dim) * 32 < (size_t(1) << 32) &&
-                          (size_t(Mc) + 128) * f->nGp * 8 < (size_t(1) << 32) && size_t(f->n1) * f->n1 * 64 * BK * 8 < (size_t(1) << 32);
-#else
-  const bool persistent = false;
-#endif
   const bool fold_expand = f->nexp > 0 && f->npre == 0 && f->n_edges == 0 && f->n_gen_blocks == 0 && f->n_lr_blocks > 0 &&
-                           wide && !persistent && !f->sw_no_fold;
+                           wide && !f->sw_no_fold;
   if (f->nGp > 0) {
     if (f->nexp > 0 && !fold_expand) {
       ROM_PROF(ctx, "expand", Mc * 2.0 * f->n1p * 32.0 * f->nexp, 8.0 * Mc * f->n1p * f->nexp);
@@ -209,39 +202,10 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
               xa.blocks[z] = f->lr_blocks_host[z0 + z];
               xa.sides[z] = f->sides[xa.blocks[z]];
             }
-#ifdef ROMHC_EXPERIMENTAL
-            if (persistent) {
-              static bool lds_set = false;  // (more than 64 KB of dynamic LDS must be asked for once per kernel)
-              if (!lds_set) {
-                ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_p<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(XP_LDS_BYTES)));
-                ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_p<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(XP_LDS_BYTES)));
-#ifdef ROMHC_XP_PROBES
-                ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_p<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(XP_LDS_BYTES)));
-                ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_p<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(XP_LDS_BYTES)));
-                ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_extend_p<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, int(XP_LDS_BYTES)));
-#endif
-                lds_set = true;
-              }
-              const int nwg = 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256);  // two resident workgroups per CU
-              if (flat) k_extend_p<true, 0><<<nwg, 256, XP_LDS_BYTES, st>>>(d, xa, am, Mc, U, row, nz);
-#ifdef ROMHC_XP_PROBES
-              else if (f->sw_ext_p == 2) k_extend_p<false, 1><<<nwg, 256, XP_LDS_BYTES, st>>>(d, xa, am, Mc, U, row, nz);
-              else if (f->sw_ext_p == 3) k_extend_p<false, 2><<<nwg, 256, XP_LDS_BYTES, st>>>(d, xa, am, Mc, U, row, nz);
-              else if (f->sw_ext_p == 17) k_extend_p<false, 16><<<nwg, 256, XP_LDS_BYTES, st>>>(d, xa, am, Mc, U, row, nz);
-#endif
-              else k_extend_p<false, 0><<<nwg, 256, XP_LDS_BYTES, st>>>(d, xa, am, Mc, U, row, nz);
-              continue;
-            }
-#endif
             const int extra = fold_expand && z0 == 0 ? (items + mt * nz - 1) / (mt * nz) : 0;
             dim3 grid(t128 + extra, mt, nz);
-#ifdef ROMHC_STAMPS  // (timeline builds: ROMHC_EXT_LDS_PAD = unused dynamic LDS per workgroup, to run one workgroup per CU)
-            static const size_t pad = getenv("ROMHC_EXT_LDS_PAD") ? size_t(atoi(getenv("ROMHC_EXT_LDS_PAD"))) : 0;
-#else
-            constexpr size_t pad = 0;
-#endif
-            if (flat) k_extend128<true><<<grid, 512, pad, st>>>(d, xa, am, Mc, U, row, extra);
-            else k_extend128<false><<<grid, 512, pad, st>>>(d, xa, am, Mc, U, row, extra);
+            if (flat) k_extend128<true><<<grid, 512, 0, st>>>(d, xa, am, Mc, U, row, extra);
+            else k_extend128<false><<<grid, 512, 0, st>>>(d, xa, am, Mc, U, row, extra);
           }
         } else {
           dim3 grid(f->n1 * ((f->n1 + 63) / 64), (Mc + 63) / 64, f->n_lr_blocks);

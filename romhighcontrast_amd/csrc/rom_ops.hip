@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "rom_mma.h"
+#include "rom_ops.h"
 
 // ============================================================================================
 // generic NT GEMM:  C[m,n] = alpha * sum_k A[m,k] B[n,k] + beta C      (64x64 tiles, split-K)
@@ -376,6 +377,12 @@ static int launch_gram128(rom_ctx* ctx, int64_t m, int64_t k, const double* A, i
   return ROM_OK;
 }
 
+int rom_launch_gram(rom_ctx* ctx, int64_t m, int64_t k, const double* A, int64_t lda, double* C, int64_t ldc) {
+  if (m <= 0) return ROM_OK;
+  if (m >= 512 && k >= 4096 && size_t(lda) * 8 * 128 < (size_t(1) << 32)) return launch_gram128(ctx, m, k, A, lda, C, ldc);
+  return rom_launch_gemm_nt_ex(ctx, m, m, k, 1.0, A, lda, A, lda, 0.0, C, ldc, "gram", 1);
+}
+
 extern "C" int rom_gram(rom_ctx* ctx, int64_t m, int64_t k, rom_buf* A, size_t a_off, int64_t lda, rom_buf* C,
                         size_t c_off, int64_t ldc) {
   ROM_CHECK(ctx && A && C, "rom_gram: null argument");
@@ -383,9 +390,7 @@ extern "C" int rom_gram(rom_ctx* ctx, int64_t m, int64_t k, rom_buf* A, size_t a
   if (m == 0) return ROM_OK;
   ROM_CHECK(a_off + size_t(m - 1) * lda + k <= A->n, "rom_gram: A out of range");
   ROM_CHECK(c_off + size_t(m - 1) * ldc + m <= C->n, "rom_gram: C out of range");
-  if (m >= 512 && k >= 4096 && size_t(lda) * 8 * 128 < (size_t(1) << 32)) return launch_gram128(ctx, m, k, A->p + a_off, lda, C->p + c_off, ldc);
-  return rom_launch_gemm_nt_ex(ctx, m, m, k, 1.0, A->p + a_off, lda, A->p + a_off, lda, 0.0, C->p + c_off, ldc, "gram",
-                               1);
+  return rom_launch_gram(ctx, m, k, A->p + a_off, lda, C->p + c_off, ldc);
 }
 
 // ============================================================================================
@@ -440,6 +445,21 @@ __global__ __launch_bounds__(256) void k_gemm_nn(long long m, long long n, long 
     }
 }
 
+int rom_launch_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+  if (m <= 0 || n <= 0) return ROM_OK;
+  dim3 grid(unsigned((n + 63) / 64), unsigned((m + 63) / 64));
+  {
+    static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-shape names in the profile records
+    char nm[64];
+    detail ? snprintf(nm, sizeof nm, "gemm_nn_%lldx%lldx%lld", (long long)m, (long long)n, (long long)k) : snprintf(nm, sizeof nm, "gemm_nn");
+    ROM_PROF(ctx, nm, 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(m) * n));
+    k_gemm_nn<<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
 extern "C" int rom_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, rom_buf* A, size_t a_off,
                            int64_t lda, rom_buf* B, size_t b_off, int64_t ldb, double beta, rom_buf* C,
                            size_t c_off, int64_t ldc) {
@@ -449,27 +469,12 @@ extern "C" int rom_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double
   ROM_CHECK(a_off + size_t(m - 1) * lda + k <= A->n, "rom_gemm_nn: A out of range");
   ROM_CHECK(k == 0 || b_off + size_t(k - 1) * ldb + n <= B->n, "rom_gemm_nn: B out of range");
   ROM_CHECK(c_off + size_t(m - 1) * ldc + n <= C->n, "rom_gemm_nn: C out of range");
-  dim3 grid(unsigned((n + 63) / 64), unsigned((m + 63) / 64));
-  {
-    static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-shape names in the profile records
-    char nm[64];
-    detail ? snprintf(nm, sizeof nm, "gemm_nn_%lldx%lldx%lld", (long long)m, (long long)n, (long long)k) : snprintf(nm, sizeof nm, "gemm_nn");
-    ROM_PROF(ctx, nm, 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(m) * n));
-    k_gemm_nn<<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A->p + a_off, lda, B->p + b_off, ldb, beta,
-                                             C->p + c_off, ldc);
-  }
-  ROM_HIP(hipGetLastError());
-  return ROM_OK;
+  return rom_launch_gemm_nn(ctx, m, n, k, alpha, A->p + a_off, lda, B->p + b_off, ldb, beta, C->p + c_off, ldc);
 }
 
 // ============================================================================================
 // stencil application and norms
 // ============================================================================================
-struct StencilGeom {
-  int nr, nc, N, ncb, kblk;
-  long long dim;
-};
-
 // Y = A(coef) X for the 5-point operator with block coefficients (kappa of the four cells around a vertex: SURVEY 8a-1).
 // Every entry is loaded ONCE: a thread owns a mesh column and walks down a slab of rows with the entry above, the entry
 // itself and the entry below in registers; the east / west neighbours come from the next / previous lane (the wave's edge
@@ -608,14 +613,29 @@ __global__ __launch_bounds__(256) void k_sq_partial(long long dim, const double*
 }
 
 __global__ __launch_bounds__(256) void k_finish_norm(const double* __restrict__ partial, int nblk,
-                                                     double* __restrict__ out) {
+                                                     double* __restrict__ out, int take_sqrt) {
   double s = 0.0;
   for (int i = threadIdx.x; i < nblk; i += 256) s += partial[blockIdx.x * (long long)nblk + i];
   s = block_reduce_sum(s);
-  if (threadIdx.x == 0) out[blockIdx.x] = sqrt(s);
+  if (threadIdx.x == 0) out[blockIdx.x] = take_sqrt ? sqrt(s) : s;
 }
 
-static StencilGeom make_geom(int nrb, int ncb, int N) {
+// partial[k][blk] = this block's share of U_k . z
+__global__ __launch_bounds__(256) void k_rowdot_partial(long long dim, const double* __restrict__ U,
+                                                        const double* __restrict__ z, double* __restrict__ partial,
+                                                        int nblk, int per_thread) {
+  const double* u = U + blockIdx.y * dim;
+  double s = 0.0;
+  long long base = blockIdx.x * (long long)(256 * per_thread);
+  for (int it = 0; it < per_thread; ++it) {
+    long long idx = base + it * 256 + threadIdx.x;
+    if (idx < dim) s += u[idx] * z[idx];
+  }
+  s = block_reduce_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.y * (long long)nblk + blockIdx.x] = s;
+}
+
+StencilGeom rom_make_geom(int nrb, int ncb, int N) {
   StencilGeom g;
   g.N = N;
   g.ncb = ncb;
@@ -624,6 +644,21 @@ static StencilGeom make_geom(int nrb, int ncb, int N) {
   g.nc = ncb * N - 1;
   g.dim = (long long)g.nr * g.nc;
   return g;
+}
+
+int rom_launch_stencil_apply(rom_fem* f, const double* d_coef, const double* X, int K, double* Y) {
+  if (K <= 0) return ROM_OK;
+  rom_ctx* ctx = f->ctx;
+  StencilGeom g = rom_make_geom(f->nrb, f->ncb, f->N);
+  ROM_CHECK(K <= 65535, "stencil apply: at most 65535 vectors per call");
+  {
+    ROM_PROF(ctx, "stencil_apply", 14.0 * g.dim * K, 16.0 * g.dim * K);
+    const dim3 grid((g.nc + 255) / 256, (g.nr + SA_ROWS - 1) / SA_ROWS, K);
+    if (!d_coef) k_stencil_apply_cols<true><<<grid, 256, 0, ctx->stream>>>(g, nullptr, X, Y);
+    else k_stencil_apply_cols<false><<<grid, 256, 0, ctx->stream>>>(g, d_coef, X, Y);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
 }
 
 extern "C" int rom_stencil_apply(rom_fem* f, const double* a_one_host, int unit, rom_buf* X, int64_t x_row0,
@@ -635,22 +670,33 @@ extern "C" int rom_stencil_apply(rom_fem* f, const double* a_one_host, int unit,
             "rom_stencil_apply: rows out of range");
   if (K == 0) return ROM_OK;
   rom_ctx* ctx = f->ctx;
-  StencilGeom g = make_geom(f->nrb, f->ncb, f->N);
   double* d_a = nullptr;
   if (!unit) {
     ROM_TRY(rom_ctx_scratch(ctx, 64, &d_a));
-    ROM_HIP(hipMemcpyAsync(d_a, a_one_host, g.kblk * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ROM_HIP(hipMemcpyAsync(d_a, a_one_host, f->nrb * f->ncb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     ROM_HIP(hipStreamSynchronize(ctx->stream));
   }
-  ROM_CHECK(K <= 65535, "rom_stencil_apply: at most 65535 vectors per call");
+  ROM_TRY(rom_launch_stencil_apply(f, d_a, X->p + x_row0 * f->dim, K, Y->p + y_row0 * f->dim));
+  if (!unit) ROM_HIP(hipStreamSynchronize(ctx->stream));  // scratch may be re-used by the next call
+  return ROM_OK;
+}
+
+int rom_launch_h10norm(rom_fem* f, const double* U, const double* V, int K, double* d_out, bool take_sqrt) {
+  if (K <= 0) return ROM_OK;
+  rom_ctx* ctx = f->ctx;
+  StencilGeom g = rom_make_geom(f->nrb, f->ncb, f->N);
+  const dim3 grid((g.nc + 255) / 256, (g.nr + H10_ROWS - 1) / H10_ROWS, K);
+  const int nblk = int(grid.x * grid.y);
+  ROM_CHECK(K <= 65535, "H10 norm: at most 65535 vectors per call");
+  double* scratch = nullptr;
+  ROM_TRY(rom_ctx_scratch(ctx, size_t(K) * nblk, &scratch));
   {
-    ROM_PROF(ctx, "stencil_apply", 14.0 * g.dim * K, 16.0 * g.dim * K);
-    const dim3 grid((g.nc + 255) / 256, (g.nr + SA_ROWS - 1) / SA_ROWS, K);
-    if (unit) k_stencil_apply_cols<true><<<grid, 256, 0, ctx->stream>>>(g, d_a, X->p + x_row0 * f->dim, Y->p + y_row0 * f->dim);
-    else k_stencil_apply_cols<false><<<grid, 256, 0, ctx->stream>>>(g, d_a, X->p + x_row0 * f->dim, Y->p + y_row0 * f->dim);
+    ROM_PROF(ctx, "h10norm", 10.0 * g.dim * K, (V ? 16.0 : 8.0) * g.dim * K);
+    if (V) k_h10_partial<true><<<grid, 256, 0, ctx->stream>>>(g, U, V, scratch, nblk);
+    else k_h10_partial<false><<<grid, 256, 0, ctx->stream>>>(g, U, nullptr, scratch, nblk);
+    k_finish_norm<<<K, 256, 0, ctx->stream>>>(scratch, nblk, d_out, take_sqrt ? 1 : 0);
   }
   ROM_HIP(hipGetLastError());
-  if (!unit) ROM_HIP(hipStreamSynchronize(ctx->stream));  // scratch may be re-used by the next call
   return ROM_OK;
 }
 
@@ -662,22 +708,43 @@ extern "C" int rom_h10norm(rom_fem* f, rom_buf* U, int64_t u_row0, rom_buf* V, i
   ROM_CHECK(!V || size_t(v_row0 + K) * f->dim <= V->n, "rom_h10norm: V rows out of range");
   if (K == 0) return ROM_OK;
   rom_ctx* ctx = f->ctx;
-  StencilGeom g = make_geom(f->nrb, f->ncb, f->N);
-  const dim3 grid((g.nc + 255) / 256, (g.nr + H10_ROWS - 1) / H10_ROWS, K);
-  const int nblk = int(grid.x * grid.y);
-  ROM_CHECK(K <= 65535, "rom_h10norm: at most 65535 vectors per call");
+  rom_buf* out = nullptr;
+  ROM_TRY(rom_buf_alloc(ctx, size_t(K), &out));
+  int st = rom_launch_h10norm(f, U->p + u_row0 * f->dim, V ? V->p + v_row0 * f->dim : nullptr, K, out->p, true);
+  if (st == ROM_OK) st = rom_buf_download(out, 0, out_host, size_t(K));
+  rom_buf_free(out);
+  return st;
+}
+
+int rom_launch_l2norm(rom_ctx* ctx, const double* U, int K, int64_t dim, double* d_out, bool take_sqrt) {
+  if (K <= 0) return ROM_OK;
+  const int per_thread = 8;
+  const int nblk = int(std::max<int64_t>(1, (dim + 256 * per_thread - 1) / (256 * per_thread)));
+  ROM_CHECK(K <= 65535, "l2 norm: at most 65535 vectors per call");
   double* scratch = nullptr;
-  ROM_TRY(rom_ctx_scratch(ctx, size_t(K) * nblk + K, &scratch));
-  double* d_out = scratch + size_t(K) * nblk;
+  ROM_TRY(rom_ctx_scratch(ctx, size_t(K) * nblk, &scratch));
   {
-    ROM_PROF(ctx, "h10norm", 10.0 * g.dim * K, (V ? 16.0 : 8.0) * g.dim * K);
-    if (V) k_h10_partial<true><<<grid, 256, 0, ctx->stream>>>(g, U->p + u_row0 * f->dim, V->p + v_row0 * f->dim, scratch, nblk);
-    else k_h10_partial<false><<<grid, 256, 0, ctx->stream>>>(g, U->p + u_row0 * f->dim, nullptr, scratch, nblk);
-    k_finish_norm<<<K, 256, 0, ctx->stream>>>(scratch, nblk, d_out);
+    ROM_PROF(ctx, "l2norm", 2.0 * dim * K, 8.0 * dim * K);
+    k_sq_partial<<<dim3(nblk, K), 256, 0, ctx->stream>>>(dim, U, scratch, nblk, per_thread);
+    k_finish_norm<<<K, 256, 0, ctx->stream>>>(scratch, nblk, d_out, take_sqrt ? 1 : 0);
   }
   ROM_HIP(hipGetLastError());
-  ROM_HIP(hipMemcpyAsync(out_host, d_out, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  return ROM_OK;
+}
+
+int rom_launch_rowdot(rom_ctx* ctx, const double* U, int K, int64_t dim, const double* z, double* d_out) {
+  if (K <= 0) return ROM_OK;
+  const int per_thread = 8;
+  const int nblk = int(std::max<int64_t>(1, (dim + 256 * per_thread - 1) / (256 * per_thread)));
+  ROM_CHECK(K <= 65535, "row dot: at most 65535 vectors per call");
+  double* scratch = nullptr;
+  ROM_TRY(rom_ctx_scratch(ctx, size_t(K) * nblk, &scratch));
+  {
+    ROM_PROF(ctx, "rowdot", 2.0 * dim * K, 8.0 * dim * K);
+    k_rowdot_partial<<<dim3(nblk, K), 256, 0, ctx->stream>>>(dim, U, z, scratch, nblk, per_thread);
+    k_finish_norm<<<K, 256, 0, ctx->stream>>>(scratch, nblk, d_out, 0);
+  }
+  ROM_HIP(hipGetLastError());
   return ROM_OK;
 }
 
@@ -686,20 +753,12 @@ extern "C" int rom_l2norm(rom_ctx* ctx, rom_buf* U, int64_t row0, int K, int64_t
   ROM_CHECK(K >= 0 && row0 >= 0 && dim >= 0, "rom_l2norm: negative size");
   ROM_CHECK(size_t(row0 + K) * dim <= U->n, "rom_l2norm: rows out of range");
   if (K == 0) return ROM_OK;
-  const int per_thread = 8;
-  const int nblk = int(std::max<int64_t>(1, (dim + 256 * per_thread - 1) / (256 * per_thread)));
-  double* scratch = nullptr;
-  ROM_TRY(rom_ctx_scratch(ctx, size_t(K) * nblk + K, &scratch));
-  double* d_out = scratch + size_t(K) * nblk;
-  {
-    ROM_PROF(ctx, "l2norm", 2.0 * dim * K, 8.0 * dim * K);
-    k_sq_partial<<<dim3(nblk, K), 256, 0, ctx->stream>>>(dim, U->p + row0 * dim, scratch, nblk, per_thread);
-    k_finish_norm<<<K, 256, 0, ctx->stream>>>(scratch, nblk, d_out);
-  }
-  ROM_HIP(hipGetLastError());
-  ROM_HIP(hipMemcpyAsync(out_host, d_out, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  ROM_HIP(hipStreamSynchronize(ctx->stream));
-  return ROM_OK;
+  rom_buf* out = nullptr;
+  ROM_TRY(rom_buf_alloc(ctx, size_t(K), &out));
+  int st = rom_launch_l2norm(ctx, U->p + row0 * dim, K, dim, out->p, true);
+  if (st == ROM_OK) st = rom_buf_download(out, 0, out_host, size_t(K));
+  rom_buf_free(out);
+  return st;
 }
 
 // ============================================================================================
@@ -710,7 +769,7 @@ extern "C" int rom_l2norm(rom_ctx* ctx, rom_buf* U, int64_t row0, int K, int64_t
 // ============================================================================================
 constexpr int REDUCED_LDS_DEFAULT = 64 * 1024, REDUCED_LDS_MAX = 160 * 1024;
 
-__global__ __launch_bounds__(256) void k_reduced_solve(int n, int kb, const double* __restrict__ Ahat,
+__global__ __launch_bounds__(256) void k_reduced_solve(int n, int ldA, int kb, const double* __restrict__ Ahat,
                                                        const double* __restrict__ w, const double* __restrict__ rhs,
                                                        int rhs_per_system, double* __restrict__ cout, int* status,
                                                        double* gws) {
@@ -724,7 +783,7 @@ __global__ __launch_bounds__(256) void k_reduced_solve(int n, int kb, const doub
   for (int idx = t; idx < n * n; idx += 256) {
     int r = idx / n, c = idx % n;
     double s = 0.0;
-    for (int q = 0; q < kb; ++q) s += w[size_t(m) * kb + q] * Ahat[(size_t(q) * n + r) * n + c];
+    for (int q = 0; q < kb; ++q) s += w[size_t(m) * kb + q] * Ahat[(size_t(q) * ldA + r) * ldA + c];
     Am[r * ld + c] = s;
   }
   for (int i = t; i < n; i += 256) b[i] = rhs_per_system ? rhs[size_t(m) * n + i] : rhs[i];
@@ -767,6 +826,35 @@ __global__ __launch_bounds__(256) void k_reduced_solve(int n, int kb, const doub
   for (int i = t; i < n; i += 256) cout[size_t(m) * n + i] = b[i];
 }
 
+int rom_launch_reduced_solve(rom_ctx* ctx, int n, int ldA, int kb, int M, const double* Ahat, const double* w,
+                             const double* rhs, int rhs_per_system, double* c_out) {
+  if (M <= 0) return ROM_OK;
+  const size_t mat = size_t(n) * (n + 1) * sizeof(double), vecs = 2 * size_t(n) * sizeof(double);
+  const bool in_lds = mat + vecs <= size_t(REDUCED_LDS_MAX);
+  const size_t lds = in_lds ? mat + vecs : vecs;
+  if (lds > size_t(REDUCED_LDS_DEFAULT)) {
+    if (!ctx->lds_optin_reduced_solve) {  // once per device: the attribute belongs to the kernel as loaded on THIS device
+      ROM_HIP(hipSetDevice(ctx->device));
+      ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reduced_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  REDUCED_LDS_MAX));
+      ctx->lds_optin_reduced_solve = true;
+    }
+  }
+  // matrices beyond the LDS: slabs of the scratch block, as many systems per launch as 1 GiB of it holds
+  const int per_launch = in_lds ? M : int(std::max<size_t>(1, std::min<size_t>(size_t(M), (size_t(1) << 30) / mat)));
+  double* gws = nullptr;
+  if (!in_lds) ROM_TRY(rom_ctx_scratch(ctx, size_t(per_launch) * n * (n + 1), &gws));
+  for (int m0 = 0; m0 < M; m0 += per_launch) {
+    const int Mc = std::min(per_launch, M - m0);
+    ROM_PROF(ctx, "reduced_solve", Mc * (double(n) * n * n / 3 + 2.0 * kb * n * n), 8.0 * Mc * (kb + 2.0 * n));
+    k_reduced_solve<<<Mc, 256, lds, ctx->stream>>>(n, ldA, kb, Ahat, w + size_t(m0) * kb,
+                                                   rhs + (rhs_per_system ? size_t(m0) * n : 0), rhs_per_system,
+                                                   c_out + size_t(m0) * n, ctx->d_status, gws);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
 extern "C" int rom_reduced_solve_batch(rom_ctx* ctx, int n, int kb, int M, rom_buf* Ahat, rom_buf* w, rom_buf* rhs,
                                        int rhs_per_system, rom_buf* c_out) {
   ROM_CHECK(ctx && Ahat && w && rhs && c_out, "rom_reduced_solve_batch: null argument");
@@ -777,29 +865,7 @@ extern "C" int rom_reduced_solve_batch(rom_ctx* ctx, int n, int kb, int M, rom_b
             "rom_reduced_solve_batch: buffer too small");
   if (M == 0) return ROM_OK;
   ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
-  const size_t mat = size_t(n) * (n + 1) * sizeof(double), vecs = 2 * size_t(n) * sizeof(double);
-  const bool in_lds = mat + vecs <= size_t(REDUCED_LDS_MAX);
-  const size_t lds = in_lds ? mat + vecs : vecs;
-  if (lds > size_t(REDUCED_LDS_DEFAULT)) {
-    static bool opted_in = false;  // (per process; the attribute is a property of the loaded kernel)
-    if (!opted_in) {
-      ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reduced_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  REDUCED_LDS_MAX));
-      opted_in = true;
-    }
-  }
-  // matrices beyond the LDS: slabs of the scratch block, as many systems per launch as 1 GiB of it holds
-  const int per_launch = in_lds ? M : int(std::max<size_t>(1, std::min<size_t>(size_t(M), (size_t(1) << 30) / mat)));
-  double* gws = nullptr;
-  if (!in_lds) ROM_TRY(rom_ctx_scratch(ctx, size_t(per_launch) * n * (n + 1), &gws));
-  for (int m0 = 0; m0 < M; m0 += per_launch) {
-    const int Mc = std::min(per_launch, M - m0);
-    ROM_PROF(ctx, "reduced_solve", Mc * (double(n) * n * n / 3 + 2.0 * kb * n * n), 8.0 * Mc * (kb + 2.0 * n));
-    k_reduced_solve<<<Mc, 256, lds, ctx->stream>>>(n, kb, Ahat->p, w->p + size_t(m0) * kb,
-                                                   rhs->p + (rhs_per_system ? size_t(m0) * n : 0), rhs_per_system,
-                                                   c_out->p + size_t(m0) * n, ctx->d_status, gws);
-  }
-  ROM_HIP(hipGetLastError());
+  ROM_TRY(rom_launch_reduced_solve(ctx, n, n, kb, M, Ahat->p, w->p, rhs->p, rhs_per_system, c_out->p));
   int status = 0;
   ROM_HIP(hipMemcpyAsync(&status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   ROM_HIP(hipStreamSynchronize(ctx->stream));
@@ -857,20 +923,24 @@ __global__ void k_center_apply(double* __restrict__ X, int M, long long dim, con
   for (int m = m0; m < m1; ++m) X[m * dim + j] -= s;
 }
 
-extern "C" int rom_center_rows(rom_ctx* ctx, rom_buf* X, int64_t row0, int M, int64_t dim, rom_buf* mean) {
-  ROM_CHECK(ctx && X && mean, "rom_center_rows: null argument");
-  ROM_CHECK(M >= 1 && dim >= 1 && row0 >= 0, "rom_center_rows: bad sizes");
-  ROM_CHECK(size_t(row0 + M) * dim <= X->n && size_t(dim) <= mean->n, "rom_center_rows: buffers too small");
+int rom_launch_center_rows(rom_ctx* ctx, double* X, int M, int64_t dim, double* d_mean) {
   double* part = nullptr;
   ROM_TRY(rom_ctx_scratch(ctx, size_t(CENTER_SLABS) * dim, &part));
   const dim3 grid(unsigned((dim + 255) / 256), CENTER_SLABS);
   {
     ROM_PROF(ctx, "center_rows", 2.0 * M * dim, 24.0 * M * dim);
-    k_center_partial<<<grid, 256, 0, ctx->stream>>>(X->p + row0 * dim, M, dim, part);
-    k_center_apply<<<grid, 256, 0, ctx->stream>>>(X->p + row0 * dim, M, dim, part, mean->p);
+    k_center_partial<<<grid, 256, 0, ctx->stream>>>(X, M, dim, part);
+    k_center_apply<<<grid, 256, 0, ctx->stream>>>(X, M, dim, part, d_mean);
   }
   ROM_HIP(hipGetLastError());
   return ROM_OK;
+}
+
+extern "C" int rom_center_rows(rom_ctx* ctx, rom_buf* X, int64_t row0, int M, int64_t dim, rom_buf* mean) {
+  ROM_CHECK(ctx && X && mean, "rom_center_rows: null argument");
+  ROM_CHECK(M >= 1 && dim >= 1 && row0 >= 0, "rom_center_rows: bad sizes");
+  ROM_CHECK(size_t(row0 + M) * dim <= X->n && size_t(dim) <= mean->n, "rom_center_rows: buffers too small");
+  return rom_launch_center_rows(ctx, X->p + row0 * dim, M, dim, mean->p);
 }
 
 // X[row0 + i, :] *= factors[i]  (i < rows; `factors` on the host): the 1/sigma scaling of the lifted POD modes
@@ -881,6 +951,13 @@ __global__ void k_rows_scale(double* __restrict__ X, long long dim, const double
     row[j] *= a;
 }
 
+int rom_launch_rows_scale(rom_ctx* ctx, double* X, int rows, int64_t dim, const double* d_fac) {
+  if (rows <= 0) return ROM_OK;
+  k_rows_scale<<<dim3(unsigned(std::min<int64_t>((dim + 255) / 256, 64)), rows), 256, 0, ctx->stream>>>(X, dim, d_fac);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
 extern "C" int rom_rows_scale(rom_ctx* ctx, rom_buf* X, int64_t row0, int rows, int64_t dim, const double* factors_host) {
   ROM_CHECK(ctx && X && (factors_host || rows == 0), "rom_rows_scale: null argument");
   ROM_CHECK(rows >= 0 && dim >= 1 && row0 >= 0 && size_t(row0 + rows) * dim <= X->n, "rom_rows_scale: bad sizes");
@@ -889,9 +966,7 @@ extern "C" int rom_rows_scale(rom_ctx* ctx, rom_buf* X, int64_t row0, int rows, 
   ROM_TRY(rom_ctx_scratch(ctx, size_t(rows), &fac));
   ROM_HIP(hipMemcpyAsync(fac, factors_host, size_t(rows) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   ROM_HIP(hipStreamSynchronize(ctx->stream));  // the host array may be reused by the caller
-  k_rows_scale<<<dim3(unsigned(std::min<int64_t>((dim + 255) / 256, 64)), rows), 256, 0, ctx->stream>>>(X->p + row0 * dim, dim, fac);
-  ROM_HIP(hipGetLastError());
-  return ROM_OK;
+  return rom_launch_rows_scale(ctx, X->p + row0 * dim, rows, dim, fac);
 }
 
 // sklearn's svd_flip(u_based_decision=False) (PCA call at src/lib/ReducedBasis.py:196): every row is multiplied by
@@ -923,13 +998,17 @@ __global__ __launch_bounds__(256) void k_rows_sign_flip(double* __restrict__ X, 
     for (long long j = threadIdx.x; j < dim; j += blockDim.x) row[j] = -row[j];
 }
 
+int rom_launch_rows_sign_flip(rom_ctx* ctx, double* X, int rows, int64_t dim) {
+  if (rows <= 0) return ROM_OK;
+  k_rows_sign_flip<<<rows, 256, 0, ctx->stream>>>(X, dim);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
 extern "C" int rom_rows_sign_flip(rom_ctx* ctx, rom_buf* X, int64_t row0, int rows, int64_t dim) {
   ROM_CHECK(ctx && X, "rom_rows_sign_flip: null argument");
   ROM_CHECK(rows >= 0 && dim >= 1 && row0 >= 0 && size_t(row0 + rows) * dim <= X->n, "rom_rows_sign_flip: bad sizes");
-  if (rows == 0) return ROM_OK;
-  k_rows_sign_flip<<<rows, 256, 0, ctx->stream>>>(X->p + row0 * dim, dim);
-  ROM_HIP(hipGetLastError());
-  return ROM_OK;
+  return rom_launch_rows_sign_flip(ctx, X->p + row0 * dim, rows, dim);
 }
 
 // evaluate_solutions (src/lib/SolutionsManagers.py:221-244): P1 interpolation on the SW-NE split

@@ -79,8 +79,15 @@ struct rom_ctx {
   void* comm = nullptr;
   int rank = 0, nranks = 1;
   hipStream_t comm_stream = nullptr;  // collectives overlapped with compute (rom_comm_allgather_async)
-  hipEvent_t ev_comm = nullptr, ev_slot[2] = {nullptr, nullptr};
+  hipEvent_t ev_comm = nullptr, ev_slot[2] = {nullptr, nullptr};  // ev_comm: fork / join-all; ev_slot: end of a slot's collective
   bool slot_used[2] = {false, false};
+  // the device ranges the last collective of each slot reads and writes, and whether the compute stream has been
+  // ordered behind that collective since (rom_comm_wait_slot / rom_comm_wait): rom_buf_free consults them
+  const double* slot_lo[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  const double* slot_hi[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  bool slot_joined[2] = {true, true};
+  // kernels that need more than 64 KB of dynamic LDS must opt in once per DEVICE (a context is one device)
+  bool lds_optin_reduced_solve = false, lds_optin_small_eig = false;
 };
 
 struct rom_buf {
@@ -244,7 +251,6 @@ struct rom_fem {
   bool sw_no_fused = false, sw_no_ext128 = false, sw_no_fold = false;
   int sw_ext_flat = -1;
   bool sw_no_tile_pairs = false;  // ROMHC_NO_TILE_PAIRS: tile Cholesky with one system per workgroup
-  int sw_ext_p = 0;     // ROMHC_EXT_P=1: the persistent extension kernel (k_extend_p, rom_fem_extend_p.hip)
   DenseGroup* d_dgroups = nullptr;
   int* d_dweight = nullptr;    // per (dense group, source position): block of the weight, -1 cross point, -2 none
   int* d_ditem_group = nullptr;

@@ -221,10 +221,13 @@ def pod_modes_factored(fs: FactoredSnapshots, n: int, center=True):
         return np.zeros((0, dim)), sig
     W = modes_z @ Einv.T                       # (nz, Kc): the modes as interface vectors
     V = ctx.alloc(n * dim)
-    if nz < n:
-        V.fill(0.0)                            # (more modes requested than the snapshot manifold has dimensions)
     em.expand_compact(ctx.upload(W), nz, V)
-    ctx.rows_sign_flip(V, nz, dim)  # svd_flip(u_based_decision=False)
+    if nz < n:
+        # more modes requested than the snapshot manifold has dimensions: completed like pod_modes completes what the
+        # data do not determine (orthonormal directions of singular value 0)
+        ctx.complete_orthonormal(V, nz, n - nz, dim)
+        info["completed_modes"] = info.get("completed_modes", 0) + n - nz
+    ctx.rows_sign_flip(V, n, dim)  # svd_flip(u_based_decision=False)
     info["executed_flops"] = info.get("executed_flops", 0.0) + 2.0 * M * K * kp + 2.0 * nz * K * dim
     info.pop("useful_flops", None)
     pod_modes_factored.last_info = info

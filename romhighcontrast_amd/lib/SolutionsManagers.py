@@ -156,58 +156,17 @@ class SolutionsManager:
         else:
             raise Exception("Not implemented.")
 
-    # -- reduced operators ------------------------------------------------------------------------------
-    def _reduced_tensor(self, C: DeviceArray) -> _ffi.Buffer:
-        """``A_kl[p,q] = C A_pq C^T`` (:93-101): (k, n, n) on the device."""
-        ctx, fem, n, dim = self._ctx, self._fem, C.rows, self.vspace_dim
-        k = fem.kblk
-        Ahat = ctx.alloc(k * n * n)
-        AC = ctx.alloc(n * dim)
-        for b in range(k):
-            e = np.zeros(k)
-            e[b] = 1.0
-            fem.stencil_apply(C.buf, n, AC, a_one=e)
-            ctx.gemm_nt(n, n, dim, AC, 0, dim, C.buf, 0, dim, Ahat, b * n * n, n)
-        return Ahat
-
-    def _reduced_tensor_grow(self, C: DeviceArray, Ahat_prev):
-        """The reduced tensor of the rows C[0:n] given the one of C[0:n-1] (host array (k, n-1, n-1) or None): only the
-        entries of the new row / column are computed (A_pq is symmetric).  Used by the greedy builder, whose
-        orthonormal basis grows by one row per iteration.  Returns the host array (k, n, n)."""
-        ctx, fem, n, dim = self._ctx, self._fem, C.rows, self.vspace_dim
-        k = fem.kblk
-        AC = ctx.alloc(k * dim)  # A_b q_new for every block b
-        for b in range(k):
-            e = np.zeros(k)
-            e[b] = 1.0
-            fem.stencil_apply(C.buf, 1, AC, a_one=e, x_row0=n - 1, y_row0=b)
-        col = ctx.alloc(n * k)
-        ctx.gemm_nt(n, k, dim, C.buf, 0, dim, AC, 0, dim, col, 0, k)  # col[i, b] = q_i . A_b q_new
-        colh = col.download(n * k, shape=(n, k))
-        out = np.zeros((k, n, n))
-        if Ahat_prev is not None and n > 1:
-            out[:, :n - 1, :n - 1] = Ahat_prev
-        out[:, n - 1, :] = colh.T
-        out[:, :, n - 1] = colh.T
-        return out
-
-    def generate_fm_solutions_device(self, a, coefficients_rom, reduced_tensor=None) -> DeviceArray:
-        """``reduced_tensor``: optional host array (k, n, n) = C A_pq C^T if the caller already has it."""
+    # -- reduced operators: one C call each (rom_galerkin_rom / rom_project_h10) -------------------------
+    def generate_fm_solutions_device(self, a, coefficients_rom) -> DeviceArray:
         _check_method(self.method)
         a = self._a_batch(a)
         M, dim, ctx = a.shape[0], self.vspace_dim, self._ctx
         out = ctx.alloc(max(M * dim, 1))
-        if len(coefficients_rom) == 0 or M == 0:
-            out.fill(0.0)  # (:89-91)
-            return DeviceArray(out, M, dim)
-        C = _as_device(ctx, coefficients_rom, dim)
-        n, k = C.rows, self._fem.kblk
-        Ahat = self._reduced_tensor(C) if reduced_tensor is None else ctx.upload(reduced_tensor)
-        Bk = ctx.alloc(n)  # B_k = C @ B_total (:103)
-        ctx.gemm_nt(n, 1, dim, C.buf, 0, dim, ctx.upload(self.B_total), 0, dim, Bk, 0, 1)
-        c = ctx.alloc(M * n)
-        ctx.reduced_solve_batch(n, k, M, Ahat, ctx.upload(a), Bk, False, c)  # (:104-105)
-        ctx.gemm_nn(M, dim, n, c, 0, n, C.buf, 0, dim, out, 0, dim)  # (:106)
+        if M == 0:
+            return DeviceArray(out, 0, dim)
+        n = len(coefficients_rom)
+        C = _as_device(ctx, coefficients_rom, dim) if n else None          # empty basis: zeros (:89-91)
+        self._fem.galerkin_rom(ctx.upload(a), M, C.buf if n else None, C.rows if n else 0, out)
         return DeviceArray(out, M, dim)
 
     def generate_fm_solutions(self, a: Union[np.ndarray, List[np.ndarray]], coefficients_rom: List[np.ndarray]):
@@ -216,24 +175,15 @@ class SolutionsManager:
 
     def project_solutions_device(self, solutions, coefficients_rom) -> DeviceArray:
         _check_method(self.method)
-        ctx, fem, dim = self._ctx, self._fem, self.vspace_dim
+        ctx, dim = self._ctx, self.vspace_dim
         U = _as_device(ctx, solutions, dim)
         M = U.rows
         out = ctx.alloc(max(M * dim, 1))
-        if len(coefficients_rom) == 0 or M == 0:
-            out.fill(0.0)  # (:109-111)
-            return DeviceArray(out, M, dim)
-        C = _as_device(ctx, coefficients_rom, dim)
-        n = C.rows
-        AC = ctx.alloc(n * dim)
-        fem.stencil_apply(C.buf, n, AC)  # A_1 C^T  (sum over blocks, :123)
-        G = ctx.alloc(n * n)
-        ctx.gemm_nt(n, n, dim, AC, 0, dim, C.buf, 0, dim, G, 0, n)  # A_kl summed with a = ones (:136)
-        R = ctx.alloc(M * n)
-        ctx.gemm_nt(M, n, dim, U.buf, 0, dim, AC, 0, dim, R, 0, n)  # B_km^T (:113-124)
-        c = ctx.alloc(M * n)
-        ctx.reduced_solve_batch(n, 1, M, G, ctx.upload(np.ones(M)), R, True, c)  # (:135-138)
-        ctx.gemm_nn(M, dim, n, c, 0, n, C.buf, 0, dim, out, 0, dim)  # (:139)
+        if M == 0:
+            return DeviceArray(out, 0, dim)
+        n = len(coefficients_rom)
+        C = _as_device(ctx, coefficients_rom, dim) if n else None          # empty basis: zeros (:109-111)
+        self._fem.project_h10(U.buf, M, C.buf if n else None, C.rows if n else 0, out)
         return DeviceArray(out, M, dim)
 
     def project_solutions(self, solutions: List[np.ndarray], coefficients_rom: List[np.ndarray]):

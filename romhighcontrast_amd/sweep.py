@@ -48,6 +48,70 @@ def sharded_sweep(a_all, world: int, rank: int, solve_local, allgather, finish=N
     return (finish(full) if finish is not None else full), M
 
 
+# ---- the double-buffered step loop of the N > 1 sweep ---------------------------------------------------------------------
+def run_step(backend, step_no: int) -> int:
+    """One step of the overlapped sweep; returns the buffer slot it used.  Two buffer pairs alternate: the all-gather of
+    step s (communication stream) overlaps the expansion of step s and the reduced solves of step s + 1 (compute stream),
+    so before slot k is rewritten the collective that last read it (step s - 2) must have finished.  `backend`:
+        wait_slot(k)        compute stream waits for the collective last issued with slot k (no-op if none)
+        solve_local(k)      this rank's shard -> interface vectors into the send buffer of slot k (a short shard is padded)
+        allgather_async(k)  send buffer of slot k -> gathered buffer of slot k, not blocking the compute stream
+        expand(k)           snapshot rows from the interface vectors of slot k (own shard, or all after waiting)
+    bench.py drives GpuStepBackend with it; tests/test_host_logic.py drives a gloo stand-in through the SAME function
+    (two processes, even and ragged M, slot reuse over several steps)."""
+    k = step_no & 1
+    backend.wait_slot(k)
+    backend.solve_local(k)
+    backend.allgather_async(k)
+    backend.expand(k)
+    return k
+
+
+def drain(backend):
+    """End of a timed region: everything enqueued by run_step has finished, the last all-gather has landed."""
+    backend.drain()
+
+
+class GpuStepBackend:
+    """libromhc realisation of the step protocol: rom_solve_reduced_async / rom_comm_allgather_async (RCCL over xGMI,
+    on the context's communication stream) / rom_expand_batch_async, parameters resident in HBM.
+    `M` rows per rank; a rank whose shard is short (`m_valid` < M) pads its send buffer with zero vectors once."""
+
+    def __init__(self, ctx, fem, a_dev, M, world, *, U_loc=None, replicate=None, m_valid=None):
+        self.ctx, self.fem, self.a_dev, self.M, self.world = ctx, fem, a_dev, int(M), int(world)
+        self.m_valid = self.M if m_valid is None else int(m_valid)
+        self.stride = fem.reduced_stride
+        self.Y_loc = [ctx.alloc(max(self.M * self.stride, 1)) for _ in range(2)]
+        self.Y_all = [ctx.alloc(max(self.world * self.M * self.stride, 1)) for _ in range(2)]
+        if self.m_valid < self.M:
+            for y in self.Y_loc:
+                y.fill(0.0)  # padding rows are gathered (and expanded by --replicate): they must hold finite numbers
+        self.U_loc = U_loc if U_loc is not None else ctx.alloc(max(self.M * fem.dim, 1))
+        self.replicate = replicate  # None, or (a_all_dev, U_all): also expand the gathered block on every rank
+
+    def wait_slot(self, k):
+        self.ctx.comm_wait_slot(k)
+
+    def solve_local(self, k):
+        if self.m_valid:
+            self.fem.solve_reduced(self.a_dev, self.m_valid, self.Y_loc[k])
+
+    def allgather_async(self, k):
+        self.ctx.allgather_async(self.Y_loc[k], 0, self.Y_all[k], 0, self.M * self.stride, slot=k)
+
+    def expand(self, k):
+        if self.replicate is not None:
+            a_all_dev, U_all = self.replicate
+            self.ctx.comm_wait(False)                                       # compute stream waits for the gathered vectors
+            self.fem.expand(a_all_dev, self.world * self.M, self.Y_all[k], U_all)   # the whole block as rows, on every rank
+        elif self.m_valid:
+            self.fem.expand(self.a_dev, self.m_valid, self.Y_loc[k], self.U_loc)    # rows of the own shard, while the vectors travel
+
+    def drain(self):
+        self.ctx.solve_status()  # waits for the compute stream; raises if any system was not positive definite
+        self.ctx.comm_wait(True)
+
+
 # ---- rendezvous for the RCCL unique id (one node, processes started by torch.distributed.run) ----
 def _launcher_start_time() -> str:
     """Start time (clock ticks since boot) of the parent process = the launcher that spawned all ranks;

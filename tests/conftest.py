@@ -32,3 +32,25 @@ def rel_h10(oracle_geom, U, Uref):
     """max_i ||U_i - Uref_i||_{H10} / ||Uref_i||_{H10} using the oracle norm."""
     from oracle import rom_oracle as ro
     return float(np.max(ro.H10norm(oracle_geom, np.asarray(U) - np.asarray(Uref)) / ro.H10norm(oracle_geom, Uref)))
+
+
+# ---- observed parity values -------------------------------------------------------------------------------------------
+# Every parity assertion that goes through observed() leaves its measured value next to its bound in the terminal
+# summary -- also when it passes -- so a green log shows HOW far inside the bar the run was (VERDICT r02, weak #2).
+_OBSERVED = []
+
+
+def observed(name, value, bound, *, detail=""):
+    """assert value <= bound, recording both.  `value` may be an array (its maximum is recorded)."""
+    v = float(np.max(value)) if np.size(value) else 0.0
+    _OBSERVED.append((name, v, float(bound)))
+    assert v <= bound, f"{name}: observed {v:.3e} > bound {bound:.3e} {detail}"
+    return v
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _OBSERVED:
+        return
+    terminalreporter.write_sep("-", "observed parity values (max over the assertion's entries) vs bound")
+    for name, v, b in _OBSERVED:
+        terminalreporter.write_line(f"  {name:<78s} {v:10.3e}  <= {b:8.1e}")

@@ -4,22 +4,26 @@ committed golden fixtures (reference outputs) and the pinned CPU oracle.  Needs 
 Tolerances (relative H^1_0 norm of the difference unless stated):
   * snapshots: 1e-11 (observed 1e-15 .. 4e-13; the substructured direct solve and LAPACK/SuperLU
     are both backward stable, kappa(A) <= 1e9 on these inputs);
-  * rows with an interior ("floating") block at INFINIT_A = 1e10: kappa(A) ~ 3e11 and the plateau level
-    of that block is only determined to ~contrast*eps; the reference's own two direct solvers
-    (fixtures hold both) disagree by 8.5e-6 (3x3) / 2.6e-7 (4x4) there.  Bound: FLOATING_TOL = 5e-5
-    (~6x the reference's largest self-disagreement); every other row keeps 1e-11;
+  * rows with an interior ("floating") block that dominates its neighbours (INFINIT_A = 1e10 in fixture g4, 1e8 in C4
+    row 5): the plateau level of that block is only determined to ~contrast * eps * N by ANY fp64 direct solver.  An
+    extended-precision referee (tests/golden/make_referee.py: SuperLU + iterative refinement with long-double
+    edge-form residuals) gives the truth: at (3,3)/N=11 the reference's lsq is 7.2e-6 and its lsqsparse 1.3e-6 from
+    it, at (4,4)/N=8 both are 5e-6 from it while agreeing with each other to 2.6e-7, at C4 row 5 SuperLU is 6.8e-5
+    from it -- and the GPU 9.4e-9 (profiles/r03_referee_floating_rows.txt).  Those rows are compared with the TRUTH:
+    bound = FLOATING_FACTOR x the worse of the reference's two solvers on the same row; every other row keeps 1e-11;
   * reduced-basis relative errors: |err_gpu - err_ref| <= 1e-10 (BASELINE.json target).
 """
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, observed
 from oracle import rom_oracle as ro
 
 pytestmark = pytest.mark.gpu
 
 SNAP_TOL = 1e-11
-FLOATING_TOL = 5e-5
+FLOATING_FACTOR = 2.0   # floating rows: GPU-vs-truth <= this x max(reference lsq, lsqsparse vs truth)
+FLOATING_TOL = 5e-5     # floating rows without a referee fixture (g8: (2,2)/N=6 with INFINIT_A blocks)
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +54,7 @@ def test_g1_snapshots_norms_eval(api):
     assert np.array_equal(sm.points_c, z["points_c"]) and np.array_equal(sm.points_r, z["points_r"])
     U = sm.generate_solutions(z["a"])
     assert U.shape == z["U"].shape
-    assert relh10(g, U, z["U"]).max() < SNAP_TOL
+    observed("g1: snapshots vs reference (rel H10)", relh10(g, U, z["U"]), SNAP_TOL)
     # integer-typed parameters are accepted (InverseProblemPipeline.ipynb cell 17)
     Ui = sm.generate_solutions(np.array([[[1, 2], [3, 4]]]))
     assert relh10(g, Ui, z["U"][2:3]).max() < SNAP_TOL
@@ -73,8 +77,8 @@ def test_g2_config_c1(api):
     for method in ("lsq", "lsqsparse"):
         sm = SM.SolutionsManagerFEM(tuple(z["blocks"]), int(z["N"]), method=method)
         U = sm.generate_solutions(z["a"])
-        assert relh10(g, U, z["U_lsq"]).max() < SNAP_TOL
-        assert relh10(g, U, z["U_lsqsparse"]).max() < SNAP_TOL
+        observed(f"g2/C1 method={method}: snapshots vs reference lsq (rel H10)", relh10(g, U, z["U_lsq"]), SNAP_TOL)
+        observed(f"g2/C1 method={method}: snapshots vs reference lsqsparse (rel H10)", relh10(g, U, z["U_lsqsparse"]), SNAP_TOL)
     np.testing.assert_allclose(sm.H10norm(U), z["H10"], rtol=1e-12)
 
 
@@ -85,7 +89,7 @@ def test_g3_rectangular(api, name):
     blocks, N = tuple(z[f"{name}_blocks"]), int(z[f"{name}_N"])
     sm = SM.SolutionsManagerFEM(blocks, N)
     g = ro.Geometry(blocks, N)
-    assert relh10(g, sm.generate_solutions(z[f"{name}_a"]), z[f"{name}_U"]).max() < SNAP_TOL
+    observed(f"g3/{name}: snapshots vs reference (rel H10)", relh10(g, sm.generate_solutions(z[f"{name}_a"]), z[f"{name}_U"]), SNAP_TOL)
     np.testing.assert_allclose(sm.H10norm(z[f"{name}_U"]), z[f"{name}_H10"], rtol=1e-13)
     d, e, n = sm.stencil_arrays(z[f"{name}_a"][:1])
     assert np.array_equal(d[0], z[f"{name}_diag"]) and np.array_equal(n[0], z[f"{name}_north"])
@@ -102,12 +106,21 @@ def test_g4_high_contrast(api, name):
     err = relh10(g, U, z[f"{name}_U"])
     self_gap = relh10(g, z[f"{name}_U_lsqsparse"], z[f"{name}_U"])
     assert self_gap[:7].max() < 1e-13  # the reference agrees with itself except on the floating-block row
-    bound = np.where(self_gap > 1e-9, FLOATING_TOL, SNAP_TOL)
+    floating = self_gap > 1e-9
     # (the message keeps everything needed to read a failure from the log alone: DESIGN.md section 9)
-    assert np.all(err <= bound), (
-        f"{name}: rel H10 err {err.tolist()} vs bound {bound.tolist()}; rows with NaN {np.flatnonzero(np.isnan(U).any(axis=1)).tolist()}, "
-        f"with Inf {np.flatnonzero(np.isinf(U).any(axis=1)).tolist()}, all-zero rows {np.flatnonzero(~U.any(axis=1)).tolist()}, "
-        f"max |U| per row {np.abs(U).max(axis=1).tolist()}")
+    observed(f"g4/{name}: snapshots vs reference, ordinary rows (rel H10)", err[~floating], SNAP_TOL, detail=(
+        f"rows with NaN {np.flatnonzero(np.isnan(U).any(axis=1)).tolist()}, with Inf {np.flatnonzero(np.isinf(U).any(axis=1)).tolist()}, "
+        f"all-zero rows {np.flatnonzero(~U.any(axis=1)).tolist()}, max |U| per row {np.abs(U).max(axis=1).tolist()}"))
+    if floating.any():
+        # the floating row against the extended-precision truth, relative to how close the reference itself gets
+        ref = load_golden("referee_g4_floating.npz")
+        row = int(ref[f"{name}_row"])
+        assert floating.sum() == 1 and floating[row] and np.array_equal(ref[f"{name}_a"], z[f"{name}_a"][row])
+        truth = ref[f"{name}_truth"][None]
+        e_gpu = float(relh10(g, U[row:row + 1], truth)[0])
+        e_ref = max(float(ref[f"{name}_err_ref_lsq_vs_truth"]), float(ref[f"{name}_err_ref_lsqsparse_vs_truth"]))
+        observed(f"g4/{name}: floating row {row} vs long-double truth (reference's solvers: {e_ref:.2e})", e_gpu,
+                 FLOATING_FACTOR * e_ref)
 
 
 def test_g5_projectors(api):
@@ -118,8 +131,8 @@ def test_g5_projectors(api):
     for tag in ("0", "1", "5", "10", "snap"):
         C = z["C" + tag] if tag != "snap" else z["Csnap"]
         pk, fk = ("proj" + tag, "fm" + tag) if tag != "snap" else ("proj_snap", "fm_snap")
-        np.testing.assert_allclose(sm.project_solutions(z["U"], C), z[pk], atol=1e-11 * scale)
-        np.testing.assert_allclose(sm.generate_fm_solutions(z["a"], C), z[fk], atol=1e-11 * scale)
+        observed(f"g5: project_solutions, basis {tag} (abs / max|U|)", np.abs(sm.project_solutions(z["U"], C) - z[pk]) / scale, 1e-11)
+        observed(f"g5: generate_fm_solutions, basis {tag} (abs / max|U|)", np.abs(sm.generate_fm_solutions(z["a"], C) - z[fk]) / scale, 1e-11)
     # empty inputs
     assert sm.project_solutions(z["U"], np.empty((0, 0))).shape == z["U"].shape
     assert sm.generate_solutions(np.empty((0, 2, 2))).shape == (0, sm.vspace_dim)
@@ -154,8 +167,9 @@ def test_g6_greedy(api, tag, mode_name):
         sub.orthonormalize()
         ep = sm.H10norm(sub.projection(sm, z["U"]) - z["U"]) / h1
         ef = sm.H10norm(sub.forward_modeling(sm, z["a"]) - z["U"]) / h1
-        assert np.max(np.abs(ep - z[f"{tag}_errs_proj"][m - 1])) < 1e-10  # BASELINE: within 1e-10 of reference
-        assert np.max(np.abs(ef - z[f"{tag}_errs_fm"][m - 1])) < 1e-10
+        # BASELINE: reduced-basis H1 errors within 1e-10 of the reference's
+        observed(f"g6/{tag}: projection errors of rb[:{m}] vs reference", np.abs(ep - z[f"{tag}_errs_proj"][m - 1]), 1e-10)
+        observed(f"g6/{tag}: Galerkin errors of rb[:{m}] vs reference", np.abs(ef - z[f"{tag}_errs_fm"][m - 1]), 1e-10)
     rb.orthonormalize()
     ref = z[f"{tag}_basis"]
     signs = np.sign(np.sum(rb.basis * ref, axis=1))
@@ -165,10 +179,12 @@ def test_g6_greedy(api, tag, mode_name):
 
 
 @pytest.mark.parametrize("mode_name", ["GREEDY_FOR_H10", "GREEDY_FOR_GALERKIN"])
-def test_greedy_incremental_basis_equals_resorted(api, mode_name, monkeypatch):
-    """The builder grows its orthonormal basis by one row per iteration; the reference re-orthonormalises the
-    contrast-sorted picks from scratch (src/lib/ReducedBasis.py:135-136).  Same span, so the same picks and error
-    curve (ROMHC_GREEDY_RESORT=1 runs the from-scratch variant)."""
+def test_greedy_call_matches_its_definition(api, mode_name):
+    """rom_greedy carries the span of the picks as an A_1-orthonormal basis and updates the projection residuals of the
+    training block by one vector per iteration; the reference re-orthonormalises the contrast-sorted picks from scratch
+    and recomputes every approximation (src/lib/ReducedBasis.py:120-136).  Iteration by iteration, the error vector the
+    reference's definition gives -- the standalone projectors on the orthonormalised picks, H10norm of the differences
+    -- must have its maximum where the call picked, with the value the call reports."""
     SM, RB = api
     blocks, N, M, n = (2, 3), 12, 60, 10
     sm = SM.SolutionsManagerFEM(blocks, N)
@@ -177,13 +193,74 @@ def test_greedy_incremental_basis_equals_resorted(api, mode_name, monkeypatch):
     U = sm.generate_solutions(a)
     h1 = sm.H10norm(U)
     mode = getattr(RB, mode_name)
-    monkeypatch.delenv("ROMHC_GREEDY_RESORT", raising=False)
-    inc = RB.ReducedBasisGreedy(greedy_for=mode).build(n=n, sm=sm, solutions2train=U, a2train=a, solutions2train_h1norm=h1)
-    monkeypatch.setenv("ROMHC_GREEDY_RESORT", "1")
-    ref = RB.ReducedBasisGreedy(greedy_for=mode).build(n=n, sm=sm, solutions2train=U, a2train=a, solutions2train_h1norm=h1)
-    assert inc.picks == ref.picks
-    np.testing.assert_allclose(inc.max_errors, ref.max_errors, rtol=1e-7, atol=1e-11)
-    assert np.array_equal(inc.basis, ref.basis)
+    rb = RB.ReducedBasisGreedy(greedy_for=mode).build(n=n, sm=sm, solutions2train=U, a2train=a, solutions2train_h1norm=h1)
+    assert rb.picks[0] == 0 and rb.max_errors[0] == 1.0 and len(set(rb.picks)) == n
+    for i in range(1, n):
+        sub = rb[:i]
+        sub.orthonormalize()                                   # (:135-136)
+        approx = sub.projection(sm, U) if mode == RB.GREEDY_FOR_H10 else sub.forward_modeling(sm, a)   # (:122 / :124)
+        rel = sm.H10norm(approx - U) / h1                       # (:129)
+        observed(f"greedy definition/{mode_name}: |max error - reported| at iteration {i}", abs(rel.max() - rb.max_errors[i]), 1e-10)
+        assert rel[rb.picks[i]] >= rel.max() * (1 - 1e-9), (i, rb.picks[i], int(np.argmax(rel)))
+    # a normalisation other than the snapshots' own norms: the first pick is the largest ||u|| / h1, not index 0
+    h1b = np.ones(M)
+    rb1 = RB.ReducedBasisGreedy(greedy_for=mode).build(n=2, sm=sm, solutions2train=U, a2train=a, solutions2train_h1norm=h1b)
+    assert rb1.picks[0] == int(np.argmax(h1)) and abs(rb1.max_errors[0] - h1.max()) <= 1e-13 * h1.max()
+    # a training set with a duplicated snapshot: once the errors reach roundoff the duplicate may be picked; the build
+    # must stay finite and the reduced systems positive definite
+    U2, a2 = np.vstack((U[:6], U[2:3])), np.concatenate((a[:6], a[2:3]))
+    rb2 = RB.ReducedBasisGreedy(greedy_for=mode).build(n=7, sm=sm, solutions2train=U2, a2train=a2, solutions2train_h1norm=sm.H10norm(U2))
+    assert np.all(np.isfinite(rb2.max_errors)) and len(rb2.picks) == 7
+
+
+def test_small_symmetric_eigensolver_vs_lapack():
+    """The one-workgroup Jacobi kernel behind the whitening / Rayleigh-Ritz steps of rom_pod and rom_greedy, against
+    numpy.linalg.eigh: random symmetric matrices in LDS (n <= 96) and in the global workspace (n > 96), and a graded
+    positive definite matrix whose small eigenvalues must come out to high RELATIVE accuracy."""
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 5, 61, 62, 96, 97, 130):
+        A = rng.standard_normal((n, n))
+        A = A + A.T
+        lam, T = ctx.small_eig(A, mode=0)
+        ref = np.linalg.eigh(A)[0][::-1]
+        observed(f"small_eig n={n}: eigenvalues vs LAPACK (abs / ||A||)", np.abs(lam - ref) / np.abs(ref).max(), 2e-14)
+        observed(f"small_eig n={n}: orthonormality of the eigenvector rows", np.abs(T @ T.T - np.eye(n)), 1e-13)
+        observed(f"small_eig n={n}: residual T A T^T - diag (abs / ||A||)", np.abs(T @ A @ T.T - np.diag(lam)) / np.abs(ref).max(), 1e-13)
+    # graded: A = D B D with B well conditioned, D over 16 orders of magnitude
+    n = 40
+    B = rng.standard_normal((n, 3 * n))
+    B = B @ B.T / (3 * n)
+    d = 10.0 ** np.linspace(0, -8, n)
+    A = B * np.outer(d, d)
+    lam, T = ctx.small_eig(A, mode=0)
+    Bl = B.astype(np.longdouble) * np.outer(d, d).astype(np.longdouble)
+    # reference for the small eigenvalues: eigh of the scaled problem is useless (absolute accuracy only), so check the
+    # defining relations in long double: Rayleigh quotients of the returned vectors and their relative residuals
+    Tl = T.astype(np.longdouble)
+    rq = np.einsum("ij,jk,ik->i", Tl, Bl, Tl)
+    observed("small_eig graded: eigenvalues vs Rayleigh quotients (relative)", np.abs(rq - lam) / np.abs(rq), 1e-12)
+    assert lam.min() > 0 and lam.max() / lam.min() > 1e14
+    # whitening and symmetric inverse square root
+    X = rng.standard_normal((12, 300))
+    X[7] = X[3] + 1e-9 * X[5]                      # nearly dependent row
+    G = X @ X.T
+    _, Tw = ctx.small_eig(G, mode=1, rel_tol=1e-26)
+    Q = Tw @ X
+    observed("small_eig whitening: (T X)(T X)^T - I", np.abs(Q @ Q.T - np.eye(12)), 1e-6)
+    X[7] = X[3]                                     # exactly dependent: one direction is dropped (a zero row)
+    _, Tw = ctx.small_eig(X @ X.T, mode=1, rel_tol=1e-13)
+    Q = Tw @ X
+    gram = Q @ Q.T
+    assert np.abs(gram - np.diag(np.diag(gram))).max() < 1e-10 and sorted(np.round(np.diag(gram), 8))[:1] == [0.0]
+    assert np.allclose(sorted(np.diag(gram))[1:], 1.0, atol=1e-10)
+    Y = rng.standard_normal((9, 200))
+    Y = np.linalg.qr(Y.T)[0].T + 1e-3 * rng.standard_normal((9, 200))
+    _, Tl_ = ctx.small_eig(Y @ Y.T, mode=2, rel_tol=1e-30)
+    Z = Tl_ @ Y
+    observed("small_eig Loewdin: orthonormality", np.abs(Z @ Z.T - np.eye(9)), 1e-12)
+    assert np.abs(Tl_ - Tl_.T).max() < 1e-13 and np.abs(Z - Y).max() < 2e-2   # symmetric; rows stay close to what they were
 
 
 def test_g7_pca_random(api):
@@ -476,9 +553,67 @@ def test_full_size_c2_properties(api):
     idx = [0, 511, 1023]
     Uo = ro.generate_solutions(g, a[idx])
     Ug = np.stack([Ud.buf.download(dim, offset=i * dim) for i in idx])
-    assert relh10(g, Ug, Uo).max() < SNAP_TOL
+    observed("C2: rows 0, 511, 1023 vs SuperLU oracle (rel H10)", relh10(g, Ug, Uo), SNAP_TOL)
     # norms on the device agree with the oracle's on the same vectors
     np.testing.assert_allclose(sm.H10norm(Ud)[idx], ro.H10norm(g, Ug), rtol=1e-12)
+
+
+def test_full_size_c3_workload(api):
+    """BASELINE config C3 on one GPU: the 8192-parameter sweep of C2's geometry ((2,2)/N=128) through the library's
+    sharded-sweep entry (RcclSweep with world = 1: the same code path every rank of the 8-GPU job runs, gathered block in
+    factored form), a 50-mode POD of the 4.26 GB block from its interface vectors AND from the materialised rows (rom_pod),
+    against each other and -- on a 256-row subsample -- against numpy.linalg.svd of the centred rows (the call inside
+    scikit-learn's PCA, src/lib/ReducedBasis.py:196); three rows against the SuperLU oracle."""
+    SM, RB = api
+    import bench
+    from romhighcontrast_amd import factored, sweep
+    blocks, N, M, r = (2, 2), 128, 8192, 50
+    sm = SM.SolutionsManagerFEM(blocks, N)
+    ctx, fem, dim = sm._ctx, sm._fem, sm.vspace_dim
+    a = bench.workload_parameters("c2", blocks, M)
+    assert np.array_equal(a[:1024], bench.workload_parameters("c2", blocks, 1024))   # rank 0's shard is config C2's sweep
+    fs = sweep.RcclSweep(sm, 0, 1).generate_factored(a)
+    assert fs.M == M
+    Ud = fs.rows()
+    assert Ud.shape == (M, dim)
+    # the factored block reproduces a plain sweep bit for bit (rows of three "ranks")
+    for lo in (0, 3 * 1024 + 5, 7 * 1024):
+        chk = sm.generate_solutions_device(a[lo:lo + 4])
+        assert np.array_equal(chk.numpy(), Ud.buf.download(4 * dim, offset=lo * dim, shape=(4, dim)))
+    g = ro.Geometry(blocks, N)
+    idx = [1024, 4097, M - 1]
+    Uo = ro.generate_solutions(g, a[idx])
+    Ug = np.stack([Ud.buf.download(dim, offset=i * dim) for i in idx])
+    observed("C3: rows 1024, 4097, 8191 vs SuperLU oracle (rel H10)", relh10(g, Ug, Uo), SNAP_TOL)
+    h1 = sm.H10norm(Ud)
+    observed("C3: H10 norms from the interface vectors vs stencil norms (relative)",
+             np.abs(factored.h10norm_factored(fs) - h1) / h1, 1e-10)
+    # POD: factored vs rows
+    modes_f, sig_f = factored.pod_modes_factored(fs, r)
+    X = ctx.alloc(M * dim).copy_from(Ud.buf, M * dim)
+    modes_r, sig_r = RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), r)
+    info = dict(RB.pod_modes.last_info)
+    del X
+    assert info["gram_passes"] == 1 and info["resolved_modes"] >= 25
+    big = sig_r > 1e-6 * sig_r[0]
+    assert big.sum() >= 12
+    observed("C3 POD: singular values > 1e-6 sigma_1, rows vs factored (relative)", np.abs(sig_f[big] - sig_r[big]) / sig_r[big], 1e-7)
+    observed("C3 POD: |<mode_rows, mode_factored>| - 1 for those modes", np.abs(np.abs(np.sum(modes_f[big] * modes_r[big], axis=1)) - 1.0), 1e-6)
+    observed("C3 POD: orthonormality of all 50 rows (rows path)", np.abs(modes_r @ modes_r.T - np.eye(r)), 1e-9)
+    observed("C3 POD: orthonormality of all 50 rows (factored path)", np.abs(modes_f @ modes_f.T - np.eye(r)), 1e-9)
+    # a 256-row subsample against LAPACK on the host
+    Ms = 256
+    Xs = Ud.buf.download(Ms * dim, shape=(Ms, dim))
+    _, sv, Vt = np.linalg.svd(Xs - Xs.mean(axis=0), full_matrices=False)
+    Xd = ctx.alloc(Ms * dim).copy_from(Ud.buf, Ms * dim)
+    comps, sig_s = RB.pod_modes(ctx, SM.DeviceArray(Xd, Ms, dim), 30)
+    keep = sv[:30] > 1e-7 * sv[0]
+    observed("C3 POD (256-row subsample): singular values > 1e-7 sigma_1 vs LAPACK (relative)",
+             np.abs(sig_s[keep] - sv[:30][keep]) / sv[:30][keep], 1e-7)
+    lead = sv[:30] > 1e-4 * sv[0]
+    k = int(lead.sum())
+    observed("C3 POD (256-row subsample): projector onto the modes > 1e-4 sigma_1 vs LAPACK",
+             np.abs(comps[:k].T[:2000] @ comps[:k][:, :2000] - Vt[:k].T[:2000] @ Vt[:k][:, :2000]), 1e-8)
 
 
 def _oracle_rows(args):
@@ -523,29 +658,40 @@ def test_full_size_c4_workload(api):
     assert np.all(a[0] == 1) and np.all(a[10] == 1e8) and a[11:].max() <= 1e8
     Ud = sm.generate_solutions_device(a)
     Y = ctx.alloc(dim)
-    for m in (0, 3, 10, 500, M - 1):
+    for m in (0, 3, 5, 10, 500, M - 1):
         row = _ffi.Buffer(ctx, dim).copy_from(Ud.buf, dim, 0, m * dim)
         fem.stencil_apply(row, 1, Y, a_one=a[m].ravel())
         res = Y.download(dim) - sm.B_total
         u = row.download(dim)
-        assert np.abs(res).max() < 1e-11 * np.abs(u).max() * 4 * a[m].max()
+        observed(f"C4: stencil residual of row {m} (|r|_inf / (4 a_max |u|_inf))", np.abs(res).max() / (np.abs(u).max() * 4 * a[m].max()), 1e-11)
     g = ro.Geometry(blocks, N)
     Ms = 64
     Uo = oracle_sweep_parallel(blocks, N, a[:Ms])
     Ug = Ud.buf.download(Ms * dim, shape=(Ms, dim))
     # A block that touches no Dirichlet side and dominates all its neighbours "floats": its plateau level is fixed by
-    # fluxes that are 1e-8 of the matrix entries (row 5: the centre block at 1e8 among ones, kappa(A) ~ 1e13), and two
-    # backward-stable direct solvers agree on it to ~kappa * eps only (the reference's lsq / lsqsparse pair disagrees
-    # by 8.5e-6 on the same construction at N = 11, fixture g4).  Those rows get 1e-3, every other row 1e-11.
+    # fluxes that are 1e-8 of the matrix entries (row 5: the centre block at 1e8 among ones), and an fp64 direct solver
+    # gets it to ~contrast * eps * N only.  The extended-precision referee (tests/golden/make_referee.py) says who is
+    # right there: SuperLU -- the oracle -- is 6.84e-5 from the truth, the GPU 9.4e-9
+    # (profiles/r03_referee_floating_rows.txt).  So row 5 is compared with the TRUTH, and must be at least as close to
+    # it as the oracle is; every other row is compared with the oracle at 1e-11.
     centre = a[:Ms, 1, 1]
     others = np.delete(a[:Ms].reshape(Ms, 9), 4, axis=1).max(axis=1)
     floating = centre >= 1e4 * others
-    assert floating[5] and floating.sum() <= 3
+    assert floating[5] and floating.sum() == 1
+    ref = load_golden("referee_c4_row5.npz")
+    assert np.array_equal(ref["a"], a[5])
+    truth = ref["truth"][None]
+    e_oracle = float(relh10(g, Uo[5:6], truth)[0])
+    assert abs(e_oracle - float(ref["err_superlu_vs_truth"])) < 0.05 * e_oracle   # the referee's record of the oracle's error
+    e_gpu = observed(f"C4: floating row 5 vs long-double truth (SuperLU oracle: {e_oracle:.2e})",
+                     relh10(g, Ug[5:6], truth), max(e_oracle, 1e-11))
+    observed("C4: floating row 5 vs long-double truth, against contrast * eps * N = 1e8 x 1.1e-16 x 513", e_gpu, 1e8 * 1.1e-16 * 513)
+    Uo[5] = truth[0]                                   # from here on the oracle block holds the refereed row
     err = relh10(g, Ug, Uo)
-    assert err[~floating].max() < SNAP_TOL and err[floating].max() < 1e-3, (err[~floating].max(), err[floating])
+    observed("C4: first 64 training rows vs SuperLU oracle, ordinary rows (rel H10)", err[~floating], SNAP_TOL)
     h1 = sm.H10norm(Ud)
     h1o = ro.H10norm(g, Uo)
-    np.testing.assert_allclose(h1[:Ms][~floating], h1o[~floating], rtol=1e-11)
+    observed("C4: H10 norms of the first 64 rows vs oracle (relative)", np.abs(h1[:Ms] - h1o) / h1o, 1e-11)
     # greedy n = 50 on the full training set: rows vs factored block
     Yf = ctx.alloc(M * fem.reduced_stride)
     fem.solve_reduced(ctx.upload(a.reshape(M, -1)), M, Yf)
@@ -558,8 +704,9 @@ def test_full_size_c4_workload(api):
         assert rb_r.picks[0] == 0 and rb_r.max_errors[0] == 1.0 and len(rb_r.picks) == n
         er, ef = np.array(rb_r.max_errors), np.array(rb_f.max_errors)
         # picks are compared while the selection is not a coin toss between near-equal errors (relative gap of the two
-        # error curves); the curves themselves agree throughout
-        assert np.abs(er - ef).max() < 1e-7 * np.maximum(er, 1e-3).max(), (mode, np.abs(er - ef).max())
+        # error curves); the curves themselves agree throughout (the factored build works in energy coordinates of the
+        # interface vectors: a different route to the same numbers, at kappa(A) up to 1e13)
+        observed(f"C4 greedy n=50 {mode}: error curve, rows vs factored block", np.abs(er - ef), 1e-8)
         same = [p == q for p, q in zip(rb_r.picks, rb_f.picks)]
         assert sum(same) >= n - 2, (mode, rb_r.picks, rb_f.picks)
         # the worst-case error decays (nine free blocks at contrast 1e8: slowly); the H^1_0 projection error never grows
@@ -578,7 +725,10 @@ def test_full_size_c4_workload(api):
         errs_o = np.array(errs_o)
         ok = errs_o > 1e-9
         assert [p for p, k in zip(rb.picks, ok) if k] == [p for p, k in zip(picks_o, ok) if k], (mode, rb.picks, picks_o)
-        assert np.abs(np.array(rb.max_errors) - errs_o).max() < 1e-8, (mode, rb.max_errors, errs_o.tolist())
+        # (the oracle's greedy runs on the oracle's snapshots with row 5 replaced by the refereed truth: its own row 5 is
+        # 6.8e-5 off, which moved the curves by ~1e-8 in round 2)
+        observed(f"C4 greedy on 64 rows {mode}: error curve vs the oracle's greedy (BASELINE: 1e-10)",
+                 np.abs(np.array(rb.max_errors) - errs_o), 1e-10)
 
 
 def test_full_size_c5_workload(api):
@@ -613,7 +763,7 @@ def test_full_size_c5_workload(api):
     idx = [5, M - 1]
     Uo = oracle_sweep_parallel(blocks, N, a[idx], workers=2)
     Ug = np.stack([Ud.buf.download(dim, offset=i * dim) for i in idx])
-    assert relh10(g, Ug, Uo).max() < SNAP_TOL
+    observed("C5: rows 5, 4095 vs SuperLU oracle (rel H10)", relh10(g, Ug, Uo), SNAP_TOL)
     h1 = sm.H10norm(Ud)
     assert np.all(h1 > 0) and abs(h1[2] / h1[1] - 7.0) < 1e-11
     np.testing.assert_allclose(h1[idx], ro.H10norm(g, Ug), rtol=1e-11)
@@ -959,8 +1109,10 @@ def test_g8_experiment_statistics(api):
             # forward modelling / projection errors: BASELINE bound where the reference is itself accurate
             for f in ("forward_modeling", "projection"):
                 ref = z[f"err_{key}_{n}_{f}"]
-                assert np.max(np.abs(getattr(e, f) - ref)[~hard]) < 1e-9, (b.name, n, f)
-                assert np.max(np.abs(getattr(e, f) - ref)[hard]) < 1e-4, (b.name, n, f)
+                observed(f"g8 {key} n={n} {f}: error records vs reference, ordinary parameters (BASELINE: 1e-10)",
+                         np.abs(getattr(e, f) - ref)[~hard], 1e-10)
+                observed(f"g8 {key} n={n} {f}: error records vs reference, INFINIT_A parameters",
+                         np.abs(getattr(e, f) - ref)[hard], 1e-4)
             # state estimation (src/lib/ReducedBasis.py:65-70) and the two parameter estimators (:72-86,
             # src/lib/Estimators.py:24-37): a least-squares fit through the (points x n) matrix E of basis values.
             # Bases that hold INFINIT_A snapshots make E nearly rank deficient (cond(E) up to 5e12 in this fixture),

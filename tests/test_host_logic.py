@@ -126,6 +126,176 @@ def test_sharded_sweep_two_ranks_gloo(tmp_path, M):
         assert "OK" in o
 
 
+_STEP_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from romhighcontrast_amd import sweep
+from oracle import rom_oracle as ro     # the compute stand-in: interface vectors := the oracle's snapshot rows
+
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+rank, world = dist.get_rank(), dist.get_world_size()
+g = ro.Geometry((2, 2), 4)
+M = int(sys.argv[4])                   # total sweep size; the last shard is short when M is odd
+mp = sweep.shard_rows(M, world)
+lo, hi = sweep.shard_bounds(M, world, rank)
+a0 = 10.0 ** np.random.default_rng(7).uniform(0, 2, size=(M, 2, 2))
+
+
+class GlooBackend:
+    """Stand-in for GpuStepBackend: same protocol, NumPy buffers, gloo's ASYNCHRONOUS all-gather as the collective.
+    It enforces the protocol's ordering rules instead of trusting them: a send buffer may only be rewritten after the
+    collective that reads it has been waited for, a gathered buffer only read after its collective has been waited for."""
+
+    def __init__(self):
+        self.Y_loc = [np.full((mp, g.dim), np.nan) for _ in range(2)]
+        self.Y_all = [np.full((world * mp, g.dim), np.nan) for _ in range(2)]
+        self.work = [None, None]
+        self.in_flight = [False, False]
+        self.step_of_slot = [None, None]
+        self.expanded = []
+        self.step = 0
+
+    def params(self, step):
+        return a0 * (1.0 + step)       # every step sweeps different parameters: a stale buffer cannot pass
+
+    def wait_slot(self, k):
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+        self.in_flight[k] = False
+
+    def solve_local(self, k):
+        assert not self.in_flight[k], f"slot {k} rewritten while its all-gather is in flight"
+        self.Y_loc[k][:] = 0.0         # a short shard is padded with zero vectors
+        if hi > lo:
+            self.Y_loc[k][:hi - lo] = ro.generate_solutions(g, self.params(self.step)[lo:hi])
+        self.step_of_slot[k] = self.step
+
+    def allgather_async(self, k):
+        assert not self.in_flight[k]
+        self.work[k] = dist.all_gather_into_tensor(torch.from_numpy(self.Y_all[k]), torch.from_numpy(self.Y_loc[k]), async_op=True)
+        self.in_flight[k] = True
+
+    def expand(self, k):
+        self.expanded.append((self.step, self.Y_loc[k][:hi - lo].copy()))   # rows of the own shard
+        self.step += 1
+
+    def drain(self):
+        for k in range(2):
+            self.wait_slot(k)
+
+
+be = GlooBackend()
+steps = 7
+for s in range(steps):
+    k = sweep.run_step(be, s)
+    assert k == s % 2
+    if s >= 1:
+        # the PREVIOUS step's gathered block (other slot) must be complete and equal to the unsharded sweep once waited for
+        kp = (s - 1) % 2
+        be.wait_slot(kp)
+        ref = ro.generate_solutions(g, be.params(s - 1))
+        assert np.array_equal(be.Y_all[kp][:M], ref), f"step {s - 1}: gathered block differs from the unsharded sweep"
+        assert not be.Y_all[kp][M:].any(), "padding rows of a short shard must be zero"
+sweep.drain(be)
+kl = (steps - 1) % 2
+assert np.array_equal(be.Y_all[kl][:M], ro.generate_solutions(g, be.params(steps - 1)))
+assert [st for st, _ in be.expanded] == list(range(steps))
+for st, rows in be.expanded:
+    assert np.array_equal(rows, ro.generate_solutions(g, be.params(st))[lo:hi])
+# the protocol check itself must bite: rewriting a slot without waiting is refused
+be.allgather_async(0)
+try:
+    be.solve_local(0)
+    raise SystemExit("missing wait was not detected")
+except AssertionError:
+    pass
+sweep.drain(be)
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+@pytest.mark.parametrize("M", [8, 7])
+def test_step_loop_two_ranks_gloo(tmp_path, M):
+    """The double-buffered step loop bench.py runs for N > 1 (sweep.run_step: wait-before-rewrite, solve, asynchronous
+    all-gather, expansion, slot alternation) driven by two processes through a gloo stand-in for the RCCL calls: over 7
+    steps (each slot reused three times) with different parameters per step, for an even and a ragged M, the gathered
+    block of every step equals the unsharded sweep (the reference's map over all parameters,
+    src/lib/SolutionsManagers.py:51,64-68)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "step_worker.py"
+    script.write_text(_STEP_WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r), str(M)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "OK" in o
+
+
+def test_gpu_step_backend_follows_the_protocol():
+    """GpuStepBackend against a recording fake of the ctypes layer: the call sequence of run_step on the real backend
+    class (no GPU needed) -- wait(slot) before the solve that rewrites the slot, gather after the solve, expansion last;
+    a short shard solves / expands only its valid rows and zero-fills its padded send buffers once."""
+    from romhighcontrast_amd import sweep
+    log = []
+
+    class Buf:
+        def __init__(self, n):
+            self.n = n
+
+        def fill(self, v):
+            log.append(("fill", self.n, v))
+
+    class Ctx:
+        def alloc(self, n):
+            return Buf(n)
+
+        def comm_wait_slot(self, k):
+            log.append(("wait_slot", k))
+
+        def allgather_async(self, send, so, recv, ro_, count, slot=0):
+            log.append(("allgather", send.n, recv.n, count, slot))
+
+        def comm_wait(self, host):
+            log.append(("comm_wait", host))
+
+        def solve_status(self):
+            log.append(("status",))
+
+    class Fem:
+        reduced_stride, dim = 10, 100
+
+        def solve_reduced(self, a, M, Y):
+            log.append(("solve", M, Y.n))
+
+        def expand(self, a, M, Y, U):
+            log.append(("expand", M, Y.n, U.n))
+
+    be = sweep.GpuStepBackend(Ctx(), Fem(), "a", 4, 2, m_valid=3)
+    assert log == [("fill", 40, 0.0), ("fill", 40, 0.0)]
+    del log[:]
+    for s in range(3):
+        assert sweep.run_step(be, s) == s % 2
+    sweep.drain(be)
+    per_step = [("wait_slot", None), ("solve", 3, 40), ("allgather", 40, 80, 40, None), ("expand", 3, 40, 400)]
+    want = []
+    for s in range(3):
+        for rec in per_step:
+            want.append(tuple(s % 2 if v is None else v for v in rec))
+    assert log == want + [("status",), ("comm_wait", True)], log
+
+
 def test_parameter_sampler_matches_reference():
     """get_a2test_and_train's sampling (src/experiments/HighContrast.py:99-115) against the reference's
     own output for three (geometry, groups, seed) settings (fixture g8)."""
