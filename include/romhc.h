@@ -213,14 +213,18 @@ int rom_greedy(rom_fem* fem, rom_buf* U, int64_t u_row0, int M, rom_buf* a, cons
  * passes, sketch passes, executed flops, useful flops (M(M+1)dim + 2 n M dim), subspace iterations, 0. */
 int rom_pod(rom_ctx* ctx, rom_buf* X, int64_t x_row0, int M, int64_t dim, int n, int center, rom_buf* V, int64_t v_row0,
             double* sigma_host, double* info_host);
+/* n nearly orthonormal rows of V -> orthonormal rows, each as close as possible to what it was: V <- (V V^T)^(-1/2) V */
+int rom_symmetric_orthonormalize(rom_ctx* ctx, rom_buf* V, int64_t v_row0, int n, int64_t dim);
 /* rows V[v_row0+found .. +found+rest) <- deterministic pseudo-random directions, orthonormal and orthogonal to the
  * orthonormal rows V[v_row0 .. +found): how rom_pod completes a request beyond what the data determine */
 int rom_complete_orthonormal(rom_ctx* ctx, rom_buf* V, int64_t v_row0, int found, int rest, int64_t dim);
 /* the device eigen-solver the calls above use for their small symmetric problems (cyclic Jacobi, one workgroup), for
  * n x n host matrices, n <= 1024: mode 0 T = eigenvector rows (eigenvalues descending in lam_host); 1 T = whitening
- * transform Lambda^-1/2 Q^T (rows with lambda <= rel_tol lambda_max zero); 2 T = Q Lambda^-1/2 Q^T.  Test hook. */
-int rom_small_eig_host(rom_ctx* ctx, int n, const double* A_host, int mode, double rel_tol, double* lam_host,
-                       double* T_host);
+ * transform Lambda^-1/2 Q^T (rows with lambda <= rel_tol lambda_max zero); 2 T = Q Lambda^-1/2 Q^T.
+ * gram_like != 0: A is a Gram matrix of explicit rows (entries accurate relative to sqrt(a_pp a_qq): small eigenvalues
+ * of graded matrices come out to high relative accuracy); 0: general symmetric matrix (absolute accuracy).  Test hook. */
+int rom_small_eig_host(rom_ctx* ctx, int n, const double* A_host, int mode, double rel_tol, int gram_like,
+                       double* lam_host, double* T_host);
 
 /* ---- multi-GPU: RCCL all-gather of the snapshot block --------------------- */
 /* id_out: 128 bytes (ncclUniqueId).  librccl is dlopen()ed on first use. */

@@ -88,8 +88,9 @@ PROTOTYPES = {
     "rom_orthonormalize_rows": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp, C.c_int64]),
     "rom_greedy": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rom_pod": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp]),
+    "rom_symmetric_orthonormalize": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64]),
     "rom_complete_orthonormal": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int64]),
-    "rom_small_eig_host": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, _vp, _vp]),
+    "rom_small_eig_host": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]),
     "rom_comm_unique_id": (C.c_int, [C.c_char_p, C.c_size_t]),
     "rom_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.c_int, C.c_int]),
     "rom_comm_destroy": (C.c_int, [_vp]),
@@ -273,14 +274,18 @@ class Context:
         d.update(executed_flops=float(info[4]), useful_flops=float(info[5]), subspace_iterations=int(info[6]))
         return sigma[:n], d
 
+    def symmetric_orthonormalize(self, V: "Buffer", n, dim, v_row0=0):
+        check(self.lib.rom_symmetric_orthonormalize(self.h, V.h, v_row0, n, dim))
+
     def complete_orthonormal(self, V: "Buffer", found, rest, dim, v_row0=0):
         check(self.lib.rom_complete_orthonormal(self.h, V.h, v_row0, found, rest, dim))
 
-    def small_eig(self, A, mode=0, rel_tol=0.0):
+    def small_eig(self, A, mode=0, rel_tol=0.0, gram_like=True):
         A = _host(A)
         n = A.shape[0]
         lam, T = np.empty(n), np.empty((n, n))
-        check(self.lib.rom_small_eig_host(self.h, n, A.ctypes.data, mode, rel_tol, lam.ctypes.data, T.ctypes.data))
+        check(self.lib.rom_small_eig_host(self.h, n, A.ctypes.data, mode, rel_tol, 1 if gram_like else 0, lam.ctypes.data,
+                                          T.ctypes.data))
         return lam, T
 
     # -- RCCL ----------------------------------------------------------------------------------

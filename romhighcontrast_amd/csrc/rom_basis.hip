@@ -141,28 +141,72 @@ enum { SE_EIG = 0, SE_WHITEN = 1, SE_LOWDIN = 2 };
 constexpr int SE_LDS_MAX = 96, SE_MAX = 1024;
 
 __global__ __launch_bounds__(256) void kb_small_eig(int n, const double* __restrict__ A, int lda, double* __restrict__ lam,
-                                                    double* __restrict__ T, int ldt, int mode, double rel_tol,
+                                                    double* __restrict__ T, int ldt, int mode, double rel_tol, int gram_like,
                                                     double* __restrict__ gws) {
   extern __shared__ __align__(16) double sm[];
   const int t = threadIdx.x, ld = n | 1, ne = n + (n & 1), half = ne / 2;
   double* As = gws ? gws : sm;
   double* Vt = As + size_t(n) * ld;
-  double* vec = gws ? sm : Vt + size_t(n) * ld;  // [cs half | sn half | lam n | (int) pp half, qq half, perm n, flag]
+  double* vec = gws ? sm : Vt + size_t(n) * ld;  // [cs half | sn half | ev n | nu2 n | red 4 | (int) pp half, qq half, perm n, flag]
   double* cs = vec;
   double* sn = vec + half;
   double* ev = vec + 2 * half;
-  int* pp = reinterpret_cast<int*>(ev + n);
+  double* nu2 = ev + n;
+  double* red = nu2 + n;
+  int* pp = reinterpret_cast<int*>(red + 4);
   int* qq = pp + half;
   int* perm = qq + half;
   int* flag = perm + n;
+  double dmax = 0.0;
   for (int idx = t; idx < n * n; idx += 256) {
     const int r = idx / n, c = idx % n;
-    As[r * ld + c] = 0.5 * (A[size_t(r) * lda + c] + A[size_t(c) * lda + r]);
+    const double v = 0.5 * (A[size_t(r) * lda + c] + A[size_t(c) * lda + r]);
+    As[r * ld + c] = v;
     Vt[r * ld + c] = r == c ? 1.0 : 0.0;
+    if (r == c) dmax = fmax(dmax, fabs(v));
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_down(dmax, o, 64));
+  if ((t & 63) == 0) red[t >> 6] = dmax;
   __syncthreads();
-  const double eps = 1.1e-16;
-  for (int sweep = 0; sweep < 60; ++sweep) {
+  dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (mode != SE_EIG) {
+    // Nearly orthonormal rows (G = I + E, |E| small): (I + E)^(-1/2) = I - E/2 + 3 E^2 / 8 - ..., no eigen-decomposition.
+    // The third-order remainder is below 1e-16 for max |E_ij| < 1e-6 / n.  (Most orthonormalisations of the POD are of
+    // this kind: rotated Ritz vectors, lifted modes, second whitening rounds.)  The transform is symmetric, so it serves
+    // both modes; the eigenvalues reported are the diagonal of G (all ~1), descending order not attempted.
+    double emax = 0.0;
+    for (int idx = t; idx < n * n; idx += 256) {
+      const int r = idx / n, c = idx % n;
+      emax = fmax(emax, fabs(As[r * ld + c] - (r == c ? 1.0 : 0.0)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) emax = fmax(emax, __shfl_down(emax, o, 64));
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = emax;
+    __syncthreads();
+    emax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (emax * n < 1e-6) {
+      for (int idx = t; idx < n * n; idx += 256) {
+        const int r = idx / n, c = idx % n;
+        double e2 = 0.0;  // (E^2)_rc
+        for (int k = 0; k < n; ++k) e2 += (As[r * ld + k] - (r == k ? 1.0 : 0.0)) * (As[k * ld + c] - (k == c ? 1.0 : 0.0));
+        const double e = As[r * ld + c] - (r == c ? 1.0 : 0.0);
+        T[size_t(r) * ldt + c] = (r == c ? 1.0 : 0.0) - 0.5 * e + 0.375 * e2;
+      }
+      for (int i = t; i < n; i += 256) lam[i] = As[i * ld + i];
+      return;
+    }
+  }
+  // A rotation is applied when |a_pq| > tol sqrt(|a_pp a_qq|) -- the relative criterion under which graded matrices keep
+  // their small eigenvalues -- AND |a_pq| > tol nu_p nu_q, the rounding noise of the entry: nu_i^2 is what a_ii would be
+  // had no cancellation happened (initially |a_ii| for a Gram-like matrix; under a rotation c^2 nu_p^2 + s^2 nu_q^2).
+  // A direction that rank deficiency has cancelled to nothing keeps its nu, so the rounding residue that couples it to
+  // the rest is recognised as such and the sweeps end; without it they never do (each rotation re-creates the residue).
+  // gram_like == 0 (a general symmetric matrix such as Y G Y^T: all entries carry eps ||A||): nu_i^2 = max |a_ii|.
+  const double tol = double(n > 8 ? n : 8) * 1.1e-16, floor_abs = fmax(1e-300, 1e-40 * dmax);
+  for (int i = t; i < n; i += 256) nu2[i] = gram_like ? fabs(As[i * ld + i]) : dmax;
+  for (int sweep = 0; sweep < 40; ++sweep) {
     if (t == 0) *flag = 0;
     __syncthreads();
     for (int r = 0; r < ne - 1; ++r) {
@@ -172,17 +216,18 @@ __global__ __launch_bounds__(256) void kb_small_eig(int n, const double* __restr
         double c = 1.0, s = 0.0;
         if (q < n) {
           const double app = As[p * ld + p], aqq = As[q * ld + q], apq = As[p * ld + q];
-          if (fabs(apq) > eps * sqrt(fabs(app * aqq)) && fabs(apq) > 1e-300) {
+          const double np2 = nu2[p], nq2 = nu2[q];
+          if (fabs(apq) > tol * sqrt(fabs(app * aqq)) && fabs(apq) > floor_abs && fabs(apq) > tol * sqrt(np2 * nq2)) {
             const double theta = (aqq - app) / (2.0 * apq);
             const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
             c = 1.0 / sqrt(tt * tt + 1.0);
             s = tt * c;
+            nu2[p] = c * c * np2 + s * s * nq2;
+            nu2[q] = s * s * np2 + c * c * nq2;
             *flag = 1;
-          } else {
-            q = -1;
           }
         } else {
-          q = -1;
+          q = -1;  // p is paired with the dummy index of an odd n: no rotation, but its row / column still takes the others'
         }
         cs[t] = c;
         sn[t] = s;
@@ -190,29 +235,34 @@ __global__ __launch_bounds__(256) void kb_small_eig(int n, const double* __restr
         qq[t] = q;
       }
       __syncthreads();
-      // rows p, q of A and of Vt
+      // A <- J^T A J as disjoint 2 x 2 blocks: block (k, l) = rows (p_k, q_k) x columns (p_l, q_l) becomes R_k B R_l^T;
+      // one pass, no barrier between the row and the column rotations.  (c, s) = (1, 0) for pairs that do not rotate.
+      for (int idx = t; idx < half * half; idx += 256) {
+        const int k = idx / half, l = idx - k * half;
+        const double sk = sn[k], sl = sn[l];
+        if (sk == 0.0 && sl == 0.0) continue;  // neither pair rotates (s, not c, is the test: c rounds to 1 for tiny angles)
+        const int pk = pp[k], qk = qq[k], pl = pp[l], ql = qq[l];
+        const double ck = cs[k], cl = cs[l];
+        const bool vk = qk >= 0, vl = ql >= 0;  // (a pair with the dummy index has one real row / column)
+        const double b00 = As[pk * ld + pl], b01 = vl ? As[pk * ld + ql] : 0.0;
+        const double b10 = vk ? As[qk * ld + pl] : 0.0, b11 = (vk && vl) ? As[qk * ld + ql] : 0.0;
+        const double r00 = ck * b00 - sk * b10, r01 = ck * b01 - sk * b11;   // rows
+        const double r10 = sk * b00 + ck * b10, r11 = sk * b01 + ck * b11;
+        As[pk * ld + pl] = cl * r00 - sl * r01;                               // columns
+        if (vl) As[pk * ld + ql] = sl * r00 + cl * r01;
+        if (vk) As[qk * ld + pl] = cl * r10 - sl * r11;
+        if (vk && vl) As[qk * ld + ql] = sl * r10 + cl * r11;
+      }
+      // eigenvector rows: Vt <- J^T Vt
       for (int idx = t; idx < half * n; idx += 256) {
-        const int k = idx / n, j = idx % n, q = qq[k];
-        if (q < 0) continue;
-        const int p = pp[k];
-        const double c = cs[k], s = sn[k];
-        const double ap = As[p * ld + j], aq = As[q * ld + j];
-        As[p * ld + j] = c * ap - s * aq;
-        As[q * ld + j] = s * ap + c * aq;
+        const int k = idx / n, j = idx - k * n;
+        const double s = sn[k];
+        if (s == 0.0) continue;  // (also every pair with the dummy index)
+        const int p = pp[k], q = qq[k];
+        const double c = cs[k];
         const double vp = Vt[p * ld + j], vq = Vt[q * ld + j];
         Vt[p * ld + j] = c * vp - s * vq;
         Vt[q * ld + j] = s * vp + c * vq;
-      }
-      __syncthreads();
-      // columns p, q of A
-      for (int idx = t; idx < half * n; idx += 256) {
-        const int k = idx % half, i = idx / half, q = qq[k];
-        if (q < 0) continue;
-        const int p = pp[k];
-        const double c = cs[k], s = sn[k];
-        const double ap = As[i * ld + p], aq = As[i * ld + q];
-        As[i * ld + p] = c * ap - s * aq;
-        As[i * ld + q] = s * ap + c * aq;
       }
       __syncthreads();
     }
@@ -255,11 +305,12 @@ __global__ __launch_bounds__(256) void kb_small_eig(int n, const double* __restr
   }
 }
 
-static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, int mode, double rel_tol) {
+static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, int mode, double rel_tol,
+                     bool gram_like = true) {
   if (n <= 0) return ROM_OK;
   ROM_CHECK(n <= SE_MAX, "small symmetric eigenproblem: n = %d beyond %d", n, SE_MAX);
   const int ld = n | 1, half = (n + (n & 1)) / 2;
-  const size_t vec = (2 * size_t(half) + n) * sizeof(double) + (2 * size_t(half) + n + 2) * sizeof(int);
+  const size_t vec = (2 * size_t(half) + 2 * size_t(n) + 4) * sizeof(double) + (2 * size_t(half) + n + 2) * sizeof(int);
   double* gws = nullptr;
   size_t lds = vec + 16;
   if (n <= SE_LDS_MAX) {
@@ -274,15 +325,15 @@ static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam,
   }
   {
     ROM_PROF(ctx, "small_eig", 30.0 * n * n * n, 16.0 * n * n);
-    kb_small_eig<<<1, 256, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gws);
+    kb_small_eig<<<1, 256, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws);
   }
   ROM_HIP(hipGetLastError());
   return ROM_OK;
 }
 
 // test / diagnostic entry: eigen-decomposition of a small symmetric matrix given on the host
-extern "C" int rom_small_eig_host(rom_ctx* ctx, int n, const double* A_host, int mode, double rel_tol, double* lam_host,
-                                  double* T_host) {
+extern "C" int rom_small_eig_host(rom_ctx* ctx, int n, const double* A_host, int mode, double rel_tol, int gram_like,
+                                  double* lam_host, double* T_host) {
   ROM_CHECK(ctx && A_host && lam_host && T_host && n >= 1 && n <= SE_MAX, "rom_small_eig_host: bad arguments");
   ROM_CHECK(mode >= 0 && mode <= 2, "rom_small_eig_host: mode must be 0, 1 or 2");
   Tmp A, lam, T;
@@ -290,7 +341,7 @@ extern "C" int rom_small_eig_host(rom_ctx* ctx, int n, const double* A_host, int
   ROM_TRY(lam.get(ctx, n));
   ROM_TRY(T.get(ctx, size_t(n) * n));
   ROM_HIP(hipMemcpyAsync(A.p(), A_host, size_t(n) * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  ROM_TRY(small_eig(ctx, n, A, n, lam, T, n, mode, rel_tol));
+  ROM_TRY(small_eig(ctx, n, A, n, lam, T, n, mode, rel_tol, gram_like != 0));
   ROM_TRY(download(ctx, lam, lam_host, n));
   return download(ctx, T, T_host, size_t(n) * n);
 }
@@ -332,7 +383,9 @@ static int orthonormalize_against(rom_ctx* ctx, double* V, int found, int take, 
   }
   Tmp Y;
   ROM_TRY(Y.get(ctx, size_t(take) * dim));
-  return gram_transform(ctx, Vn, Y, take, dim, SE_LOWDIN, 1e-30, 2);
+  // (the new rows are orthonormal to ~1e-6 at worst -- lifted Gram modes -- and the symmetric orthonormalisation is second
+  // order in that defect: one round)
+  return gram_transform(ctx, Vn, Y, take, dim, SE_LOWDIN, 1e-30, 1);
 }
 
 // kb_cgs_finish: v <- v / ||v||_2 (norm squared given on the device), zero row if the norm underflows
@@ -368,6 +421,17 @@ extern "C" int rom_orthonormalize_rows(rom_ctx* ctx, rom_buf* X, int64_t x_row0,
     ROM_HIP(hipGetLastError());
   }
   return ROM_OK;
+}
+
+// nearly orthonormal rows -> orthonormal rows, each as close as possible to what it was (symmetric / Loewdin
+// orthonormalisation: V <- (V V^T)^(-1/2) V, two rounds): the clean-up of modes that were expanded from another basis
+extern "C" int rom_symmetric_orthonormalize(rom_ctx* ctx, rom_buf* V, int64_t v_row0, int n, int64_t dim) {
+  ROM_CHECK(ctx && V, "rom_symmetric_orthonormalize: null argument");
+  ROM_CHECK(n >= 0 && n <= SE_MAX && dim >= 1 && v_row0 >= 0 && size_t(v_row0 + n) * dim <= V->n, "rom_symmetric_orthonormalize: bad sizes");
+  if (n == 0) return ROM_OK;
+  Tmp Y;
+  ROM_TRY(Y.get(ctx, size_t(n) * dim));
+  return gram_transform(ctx, V->p + v_row0 * dim, Y, n, dim, SE_LOWDIN, 1e-30, 2);
 }
 
 // rows V[found : found + rest] <- pseudo-random directions (seeded: deterministic) made orthonormal and orthogonal to the
@@ -471,14 +535,21 @@ extern "C" int rom_galerkin_rom(rom_fem* f, rom_buf* a, int M, rom_buf* C, int64
 // (H^1_0 projection or Galerkin ROM) and the H^1_0 norm of the differences.  Both depend on the SPAN of the basis only,
 // so the span is carried as an A_1-orthonormal basis W (w_j^T A_1 w_i = delta_ij) and the projection residuals
 //     R_m = u_m - sum_j p_mj w_j ,   p_mj = <u_m, w_j>_{A_1}
-// are kept in HBM and UPDATED by one vector per iteration (modified Gram-Schmidt over the training block):
-//     w   = R_pick / ||R_pick||_A        (the residual of the pick is already orthogonal to W; one re-orthogonalisation)
-//     p_m = R_m . (A_1 w) ,  R_m <- R_m - p_m w ,  ||R_m||_A  (edge form, fused with the update: one read + one write)
-// The Galerkin approximation g_m = sum_j c_mj w_j differs from the projection inside span W only, so by Pythagoras
-//     ||u_m - g_m||_A^2 = ||R_m||_A^2 + sum_j (p_mj - c_mj)^2      (no cancellation: both terms >= 0)
+// are kept in HBM and UPDATED by one vector per iteration (modified Gram-Schmidt over the training block), ONE pass over
+// the block per iteration.  With w_j = R_pick / ||R_pick||_A (the residual of the pick is already orthogonal to W; one
+// re-orthogonalisation) and z_j = A_1 w_j, pass j
+//     applies the PREVIOUS update          R_m <- R_m - p_{m,j-1} w_{j-1}        (read + write)
+//     takes the exact norm of the result   N_m = ||R_m||_A^2                      (edge form, no cancellation)
+//     and the new coefficient              p_mj = R_m . z_j
+// so that the residual norm after update j is  ||R_m - p_mj w_j||_A^2 = N_m - p_mj^2  (w_j is A_1-orthogonal to R_m's
+// complement): ONE step of Pythagoras from a norm that is exact -- its cancellation error is eps N_m, i.e. a relative
+// error eps (||R_before|| / ||R_after||)^2 of the new norm, harmless unless a single basis vector takes a residual
+// down by more than four orders of magnitude (rows that happens to -- the pick itself, duplicates of it -- are not the
+// next maximum), and it does not accumulate: the next pass measures N_m afresh.
+// The Galerkin approximation g_m = sum_j c_mj w_j differs from the projection inside span W only, so
+//     ||u_m - g_m||_A^2 = ||R_m||_A^2 + sum_j (p_mj - c_mj)^2      (both terms >= 0)
 // with c_m from the reduced systems in the W basis, whose tensor W A_b W^T grows by one row per iteration.
-// Per iteration the training block is read twice and written once, whatever the basis size; the reference's dense
-// contractions are O(n M dim) per iteration.
+// The reference's dense contractions are O(n M dim) per iteration; this is one read and one write of the block.
 
 // err[m] = sqrt(nrm2[m]); rel = err / h1; first maximum -> picks[it], maxerr[it]; one workgroup
 __global__ __launch_bounds__(1024) void kb_greedy_select(int M, const double* __restrict__ err2, const double* __restrict__ extra2,
@@ -510,17 +581,20 @@ __global__ __launch_bounds__(1024) void kb_greedy_select(int M, const double* __
   }
 }
 
-// w <- R[pick] / ||R[pick]||_A ; a pick whose residual is at roundoff of its snapshot (a duplicate) gives w = 0
-__global__ void kb_take_pick(double* __restrict__ w, const double* __restrict__ R, long long dim, const int* __restrict__ picks,
-                             int it, const double* __restrict__ err2, const double* __restrict__ norm0sq,
-                             int* __restrict__ degenerate) {
+// w <- (Rs[pick] - pc w_prev) / ||.||_A, pc = p_prev[pick] (the one update the block in HBM does not hold yet);
+// a pick whose residual is at roundoff of its snapshot (a duplicate) gives w = 0
+__global__ void kb_take_pick(double* __restrict__ w, const double* __restrict__ Rs, const double* __restrict__ w_prev,
+                             const double* __restrict__ p_prev, long long dim, const int* __restrict__ picks, int it,
+                             const double* __restrict__ err2, const double* __restrict__ norm0sq, int* __restrict__ degenerate) {
   const int p = picks[it];
   const double e2 = err2[p];
   const bool dead = !(e2 > 1e-26 * norm0sq[p]) || !(e2 > 0.0);
   const double a = dead ? 0.0 : 1.0 / sqrt(e2);
   if (blockIdx.x == 0 && threadIdx.x == 0) degenerate[it] = dead ? 1 : 0;
-  const double* r = R + (long long)p * dim;
-  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < dim; j += (long long)gridDim.x * blockDim.x) w[j] = a * r[j];
+  const double* r = Rs + (long long)p * dim;
+  const double pc = w_prev ? p_prev[p] : 0.0;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < dim; j += (long long)gridDim.x * blockDim.x)
+    w[j] = a * (w_prev ? r[j] - pc * w_prev[j] : r[j]);
 }
 
 // w <- w / sqrt(nrm2) unless the vector is dead
@@ -531,68 +605,108 @@ __global__ void kb_renormalise(double* __restrict__ w, long long dim, const doub
   for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < dim; j += (long long)gridDim.x * blockDim.x) w[j] *= a;
 }
 
-// Rout[m] = Rin[m] - p[m] w, and partial sums of ||Rout[m]||_A^2 in edge form (the layout of k_h10_partial, rom_ops.hip:
-// a thread owns a mesh column and walks down a slab of rows; every entry is read once, the halo row above the slab and
-// the wave's east neighbour a second time -- which is why the update goes to a second buffer, not in place)
-constexpr int GU_ROWS = 32, GU_UNROLL = 8;
-__global__ __launch_bounds__(256) void kb_greedy_update(StencilGeom g, const double* __restrict__ Rin, double* __restrict__ Rout,
-                                                        const double* __restrict__ w, const double* __restrict__ p, long long ldp,
-                                                        double* __restrict__ partial, int nblk) {
-  __shared__ double red[4];
+// The pass of one greedy iteration over the training block (see above): d = Rs_m - p_prev[m] w_prev (written to Rout when
+// there is a previous update), partial sums of ||d||_A^2 in edge form and of d . z.  Layout of k_h10_partial
+// (rom_ops.hip): a thread owns a mesh column and walks down a slab of rows, every entry is read once, the halo row above
+// the slab a second time; the east neighbour comes from the next lane, across waves through LDS, across workgroups by a
+// load of the workgroup's last thread.  The update goes to a second buffer, not in place: halo entries belong to other
+// workgroups.  partial: [2][M][nblk] (norms, dots).
+constexpr int GU_ROWS = 32, GU_UNROLL = 4;
+template <bool PREV>
+__global__ __launch_bounds__(256) void kb_greedy_pass(StencilGeom g, const double* __restrict__ Rs, double* __restrict__ Rout,
+                                                      const double* __restrict__ w_prev, const double* __restrict__ p_prev,
+                                                      const double* __restrict__ z, double* __restrict__ partial, int nblk, int M) {
+  __shared__ double red[2][4];
+  __shared__ double west[2][4][GU_UNROLL];  // first column of every wave, per row of the chunk (double buffered)
   const long long base = blockIdx.z * g.dim;
-  const double* u = Rin + base;
-  double* o = Rout + base;
-  const double pm = p[blockIdx.z * ldp];
+  const double* u = Rs + base;
+  double* o = PREV ? Rout + base : nullptr;
+  const double pm = PREV ? p_prev[blockIdx.z] : 0.0;
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * GU_ROWS, r1 = min(g.nr, r0 + GU_ROWS);
   const bool in = c < g.nc;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   auto at = [&](int r, int cc) -> double {
     const long long i = (long long)r * g.nc + cc;
-    return u[i] - pm * w[i];
+    return PREV ? u[i] - pm * w_prev[i] : u[i];
   };
-  double s = 0.0;
+  double s = 0.0, dt = 0.0;
   double north = (in && r0 > 0) ? at(r0 - 1, c) : 0.0;
-  for (int rb = r0; rb < r1; rb += GU_UNROLL) {
-    double x[GU_UNROLL], xl[GU_UNROLL];
+  int buf = 0;
+  for (int rb = r0; rb < r1; rb += GU_UNROLL, buf ^= 1) {
+    double x[GU_UNROLL], xe[GU_UNROLL], zz[GU_UNROLL];
 #pragma unroll
     for (int q = 0; q < GU_UNROLL; ++q) {
       const int r = rb + q;
       x[q] = (in && r < r1) ? at(r, c) : 0.0;
-      xl[q] = (lane == 63 && c + 1 < g.nc && r < r1) ? at(r, c + 1) : 0.0;
+      zz[q] = (in && r < r1) ? z[(long long)r * g.nc + c] : 0.0;
+      xe[q] = (threadIdx.x == 255 && c + 1 < g.nc && r < r1) ? at(r, c + 1) : 0.0;
     }
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < GU_UNROLL; ++q) west[buf][wave][q] = x[q];
+    }
+    // (uniform trip count: r0, r1 depend on the block only; the other buffer is read one barrier later.  The barrier
+    // waits for the LDS writes only: __syncthreads() would also drain every global load in flight -- the z values and
+    // whatever the compiler has hoisted from the next chunk -- once per four rows)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int q = 0; q < GU_UNROLL; ++q) {
       const int r = rb + q;
       double east = __shfl_down(x[q], 1, 64);
-      if (lane == 63) east = xl[q];
+      if (lane == 63) east = wave < 3 ? west[buf][wave + 1][q] : xe[q];
       if (in && r < r1) {
-        o[(long long)r * g.nc + c] = x[q];
+        if (PREV) __builtin_nontemporal_store(x[q], &o[(long long)r * g.nc + c]);  // (written once, read by the next pass: +3 %)
         if (c + 1 >= g.nc) east = 0.0;
         const double dh = x[q] - east, dv = x[q] - north;
         s += dh * dh + dv * dv;
         if (c == 0) s += x[q] * x[q];
         if (r == g.nr - 1) s += x[q] * x[q];
+        dt += x[q] * zz[q];
         north = x[q];
       }
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (lane == 0) red[threadIdx.x >> 6] = s;
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    dt += __shfl_down(dt, off, 64);
+  }
+  if (lane == 0) {
+    red[0][wave] = s;
+    red[1][wave] = dt;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.z * (long long)nblk + blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x < 2) {
+    const long long at_ = (threadIdx.x * (long long)M + blockIdx.z) * nblk + blockIdx.y * gridDim.x + blockIdx.x;
+    partial[at_] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+  }
 }
 
-__global__ __launch_bounds__(256) void kb_sum_partials(const double* __restrict__ partial, int nblk, double* __restrict__ out) {
-  __shared__ double red[4];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < nblk; i += 256) s += partial[blockIdx.x * (long long)nblk + i];
+// N_m = sum of the norm partials, p_m = sum of the dot partials, err2_m = max(N_m - p_m^2, 0)
+__global__ __launch_bounds__(256) void kb_greedy_finish(const double* __restrict__ partial, int nblk, int M,
+                                                        double* __restrict__ p_new, double* __restrict__ err2) {
+  __shared__ double red[2][4];
+  double s = 0.0, d = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) {
+    s += partial[blockIdx.x * (long long)nblk + i];
+    d += partial[(M + blockIdx.x) * (long long)nblk + i];
+  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    d += __shfl_down(d, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s;
+    red[1][threadIdx.x >> 6] = d;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) {
+    const double N = red[0][0] + red[0][1] + red[0][2] + red[0][3], pp = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    p_new[blockIdx.x] = pp;
+    err2[blockIdx.x] = fmax(N - pp * pp, 0.0);
+  }
 }
 
 // row / column j of the reduced tensor (k, ld, ld) from col[i, b] = w_i^T A_b w_j (i <= j); a dead vector gets a unit
@@ -608,14 +722,14 @@ __global__ void kb_grow_ahat(double* __restrict__ Ahat, int k, int ld, int j, co
   Ahat[(size_t(b) * ld + i) * ld + j] = v;
 }
 
-// extra2[m] = sum_{j < n} (P[m, j] - c[m, j])^2   (P: ld ldp, c: packed n)
-__global__ void kb_galerkin_gap(int M, int n, const double* __restrict__ P, int ldp, const double* __restrict__ c,
+// extra2[m] = sum_{j < n} (P[j, m] - c[m, j])^2   (P: row j = projection coefficients of basis vector j; c: packed n)
+__global__ void kb_galerkin_gap(int M, int n, const double* __restrict__ P, const double* __restrict__ c,
                                 double* __restrict__ extra2) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   double s = 0.0;
   for (int j = 0; j < n; ++j) {
-    const double d = P[size_t(m) * ldp + j] - c[size_t(m) * n + j];
+    const double d = P[size_t(j) * M + m] - c[size_t(m) * n + j];
     s += d * d;
   }
   extra2[m] = s;
@@ -643,12 +757,12 @@ extern "C" int rom_greedy(rom_fem* f, rom_buf* U, int64_t u_row0, int M, rom_buf
   const StencilGeom g = rom_make_geom(f->nrb, f->ncb, f->N);
   const double* u = U->p + u_row0 * dim;
   const int nb = std::max(n - 1, 1);  // basis vectors ever built
-  Tmp Ra, Rb, W, AW, P, pcol, err2, norm0, h1, ipick, idead, maxerr, t, nrm, part, Ahat, bhat, cg, extra, ZB, col, onehot, Bt;
+  Tmp Ra, Rb, W, AW, P, err2, norm0, h1, ipick, idead, maxerr, t, nrm, part, Ahat, bhat, cg, extra, ZB, col, onehot, Bt;
   ROM_TRY(Ra.get(ctx, size_t(M) * dim));
   ROM_TRY(Rb.get(ctx, size_t(M) * dim));
   ROM_TRY(W.get(ctx, size_t(nb) * dim));
   ROM_TRY(AW.get(ctx, size_t(nb) * dim));
-  ROM_TRY(pcol.get(ctx, M));
+  ROM_TRY(P.get(ctx, size_t(nb) * M));   // row j: p_mj = <R_m, w_j>_A, the projection coefficients
   ROM_TRY(err2.get(ctx, M));
   ROM_TRY(norm0.get(ctx, M));
   ROM_TRY(h1.get(ctx, M));
@@ -659,12 +773,11 @@ extern "C" int rom_greedy(rom_fem* f, rom_buf* U, int64_t u_row0, int M, rom_buf
   ROM_TRY(nrm.get(ctx, 1));
   const dim3 ugrid((g.nc + 255) / 256, (g.nr + GU_ROWS - 1) / GU_ROWS, M);
   const int nblk = int(ugrid.x * ugrid.y);
-  ROM_TRY(part.get(ctx, size_t(M) * nblk));
+  ROM_TRY(part.get(ctx, 2 * size_t(M) * nblk));
   int* d_picks = reinterpret_cast<int*>(ipick.p());
   int* d_dead = reinterpret_cast<int*>(idead.p());
   double* d_maxerr = maxerr.p();
   if (mode == 1) {
-    ROM_TRY(P.get(ctx, size_t(M) * nb));   // projection coefficients p_mj (needed for the Galerkin gap only)
     ROM_TRY(Ahat.get(ctx, size_t(k) * nb * nb));
     ROM_TRY(bhat.get(ctx, nb));
     ROM_TRY(cg.get(ctx, size_t(M) * nb));
@@ -692,41 +805,47 @@ extern "C" int rom_greedy(rom_fem* f, rom_buf* U, int64_t u_row0, int M, rom_buf
   ROM_HIP(hipMemcpyAsync(err2.p(), norm0.p(), size_t(M) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   kb_greedy_select<<<1, 1024, 0, ctx->stream>>>(M, err2, nullptr, h1, 0, d_picks, d_maxerr);
   ROM_HIP(hipGetLastError());
-  const double* Rcur = u;  // residuals of the empty basis are the snapshots themselves (never written)
+  const double* Rs = u;  // the block in HBM: all updates but the latest applied (the snapshots themselves are never written)
   double* bufs[2] = {Ra.p(), Rb.p()};
+  const double *w_prev = nullptr, *p_prev = nullptr;
   const unsigned vgrid = unsigned(std::min<int64_t>((dim + 255) / 256, 512));
   for (int it = 1; it < n; ++it) {
     const int j = it - 1;  // index of the basis vector built from pick it - 1
     double* wj = W.p() + size_t(j) * dim;
     double* zj = AW.p() + size_t(j) * dim;
-    kb_take_pick<<<vgrid, 256, 0, ctx->stream>>>(wj, Rcur, dim, d_picks, it - 1, err2, norm0, d_dead);
+    double* pj = P.p() + size_t(j) * M;
+    kb_take_pick<<<vgrid, 256, 0, ctx->stream>>>(wj, Rs, w_prev, p_prev, dim, d_picks, it - 1, err2, norm0, d_dead);
     ROM_HIP(hipGetLastError());
     if (j > 0) {  // one re-orthogonalisation against W in the A_1 inner product, then renormalise
-      ROM_TRY(rom_launch_gemm_nt(ctx, j, 1, dim, 1.0, AW, dim, wj, dim, 0.0, t, 1, "gemm_nt"));
-      ROM_TRY(rom_launch_gemm_nn(ctx, 1, dim, j, -1.0, t, j, W, dim, 1.0, wj, dim));
+      ROM_TRY(rom_launch_rowdot(ctx, AW, j, dim, wj, t));                                    // t_i = <w_i, w>_A
+      ROM_TRY(rom_launch_gemm_nn(ctx, 1, dim, j, -1.0, t, j, W, dim, 1.0, wj, dim));         // w -= t^T W
       ROM_TRY(rom_launch_h10norm(f, wj, nullptr, 1, nrm, false));
       kb_renormalise<<<vgrid, 256, 0, ctx->stream>>>(wj, dim, nrm, d_dead, it - 1);
       ROM_HIP(hipGetLastError());
     }
-    ROM_TRY(rom_launch_stencil_apply(f, nullptr, wj, 1, zj));                      // z = A_1 w
-    ROM_TRY(rom_launch_rowdot(ctx, Rcur, M, dim, zj, pcol));                        // p_m = R_m . z
-    if (mode == 1) ROM_TRY(transpose(ctx, P.p() + j, nb, pcol, M, 1, M));            // column j of P
+    ROM_TRY(rom_launch_stencil_apply(f, nullptr, wj, 1, zj));                                // z = A_1 w
     {
-      ROM_PROF(ctx, "greedy_update", 12.0 * double(M) * dim, 16.0 * double(M) * dim);
-      double* Rnext = bufs[it & 1];
-      kb_greedy_update<<<ugrid, 256, 0, ctx->stream>>>(g, Rcur, Rnext, wj, pcol, 1, part, nblk);
-      kb_sum_partials<<<M, 256, 0, ctx->stream>>>(part, nblk, err2);
-      Rcur = Rnext;
+      ROM_PROF(ctx, w_prev ? "greedy_pass" : "greedy_pass_first", 16.0 * double(M) * dim, (w_prev ? 16.0 : 8.0) * double(M) * dim);
+      if (w_prev) {
+        double* Rnext = bufs[it & 1];
+        kb_greedy_pass<true><<<ugrid, 256, 0, ctx->stream>>>(g, Rs, Rnext, w_prev, p_prev, zj, part, nblk, M);
+        Rs = Rnext;
+      } else {
+        kb_greedy_pass<false><<<ugrid, 256, 0, ctx->stream>>>(g, Rs, nullptr, nullptr, nullptr, zj, part, nblk, M);
+      }
+      kb_greedy_finish<<<M, 256, 0, ctx->stream>>>(part, nblk, M, pj, err2);
     }
     ROM_HIP(hipGetLastError());
+    w_prev = wj;
+    p_prev = pj;
     if (mode == 1) {
-      for (int b = 0; b < k; ++b) ROM_TRY(rom_launch_stencil_apply(f, onehot.p() + size_t(b) * k, wj, 1, ZB.p() + size_t(b) * dim));
-      ROM_TRY(rom_launch_gemm_nt(ctx, j + 1, k, dim, 1.0, W, dim, ZB, dim, 0.0, col, k, "gemm_nt"));  // col[i, b] = w_i . A_b w_j
+      ROM_TRY(rom_launch_stencil_apply_blocks(f, onehot, wj, ZB));                                       // A_b w_j, all b
+      ROM_TRY(rom_launch_gemm_nt(ctx, j + 1, k, dim, 1.0, W, dim, ZB, dim, 0.0, col, k, "gemm_nt"));      // col[i, b] = w_i . A_b w_j
       kb_grow_ahat<<<unsigned(((j + 1) * k + 255) / 256), 256, 0, ctx->stream>>>(Ahat, k, nb, j, col, d_dead, it - 1);
       ROM_HIP(hipGetLastError());
-      ROM_TRY(rom_launch_gemm_nt(ctx, 1, 1, dim, 1.0, wj, dim, Bt, dim, 0.0, bhat.p() + j, 1, "gemm_nt"));  // w_j . B_total
+      ROM_TRY(rom_launch_rowdot(ctx, wj, 1, dim, Bt, bhat.p() + j));                                      // w_j . B_total
       ROM_TRY(rom_launch_reduced_solve(ctx, j + 1, nb, k, M, Ahat, a->p, bhat, 0, cg));
-      kb_galerkin_gap<<<unsigned((M + 255) / 256), 256, 0, ctx->stream>>>(M, j + 1, P, nb, cg, extra);
+      kb_galerkin_gap<<<unsigned((M + 255) / 256), 256, 0, ctx->stream>>>(M, j + 1, P, cg, extra);
       ROM_HIP(hipGetLastError());
     }
     kb_greedy_select<<<1, 1024, 0, ctx->stream>>>(M, err2, mode == 1 ? extra.p() : nullptr, h1, it, d_picks, d_maxerr);
@@ -769,7 +888,10 @@ __global__ void kb_inv_sqrt(const double* __restrict__ lam, double* __restrict__
 namespace {
 
 constexpr double GRAM_ACCEPT = 1e-10;    // eigenvalues of a Gram matrix are taken down to this fraction of its largest one
-constexpr double SKETCH_ACCEPT = 1e-6;   // singular values of a sketch down to this fraction of its largest one
+// singular values of a sketch are taken down to this fraction of its largest one: the power step of the range finder
+// weighs a direction with sigma^3, so what lies four orders below the top of a pass is still resolved to ~1e-16 / 1e-12
+// of itself, what lies six orders below is not (measured: angle 1.4e-3 instead of 7e-6 for a mode at 1e-11 sigma_1)
+constexpr double SKETCH_ACCEPT = 1e-4;
 constexpr double NOISE_FLOOR = 1e-13;    // modes below this fraction of sigma_1 are fp64 noise of the snapshots
 
 struct PodInfo {
@@ -795,14 +917,14 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
   ROM_TRY(scr.get(ctx, size_t(b) * M));
   double* d_res = lam.p() + b;
   ROM_TRY(fill_random(ctx, Y, size_t(b) * M, 0x5eed0000ull + unsigned(b) * 131u + unsigned(M), true));
-  ROM_TRY(gram_transform(ctx, Y, scr, b, M, SE_WHITEN, 1e-30, 2));  // Gaussian rows: kappa ~ 1
+  ROM_TRY(gram_transform(ctx, Y, scr, b, M, SE_WHITEN, 1e-30, M >= 4 * b ? 1 : 2));  // Gaussian rows: kappa(Gram) ~ 3 when M >> b
   std::vector<double> th(2 * size_t(b));
   double best = 1e300;
   int stall = 0;
   for (int it = 0; it < max_iter; ++it) {
     ROM_TRY(rom_launch_gemm_nt(ctx, b, M, M, 1.0, Y, M, G, M, 0.0, Z, M, "gemm_nt"));   // Z = Y G (G symmetric)
     ROM_TRY(rom_launch_gemm_nt(ctx, b, b, M, 1.0, Z, M, Y, M, 0.0, H, b, "gemm_nt"));   // H = Y G Y^T
-    ROM_TRY(small_eig(ctx, b, H, b, lam, St, b, SE_EIG, 0.0));                          // rows of St: Ritz rotations
+    ROM_TRY(small_eig(ctx, b, H, b, lam, St, b, SE_EIG, 0.0, false));                   // rows of St: Ritz rotations
     ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Y, M, 0.0, Yr, M));            // Ritz vectors
     info.eig_iterations = it + 1;
     if (b == M) {  // full space: exact after one Ritz step
@@ -822,7 +944,7 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
     if (worst <= tol || stall >= 3 || it == max_iter - 1) break;
     kb_next_block<<<dim3(unsigned(std::min((M + 255) / 256, 64)), b), 256, 0, ctx->stream>>>(Zs, Zr, Yr, lam, M);
     ROM_HIP(hipGetLastError());
-    ROM_TRY(gram_transform(ctx, Zs, scr, b, M, SE_WHITEN, 1e-30, 2));
+    ROM_TRY(gram_transform(ctx, Zs, scr, b, M, SE_WHITEN, 1e-30, it == 0 ? 2 : 1));  // (rows are rotated Ritz vectors: nearly orthonormal)
     ROM_HIP(hipMemcpyAsync(Y.p(), Zs.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   }
   theta_host.assign(th.begin(), th.begin() + nev);
@@ -929,7 +1051,7 @@ extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t
     info.executed += (last ? 2.0 : 4.0) * take * M * double(dim);
     return ROM_OK;
   };
-  const int passes = 6;
+  const int passes = 12;
   if (n > 0) {
     Tmp G, W, fac;
     ROM_TRY(G.get(ctx, size_t(M) * M));
@@ -963,7 +1085,10 @@ extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t
     Tmp Vs;
     std::vector<double> ss;
     int b = 0;
-    const int want = n - found;
+    // a pass accepts modes over four orders of magnitude -- a dozen of them in a spectrum that decays like the snapshot
+    // blocks' do -- so it asks for at most 16 (+ 8 of oversampling): the thin products scale with b, the small dense
+    // problems with b^3; a spectrum that decays more slowly takes more passes
+    const int want = std::min(n - found, 16);
     const int bmax = int(std::min<int64_t>(std::min<int64_t>(M, dim), want + 8));
     ROM_TRY(Vs.get(ctx, size_t(bmax) * dim));
     ROM_TRY(sketched_modes(ctx, X, M, dim, want, p, Vs, ss, b, info));

@@ -124,6 +124,27 @@ __global__ void k_splitk_reduce(long long m, long long n, int splits, double alp
   *p = beta == 0.0 ? alpha * s : alpha * s + beta * *p;
 }
 
+// the same reduction with one WAVE per output element (the splits are spread over its lanes): thin outputs with hundreds
+// of splits -- m x 1 dot products over a snapshot-long K -- are latency bound with one thread walking all the partials
+__global__ __launch_bounds__(256) void k_splitk_reduce_wave(long long m, long long n, int splits, double alpha,
+                                                            const double* __restrict__ part, double beta,
+                                                            double* __restrict__ C, long long ldc, int lower_only) {
+  const long long idx = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (idx >= m * n) return;
+  if (lower_only && (idx % n) / 64 > (idx / n) / 64) return;
+  const int lane = threadIdx.x & 63;
+  // fixed order: lane l sums splits l, l + 64, ...; then the lanes are folded pairwise -- deterministic
+  double s = 0.0;
+  for (int z = lane; z < splits; z += 64) s += part[z * m * n + idx];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) {
+    const long long r = idx / n, c = idx % n;
+    double* p = C + r * ldc + c;
+    *p = beta == 0.0 ? alpha * s : alpha * s + beta * *p;
+  }
+}
+
 int rom_launch_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const char* prof_name) {
   return rom_launch_gemm_nt_ex(ctx, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, prof_name, 0);
@@ -167,8 +188,11 @@ int rom_launch_gemm_nt_ex(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double 
   ROM_HIP(hipGetLastError());
   if (splits > 1) {
     ROM_PROF(ctx, "splitk_reduce", double(splits) * m * n, 8.0 * double(splits + 1) * m * n);
-    k_splitk_reduce<<<unsigned((m * n + 255) / 256), 256, 0, ctx->stream>>>(m, n, splits, alpha, part, beta, C, ldc,
-                                                                           lower_only);
+    if (splits >= 16 && m * n <= 65536)
+      k_splitk_reduce_wave<<<unsigned((m * n + 3) / 4), 256, 0, ctx->stream>>>(m, n, splits, alpha, part, beta, C, ldc, lower_only);
+    else
+      k_splitk_reduce<<<unsigned((m * n + 255) / 256), 256, 0, ctx->stream>>>(m, n, splits, alpha, part, beta, C, ldc,
+                                                                             lower_only);
     ROM_HIP(hipGetLastError());
   }
   if (lower_only) {
@@ -484,13 +508,15 @@ extern "C" int rom_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double
 constexpr int SA_ROWS = 32;    // rows per slab (+ one halo row above and below: 6 % extra reads)
 constexpr int SA_UNROLL = 8;   // loads in flight per thread
 template <bool UNIT>
-__global__ __launch_bounds__(256) void k_stencil_apply_cols(StencilGeom g, const double* __restrict__ a_one,
-                                                            const double* __restrict__ X, double* __restrict__ Y) {
+__global__ __launch_bounds__(256) void k_stencil_apply_cols(StencilGeom g, const double* __restrict__ a_one, int coef_stride,
+                                                            const double* __restrict__ X, long long x_stride,
+                                                            double* __restrict__ Y) {
+  // vector z of the launch: input row X + z x_stride (0: the same row for every z), coefficients a_one + z coef_stride
   __shared__ double am[64];
   if (!UNIT)
-    for (int i = threadIdx.x; i < g.kblk; i += blockDim.x) am[i] = a_one[i];
+    for (int i = threadIdx.x; i < g.kblk; i += blockDim.x) am[i] = a_one[blockIdx.z * (long long)coef_stride + i];
   __syncthreads();
-  const double* x = X + blockIdx.z * g.dim;
+  const double* x = X + blockIdx.z * x_stride;
   double* y = Y + blockIdx.z * g.dim;
   const int c = blockIdx.x * 256 + threadIdx.x;  // 0-based interior column
   const int r0 = blockIdx.y * SA_ROWS, r1 = min(g.nr, r0 + SA_ROWS);
@@ -654,8 +680,22 @@ int rom_launch_stencil_apply(rom_fem* f, const double* d_coef, const double* X, 
   {
     ROM_PROF(ctx, "stencil_apply", 14.0 * g.dim * K, 16.0 * g.dim * K);
     const dim3 grid((g.nc + 255) / 256, (g.nr + SA_ROWS - 1) / SA_ROWS, K);
-    if (!d_coef) k_stencil_apply_cols<true><<<grid, 256, 0, ctx->stream>>>(g, nullptr, X, Y);
-    else k_stencil_apply_cols<false><<<grid, 256, 0, ctx->stream>>>(g, d_coef, X, Y);
+    if (!d_coef) k_stencil_apply_cols<true><<<grid, 256, 0, ctx->stream>>>(g, nullptr, 0, X, g.dim, Y);
+    else k_stencil_apply_cols<false><<<grid, 256, 0, ctx->stream>>>(g, d_coef, 0, X, g.dim, Y);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// Y[b, :] = A_b x for every block b (one-hot coefficients, `d_onehot`: kblk x kblk identity on the device): the k
+// stencil applications that grow the reduced tensor by one basis vector, in one launch
+int rom_launch_stencil_apply_blocks(rom_fem* f, const double* d_onehot, const double* x, double* Y) {
+  rom_ctx* ctx = f->ctx;
+  StencilGeom g = rom_make_geom(f->nrb, f->ncb, f->N);
+  {
+    ROM_PROF(ctx, "stencil_apply_blocks", 14.0 * g.dim * g.kblk, 16.0 * g.dim * g.kblk);
+    const dim3 grid((g.nc + 255) / 256, (g.nr + SA_ROWS - 1) / SA_ROWS, g.kblk);
+    k_stencil_apply_cols<false><<<grid, 256, 0, ctx->stream>>>(g, d_onehot, g.kblk, x, 0, Y);
   }
   ROM_HIP(hipGetLastError());
   return ROM_OK;

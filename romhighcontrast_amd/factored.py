@@ -222,6 +222,8 @@ def pod_modes_factored(fs: FactoredSnapshots, n: int, center=True):
     W = modes_z @ Einv.T                       # (nz, Kc): the modes as interface vectors
     V = ctx.alloc(n * dim)
     em.expand_compact(ctx.upload(W), nz, V)
+    # B Einv has orthonormal columns to the accuracy of the eigen-decomposition of S (~1e-9): clean up the expanded modes
+    ctx.symmetric_orthonormalize(V, nz, dim)
     if nz < n:
         # more modes requested than the snapshot manifold has dimensions: completed like pod_modes completes what the
         # data do not determine (orthonormal directions of singular value 0)

@@ -217,7 +217,7 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True):
     MFMA Gram matrix ``G = Xc Xc^T`` -> leading eigenpairs by subspace iteration (projected problems by a one-workgroup
     Jacobi on the device) -> lift; the Gram matrix squares the condition number, so only the modes with lambda_k >
     1e-10 lambda_1 come from it, the rest from the DEFLATED block through a randomised range finder (thin GEMMs), each
-    pass six orders of magnitude further down, until the request is filled or the spectrum has reached the fp64 noise
+    pass four orders of magnitude further down, until the request is filled or the spectrum has reached the fp64 noise
     of the snapshots (1e-13 sigma_1); a Rayleigh-Ritz step over the collected modes orders them.  What is still missing
     then does not exist in the data; like LAPACK / scikit-learn, which return SOME orthonormal directions there, the
     basis is completed with orthonormalised pseudo-random directions (singular value 0, seeded by the number of

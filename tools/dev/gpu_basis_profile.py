@@ -1,0 +1,54 @@
+"""Dev probe: per-kernel HIP-event times (rom_profile_*) of one rom_pod call at C2 size and one rom_greedy call at C4 size."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench
+from romhighcontrast_amd.lib import SolutionsManagers as SM, ReducedBasis as RB
+
+def report(ctx, title, wall):
+    rep = ctx.profile_report()
+    tot = sum(v["total_ms"] for v in rep.values())
+    print(f"== {title}: wall {wall*1e3:.2f} ms, kernels {tot:.2f} ms")
+    for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"]):
+        print(f"   {k:34s} {v['total_ms']:9.3f} ms  {v['launches']:5d} launches  {v['flops']/max(v['total_ms'],1e-9)*1e-9:8.2f} TF/s  {v['bytes']/max(v['total_ms'],1e-9)*1e-6:8.1f} GB/s")
+
+which = sys.argv[1] if len(sys.argv) > 1 else "pod"
+os.environ["ROMHC_PROF_DETAIL"] = "1"
+if which in ("pod", "all"):
+    sm = SM.SolutionsManagerFEM((2, 2), 128)
+    ctx, dim = sm._ctx, sm.vspace_dim
+    M = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    a = bench.workload_parameters("c2", (2, 2), M)
+    Ud = sm.generate_solutions_device(a)
+    X = ctx.alloc(M * dim)
+    for rep in range(3):
+        X.copy_from(Ud.buf, M * dim)
+        ctx.synchronize()
+        if rep == 2:
+            ctx.profile_reset(); ctx.profile(True)
+        t0 = time.perf_counter()
+        RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), 50)
+        ctx.synchronize()
+        w = time.perf_counter() - t0
+        print("pod wall", w)
+    ctx.profile(False)
+    report(ctx, f"rom_pod {M} x {dim}", w)
+if which in ("greedy", "all"):
+    sm = SM.SolutionsManagerFEM((3, 3), 171)
+    ctx, dim = sm._ctx, sm.vspace_dim
+    M = 1024
+    a = bench.workload_parameters("c4", (3, 3), M)
+    Ud = sm.generate_solutions_device(a)
+    h1 = sm.H10norm(Ud)
+    for mode in (RB.GREEDY_FOR_H10, RB.GREEDY_FOR_GALERKIN):
+        for rep in range(2):
+            ctx.synchronize()
+            if rep == 1:
+                ctx.profile_reset(); ctx.profile(True)
+            t0 = time.perf_counter()
+            RB.ReducedBasisGreedy(mode).build(50, sm, Ud, a, h1)
+            ctx.synchronize()
+            w = time.perf_counter() - t0
+        ctx.profile(False)
+        report(ctx, f"rom_greedy {mode} n=50", w)
