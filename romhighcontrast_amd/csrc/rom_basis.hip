@@ -140,61 +140,74 @@ static int transpose(rom_ctx* ctx, double* dst, long long ldd, const double* src
 enum { SE_EIG = 0, SE_WHITEN = 1, SE_LOWDIN = 2 };
 constexpr int SE_LDS_MAX = 96, SE_MAX = 1024;
 
-__global__ __launch_bounds__(256) void kb_small_eig(int n, const double* __restrict__ A, int lda, double* __restrict__ lam,
-                                                    double* __restrict__ T, int ldt, int mode, double rel_tol, int gram_like,
-                                                    double* __restrict__ gws) {
+constexpr int SE_TPB = 512;  // threads of the eigen-solver's workgroup
+
+// 1 / sqrt(x) to full precision from the hardware estimate (two Newton steps): the cosine of a rotation must satisfy
+// c^2 (1 + t^2) = 1 to rounding, or the accumulated eigenvector rows drift from orthonormality
+__device__ inline double se_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+
+__global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __restrict__ A, int lda, double* __restrict__ lam,
+                                                       double* __restrict__ T, int ldt, int mode, double rel_tol, int gram_like,
+                                                       double* __restrict__ gws) {
   extern __shared__ __align__(16) double sm[];
   const int t = threadIdx.x, ld = n | 1, ne = n + (n & 1), half = ne / 2;
   double* As = gws ? gws : sm;
   double* Vt = As + size_t(n) * ld;
-  double* vec = gws ? sm : Vt + size_t(n) * ld;  // [cs half | sn half | ev n | nu2 n | red 4 | (int) pp half, qq half, perm n, flag]
+  double* vec = gws ? sm : Vt + size_t(n) * ld;  // [cs half | sn half | ev n | nu2 n | red 8 | (int) pp half, qq half, perm n, flag]
   double* cs = vec;
   double* sn = vec + half;
   double* ev = vec + 2 * half;
   double* nu2 = ev + n;
   double* red = nu2 + n;
-  int* pp = reinterpret_cast<int*>(red + 4);
+  int* pp = reinterpret_cast<int*>(red + 8);
   int* qq = pp + half;
   int* perm = qq + half;
   int* flag = perm + n;
+  constexpr int NW = SE_TPB / 64;
+  auto block_max = [&](double v) -> double {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = v;
+    __syncthreads();
+    double m = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmax(m, red[w]);
+    return m;
+  };
   double dmax = 0.0;
-  for (int idx = t; idx < n * n; idx += 256) {
+  for (int idx = t; idx < n * n; idx += SE_TPB) {
     const int r = idx / n, c = idx % n;
     const double v = 0.5 * (A[size_t(r) * lda + c] + A[size_t(c) * lda + r]);
     As[r * ld + c] = v;
     Vt[r * ld + c] = r == c ? 1.0 : 0.0;
     if (r == c) dmax = fmax(dmax, fabs(v));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_down(dmax, o, 64));
-  if ((t & 63) == 0) red[t >> 6] = dmax;
-  __syncthreads();
-  dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  dmax = block_max(dmax);
   if (mode != SE_EIG) {
     // Nearly orthonormal rows (G = I + E, |E| small): (I + E)^(-1/2) = I - E/2 + 3 E^2 / 8 - ..., no eigen-decomposition.
-    // The third-order remainder is below 1e-16 for max |E_ij| < 1e-6 / n.  (Most orthonormalisations of the POD are of
-    // this kind: rotated Ritz vectors, lifted modes, second whitening rounds.)  The transform is symmetric, so it serves
-    // both modes; the eigenvalues reported are the diagonal of G (all ~1), descending order not attempted.
+    // The third-order remainder is below 1e-16 for max |E_ij| < 1e-6 / n (lifted modes, rotated sketch modes).  The
+    // transform is symmetric, so it serves both modes; the eigenvalues reported are the diagonal of G (all ~1).
     double emax = 0.0;
-    for (int idx = t; idx < n * n; idx += 256) {
+    for (int idx = t; idx < n * n; idx += SE_TPB) {
       const int r = idx / n, c = idx % n;
       emax = fmax(emax, fabs(As[r * ld + c] - (r == c ? 1.0 : 0.0)));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) emax = fmax(emax, __shfl_down(emax, o, 64));
-    __syncthreads();
-    if ((t & 63) == 0) red[t >> 6] = emax;
-    __syncthreads();
-    emax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    emax = block_max(emax);
     if (emax * n < 1e-6) {
-      for (int idx = t; idx < n * n; idx += 256) {
+      for (int idx = t; idx < n * n; idx += SE_TPB) {
         const int r = idx / n, c = idx % n;
         double e2 = 0.0;  // (E^2)_rc
         for (int k = 0; k < n; ++k) e2 += (As[r * ld + k] - (r == k ? 1.0 : 0.0)) * (As[k * ld + c] - (k == c ? 1.0 : 0.0));
         const double e = As[r * ld + c] - (r == c ? 1.0 : 0.0);
         T[size_t(r) * ldt + c] = (r == c ? 1.0 : 0.0) - 0.5 * e + 0.375 * e2;
       }
-      for (int i = t; i < n; i += 256) lam[i] = As[i * ld + i];
+      for (int i = t; i < n; i += SE_TPB) lam[i] = As[i * ld + i];
       return;
     }
   }
@@ -204,8 +217,9 @@ __global__ __launch_bounds__(256) void kb_small_eig(int n, const double* __restr
   // A direction that rank deficiency has cancelled to nothing keeps its nu, so the rounding residue that couples it to
   // the rest is recognised as such and the sweeps end; without it they never do (each rotation re-creates the residue).
   // gram_like == 0 (a general symmetric matrix such as Y G Y^T: all entries carry eps ||A||): nu_i^2 = max |a_ii|.
-  const double tol = double(n > 8 ? n : 8) * 1.1e-16, floor_abs = fmax(1e-300, 1e-40 * dmax);
-  for (int i = t; i < n; i += 256) nu2[i] = gram_like ? fabs(As[i * ld + i]) : dmax;
+  const double tol = double(n > 8 ? n : 8) * 1.1e-16, tol2 = tol * tol, floor_abs = fmax(1e-300, 1e-40 * dmax);
+  for (int i = t; i < n; i += SE_TPB) nu2[i] = gram_like ? fabs(As[i * ld + i]) : dmax;
+  __syncthreads();
   for (int sweep = 0; sweep < 40; ++sweep) {
     if (t == 0) *flag = 0;
     __syncthreads();
@@ -216,11 +230,13 @@ __global__ __launch_bounds__(256) void kb_small_eig(int n, const double* __restr
         double c = 1.0, s = 0.0;
         if (q < n) {
           const double app = As[p * ld + p], aqq = As[q * ld + q], apq = As[p * ld + q];
-          const double np2 = nu2[p], nq2 = nu2[q];
-          if (fabs(apq) > tol * sqrt(fabs(app * aqq)) && fabs(apq) > floor_abs && fabs(apq) > tol * sqrt(np2 * nq2)) {
-            const double theta = (aqq - app) / (2.0 * apq);
-            const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            c = 1.0 / sqrt(tt * tt + 1.0);
+          const double np2 = nu2[p], nq2 = nu2[q], apq2 = apq * apq;
+          if (apq2 > tol2 * fabs(app * aqq) && fabs(apq) > floor_abs && apq2 > tol2 * np2 * nq2) {
+            // t = tan(phi) = sign(a) b / (|a| + sqrt(a^2 + b^2)), a = a_qq - a_pp, b = 2 a_pq (the smaller root of
+            // t^2 + 2 theta t - 1 = 0, theta = a / b); c = 1 / sqrt(1 + t^2), s = t c
+            const double a = aqq - app, bb = 2.0 * apq;
+            const double tt = (a >= 0 ? bb : -bb) / (fabs(a) + sqrt(a * a + bb * bb));
+            c = se_rsqrt(1.0 + tt * tt);
             s = tt * c;
             nu2[p] = c * c * np2 + s * s * nq2;
             nu2[q] = s * s * np2 + c * c * nq2;
@@ -237,32 +253,70 @@ __global__ __launch_bounds__(256) void kb_small_eig(int n, const double* __restr
       __syncthreads();
       // A <- J^T A J as disjoint 2 x 2 blocks: block (k, l) = rows (p_k, q_k) x columns (p_l, q_l) becomes R_k B R_l^T;
       // one pass, no barrier between the row and the column rotations.  (c, s) = (1, 0) for pairs that do not rotate.
-      for (int idx = t; idx < half * half; idx += 256) {
-        const int k = idx / half, l = idx - k * half;
-        const double sk = sn[k], sl = sn[l];
-        if (sk == 0.0 && sl == 0.0) continue;  // neither pair rotates (s, not c, is the test: c rounds to 1 for tiny angles)
-        const int pk = pp[k], qk = qq[k], pl = pp[l], ql = qq[l];
-        const double ck = cs[k], cl = cs[l];
-        const bool vk = qk >= 0, vl = ql >= 0;  // (a pair with the dummy index has one real row / column)
-        const double b00 = As[pk * ld + pl], b01 = vl ? As[pk * ld + ql] : 0.0;
-        const double b10 = vk ? As[qk * ld + pl] : 0.0, b11 = (vk && vl) ? As[qk * ld + ql] : 0.0;
-        const double r00 = ck * b00 - sk * b10, r01 = ck * b01 - sk * b11;   // rows
-        const double r10 = sk * b00 + ck * b10, r11 = sk * b01 + ck * b11;
-        As[pk * ld + pl] = cl * r00 - sl * r01;                               // columns
-        if (vl) As[pk * ld + ql] = sl * r00 + cl * r01;
-        if (vk) As[qk * ld + pl] = cl * r10 - sl * r11;
-        if (vk && vl) As[qk * ld + ql] = sl * r10 + cl * r11;
+      // Items are taken four at a time -- all loads, then all stores: the blocks are disjoint, but the compiler cannot
+      // know that, and one item at a time is a chain of LDS round trips.
+      for (int base = 0; base < half * half; base += 4 * SE_TPB) {
+        double o00[4], o01[4], o10[4], o11[4];
+        int a00[4], a01[4], a10[4], a11[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * SE_TPB + t;
+          a00[u] = a01[u] = a10[u] = a11[u] = -1;
+          if (idx < half * half) {
+            const int k = idx / half, l = idx - k * half;
+            const double sk = sn[k], sl = sn[l];
+            if (sk != 0.0 || sl != 0.0) {  // (s, not c, is the test: c rounds to 1 for tiny angles)
+              const int pk = pp[k], qk = qq[k], pl = pp[l], ql = qq[l];
+              const double ck = cs[k], cl = cs[l];
+              const bool vk = qk >= 0, vl = ql >= 0;  // (a pair with the dummy index has one real row / column)
+              const double b00 = As[pk * ld + pl], b01 = vl ? As[pk * ld + ql] : 0.0;
+              const double b10 = vk ? As[qk * ld + pl] : 0.0, b11 = (vk && vl) ? As[qk * ld + ql] : 0.0;
+              const double r00 = ck * b00 - sk * b10, r01 = ck * b01 - sk * b11;   // rows
+              const double r10 = sk * b00 + ck * b10, r11 = sk * b01 + ck * b11;
+              a00[u] = pk * ld + pl;
+              o00[u] = cl * r00 - sl * r01;                                         // columns
+              if (vl) { a01[u] = pk * ld + ql; o01[u] = sl * r00 + cl * r01; }
+              if (vk) { a10[u] = qk * ld + pl; o10[u] = cl * r10 - sl * r11; }
+              if (vk && vl) { a11[u] = qk * ld + ql; o11[u] = sl * r10 + cl * r11; }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (a00[u] >= 0) As[a00[u]] = o00[u];
+          if (a01[u] >= 0) As[a01[u]] = o01[u];
+          if (a10[u] >= 0) As[a10[u]] = o10[u];
+          if (a11[u] >= 0) As[a11[u]] = o11[u];
+        }
       }
       // eigenvector rows: Vt <- J^T Vt
-      for (int idx = t; idx < half * n; idx += 256) {
-        const int k = idx / n, j = idx - k * n;
-        const double s = sn[k];
-        if (s == 0.0) continue;  // (also every pair with the dummy index)
-        const int p = pp[k], q = qq[k];
-        const double c = cs[k];
-        const double vp = Vt[p * ld + j], vq = Vt[q * ld + j];
-        Vt[p * ld + j] = c * vp - s * vq;
-        Vt[q * ld + j] = s * vp + c * vq;
+      for (int base = 0; base < half * n; base += 4 * SE_TPB) {
+        double op[4], oq[4];
+        int ap[4], aq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * SE_TPB + t;
+          ap[u] = -1;
+          if (idx < half * n) {
+            const int k = idx / n, j = idx - k * n;
+            const double s = sn[k];
+            if (s != 0.0) {  // (also every pair with the dummy index)
+              const int p = pp[k], q = qq[k];
+              const double c = cs[k];
+              const double vp = Vt[p * ld + j], vq = Vt[q * ld + j];
+              ap[u] = p * ld + j;
+              aq[u] = q * ld + j;
+              op[u] = c * vp - s * vq;
+              oq[u] = s * vp + c * vq;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ap[u] >= 0) {
+            Vt[ap[u]] = op[u];
+            Vt[aq[u]] = oq[u];
+          }
       }
       __syncthreads();
     }
@@ -271,19 +325,19 @@ __global__ __launch_bounds__(256) void kb_small_eig(int n, const double* __restr
     if (!any) break;
   }
   // eigenvalues, descending order (stable: ties by index)
-  for (int i = t; i < n; i += 256) ev[i] = As[i * ld + i];
+  for (int i = t; i < n; i += SE_TPB) ev[i] = As[i * ld + i];
   __syncthreads();
-  for (int i = t; i < n; i += 256) {
+  for (int i = t; i < n; i += SE_TPB) {
     int rank = 0;
     const double v = ev[i];
     for (int j = 0; j < n; ++j) rank += (ev[j] > v || (ev[j] == v && j < i)) ? 1 : 0;
     perm[rank] = i;
   }
   __syncthreads();
-  for (int i = t; i < n; i += 256) lam[i] = ev[perm[i]];
+  for (int i = t; i < n; i += SE_TPB) lam[i] = ev[perm[i]];
   const double lmax = ev[perm[0]];
   if (mode == SE_LOWDIN) {
-    for (int idx = t; idx < n * n; idx += 256) {
+    for (int idx = t; idx < n * n; idx += SE_TPB) {
       const int r = idx / n, c = idx % n;
       double s = 0.0;
       for (int i = 0; i < n; ++i) {
@@ -293,7 +347,7 @@ __global__ __launch_bounds__(256) void kb_small_eig(int n, const double* __restr
       T[size_t(r) * ldt + c] = s;
     }
   } else {
-    for (int idx = t; idx < n * n; idx += 256) {
+    for (int idx = t; idx < n * n; idx += SE_TPB) {
       const int r = idx / n, c = idx % n, src = perm[r];
       double v = Vt[src * ld + c];
       if (mode == SE_WHITEN) {
@@ -310,7 +364,7 @@ static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam,
   if (n <= 0) return ROM_OK;
   ROM_CHECK(n <= SE_MAX, "small symmetric eigenproblem: n = %d beyond %d", n, SE_MAX);
   const int ld = n | 1, half = (n + (n & 1)) / 2;
-  const size_t vec = (2 * size_t(half) + 2 * size_t(n) + 4) * sizeof(double) + (2 * size_t(half) + n + 2) * sizeof(int);
+  const size_t vec = (2 * size_t(half) + 2 * size_t(n) + 8) * sizeof(double) + (2 * size_t(half) + n + 2) * sizeof(int);
   double* gws = nullptr;
   size_t lds = vec + 16;
   if (n <= SE_LDS_MAX) {
@@ -324,8 +378,11 @@ static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam,
     ctx->lds_optin_small_eig = true;
   }
   {
-    ROM_PROF(ctx, "small_eig", 30.0 * n * n * n, 16.0 * n * n);
-    kb_small_eig<<<1, 256, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws);
+    static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-shape names in the profile records
+    char nm[48];
+    detail ? snprintf(nm, sizeof nm, "small_eig_n%d_mode%d_%s", n, mode, gram_like ? "gram" : "sym") : snprintf(nm, sizeof nm, "small_eig");
+    ROM_PROF(ctx, nm, 30.0 * n * n * n, 16.0 * n * n);
+    kb_small_eig<<<1, SE_TPB, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws);
   }
   ROM_HIP(hipGetLastError());
   return ROM_OK;
@@ -996,7 +1053,10 @@ int sketched_modes(rom_ctx* ctx, const double* X, int M, int64_t dim, int k, int
   ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Om, M, X, dim, 0.0, Y, dim));                 // Y = Omega X
   info.executed += 2.0 * b * M * double(dim);
   for (int it = 0; it <= power; ++it) {
-    ROM_TRY(gram_transform(ctx, Y, scr, b, dim, SE_WHITEN, 1e-26, 2));                           // Q (rank may drop: zero rows)
+    // Q (rank may drop: zero rows).  Before the power step one round is enough: the rows only have to span the sketch
+    // and be aligned with its principal directions -- their residual non-orthogonality (eps x the condition number of
+    // the sketch's Gram matrix) does not change what the power step spans; the basis that is USED is whitened twice
+    ROM_TRY(gram_transform(ctx, Y, scr, b, dim, SE_WHITEN, 1e-26, it == power ? 2 : 1));
     ROM_TRY(rom_launch_gemm_nt(ctx, b, M, dim, 1.0, Y, dim, X, dim, 0.0, Tt, M, "gemm_nt"));      // Tt = Q X^T  (b, M)
     info.executed += 2.0 * b * M * double(dim) + 4.0 * b * b * double(dim);
     if (it == power) break;
