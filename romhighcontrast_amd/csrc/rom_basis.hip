@@ -153,7 +153,7 @@ __device__ inline double se_rsqrt(double x) {
 
 __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __restrict__ A, int lda, double* __restrict__ lam,
                                                        double* __restrict__ T, int ldt, int mode, double rel_tol, int gram_like,
-                                                       double* __restrict__ gws) {
+                                                       double* __restrict__ gws, double* __restrict__ ns_ws) {
   extern __shared__ __align__(16) double sm[];
   const int t = threadIdx.x, ld = n | 1, ne = n + (n & 1), half = ne / 2;
   double* As = gws ? gws : sm;
@@ -189,26 +189,92 @@ __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __re
     if (r == c) dmax = fmax(dmax, fabs(v));
   }
   dmax = block_max(dmax);
-  if (mode != SE_EIG) {
-    // Nearly orthonormal rows (G = I + E, |E| small): (I + E)^(-1/2) = I - E/2 + 3 E^2 / 8 - ..., no eigen-decomposition.
-    // The third-order remainder is below 1e-16 for max |E_ij| < 1e-6 / n (lifted modes, rotated sketch modes).  The
-    // transform is symmetric, so it serves both modes; the eigenvalues reported are the diagonal of G (all ~1).
-    double emax = 0.0;
-    for (int idx = t; idx < n * n; idx += SE_TPB) {
-      const int r = idx / n, c = idx % n;
-      emax = fmax(emax, fabs(As[r * ld + c] - (r == c ? 1.0 : 0.0)));
+  if (mode != SE_EIG && dmax > 0.0 && !gws) {
+    // Rows that are orthogonal up to a moderate defect -- G = g (I + E), g = mean diagonal, ||E|| < 1/2: rotated Ritz
+    // vectors of a subspace iteration, lifted modes, a Gaussian start block -- need no eigen-decomposition: the inverse
+    // square root comes from the coupled Newton-Schulz iteration
+    //     W = (3 I - Z Y) / 2 ,  Y <- Y W ,  Z <- W Z        (Y_0 = I + E, Z_0 = I;  Y -> (I+E)^(1/2), Z -> (I+E)^(-1/2))
+    // which converges quadratically: a handful of n^3 products in LDS instead of ten Jacobi sweeps of n - 1 dependent
+    // rounds each.  The transform is symmetric, so it serves the whitening and the symmetric orthonormalisation alike.
+    // Eigenvalues reported: the diagonal of G.  (W lives in the caller's T, which is overwritten at the end anyway.)
+    double tr = 0.0;
+    for (int i = t; i < n; i += SE_TPB) tr += As[i * ld + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tr += __shfl_down(tr, o, 64);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = tr;
+    __syncthreads();
+    double gmean = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) gmean += red[w];
+    gmean /= double(n);
+    double esum = 0.0;  // max row sum of |E|: an upper bound of ||E||_2
+    for (int r = t; r < n; r += SE_TPB) {
+      double rs = 0.0;
+      for (int c = 0; c < n; ++c) rs += fabs(As[r * ld + c] / gmean - (r == c ? 1.0 : 0.0));
+      esum = fmax(esum, rs);
     }
-    emax = block_max(emax);
-    if (emax * n < 1e-6) {
+    esum = block_max(esum);
+    // (||E||_2 < 1 is what the iteration needs; the row-sum bound is sufficient, not necessary: up to 3 it is tried and
+    // abandoned -- matrix reloaded, Jacobi below -- if the defect ||Z Y - I|| ever grows)
+    if (gmean > 0.0 && esum < 3.0) {
+      bool diverged = false;
+      double dev_prev = 1e300;
+      for (int i = t; i < n; i += SE_TPB) lam[i] = As[i * ld + i];
+      __syncthreads();
       for (int idx = t; idx < n * n; idx += SE_TPB) {
         const int r = idx / n, c = idx % n;
-        double e2 = 0.0;  // (E^2)_rc
-        for (int k = 0; k < n; ++k) e2 += (As[r * ld + k] - (r == k ? 1.0 : 0.0)) * (As[k * ld + c] - (k == c ? 1.0 : 0.0));
-        const double e = As[r * ld + c] - (r == c ? 1.0 : 0.0);
-        T[size_t(r) * ldt + c] = (r == c ? 1.0 : 0.0) - 0.5 * e + 0.375 * e2;
+        As[r * ld + c] /= gmean;
       }
-      for (int i = t; i < n; i += SE_TPB) lam[i] = As[i * ld + i];
-      return;
+      __syncthreads();
+      double* Yn = ns_ws;                    // new Y, Z of an iteration (global scratch, L2 resident)
+      double* Zn = ns_ws + size_t(n) * n;
+      for (int itn = 0; itn < 20; ++itn) {
+        double dev = 0.0;
+        for (int idx = t; idx < n * n; idx += SE_TPB) {
+          const int r = idx / n, c = idx % n;
+          double acc = 0.0;
+          for (int k = 0; k < n; ++k) acc += Vt[r * ld + k] * As[k * ld + c];   // (Z Y)_rc
+          dev = fmax(dev, fabs(acc - (r == c ? 1.0 : 0.0)));
+          T[size_t(r) * ldt + c] = 0.5 * ((r == c ? 3.0 : 0.0) - acc);
+        }
+        dev = block_max(dev);   // ||Z Y - I||_max; its barriers also order the writes of W before the reads below
+        if (dev < 4e-16 * n) break;
+        if (!(dev < dev_prev) || itn == 19) { diverged = true; break; }
+        dev_prev = dev;
+        for (int idx = t; idx < n * n; idx += SE_TPB) {
+          const int r = idx / n, c = idx % n;
+          double ay = 0.0, az = 0.0;
+          for (int k = 0; k < n; ++k) {
+            ay += As[r * ld + k] * T[size_t(k) * ldt + c];   // (Y W)_rc
+            az += T[size_t(r) * ldt + k] * Vt[k * ld + c];   // (W Z)_rc
+          }
+          Yn[idx] = ay;
+          Zn[idx] = az;
+        }
+        __syncthreads();   // every thread has read the old Y, Z (and written its part of the new ones)
+        for (int idx = t; idx < n * n; idx += SE_TPB) {
+          const int r = idx / n, c = idx % n;
+          As[r * ld + c] = Yn[idx];
+          Vt[r * ld + c] = Zn[idx];
+        }
+        __syncthreads();
+      }
+      if (!diverged) {
+        const double sc = 1.0 / sqrt(gmean);
+        for (int idx = t; idx < n * n; idx += SE_TPB) {
+          const int r = idx / n, c = idx % n;
+          T[size_t(r) * ldt + c] = sc * 0.5 * (Vt[r * ld + c] + Vt[c * ld + r]);
+        }
+        return;
+      }
+      __syncthreads();
+      for (int idx = t; idx < n * n; idx += SE_TPB) {  // start over for the eigen-decomposition
+        const int r = idx / n, c = idx % n;
+        As[r * ld + c] = 0.5 * (A[size_t(r) * lda + c] + A[size_t(c) * lda + r]);
+        Vt[r * ld + c] = r == c ? 1.0 : 0.0;
+      }
+      __syncthreads();
     }
   }
   // A rotation is applied when |a_pq| > tol sqrt(|a_pp a_qq|) -- the relative criterion under which graded matrices keep
@@ -367,8 +433,10 @@ static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam,
   const size_t vec = (2 * size_t(half) + 2 * size_t(n) + 8) * sizeof(double) + (2 * size_t(half) + n + 2) * sizeof(int);
   double* gws = nullptr;
   size_t lds = vec + 16;
+  double* ns_ws = nullptr;
   if (n <= SE_LDS_MAX) {
     lds += 2 * size_t(n) * ld * sizeof(double);
+    ROM_TRY(rom_ctx_scratch(ctx, 2 * size_t(n) * n, &ns_ws));   // Newton-Schulz fast path: next iterates
   } else {
     ROM_TRY(rom_ctx_scratch(ctx, 2 * size_t(n) * ld, &gws));
   }
@@ -382,7 +450,7 @@ static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam,
     char nm[48];
     detail ? snprintf(nm, sizeof nm, "small_eig_n%d_mode%d_%s", n, mode, gram_like ? "gram" : "sym") : snprintf(nm, sizeof nm, "small_eig");
     ROM_PROF(ctx, nm, 30.0 * n * n * n, 16.0 * n * n);
-    kb_small_eig<<<1, SE_TPB, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws);
+    kb_small_eig<<<1, SE_TPB, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws, ns_ws);
   }
   ROM_HIP(hipGetLastError());
   return ROM_OK;

@@ -255,6 +255,13 @@ def test_small_symmetric_eigensolver_vs_lapack():
     gram = Q @ Q.T
     assert np.abs(gram - np.diag(np.diag(gram))).max() < 1e-10 and sorted(np.round(np.diag(gram), 8))[:1] == [0.0]
     assert np.allclose(sorted(np.diag(gram))[1:], 1.0, atol=1e-10)
+    # Newton-Schulz path (rows orthogonal up to a moderate defect): a Gaussian block, and rotated orthonormal rows + 5 % noise
+    for b, m, noise in ((62, 1024, None), (40, 300, 0.05), (96, 4000, None)):
+        Yb = rng.standard_normal((b, m)) if noise is None else np.linalg.qr(rng.standard_normal((m, b)))[0].T + noise * rng.standard_normal((b, m)) / np.sqrt(m)
+        for md in (1, 2):
+            _, Tn = ctx.small_eig(Yb @ Yb.T, mode=md, rel_tol=1e-30)
+            Zb = Tn @ Yb
+            observed(f"small_eig Newton-Schulz / fallback b={b} mode={md}: orthonormality", np.abs(Zb @ Zb.T - np.eye(b)), 1e-12)
     Y = rng.standard_normal((9, 200))
     Y = np.linalg.qr(Y.T)[0].T + 1e-3 * rng.standard_normal((9, 200))
     _, Tl_ = ctx.small_eig(Y @ Y.T, mode=2, rel_tol=1e-30)

@@ -52,3 +52,22 @@ if which in ("greedy", "all"):
             w = time.perf_counter() - t0
         ctx.profile(False)
         report(ctx, f"rom_greedy {mode} n=50", w)
+if which == "pod5":
+    sm = SM.SolutionsManagerFEM((4, 4), 256)
+    ctx, dim = sm._ctx, sm.vspace_dim
+    M = 4096
+    a = bench.workload_parameters("c5", (4, 4), M)
+    Ud = sm.generate_solutions_device(a)
+    X = ctx.alloc(M * dim)
+    for rep in range(2):
+        X.copy_from(Ud.buf, M * dim)
+        ctx.synchronize()
+        if rep == 1:
+            ctx.profile_reset(); ctx.profile(True)
+        t0 = time.perf_counter()
+        RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), 50)
+        ctx.synchronize()
+        w = time.perf_counter() - t0
+        print("pod wall", w)
+    ctx.profile(False)
+    report(ctx, f"rom_pod {M} x {dim}", w)
