@@ -360,59 +360,6 @@ __global__ __launch_bounds__(256) void k_coef(FemDev f, const double* __restrict
   }
 }
 
-// 4 doubles from an address that is only 8-byte aligned (pointer may be null -> zeros)
-__device__ inline void load4_any(const double* __restrict__ p, double v[4]) {
-  if (p) {
-    v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
-  } else {
-    v[0] = v[1] = v[2] = v[3] = 0.0;
-  }
-}
-
-// Edge values of the active edges from the reduced solution, u_f = P_f z_f + p0_f / s_f, as one batched
-// MFMA GEMM (tile rows = systems, tile cols = nodes of f, K = compressed index); closed-form edges kept in
-// compressed form enter the same way with z = c_e / s_e, P = K^-1 W_e, p0 = K^-1 g_e.  The values go to the
-// snapshot rows directly (and to the nodal blocks of the interface vector).   grid (n1p/64, ceil(Mc/64), nexp [+ 1])
-// one workgroup of the expansion: (64 nodes bx) x (64 systems by) of edge bz; bz == nexp: the slice that copies
-// the interface values that need no expansion (cross points) from the interface vector to the snapshot rows
-__device__ inline void expand_tile(const FemDev& f, int Mc, double* __restrict__ U, long long row0, double* lds,
-                                   int bx, int by, int bz) {
-  if (bz == f.nexp) {
-    if (bx != 0) return;
-    for (int idx = threadIdx.x; idx < 64 * f.nscat; idx += 256) {  // (four waves, whatever the launch has)
-      const int m = by * 64 + idx / f.nscat, v = f.scat[idx % f.nscat];
-      if (m < Mc) U[(row0 + m) * f.dim + f.vmap[v]] = f.y[size_t(m) * f.nGp + v];
-    }
-    return;
-  }
-  const WavePos wp;
-  const ExpEdge ee = f.exp[bz];
-  const int srow = stage_row(), sseg = stage_seg();
-  const int mA = by * 64 + srow;
-  const double* pA = mA < Mc ? f.y + size_t(mA) * f.nGp + ee.zpos + sseg : nullptr;
-  const double* pB = f.P + (size_t(ee.ptab) * f.n1p + bx * 64 + srow) * f.n1p + sseg;
-  Acc acc;
-  acc_zero(acc);
-  gemm_loop(
-      ee.nch, [&](int ch, double* v) { load4_any(pA ? pA + ch * BK : nullptr, v); },
-      [&](int ch, double* v) { load4_aligned(pB + ch * BK, v); }, acc, lds, wp);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int m = by * 64 + acc_row(wp, i, g);
-      if (m >= Mc) continue;
-      const double inv = f.y[size_t(m) * f.nGp + ee.spos];  // 1 / (a_b0 + a_b1), from the scalar block
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb) {
-        const int node = bx * 64 + acc_col(wp, jb);
-        const double v = node < f.n1 ? acc.c[i][jb][g] + f.vec[ee.p0off + node] * inv : 0.0;
-        f.y[size_t(m) * f.nGp + ee.npos + node] = v;  // (read again by the node-by-node paths, if any)
-        if (node < f.n1) U[(row0 + m) * f.dim + f.vmap[ee.npos + node]] = v;
-      }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_expand(FemDev f, const double* __restrict__ a, int Mc, double* __restrict__ U,
                                                 long long row0) {
   __shared__ __align__(16) double lds[STAGE_TOTAL];

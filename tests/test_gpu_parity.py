@@ -872,11 +872,13 @@ def test_gram_128_tiles_vs_numpy(api, M, D):
 
 
 @pytest.mark.parametrize("blocks,N,M", [((2, 2), 128, 130), ((3, 3), 24, 140), ((2, 3), 40, 200), ((2, 2), 90, 128),
-                                        ((1, 2), 9, 129), ((3, 2), 171, 128), ((5, 4), 33, 128)])
+                                        ((1, 2), 9, 129), ((3, 2), 171, 128), ((5, 4), 33, 128), ((2, 2), 65, 257),
+                                        ((2, 2), 66, 128), ((1, 2), 128, 384), ((2, 2), 128, 1024)])
 def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
     """The extension into the blocks has three tilings (128 vertices of one mesh row, 128 consecutive vertices of the
     block, 64 vertices of one mesh row): same products in the same order, so the snapshots must be identical.
-    (5 x 4 blocks: more than the 16 block descriptors one launch of the 128-tile kernel carries.)"""
+    (5 x 4 blocks: more than the 16 block descriptors one launch of the 128-tile kernel carries; N = 65 / 66: mesh rows of
+    64 / 65 vertices; M = 130, 257: a last system group of two systems / one system.)"""
     from romhighcontrast_amd import _ffi
     ctx = _ffi.get_context()
     a = 10.0 ** np.random.default_rng(N).uniform(0, 3, size=(M, blocks[0] * blocks[1]))
