@@ -124,11 +124,14 @@ def _launcher_start_time() -> str:
 
 
 def rendezvous_path() -> str:
-    # ROMHC_LAUNCH_ID: set by bench.py's own launcher (launch_ranks); TORCHELASTIC_RUN_ID: by torch.distributed.run
-    tag = "_".join([os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
-                    os.environ.get("ROMHC_LAUNCH_ID", os.environ.get("TORCHELASTIC_RUN_ID", "none")),
-                    str(os.getppid()), _launcher_start_time()])
-    return os.path.join(tempfile.gettempdir(), f"romhc_rdzv_{tag}.bin")
+    """File through which rank 0 publishes the RCCL unique id of ONE launch.  A launcher that names its launch --
+    ROMHC_LAUNCH_ID (bench.py's own launcher, a fresh uuid per launch) or TORCHELASTIC_RUN_ID (torch.distributed.run) --
+    is identified by that name together with MASTER_ADDR / MASTER_PORT alone: the ranks may then be started through
+    wrappers (their parent pids differ).  Without a launch id the parent process (pid + start time) stands in for it."""
+    run_id = os.environ.get("ROMHC_LAUNCH_ID", os.environ.get("TORCHELASTIC_RUN_ID"))
+    tag = [os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0")]
+    tag += [run_id] if run_id else ["none", str(os.getppid()), _launcher_start_time()]
+    return os.path.join(tempfile.gettempdir(), "romhc_rdzv_" + "_".join(tag) + ".bin")
 
 
 def exchange_unique_id(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
