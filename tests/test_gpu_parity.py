@@ -469,6 +469,65 @@ def test_error_behaviour(api):
                                [0.5, 0.5])
 
 
+def test_basis_stage_calls_edge_cases(api):
+    """The single-call operations of the basis stage (rom_project_h10, rom_galerkin_rom, rom_greedy, rom_pod,
+    rom_orthonormalize_rows) on the inputs the reference's loops meet at their edges: empty bases and sweeps, one snapshot,
+    more modes / basis vectors requested than there are snapshots, dependent basis rows, bad arguments."""
+    SM, RB = api
+    from scipy.linalg import LinAlgError
+    from romhighcontrast_amd import _ffi
+    sm = SM.SolutionsManagerFEM((2, 2), 6)
+    ctx, fem, dim = sm._ctx, sm._fem, sm.vspace_dim
+    g = ro.Geometry((2, 2), 6)
+    M = 9
+    a = 10.0 ** np.random.default_rng(2).uniform(0, 3, size=(M, 2, 2))
+    U = sm.generate_solutions(a)
+    h1 = sm.H10norm(U)
+    # projectors: empty basis -> zeros (src/lib/SolutionsManagers.py:89-91,109-111); empty sweep -> (0, dim)
+    assert not sm.project_solutions(U, np.empty((0, 0))).any() and not sm.generate_fm_solutions(a, np.empty((0, 0))).any()
+    assert sm.project_solutions(np.empty((0, dim)), U[:2]).shape == (0, dim)
+    assert sm.generate_fm_solutions(np.empty((0, 2, 2)), U[:2]).shape == (0, dim)
+    # a basis that contains the snapshot reproduces it; against the oracle for a generic basis
+    C = ro.orthonormalize_base(U[:4])
+    observed("edge cases: projection of a basis member onto its basis (rel H10)", relh10(g, sm.project_solutions(U[:4], C), U[:4]), 1e-11)
+    observed("edge cases: project_solutions vs oracle (abs / max|U|)", np.abs(sm.project_solutions(U, C) - ro.project_solutions(g, U, C)) / np.abs(U).max(), 1e-12)
+    observed("edge cases: generate_fm_solutions vs oracle (abs / max|U|)", np.abs(sm.generate_fm_solutions(a, C) - ro.generate_fm_solutions(g, a, C)) / np.abs(U).max(), 1e-12)
+    # dependent basis rows: the reference's posv raises LinAlgError on the singular reduced matrix
+    with pytest.raises(LinAlgError):
+        sm.project_solutions(U, np.vstack((U[:2], U[:1])))
+    # greedy: one snapshot; more vectors than snapshots (duplicates at roundoff, finite errors); h1norm broadcast from a scalar
+    for mode in (RB.GREEDY_FOR_H10, RB.GREEDY_FOR_GALERKIN):
+        rb = RB.ReducedBasisGreedy(mode).build(1, sm, U[:1], a[:1], h1[:1])
+        assert rb.picks == [0] and rb.max_errors == [1.0] and np.array_equal(rb.basis, U[:1])
+        rb = RB.ReducedBasisGreedy(mode).build(M + 2, sm, U, a, h1)
+        assert len(rb.picks) == M + 2 and sorted(set(rb.picks[:4])) == sorted(rb.picks[:4]) and np.all(np.isfinite(rb.max_errors))
+        assert max(rb.max_errors[M:]) < 1e-6      # the nine snapshots span themselves
+        rb = RB.ReducedBasisGreedy(mode).build(3, sm, U, a, 1)
+        assert rb.picks[0] == int(np.argmax(h1))
+    # POD: more modes than the data determine -> completed, orthonormal; one snapshot; uncentred; sigma vs LAPACK
+    X = ctx.upload(U)
+    comps, sig = RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), M)
+    sv = np.linalg.svd(U - U.mean(axis=0), compute_uv=False)
+    observed("edge cases: POD singular values of 9 snapshots vs LAPACK (relative to sigma_1)", np.abs(sig - np.where(sv > 1e-13 * sv[0], sv, 0.0))[:M - 1] / sv[0], 1e-12)
+    observed("edge cases: POD with as many modes as snapshots, orthonormality", np.abs(comps @ comps.T - np.eye(M)), 1e-12)
+    comps1, sig1 = RB.pod_modes(ctx, SM.DeviceArray(ctx.upload(U[:1]), 1, dim), 1)
+    assert comps1.shape == (1, dim) and sig1[0] == 0.0 and abs(np.linalg.norm(comps1) - 1) < 1e-12     # centred single row: no variance
+    comps2, sig2 = RB.pod_modes(ctx, SM.DeviceArray(ctx.upload(U), M, dim), 2, center=False)
+    sv2, Vt2 = np.linalg.svd(U, full_matrices=False)[1:]
+    observed("edge cases: uncentred POD, leading singular values vs LAPACK (relative)", np.abs(sig2 - sv2[:2]) / sv2[:2], 1e-10)
+    # orthonormalize: zero rows in, zero rows out; nothing at all
+    Z = np.vstack((U[:2], np.zeros((1, dim))))
+    Q = RB.orthonormalize_base(Z)
+    assert not Q[2].any() and np.abs(Q[:2] @ Q[:2].T - np.eye(2)).max() < 1e-14
+    assert RB.orthonormalize_base(np.empty((0, dim))).shape == (0, dim)
+    # the C entries refuse bad arguments with a message instead of faulting
+    lib = ctx.lib
+    assert lib.rom_pod(ctx.h, X.h, 0, M, dim, M + 1, 1, X.h, 0, None, None) != 0 and b"rom_pod" in lib.rom_last_error()
+    assert lib.rom_greedy(fem.h, X.h, 0, M, None, h1.ctypes.data, 1, 2, None, None) != 0    # Galerkin mode without parameters
+    assert lib.rom_greedy(fem.h, X.h, 0, M + 5, None, h1.ctypes.data, 0, 2, h1.ctypes.data, h1.ctypes.data) != 0   # rows out of range
+    assert lib.rom_project_h10(fem.h, X.h, 0, M, X.h, 5, M, X.h, 0) != 0                        # basis rows out of range
+
+
 @pytest.mark.parametrize("n", [1, 64, 88, 89, 100, 140, 141, 150, 260])
 def test_reduced_solves_of_any_size(api, n):
     """galerkin() takes any n in the reference (src/lib/SolutionsManagers.py:17-40): the batched reduced solve keeps the
