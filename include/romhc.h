@@ -220,7 +220,9 @@ int rom_symmetric_orthonormalize(rom_ctx* ctx, rom_buf* V, int64_t v_row0, int n
 int rom_complete_orthonormal(rom_ctx* ctx, rom_buf* V, int64_t v_row0, int found, int rest, int64_t dim);
 /* the device eigen-solver the calls above use for their small symmetric problems (cyclic Jacobi, one workgroup), for
  * n x n host matrices, n <= 1024: mode 0 T = eigenvector rows (eigenvalues descending in lam_host); 1 T = whitening
- * transform Lambda^-1/2 Q^T (rows with lambda <= rel_tol lambda_max zero); 2 T = Q Lambda^-1/2 Q^T.
+ * transform Lambda^-1/2 Q^T (rows with lambda <= rel_tol lambda_max zero); 2 T = Q Lambda^-1/2 Q^T; 3 (n <= 96) T =
+ * the rank-revealing whitening transform [L_r^-1 0] P of the pivoted Cholesky factorisation P A P^T = L L^T (lam_host:
+ * squared pivots), what the orthonormalisations of rom_pod use.
  * gram_like != 0: A is a Gram matrix of explicit rows (entries accurate relative to sqrt(a_pp a_qq): small eigenvalues
  * of graded matrices come out to high relative accuracy); 0: general symmetric matrix (absolute accuracy).  Test hook. */
 int rom_small_eig_host(rom_ctx* ctx, int n, const double* A_host, int mode, double rel_tol, int gram_like,

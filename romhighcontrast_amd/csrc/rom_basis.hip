@@ -427,6 +427,124 @@ __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __re
   }
 }
 
+// Rank-revealing whitening transform by PIVOTED CHOLESKY: A = X X^T (n x n Gram matrix, symmetrised on entry),
+// P A P^T = L L^T with diagonal pivoting, stopped at the first pivot below rel_tol x the largest one (rank r);
+// T = [L_r^-1  0] P, so that the first r rows of T X are orthonormal and the rest are zero.  The rows come out graded
+// (row k is orthogonal to the k - 1 stronger ones) -- what the power steps of the range finder need -- and the whole
+// thing is n dependent steps of one column each: tens of microseconds, where the eigen-decomposition of an
+// ill-conditioned Gram matrix takes ten Jacobi sweeps of n - 1 rounds (1-2 ms).  Like every Gram-based orthonormalisation
+// it resolves directions down to ~1e-8 of the strongest per round; callers run two rounds where that matters.
+// lam: the squared pivots (descending), zeros behind the rank.  One workgroup, matrix in LDS (n <= SE_LDS_MAX).
+__global__ __launch_bounds__(256) void kb_pivchol_whiten(int n, const double* __restrict__ A, int lda, double* __restrict__ lam,
+                                                         double* __restrict__ T, int ldt, double rel_tol) {
+  extern __shared__ __align__(16) double sm[];
+  const int t = threadIdx.x, ld = n | 1;
+  double* As = sm;                       // working matrix, lower triangle used
+  double* Li = As + size_t(n) * ld;      // L^-1 (r x r, lower)
+  double* red = Li + size_t(n) * ld;     // [4] values
+  int* redi = reinterpret_cast<int*>(red + 4);  // [4] indices
+  int* perm = redi + 4;                  // perm[k] = original index of pivot k
+  __shared__ int s_rank, s_piv;
+  __shared__ double s_first;
+  for (int idx = t; idx < n * n; idx += 256) {
+    const int r = idx / n, c = idx % n;
+    As[r * ld + c] = 0.5 * (A[size_t(r) * lda + c] + A[size_t(c) * lda + r]);
+    Li[r * ld + c] = 0.0;
+  }
+  for (int i = t; i < n; i += 256) perm[i] = i;
+  if (t == 0) s_rank = n;
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    // pivot: largest remaining diagonal entry (first one on ties)
+    double best = -1e300;
+    int at = k;
+    for (int j = k + t; j < n; j += 256) {
+      const double d = As[j * ld + j];
+      if (d > best) { best = d; at = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_down(best, o, 64);
+      const int oa = __shfl_down(at, o, 64);
+      if (ob > best || (ob == best && oa < at)) { best = ob; at = oa; }
+    }
+    if ((t & 63) == 0) { red[t >> 6] = best; redi[t >> 6] = at; }
+    __syncthreads();
+    if (t == 0) {
+      double bb = red[0];
+      int ba = redi[0];
+      for (int w = 1; w < 4; ++w)
+        if (red[w] > bb || (red[w] == bb && redi[w] < ba)) { bb = red[w]; ba = redi[w]; }
+      if (k == 0) s_first = bb;
+      s_piv = (bb > rel_tol * s_first && bb > 0.0) ? ba : -1;
+      if (s_piv < 0 && s_rank == n) s_rank = k;
+    }
+    __syncthreads();
+    const int pv = s_piv;
+    if (pv < 0) break;
+    if (pv != k) {  // symmetric swap of rows / columns k and pv (full storage: both triangles kept consistent)
+      for (int j = t; j < n; j += 256) {
+        const double x = As[k * ld + j];
+        As[k * ld + j] = As[pv * ld + j];
+        As[pv * ld + j] = x;
+      }
+      __syncthreads();
+      for (int i = t; i < n; i += 256) {
+        const double x = As[i * ld + k];
+        As[i * ld + k] = As[i * ld + pv];
+        As[i * ld + pv] = x;
+      }
+      if (t == 0) { const int x = perm[k]; perm[k] = perm[pv]; perm[pv] = x; }
+      __syncthreads();
+    }
+    const double lkk = sqrt(As[k * ld + k]);
+    __syncthreads();
+    for (int i = k + t; i < n; i += 256) As[i * ld + k] = i == k ? lkk : As[i * ld + k] / lkk;   // column k of L
+    __syncthreads();
+    const int m = n - k - 1;  // trailing update, full square (symmetric storage)
+    for (int idx = t; idx < m * m; idx += 256) {
+      const int i = k + 1 + idx / m, j = k + 1 + idx % m;
+      As[i * ld + j] -= As[i * ld + k] * As[j * ld + k];
+    }
+    __syncthreads();
+  }
+  const int r = s_rank;
+  // L^-1 by forward substitution, one column per thread: L x = e_j
+  for (int j = t; j < r; j += 256) {
+    for (int i = j; i < r; ++i) {
+      double sacc = i == j ? 1.0 : 0.0;
+      for (int q = j; q < i; ++q) sacc -= As[i * ld + q] * Li[q * ld + j];
+      Li[i * ld + j] = sacc / As[i * ld + i];
+    }
+  }
+  __syncthreads();
+  // T[i, perm[q]] = Li[i, q] (q <= i < r), zero elsewhere
+  for (int idx = t; idx < n * n; idx += 256) T[size_t(idx / n) * ldt + idx % n] = 0.0;
+  __syncthreads();
+  for (int idx = t; idx < r * r; idx += 256) {
+    const int i = idx / r, q = idx % r;
+    if (q <= i) T[size_t(i) * ldt + perm[q]] = Li[i * ld + q];
+  }
+  for (int i = t; i < n; i += 256) lam[i] = i < r ? As[i * ld + i] * As[i * ld + i] : 0.0;
+}
+
+static int pivchol_whiten(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, double rel_tol) {
+  if (n <= 0) return ROM_OK;
+  const int ld = n | 1;
+  const size_t lds = 2 * size_t(n) * ld * sizeof(double) + 4 * sizeof(double) + (4 + size_t(n)) * sizeof(int) + 16;
+  if (lds > 64 * 1024 && !ctx->lds_optin_pivchol) {
+    ROM_HIP(hipSetDevice(ctx->device));
+    ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb_pivchol_whiten), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    ctx->lds_optin_pivchol = true;
+  }
+  {
+    ROM_PROF(ctx, "pivchol_whiten", 1.0 * n * n * n, 16.0 * n * n);
+    kb_pivchol_whiten<<<1, 256, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, rel_tol);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
 static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, int mode, double rel_tol,
                      bool gram_like = true) {
   if (n <= 0) return ROM_OK;
@@ -464,13 +582,15 @@ static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam,
 extern "C" int rom_small_eig_host(rom_ctx* ctx, int n, const double* A_host, int mode, double rel_tol, int gram_like,
                                   double* lam_host, double* T_host) {
   ROM_CHECK(ctx && A_host && lam_host && T_host && n >= 1 && n <= SE_MAX, "rom_small_eig_host: bad arguments");
-  ROM_CHECK(mode >= 0 && mode <= 2, "rom_small_eig_host: mode must be 0, 1 or 2");
+  ROM_CHECK(mode >= 0 && mode <= 3, "rom_small_eig_host: mode must be 0, 1, 2 or 3");
+  ROM_CHECK(mode != 3 || n <= SE_LDS_MAX, "rom_small_eig_host: the pivoted-Cholesky whitening takes n <= %d", SE_LDS_MAX);
   Tmp A, lam, T;
   ROM_TRY(A.get(ctx, size_t(n) * n));
   ROM_TRY(lam.get(ctx, n));
   ROM_TRY(T.get(ctx, size_t(n) * n));
   ROM_HIP(hipMemcpyAsync(A.p(), A_host, size_t(n) * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  ROM_TRY(small_eig(ctx, n, A, n, lam, T, n, mode, rel_tol, gram_like != 0));
+  if (mode == 3) ROM_TRY(pivchol_whiten(ctx, n, A, n, lam, T, n, rel_tol));
+  else ROM_TRY(small_eig(ctx, n, A, n, lam, T, n, mode, rel_tol, gram_like != 0));
   ROM_TRY(download(ctx, lam, lam_host, n));
   return download(ctx, T, T_host, size_t(n) * n);
 }
@@ -490,7 +610,8 @@ static int gram_transform(rom_ctx* ctx, double* X, double* Y, int b, int64_t dim
   ROM_TRY(T.get(ctx, size_t(b) * b));
   for (int r = 0; r < rounds; ++r) {
     ROM_TRY(rom_launch_gram(ctx, b, dim, X, dim, G, b));
-    ROM_TRY(small_eig(ctx, b, G, b, lam, T, b, mode, r == 0 ? rel_tol : 1e-8));
+    if (mode == SE_WHITEN && b <= SE_LDS_MAX) ROM_TRY(pivchol_whiten(ctx, b, G, b, lam, T, b, r == 0 ? rel_tol : 1e-8));
+    else ROM_TRY(small_eig(ctx, b, G, b, lam, T, b, mode, r == 0 ? rel_tol : 1e-8));
     ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, b, 1.0, T, b, X, dim, 0.0, Y, dim));
     ROM_HIP(hipMemcpyAsync(X, Y, size_t(b) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   }
@@ -1008,6 +1129,12 @@ __global__ void kb_next_block(double* __restrict__ Zs, const double* __restrict_
     Zs[o + j] = ok ? a * Zr[o + j] : Yr[o + j];
 }
 
+// out[i] = 1 / x[i] (0 where x[i] is not positive)
+__global__ void kb_inv(const double* __restrict__ x, double* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[i] > 0.0 ? 1.0 / x[i] : 0.0;
+}
+
 // out[i] = lam[i] > 0 ? 1 / sqrt(lam[i]) : 0
 __global__ void kb_inv_sqrt(const double* __restrict__ lam, double* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1032,8 +1159,9 @@ struct PodInfo {
 // b x b problems are solved on the device.  theta_host: nev values; W: (nev, M) rows = eigenvectors.
 int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std::vector<double>& theta_host, PodInfo& info,
                    int oversample = 12, double tol = 2e-14, int max_iter = 30, double accept = GRAM_ACCEPT) {
-  const int b = std::min(M, nev + oversample);
-  Tmp Y, Z, H, St, lam, Yr, Zr, Res, res, Zs, scr;
+  const int b0 = std::min(M, nev + oversample);
+  int b = b0;  // rows in play: shrinks once the spectrum shows how many pairs the caller can use (see below)
+  Tmp Y, Z, H, St, lam, Yr, Zr, Res, res, Zs, scr, nrm;
   ROM_TRY(Y.get(ctx, size_t(b) * M));
   ROM_TRY(Z.get(ctx, size_t(b) * M));
   ROM_TRY(H.get(ctx, size_t(b) * b));
@@ -1044,12 +1172,26 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
   ROM_TRY(Res.get(ctx, size_t(b) * M));
   ROM_TRY(Zs.get(ctx, size_t(b) * M));
   ROM_TRY(scr.get(ctx, size_t(b) * M));
-  double* d_res = lam.p() + b;
+  ROM_TRY(nrm.get(ctx, b));
+  double* d_res = lam.p() + b0;
   ROM_TRY(fill_random(ctx, Y, size_t(b) * M, 0x5eed0000ull + unsigned(b) * 131u + unsigned(M), true));
-  ROM_TRY(gram_transform(ctx, Y, scr, b, M, SE_WHITEN, 1e-30, M >= 4 * b ? 1 : 2));  // Gaussian rows: kappa(Gram) ~ 3 when M >> b
-  std::vector<double> th(2 * size_t(b));
+  std::vector<double> th(2 * size_t(b0), 0.0);
   double best = 1e300;
   int stall = 0;
+  if (b == M) {
+    ROM_TRY(gram_transform(ctx, Y, scr, b, M, SE_WHITEN, 1e-30, 2));  // (the full space: one exact Ritz step below)
+  } else {
+    // Iteration 0 is a plain power step: Y_1 = orthonormalised rows of (Gaussian block) G.  A Rayleigh-Ritz step on a
+    // random block only rotates noise -- it costs a b x b eigenproblem and an orthonormalisation of the start block and
+    // leaves the same subspace.
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, M, 1.0, Y, M, G, M, 0.0, Zs, M, "gemm_nt"));
+    ROM_TRY(rom_launch_l2norm(ctx, Zs, b, M, nrm, true));
+    kb_inv<<<unsigned((b + 255) / 256), 256, 0, ctx->stream>>>(nrm, nrm, b);
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(rom_launch_rows_scale(ctx, Zs, b, M, nrm));
+    ROM_TRY(gram_transform(ctx, Zs, scr, b, M, SE_WHITEN, 1e-30, 2));
+    ROM_HIP(hipMemcpyAsync(Y.p(), Zs.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
   for (int it = 0; it < max_iter; ++it) {
     ROM_TRY(rom_launch_gemm_nt(ctx, b, M, M, 1.0, Y, M, G, M, 0.0, Z, M, "gemm_nt"));   // Z = Y G (G symmetric)
     ROM_TRY(rom_launch_gemm_nt(ctx, b, b, M, 1.0, Z, M, Y, M, 0.0, H, b, "gemm_nt"));   // H = Y G Y^T
@@ -1063,21 +1205,35 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
     ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Z, M, 0.0, Zr, M));            // G applied to them
     kb_rows_axpy<<<dim3(unsigned(std::min((M + 255) / 256, 64)), b), 256, 0, ctx->stream>>>(Res, Zr, Yr, lam, -1.0, M);
     ROM_HIP(hipGetLastError());
-    ROM_TRY(rom_launch_l2norm(ctx, Res, nev, M, d_res, true));
-    ROM_TRY(download(ctx, lam, th.data(), 2 * size_t(b)));
+    const int ncheck = std::min(nev, b);
+    ROM_TRY(rom_launch_l2norm(ctx, Res, ncheck, M, d_res, true));
+    ROM_TRY(download(ctx, lam, th.data(), size_t(b0) + ncheck));
+    for (int i = b; i < b0; ++i) th[i] = 0.0;  // (pairs dropped from the block)
     const double t0 = std::max(std::fabs(th[0]), 1e-300);
     double worst = 0.0;
-    for (int i = 0; i < nev; ++i)
-      if (th[i] > accept * std::fabs(th[0])) worst = std::max(worst, th[b + i] / t0);
+    for (int i = 0; i < ncheck; ++i)
+      if (th[i] > accept * std::fabs(th[0])) worst = std::max(worst, th[b0 + i] / t0);
     if (worst < 0.7 * best) { best = worst; stall = 0; } else { ++stall; }
     if (worst <= tol || stall >= 3 || it == max_iter - 1) break;
+    // The caller only takes pairs with theta_i > accept * theta_0.  Once a Rayleigh-Ritz step on an orthonormal block
+    // has shown how many there can be (two orders of magnitude of slack on the threshold), the block is cut down to
+    // those + the oversampling: the rows are Ritz vectors in descending order, so the cut keeps the leading ones.
+    // (A snapshot block with 16 usable pairs out of 50 requested then iterates with 28 rows instead of 62.)
+    {
+      int count = 0;
+      while (count < b && th[count] > 1e-2 * accept * std::fabs(th[0])) ++count;
+      b = std::min(b, std::min(nev, count) + oversample);
+    }
     kb_next_block<<<dim3(unsigned(std::min((M + 255) / 256, 64)), b), 256, 0, ctx->stream>>>(Zs, Zr, Yr, lam, M);
     ROM_HIP(hipGetLastError());
-    ROM_TRY(gram_transform(ctx, Zs, scr, b, M, SE_WHITEN, 1e-30, it == 0 ? 2 : 1));  // (rows are rotated Ritz vectors: nearly orthonormal)
+    ROM_TRY(gram_transform(ctx, Zs, scr, b, M, SE_WHITEN, 1e-30, 1));  // (rows are rotated Ritz vectors: nearly orthonormal)
     ROM_HIP(hipMemcpyAsync(Y.p(), Zs.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   }
   theta_host.assign(th.begin(), th.begin() + nev);
-  ROM_HIP(hipMemcpyAsync(W, Yr.p(), size_t(nev) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  for (int i = b; i < nev; ++i) theta_host[i] = 0.0;
+  const int ncopy = std::min(nev, b);
+  ROM_HIP(hipMemcpyAsync(W, Yr.p(), size_t(ncopy) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  if (ncopy < nev) ROM_HIP(hipMemsetAsync(W + size_t(ncopy) * M, 0, size_t(nev - ncopy) * M * sizeof(double), ctx->stream));
   return ROM_OK;
 }
 

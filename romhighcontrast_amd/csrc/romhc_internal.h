@@ -87,7 +87,7 @@ struct rom_ctx {
   const double* slot_hi[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   bool slot_joined[2] = {true, true};
   // kernels that need more than 64 KB of dynamic LDS must opt in once per DEVICE (a context is one device)
-  bool lds_optin_reduced_solve = false, lds_optin_small_eig = false;
+  bool lds_optin_reduced_solve = false, lds_optin_small_eig = false, lds_optin_pivchol = false;
 };
 
 struct rom_buf {

@@ -255,6 +255,26 @@ def test_small_symmetric_eigensolver_vs_lapack():
     gram = Q @ Q.T
     assert np.abs(gram - np.diag(np.diag(gram))).max() < 1e-10 and sorted(np.round(np.diag(gram), 8))[:1] == [0.0]
     assert np.allclose(sorted(np.diag(gram))[1:], 1.0, atol=1e-10)
+    # pivoted-Cholesky whitening (mode 3: what rom_pod's orthonormalisations use): ill-conditioned, rank-deficient and plain blocks
+    for b, m, kind in ((24, 500, "decay"), (62, 1024, "decay"), (62, 1024, "plain"), (30, 400, "rank10"), (96, 2000, "plain"), (1, 9, "plain")):
+        Xb = rng.standard_normal((b, m))
+        if kind == "decay":
+            Xb = (10.0 ** -np.linspace(0, 7, b))[:, None] * np.linalg.qr(Xb.T)[0].T + 1e-3 * (10.0 ** -np.linspace(0, 7, b))[:, None] * rng.standard_normal((b, m)) / np.sqrt(m)
+            Xb = np.linalg.qr(rng.standard_normal((b, b)))[0] @ Xb     # mixed rows: kappa(X) = 1e7, kappa(Gram) = 1e14
+        if kind == "rank10":
+            Xb = rng.standard_normal((b, 10)) @ rng.standard_normal((10, m))
+        Tc = None
+        Zb = Xb
+        for rnd in range(2):                                            # two rounds, as the library runs them
+            lam_c, Tc = ctx.small_eig(Zb @ Zb.T, mode=3, rel_tol=1e-26 if rnd == 0 else 1e-8)
+            Zb = Tc @ Zb
+        r = int((np.abs(Zb).max(axis=1) > 0).sum())
+        gram = Zb @ Zb.T
+        observed(f"pivoted-Cholesky whitening b={b} {kind}: orthonormality of the {r} rows kept (2 rounds)", np.abs(gram[:r, :r] - np.eye(r)), 1e-10)
+        assert not Zb[r:].any() and (r == b if kind != "rank10" else r == 10), (b, kind, r)
+        # the rows kept span the row space: projecting X onto them loses nothing above the rank threshold
+        lost = np.linalg.norm(Xb - (Xb @ Zb[:r].T) @ Zb[:r], axis=1) / np.linalg.norm(Xb, axis=1).max()
+        observed(f"pivoted-Cholesky whitening b={b} {kind}: rows of X outside the span (relative to the largest row)", lost, 1e-6 if kind == "decay" else 1e-10)
     # Newton-Schulz path (rows orthogonal up to a moderate defect): a Gaussian block, and rotated orthonormal rows + 5 % noise
     for b, m, noise in ((62, 1024, None), (40, 300, 0.05), (96, 4000, None)):
         Yb = rng.standard_normal((b, m)) if noise is None else np.linalg.qr(rng.standard_normal((m, b)))[0].T + noise * rng.standard_normal((b, m)) / np.sqrt(m)
