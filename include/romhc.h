@@ -205,7 +205,7 @@ int rom_orthonormalize_rows(rom_ctx* ctx, rom_buf* X, int64_t x_row0, int n, int
 int rom_greedy(rom_fem* fem, rom_buf* U, int64_t u_row0, int M, rom_buf* a, const double* h1norm_host, int mode, int n,
                int64_t* picks_out, double* max_err_out);
 /* PCA(n_components = n).fit (src/lib/ReducedBasis.py:196): leading n right singular vectors of the (M, dim) block
- * X[x_row0 ...] -- OVERWRITTEN (centred when center != 0, deflated) -- into V[v_row0 ...] (n x dim, orthonormal rows,
+ * X[x_row0 ...] -- OVERWRITTEN when center != 0 (the column means are subtracted in place) -- into V[v_row0 ...] (n x dim, orthonormal rows,
  * scikit-learn's svd_flip(u_based_decision=False) signs) and their singular values into sigma_host (n).  MFMA Gram
  * matrix + subspace iteration for the modes above 1e-5 sigma_1, deflation + randomised range finder below, Rayleigh-
  * Ritz over the collected modes; modes below 1e-13 sigma_1 do not exist in fp64 data and are completed with

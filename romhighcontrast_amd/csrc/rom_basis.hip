@@ -1266,11 +1266,23 @@ int tall_svd_rotation(rom_ctx* ctx, double* Tt, int b, int M, double* Rt, double
 // Leading k right singular vectors / singular values of the (M, dim) block X by a randomised range finder with one power
 // iteration: thin GEMMs (2 b M dim flops each) instead of the 2 M^2 dim of a Gram matrix.  Used for the DEFLATED
 // remainder of a snapshot block.  Vs: (b, dim) block, its first k rows are the modes; ss_host: b singular values.
-int sketched_modes(rom_ctx* ctx, const double* X, int M, int64_t dim, int k, int seed, double* Vs, std::vector<double>& ss_host,
-                   int& b_out, PodInfo& info, int oversample = 8, int power = 1) {
+// The block is DEFLATED IMPLICITLY: X_d = X - Bt^T V with the `found` modes accepted so far (V: found x dim, orthonormal
+// rows; Bt: found x M, row j = X v_j).  Every product with X_d is the product with X followed by a rank-`found`
+// correction (two small GEMMs) -- X itself is never rewritten, which saves a read + write of the whole block per
+// accepted batch of modes.  The rounding error is what the explicit subtraction leaves in X_d as well: eps x sigma_1.
+int sketched_modes(rom_ctx* ctx, const double* X, int M, int64_t dim, const double* V, const double* Bt, int found, int k,
+                   int seed, double* Vs, std::vector<double>& ss_host, int& b_out, PodInfo& info, int oversample = 8,
+                   int power = 1) {
   const int b = int(std::min<int64_t>(std::min<int64_t>(M, dim), k + oversample));
   b_out = b;
-  Tmp Om, Y, scr, Tt, Rt, s2;
+  Tmp Om, Y, scr, Tt, Rt, s2, Cc;
+  ROM_TRY(Cc.get(ctx, size_t(b) * std::max(found, 1)));
+  // out (b x ncols, ld ncols... ) -= ((lhs (b x kk) rhs_t^T (found x kk)) ) other: the two correction shapes below
+  auto correct_rows = [&](double* out /* b x dim */, const double* left /* b x M */) -> int {   // out -= (left Bt^T) V
+    if (found == 0) return ROM_OK;
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, found, M, 1.0, left, M, Bt, M, 0.0, Cc, found, "gemm_nt"));
+    return rom_launch_gemm_nn(ctx, b, dim, found, -1.0, Cc, found, V, dim, 1.0, out, dim);
+  };
   ROM_TRY(Om.get(ctx, size_t(b) * M));
   ROM_TRY(Y.get(ctx, size_t(b) * dim));
   ROM_TRY(scr.get(ctx, size_t(b) * dim));
@@ -1278,17 +1290,23 @@ int sketched_modes(rom_ctx* ctx, const double* X, int M, int64_t dim, int k, int
   ROM_TRY(Rt.get(ctx, size_t(b) * b));
   ROM_TRY(s2.get(ctx, b));
   ROM_TRY(fill_random(ctx, Om, size_t(b) * M, 0xabcd0000ull + unsigned(seed) * 7919u + unsigned(b), true));
-  ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Om, M, X, dim, 0.0, Y, dim));                 // Y = Omega X
+  ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Om, M, X, dim, 0.0, Y, dim));                 // Y = Omega X_d
+  ROM_TRY(correct_rows(Y, Om));
   info.executed += 2.0 * b * M * double(dim);
   for (int it = 0; it <= power; ++it) {
     // Q (rank may drop: zero rows).  Before the power step one round is enough: the rows only have to span the sketch
     // and be aligned with its principal directions -- their residual non-orthogonality (eps x the condition number of
     // the sketch's Gram matrix) does not change what the power step spans; the basis that is USED is whitened twice
     ROM_TRY(gram_transform(ctx, Y, scr, b, dim, SE_WHITEN, 1e-26, it == power ? 2 : 1));
-    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, dim, 1.0, Y, dim, X, dim, 0.0, Tt, M, "gemm_nt"));      // Tt = Q X^T  (b, M)
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, dim, 1.0, Y, dim, X, dim, 0.0, Tt, M, "gemm_nt"));      // Tt = Q X_d^T  (b, M)
+    if (found) {                                                                                  // ... - (Q V^T) Bt
+      ROM_TRY(rom_launch_gemm_nt(ctx, b, found, dim, 1.0, Y, dim, V, dim, 0.0, Cc, found, "gemm_nt"));
+      ROM_TRY(rom_launch_gemm_nn(ctx, b, M, found, -1.0, Cc, found, Bt, M, 1.0, Tt, M));
+    }
     info.executed += 2.0 * b * M * double(dim) + 4.0 * b * b * double(dim);
     if (it == power) break;
-    ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Tt, M, X, dim, 0.0, scr, dim));               // Q X^T X
+    ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Tt, M, X, dim, 0.0, scr, dim));               // Q X_d^T X_d
+    ROM_TRY(correct_rows(scr, Tt));
     ROM_HIP(hipMemcpyAsync(Y.p(), scr.p(), size_t(b) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     info.executed += 2.0 * b * M * double(dim);
   }
@@ -1304,7 +1322,7 @@ int sketched_modes(rom_ctx* ctx, const double* X, int M, int64_t dim, int k, int
 
 }  // namespace
 
-// Leading n right singular vectors / singular values of the (M, dim) block X (overwritten: centred and deflated).
+// Leading n right singular vectors / singular values of the (M, dim) block X (overwritten when it is centred).
 // center != 0: subtract the column means first (sklearn PCA.fit).  V: (n, dim) rows = modes, sign convention of
 // sklearn's svd_flip(u_based_decision=False); sigma_host: n singular values (0 for completed modes);
 // info_host (8 doubles, may be null): resolved modes, completed modes, Gram passes, sketch passes, executed flops,
@@ -1329,14 +1347,11 @@ extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t
   double sigma_1 = 0.0;
   Tmp Bt;  // coefficients of the accepted modes, (n, M): row j = X v_j
   ROM_TRY(Bt.get(ctx, size_t(std::max(n, 1)) * M));
-  auto deflate = [&](int lo, int take, bool last) -> int {
-    // coefficients of the modes V[lo : lo + take] into Bt, and those modes out of X (not when nothing reads X afterwards)
-    Tmp Yc;
-    ROM_TRY(Yc.get(ctx, size_t(M) * take));
-    ROM_TRY(rom_launch_gemm_nt(ctx, M, take, dim, 1.0, X, dim, V + size_t(lo) * dim, dim, 0.0, Yc, take, "gemm_nt"));
-    if (!last) ROM_TRY(rom_launch_gemm_nn(ctx, M, dim, take, -1.0, Yc, take, V + size_t(lo) * dim, dim, 1.0, X, dim));
-    ROM_TRY(transpose(ctx, Bt.p() + size_t(lo) * M, M, Yc, take, M, take));
-    info.executed += (last ? 2.0 : 4.0) * take * M * double(dim);
+  auto deflate = [&](int lo, int take) -> int {
+    // coefficients of the modes V[lo : lo + take] into Bt (row j = X v_j; the modes are orthogonal to the earlier ones, so
+    // X and the deflated block give the same coefficients).  X is not touched: the deflation is implicit (sketched_modes)
+    ROM_TRY(rom_launch_gemm_nt(ctx, take, M, dim, 1.0, V + size_t(lo) * dim, dim, X, dim, 0.0, Bt.p() + size_t(lo) * M, M, "gemm_nt"));
+    info.executed += 2.0 * take * M * double(dim);
     return ROM_OK;
   };
   const int passes = 12;
@@ -1364,7 +1379,7 @@ extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t
       ROM_TRY(rom_launch_gemm_nn(ctx, take, dim, M, 1.0, W, M, X, dim, 0.0, V, dim));   // V = S^-1 W^T Xc
       info.executed += 2.0 * take * M * double(dim);
       ROM_TRY(orthonormalize_against(ctx, V, 0, take, dim));
-      ROM_TRY(deflate(0, take, take >= n || passes <= 1));
+      ROM_TRY(deflate(0, take));
       found = take;
     }
   }
@@ -1379,7 +1394,7 @@ extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t
     const int want = std::min(n - found, 16);
     const int bmax = int(std::min<int64_t>(std::min<int64_t>(M, dim), want + 8));
     ROM_TRY(Vs.get(ctx, size_t(bmax) * dim));
-    ROM_TRY(sketched_modes(ctx, X, M, dim, want, p, Vs, ss, b, info));
+    ROM_TRY(sketched_modes(ctx, X, M, dim, V, Bt, found, want, p, Vs, ss, b, info));
     info.sketch_passes += 1;
     int take = 0;
     while (take < std::min(b, want) && ss[take] > SKETCH_ACCEPT * ss[0] && ss[take] > NOISE_FLOOR * sigma_1) ++take;
@@ -1387,7 +1402,7 @@ extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t
     ROM_HIP(hipMemcpyAsync(V + size_t(found) * dim, Vs.p(), size_t(take) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     ROM_TRY(orthonormalize_against(ctx, V, found, take, dim));
     const bool at_floor = take < b && ss[take] <= NOISE_FLOOR * sigma_1;
-    ROM_TRY(deflate(found, take, at_floor || found + take >= n || p == passes - 1));
+    ROM_TRY(deflate(found, take));
     found += take;
     if (at_floor) break;  // the spectrum has reached the noise floor: nothing left to find
   }
