@@ -1,7 +1,7 @@
-"""Dev probe: per-kernel HIP-event times (rom_profile_*) of one rom_pod call at C2 size and one rom_greedy call at C4 size."""
+"""Per-kernel HIP-event times (rom_profile_*) of the basis-stage calls: rom_pod at C2 / C3 / C5 size (`pod [M]`, `pod5`), rom_greedy at C4 size in both modes (`greedy`), or `all`.  Also the program the round-3 rocprofv3 --kernel-trace --stats summary of the basis stage was taken from (REPS=1 keeps it short)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 from romhighcontrast_amd.lib import SolutionsManagers as SM, ReducedBasis as RB
