@@ -108,7 +108,7 @@ struct X128Args {
 };
 
 template <bool FLAT>
-__global__ void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, int with_expand);
+__global__ void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc, double* __restrict__ U, long long row0, int with_expand, int sys_fast);
 // 4 doubles from an address that is only 8-byte aligned (pointer may be null -> zeros)
 __device__ inline void load4_any(const double* __restrict__ p, double v[4]) {
   if (p) {

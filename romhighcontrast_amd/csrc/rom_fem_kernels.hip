@@ -1136,7 +1136,8 @@ constexpr int X128_SLOT = 4 * 128 * 64;  // bytes
 // 340); a pair of adjacent vertices may then straddle two mesh rows and is stored as two 8-byte halves.
 template <bool FLAT>
 __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc,
-                                                      double* __restrict__ U, long long row0, int with_expand) {
+                                                      double* __restrict__ U, long long row0, int with_expand,
+                                                      int sys_fast) {
   __shared__ __align__(16) char lds_bytes[2 * X128_SLOT];  // two chunk slots = 65,536 B: two workgroups per CU
   __shared__ double scs[128];                               // h^2 / a_b of the workgroup's systems
   double* const lds = reinterpret_cast<double*>(lds_bytes);
@@ -1144,12 +1145,21 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
   const int nct = (n1 + 127) / 128;
   const int nvert = n1 * n1;
   const int ntile = FLAT ? (nvert + 127) / 128 : n1 * nct;
-  if (int(blockIdx.x) >= ntile) {
+  // Workgroup order.  Classic (sys_fast = 0): grid (tiles, system groups, blocks) -- consecutive workgroups walk the
+  // vertex tiles of ONE system group: they share the interface vectors (small) and each reads its own slab of the tables.
+  // sys_fast = number of system groups: 1-D grid in x, the system group varies fastest -- the workgroups in flight at
+  // any time share a few table slabs (128 vertices x K x 8 B each), which then come out of L2 / the Infinity Cache
+  // instead of HBM once per system group; pays where the tables outgrow the caches (C4 / C5).  Placement only: the rows
+  // are the same bits.
+  const int bx = sys_fast ? int(blockIdx.x) / sys_fast : int(blockIdx.x);
+  const int by = sys_fast ? int(blockIdx.x) % sys_fast : int(blockIdx.y);
+  const int ngy = sys_fast ? sys_fast : int(gridDim.y);
+  if (bx >= ntile) {
     // with_expand: the (small) expansion of the edge values rides in `with_expand` extra workgroups per (y, z) cell
     // of this launch -- it depends on nothing here and nothing here depends on it
     static_assert(STAGE_TOTAL * sizeof(double) <= 2 * X128_SLOT, "expansion staging must fit");
     const int nx = f.n1p / 64, ny = (Mc + 63) / 64;
-    const int item = (blockIdx.x - ntile) + with_expand * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int item = (bx - ntile) + with_expand * (by + ngy * blockIdx.z);
     if (threadIdx.x >= 256) return;  // (the expansion is written for four waves)
     if (item < nx * ny * (f.nexp + 1)) expand_tile(f, Mc, U, row0, lds, item % nx, (item / nx) % ny, item / (nx * ny));
     return;
@@ -1167,15 +1177,15 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
   const int b = xa.blocks[bz];
   const int p = b / f.ncb, q = b % f.ncb;
   const BlockSide sd = xa.sides[bz];  // by value and read without branches below: one batch of scalar loads
-  const int iv = blockIdx.x / nct + 1;           // mesh row (1-based interior index)       (!FLAT)
-  const int jv0 = 128 * (blockIdx.x % nct) + 1;  // first vertex of the tile                (!FLAT)
-  const int vt0 = 128 * blockIdx.x;              // first vertex of the tile, block-local   (FLAT)
+  const int iv = bx / nct + 1;           // mesh row (1-based interior index)       (!FLAT)
+  const int jv0 = 128 * (bx % nct) + 1;  // first vertex of the tile                (!FLAT)
+  const int vt0 = 128 * bx;              // first vertex of the tile, block-local   (FLAT)
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = w >> 2, wc = w & 3;
   constexpr int NJ = 2;  // 16-vertex column blocks per wave (wave tile 64 x 32)
   const int fr = lane & 15, kq = lane >> 4;
   double my_sc = 0.0;  // h^2 / a_b of system threadIdx.x: requested now, parked in LDS after the k loop
   if (threadIdx.x < 128) {
-    const int m = blockIdx.y * 128 + threadIdx.x;
+    const int m = by * 128 + threadIdx.x;
     if (m < Mc) my_sc = f.y[size_t(m) * f.nGp + f.sblk0 + b];
   }
   // everything the epilogue needs from memory is fetched before the first store: a load after a store would
@@ -1219,7 +1229,7 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
   const unsigned lds0 = unsigned(size_t((__attribute__((address_space(3))) char*)lds_bytes));
   const unsigned du16 = unsigned(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
   const unsigned ybytes_row = unsigned(f.nGp) * 8u;
-  const int m0 = blockIdx.y * 128;
+  const int m0 = by * 128;
   unsigned voA[2];             // lane offsets behind ybytes + first system + side block
   int vi[2], vj[2];            // the lanes' vertices (1-based) in the wave's two B row groups
 #pragma unroll
@@ -1406,8 +1416,8 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
       }
     }
 }
-template __global__ void k_extend128<false>(FemDev, X128Args, const double*, int, double*, long long, int);
-template __global__ void k_extend128<true>(FemDev, X128Args, const double*, int, double*, long long, int);
+template __global__ void k_extend128<false>(FemDev, X128Args, const double*, int, double*, long long, int, int);
+template __global__ void k_extend128<true>(FemDev, X128Args, const double*, int, double*, long long, int, int);
 
 // interface values that k_expand does not write: cross points and the edges recovered node by node
 __global__ void k_scatter_interface(FemDev f, int Mc, double* __restrict__ U, long long row0) {

@@ -1266,6 +1266,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
 
   f->sw_no_fused = getenv("ROMHC_NO_FUSED") != nullptr;
+  f->sw_x128_sys_fast = getenv("ROMHC_X128_SYS_FAST") != nullptr;
   f->sw_no_ext128 = getenv("ROMHC_NO_EXT128") != nullptr;
   f->sw_no_fold = getenv("ROMHC_NO_FOLD_EXPAND") != nullptr;
   f->sw_no_tile_pairs = getenv("ROMHC_NO_TILE_PAIRS") != nullptr;

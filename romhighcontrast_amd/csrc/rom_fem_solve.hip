@@ -203,9 +203,10 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
               xa.sides[z] = f->sides[xa.blocks[z]];
             }
             const int extra = fold_expand && z0 == 0 ? (items + mt * nz - 1) / (mt * nz) : 0;
-            dim3 grid(t128 + extra, mt, nz);
-            if (flat) k_extend128<true><<<grid, 512, 0, st>>>(d, xa, am, Mc, U, row, extra);
-            else k_extend128<false><<<grid, 512, 0, st>>>(d, xa, am, Mc, U, row, extra);
+            const int sys_fast = f->sw_x128_sys_fast ? mt : 0;
+            dim3 grid(sys_fast ? (t128 + extra) * mt : t128 + extra, sys_fast ? 1 : mt, nz);
+            if (flat) k_extend128<true><<<grid, 512, 0, st>>>(d, xa, am, Mc, U, row, extra, sys_fast);
+            else k_extend128<false><<<grid, 512, 0, st>>>(d, xa, am, Mc, U, row, extra, sys_fast);
           }
         } else {
           dim3 grid(f->n1 * ((f->n1 + 63) / 64), (Mc + 63) / 64, f->n_lr_blocks);
