@@ -1151,9 +1151,19 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
   // any time share a few table slabs (128 vertices x K x 8 B each), which then come out of L2 / the Infinity Cache
   // instead of HBM once per system group; pays where the tables outgrow the caches (C4 / C5).  Placement only: the rows
   // are the same bits.
-  const int bx = sys_fast ? int(blockIdx.x) / sys_fast : int(blockIdx.x);
-  const int by = sys_fast ? int(blockIdx.x) % sys_fast : int(blockIdx.y);
-  const int ngy = sys_fast ? sys_fast : int(gridDim.y);
+  // sys_fast < 0: the same with the XCDs in mind (workgroup i runs on XCD i % 8): units of 8 tiles x all -sys_fast system
+  // groups, tile = position % 8 inside the unit -- every slab is fetched by ONE XCD's L2 instead of all eight.
+  int bx, by, ngy;
+  if (sys_fast > 0) {
+    bx = int(blockIdx.x) / sys_fast; by = int(blockIdx.x) % sys_fast; ngy = sys_fast;
+  } else if (sys_fast < 0) {
+    ngy = -sys_fast;
+    const int unit = int(blockIdx.x) / (8 * ngy), r = int(blockIdx.x) % (8 * ngy);
+    bx = unit * 8 + (r & 7); by = r >> 3;
+  } else {
+    bx = int(blockIdx.x); by = int(blockIdx.y); ngy = int(gridDim.y);
+  }
+  if (bx >= ntile + with_expand) return;  // (padding of the last unit)
   if (bx >= ntile) {
     // with_expand: the (small) expansion of the edge values rides in `with_expand` extra workgroups per (y, z) cell
     // of this launch -- it depends on nothing here and nothing here depends on it

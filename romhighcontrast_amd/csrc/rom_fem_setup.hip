@@ -1207,6 +1207,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     // the segment-major copies k_extend128 reads
     ROM_CHECK(gstotal < (1ll << 31), "rom_fem_create: extension tables too large");
     ROM_HIP(hipMalloc(&f->d_Gs, std::max<size_t>(size_t(gstotal), 1) * sizeof(double)));
+    f->gs_bytes = size_t(gstotal) * sizeof(double);
     for (auto& kv : gsoff) {
       const int c = std::get<0>(kv.first), variant = std::get<1>(kv.first), orient = std::get<2>(kv.first);
       const int nseg = (comps[c].r + 1 + 7) / 8;
@@ -1266,7 +1267,10 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
 
   f->sw_no_fused = getenv("ROMHC_NO_FUSED") != nullptr;
-  f->sw_x128_sys_fast = getenv("ROMHC_X128_SYS_FAST") != nullptr;
+  // k_extend128's workgroup order: system group fastest once the extension tables outgrow what the caches keep next to
+  // the store stream (measured: C5, 4 x 4 / N = 256, tables 100+ MB: fetch 21.7 -> 10.6 GB per sweep, kernel -2...-6 %;
+  // C4, 3 x 3 / N = 171: no gain; C2, 16 MB of tables: 5 % slower) -- ROMHC_X128_SYS_FAST = 0 / 1 / 2 overrides
+  f->sw_x128_sys_fast = getenv("ROMHC_X128_SYS_FAST") ? atoi(getenv("ROMHC_X128_SYS_FAST")) : -1;
   f->sw_no_ext128 = getenv("ROMHC_NO_EXT128") != nullptr;
   f->sw_no_fold = getenv("ROMHC_NO_FOLD_EXPAND") != nullptr;
   f->sw_no_tile_pairs = getenv("ROMHC_NO_TILE_PAIRS") != nullptr;

@@ -203,8 +203,10 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
               xa.sides[z] = f->sides[xa.blocks[z]];
             }
             const int extra = fold_expand && z0 == 0 ? (items + mt * nz - 1) / (mt * nz) : 0;
-            const int sys_fast = f->sw_x128_sys_fast ? mt : 0;
-            dim3 grid(sys_fast ? (t128 + extra) * mt : t128 + extra, sys_fast ? 1 : mt, nz);
+            const int order = f->sw_x128_sys_fast >= 0 ? f->sw_x128_sys_fast : (f->gs_bytes >= (size_t(64) << 20) && mt >= 16 ? 1 : 0);
+            const int sys_fast = order == 1 ? mt : order == 2 ? -mt : 0;
+            const int nx = sys_fast < 0 ? (t128 + extra + 7) / 8 * 8 : t128 + extra;
+            dim3 grid(sys_fast ? nx * mt : nx, sys_fast ? 1 : mt, nz);
             if (flat) k_extend128<true><<<grid, 512, 0, st>>>(d, xa, am, Mc, U, row, extra, sys_fast);
             else k_extend128<false><<<grid, 512, 0, st>>>(d, xa, am, Mc, U, row, extra, sys_fast);
           }

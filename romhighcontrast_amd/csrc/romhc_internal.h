@@ -249,7 +249,9 @@ struct rom_fem {
   // A/B switches of the kernel sequencing, read from the environment ONCE per FE space (rom_fem_create): ROMHC_NO_FUSED,
   // ROMHC_EXT_FLAT (-1: automatic), ROMHC_NO_EXT128, ROMHC_NO_FOLD_EXPAND
   bool sw_no_fused = false, sw_no_ext128 = false, sw_no_fold = false;
-  bool sw_x128_sys_fast = false;  // k_extend128: system group fastest in the workgroup order (tables out of cache, not HBM)
+  int sw_x128_sys_fast = -1;   // -1: by table size
+  size_t gs_bytes = 0;         // bytes of the segment-major extension tables (k_extend128's B operand)
+   // k_extend128: system group fastest in the workgroup order (tables out of cache, not HBM)
   int sw_ext_flat = -1;
   bool sw_no_tile_pairs = false;  // ROMHC_NO_TILE_PAIRS: tile Cholesky with one system per workgroup
   DenseGroup* d_dgroups = nullptr;
