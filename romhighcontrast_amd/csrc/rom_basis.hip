@@ -861,75 +861,119 @@ __global__ void kb_renormalise(double* __restrict__ w, long long dim, const doub
 // the slab a second time; the east neighbour comes from the next lane, across waves through LDS, across workgroups by a
 // load of the workgroup's last thread.  The update goes to a second buffer, not in place: halo entries belong to other
 // workgroups.  partial: [2][M][nblk] (norms, dots).
-constexpr int GU_ROWS = 32, GU_UNROLL = 4;
+// GU_SYS training rows per workgroup share the loads of w_prev and z (L2 resident, but two of the three loads per entry
+// when every row fetches its own).  Measured at C4 (1024 x 262 144, ms per pass; tools/dev/ab_greedy.sh): GU_SYS x
+// GU_UNROLL = 1 x 2..5: 1.15-1.17, 1 x 8: 1.59, 2 x 4: 1.46, 4 x 2: 1.58, 4 x 4: 2.28 (187 VGPRs) -- the pass lives on
+// occupancy (waves in flight hide the HBM latency), not on fewer L2 reads, so the default shares nothing.
+#ifndef GU_SYS_
+#define GU_SYS_ 1
+#endif
+#ifndef GU_UNROLL_
+#define GU_UNROLL_ 2
+#endif
+constexpr int GU_ROWS = 32, GU_UNROLL = GU_UNROLL_, GU_SYS = GU_SYS_;
 template <bool PREV>
 __global__ __launch_bounds__(256) void kb_greedy_pass(StencilGeom g, const double* __restrict__ Rs, double* __restrict__ Rout,
                                                       const double* __restrict__ w_prev, const double* __restrict__ p_prev,
                                                       const double* __restrict__ z, double* __restrict__ partial, int nblk, int M) {
-  __shared__ double red[2][4];
-  __shared__ double west[2][4][GU_UNROLL];  // first column of every wave, per row of the chunk (double buffered)
-  const long long base = blockIdx.z * g.dim;
-  const double* u = Rs + base;
-  double* o = PREV ? Rout + base : nullptr;
-  const double pm = PREV ? p_prev[blockIdx.z] : 0.0;
+  __shared__ double red[2][GU_SYS][4];
+  __shared__ double west[2][4][GU_UNROLL][GU_SYS];  // first column of every wave, per row of the chunk (double buffered)
+  const int m0 = blockIdx.z * GU_SYS;
+  const double* u[GU_SYS];
+  double* o[GU_SYS];
+  double pm[GU_SYS];
+  bool live[GU_SYS];
+#pragma unroll
+  for (int k = 0; k < GU_SYS; ++k) {
+    const int mk = min(m0 + k, M - 1);  // (the last group repeats its last row; the repeats are neither stored nor reported)
+    live[k] = m0 + k < M;
+    u[k] = Rs + mk * g.dim;
+    o[k] = PREV ? Rout + mk * g.dim : nullptr;
+    pm[k] = PREV ? p_prev[mk] : 0.0;
+  }
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * GU_ROWS, r1 = min(g.nr, r0 + GU_ROWS);
   const bool in = c < g.nc;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  auto at = [&](int r, int cc) -> double {
-    const long long i = (long long)r * g.nc + cc;
-    return PREV ? u[i] - pm * w_prev[i] : u[i];
-  };
-  double s = 0.0, dt = 0.0;
-  double north = (in && r0 > 0) ? at(r0 - 1, c) : 0.0;
+  double s[GU_SYS], dt[GU_SYS], north[GU_SYS];
+  {
+    const long long i = (long long)(r0 - 1) * g.nc + c;
+    const bool ok = in && r0 > 0;
+    const double wn = (PREV && ok) ? w_prev[i] : 0.0;
+#pragma unroll
+    for (int k = 0; k < GU_SYS; ++k) {
+      s[k] = dt[k] = 0.0;
+      north[k] = ok ? (PREV ? u[k][i] - pm[k] * wn : u[k][i]) : 0.0;
+    }
+  }
   int buf = 0;
   for (int rb = r0; rb < r1; rb += GU_UNROLL, buf ^= 1) {
-    double x[GU_UNROLL], xe[GU_UNROLL], zz[GU_UNROLL];
+    double x[GU_SYS][GU_UNROLL], xe[GU_SYS][GU_UNROLL], zz[GU_UNROLL];
 #pragma unroll
     for (int q = 0; q < GU_UNROLL; ++q) {
       const int r = rb + q;
-      x[q] = (in && r < r1) ? at(r, c) : 0.0;
-      zz[q] = (in && r < r1) ? z[(long long)r * g.nc + c] : 0.0;
-      xe[q] = (threadIdx.x == 255 && c + 1 < g.nc && r < r1) ? at(r, c + 1) : 0.0;
+      const long long i = (long long)r * g.nc + c;
+      const bool ok = in && r < r1;
+      const bool edge = threadIdx.x == 255 && c + 1 < g.nc && r < r1;
+      const double wv = (PREV && ok) ? w_prev[i] : 0.0;
+      const double we = (PREV && edge) ? w_prev[i + 1] : 0.0;
+      zz[q] = ok ? z[i] : 0.0;
+#pragma unroll
+      for (int k = 0; k < GU_SYS; ++k) {
+        x[k][q] = ok ? (PREV ? u[k][i] - pm[k] * wv : u[k][i]) : 0.0;
+        xe[k][q] = edge ? (PREV ? u[k][i + 1] - pm[k] * we : u[k][i + 1]) : 0.0;
+      }
     }
     if (lane == 0) {
 #pragma unroll
-      for (int q = 0; q < GU_UNROLL; ++q) west[buf][wave][q] = x[q];
+      for (int q = 0; q < GU_UNROLL; ++q)
+#pragma unroll
+        for (int k = 0; k < GU_SYS; ++k) west[buf][wave][q][k] = x[k][q];
     }
     // (uniform trip count: r0, r1 depend on the block only; the other buffer is read one barrier later.  The barrier
-    // waits for the LDS writes only: __syncthreads() would also drain every global load in flight -- the z values and
-    // whatever the compiler has hoisted from the next chunk -- once per four rows)
+    // waits for the LDS writes only: __syncthreads() would also drain every global load in flight -- whatever the compiler
+    // has hoisted from the next chunk -- once per four rows)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int q = 0; q < GU_UNROLL; ++q) {
       const int r = rb + q;
-      double east = __shfl_down(x[q], 1, 64);
-      if (lane == 63) east = wave < 3 ? west[buf][wave + 1][q] : xe[q];
-      if (in && r < r1) {
-        if (PREV) __builtin_nontemporal_store(x[q], &o[(long long)r * g.nc + c]);  // (written once, read by the next pass: +3 %)
-        if (c + 1 >= g.nc) east = 0.0;
-        const double dh = x[q] - east, dv = x[q] - north;
-        s += dh * dh + dv * dv;
-        if (c == 0) s += x[q] * x[q];
-        if (r == g.nr - 1) s += x[q] * x[q];
-        dt += x[q] * zz[q];
-        north = x[q];
+      const bool ok = in && r < r1;
+#pragma unroll
+      for (int k = 0; k < GU_SYS; ++k) {
+        double east = __shfl_down(x[k][q], 1, 64);
+        if (lane == 63) east = wave < 3 ? west[buf][wave + 1][q][k] : xe[k][q];
+        if (ok) {
+          if (PREV && live[k]) __builtin_nontemporal_store(x[k][q], &o[k][(long long)r * g.nc + c]);  // (read by the next pass only)
+          if (c + 1 >= g.nc) east = 0.0;
+          const double dh = x[k][q] - east, dv = x[k][q] - north[k];
+          s[k] += dh * dh + dv * dv;
+          if (c == 0) s[k] += x[k][q] * x[k][q];
+          if (r == g.nr - 1) s[k] += x[k][q] * x[k][q];
+          dt[k] += x[k][q] * zz[q];
+          north[k] = x[k][q];
+        }
       }
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    s += __shfl_down(s, off, 64);
-    dt += __shfl_down(dt, off, 64);
-  }
-  if (lane == 0) {
-    red[0][wave] = s;
-    red[1][wave] = dt;
+  for (int k = 0; k < GU_SYS; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s[k] += __shfl_down(s[k], off, 64);
+      dt[k] += __shfl_down(dt[k], off, 64);
+    }
+    if (lane == 0) {
+      red[0][k][wave] = s[k];
+      red[1][k][wave] = dt[k];
+    }
   }
   __syncthreads();
-  if (threadIdx.x < 2) {
-    const long long at_ = (threadIdx.x * (long long)M + blockIdx.z) * nblk + blockIdx.y * gridDim.x + blockIdx.x;
-    partial[at_] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+  if (threadIdx.x < 2 * GU_SYS) {
+    const int which = threadIdx.x / GU_SYS, k = threadIdx.x % GU_SYS;
+    if (m0 + k < M) {
+      const long long at_ = (which * (long long)M + m0 + k) * nblk + blockIdx.y * gridDim.x + blockIdx.x;
+      partial[at_] = red[which][k][0] + red[which][k][1] + red[which][k][2] + red[which][k][3];
+    }
   }
 }
 
@@ -1021,7 +1065,7 @@ extern "C" int rom_greedy(rom_fem* f, rom_buf* U, int64_t u_row0, int M, rom_buf
   ROM_TRY(maxerr.get(ctx, n));
   ROM_TRY(t.get(ctx, nb));
   ROM_TRY(nrm.get(ctx, 1));
-  const dim3 ugrid((g.nc + 255) / 256, (g.nr + GU_ROWS - 1) / GU_ROWS, M);
+  const dim3 ugrid((g.nc + 255) / 256, (g.nr + GU_ROWS - 1) / GU_ROWS, (M + GU_SYS - 1) / GU_SYS);
   const int nblk = int(ugrid.x * ugrid.y);
   ROM_TRY(part.get(ctx, 2 * size_t(M) * nblk));
   int* d_picks = reinterpret_cast<int*>(ipick.p());
