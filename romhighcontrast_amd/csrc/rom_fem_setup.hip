@@ -1268,7 +1268,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
 
   f->sw_no_fused = getenv("ROMHC_NO_FUSED") != nullptr;
   // k_extend128's workgroup order: system group fastest once the extension tables outgrow what the caches keep next to
-  // the store stream (measured: C5, 4 x 4 / N = 256, tables 100+ MB: fetch 21.7 -> 10.6 GB per sweep, kernel -2...-6 %;
+  // the store stream (measured: C5, 4 x 4 / N = 256, tables 100+ MB: fetch 21.7 -> 10.6 GB per launch of 2048 systems, kernel -2...-6 %;
   // C4, 3 x 3 / N = 171: no gain; C2, 16 MB of tables: 5 % slower) -- ROMHC_X128_SYS_FAST = 0 / 1 / 2 overrides
   f->sw_x128_sys_fast = getenv("ROMHC_X128_SYS_FAST") ? atoi(getenv("ROMHC_X128_SYS_FAST")) : -1;
   f->sw_no_ext128 = getenv("ROMHC_NO_EXT128") != nullptr;
