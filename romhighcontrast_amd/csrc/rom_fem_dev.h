@@ -67,7 +67,10 @@ struct FemDev {
 FemDev make_dev(const rom_fem* f);
 
 constexpr int COEF_MAX = 64;   // term weights cached in LDS per pass
-constexpr int PAIR_RING = 8;          // (term, block) pairs in flight in the single-tile assembly
+#ifndef PAIR_RING_
+#define PAIR_RING_ 8
+#endif
+constexpr int PAIR_RING = PAIR_RING_;  // (term, block) pairs in flight in the single-tile assembly
 constexpr int DENSE_GROUPS_MAX = 8;  // closed-form edges whose coefficient blocks k_solve1 builds
 
 // row of H0 that holds the extension from side s evaluated at interior vertex (i,j), 1-based
