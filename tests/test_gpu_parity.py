@@ -445,6 +445,28 @@ def test_ragged_geometries_vs_oracle(api, blocks, N):
     assert relh10(g, U, ro.generate_solutions(g, a)).max() < SNAP_TOL
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_seeded_random_geometries_vs_oracle(api, seed):
+    """Geometry fuzz: block grid, resolution, batch size and contrast drawn from a seeded generator -- strips, single
+    blocks, one-node edges, grids with several reduced tiles -- snapshots and H10 norms against the SuperLU oracle."""
+    SM, _ = api
+    rng = np.random.default_rng(1000 + seed)
+    blocks = (int(rng.integers(1, 5)), int(rng.integers(1, 5)))
+    N = int(rng.integers(2, 49))
+    if blocks[0] * blocks[1] * N * N > 12000:  # keep the oracle's sparse solves short
+        N = max(2, int((12000 / (blocks[0] * blocks[1])) ** 0.5))
+    M = int(rng.integers(1, 40))
+    decades = float(rng.uniform(0.5, 4.0))
+    a = 10.0 ** rng.uniform(0, decades, size=(M,) + blocks)
+    sm = SM.SolutionsManagerFEM(blocks, N)
+    g = ro.Geometry(blocks, N)
+    U = sm.generate_solutions(a)
+    Uo = ro.generate_solutions(g, a)
+    tag = f"fuzz {seed}: {blocks[0]}x{blocks[1]} N={N} M={M} contrast 1e{decades:.1f}"
+    observed(f"{tag}: snapshots vs oracle (rel H10)", relh10(g, U, Uo), SNAP_TOL)
+    observed(f"{tag}: H10 norms vs oracle (relative)", np.abs(sm.H10norm(U) / ro.H10norm(g, Uo) - 1.0), SNAP_TOL)
+
+
 def test_workspace_chunking_and_streams(api):
     """A small factor-workspace budget forces the sweep through several chunks (and the multi-stream
     sub-batch path); results must be bit-identical to the single-chunk run."""
@@ -964,7 +986,7 @@ def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
     ab = ctx.upload(a)
     out = {}
     for name, env in (("row", {"ROMHC_EXT_FLAT": "0"}), ("flat", {"ROMHC_EXT_FLAT": "1"}), ("t64", {"ROMHC_NO_EXT128": "1"}),
-                      ("default", {})):
+                      ("sysfast", {"ROMHC_X128_SYS_FAST": "1"}), ("xcd", {"ROMHC_X128_SYS_FAST": "2"}), ("default", {})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)  # (the switches are read once per FE space)
@@ -974,7 +996,7 @@ def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
         out[name] = U.download(shape=(M, fem.dim))
         for k in env:
             monkeypatch.delenv(k)
-    for name in ("flat", "t64", "default"):
+    for name in ("flat", "t64", "sysfast", "xcd", "default"):  # (sysfast / xcd: the two other workgroup orders of k_extend128)
         assert np.array_equal(out[name], out["row"]), name
     g = ro.Geometry(blocks, N)
     if N <= 40:
