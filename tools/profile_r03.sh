@@ -5,6 +5,7 @@
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03prof
+if [ "$1" = "c45only" ]; then mkdir -p $O; set -- c45; else
 rm -rf $O; mkdir -p $O
 cd $R
 timeout -k 10 500 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
@@ -33,3 +34,17 @@ done
 python3 $R/tools/pmc_summary.py $O/basis_greedy_FETCH_SIZE.csv $O/basis_greedy_WRITE_SIZE.csv $O/basis_greedy_pmc_traffic.json > /dev/null
 rm -f $O/*.err
 ls -la $O
+fi
+# PMC traffic of the C4 / C5 sweeps (one launch = the whole sweep: ROMHC_STREAMS=1, as in the bench's per-kernel pass)
+if [ "$1" = "c45" ] || [ "$1" = "all" ]; then
+cd /tmp
+for cfg in c4 c5; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    ROMHC_STREAMS=1 timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/p45_$c -- python3 $R/bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/p45.err
+    find $O/p45_$c -name "*counter_collection.csv" | tail -1 | xargs -I{} cp {} $O/p45_$c.csv
+    rm -rf $O/p45_$c
+  done
+  python3 $R/tools/pmc_summary.py $O/p45_FETCH_SIZE.csv $O/p45_WRITE_SIZE.csv $O/pmc_traffic_$cfg.json > /dev/null
+  rm -f $O/p45_*.csv $O/p45.err
+done
+fi
