@@ -124,19 +124,40 @@ def _launcher_start_time() -> str:
 
 
 def rendezvous_path() -> str:
-    """File through which rank 0 publishes the RCCL unique id of ONE launch.  A launcher that names its launch --
-    ROMHC_LAUNCH_ID (bench.py's own launcher, a fresh uuid per launch) or TORCHELASTIC_RUN_ID (torch.distributed.run) --
-    is identified by that name together with MASTER_ADDR / MASTER_PORT alone: the ranks may then be started through
-    wrappers (their parent pids differ).  Without a launch id the parent process (pid + start time) stands in for it."""
-    run_id = os.environ.get("ROMHC_LAUNCH_ID", os.environ.get("TORCHELASTIC_RUN_ID"))
+    """File through which rank 0 publishes the RCCL unique id of ONE launch.  A launcher that NAMES its launch --
+    ROMHC_LAUNCH_ID (bench.py's own launcher, a fresh uuid per launch) or a TORCHELASTIC_RUN_ID other than
+    torch.distributed.run's default "none" (--rdzv-id) -- is identified by that name together with MASTER_ADDR /
+    MASTER_PORT alone: the ranks may then be started through wrappers (their parent pids differ).  Without such a name
+    the parent process (pid + start time) stands in for it: direct children of one launcher share it, and a later
+    launch on the same port does not."""
+    run_id = os.environ.get("ROMHC_LAUNCH_ID") or os.environ.get("TORCHELASTIC_RUN_ID")
+    if run_id in (None, "", "none"):
+        run_id = None
     tag = [os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0")]
     tag += [run_id] if run_id else ["none", str(os.getppid()), _launcher_start_time()]
     return os.path.join(tempfile.gettempdir(), "romhc_rdzv_" + "_".join(tag) + ".bin")
 
 
+def _own_start_time() -> float:
+    """Wall-clock time at which this process was started (seconds since the epoch)."""
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            uptime = float(f.read().split()[0])
+        return time.time() - uptime + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, IndexError, ValueError):
+        return 0.0
+
+
+STALE_MARGIN_S = 30.0   # ranks of one launch start within seconds of each other; a file older than this is another launch's
+
+
 def exchange_unique_id(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
     """Rank 0 creates the id and publishes it atomically through a file unique to this launch
-    (MASTER_ADDR/PORT + run id + parent pid); the other ranks poll for it."""
+    (MASTER_ADDR/PORT + run id, or + parent pid and its start time); the other ranks poll for it.  A file written more
+    than STALE_MARGIN_S before this process started is a leftover of a launch that died before its cleanup (same port,
+    same name): it is ignored, rank 0 of THIS launch replaces it."""
     path = rendezvous_path()
     if rank == 0:
         uid = make_id()
@@ -146,12 +167,14 @@ def exchange_unique_id(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
         os.replace(tmp, path)
         return uid
     t0 = time.time()
+    not_before = _own_start_time() - STALE_MARGIN_S
     while time.time() - t0 < timeout_s:
         try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) >= 128:
-                return uid[:128]
+            if os.stat(path).st_mtime >= not_before:
+                with open(path, "rb") as f:
+                    uid = f.read()
+                if len(uid) >= 128:
+                    return uid[:128]
         except FileNotFoundError:
             pass
         time.sleep(0.02)

@@ -126,6 +126,51 @@ def test_sharded_sweep_two_ranks_gloo(tmp_path, M):
         assert "OK" in o
 
 
+def test_rendezvous_key_and_stale_files(tmp_path, monkeypatch):
+    """The RCCL unique-id file: torch.distributed.run's default run id "none" does not name a launch (the parent process
+    does), a real run id or ROMHC_LAUNCH_ID does; a leftover of an earlier launch under the same name is not taken for
+    this launch's id."""
+    import tempfile
+    import threading
+    import time
+    from romhighcontrast_amd import sweep
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    monkeypatch.delenv("ROMHC_LAUNCH_ID", raising=False)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    by_parent = sweep.rendezvous_path()
+    assert str(os.getppid()) in os.path.basename(by_parent)
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID")
+    assert sweep.rendezvous_path() == by_parent
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job42")
+    named = sweep.rendezvous_path()
+    assert "job42" in named and str(os.getppid()) not in os.path.basename(named).split("job42")[1]
+    monkeypatch.setenv("ROMHC_LAUNCH_ID", "abc")
+    assert "abc" in sweep.rendezvous_path() and "job42" not in sweep.rendezvous_path()
+    # a stale file (another launch's id, written long before this process started) is ignored until rank 0 replaces it
+    path = sweep.rendezvous_path()
+    with open(path, "wb") as f:
+        f.write(b"\xff" * 128)
+    old = time.time() - 3600.0
+    os.utime(path, (old, old))
+    fresh = bytes(range(128))
+
+    def rank0_later():
+        time.sleep(0.3)
+        sweep.exchange_unique_id(0, lambda: fresh)
+
+    th = threading.Thread(target=rank0_later)
+    th.start()
+    got = sweep.exchange_unique_id(1, None, timeout_s=20.0)
+    th.join()
+    assert got == fresh
+    sweep.cleanup_rendezvous(0)
+    assert not os.path.exists(path)
+    with pytest.raises(TimeoutError):
+        sweep.exchange_unique_id(1, None, timeout_s=0.2)
+
+
 _STEP_WORKER = r'''
 import os, sys
 import numpy as np
