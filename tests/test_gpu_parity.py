@@ -1240,3 +1240,15 @@ def test_g8_experiment_statistics(api):
                 gap = np.abs(got - ref).reshape(len(ref), -1).max(axis=1) / scale   # per test parameter
                 assert gap[~hard].max() <= tol and gap[hard].max() <= max(tol, 1e-4), \
                     (b.name, n, f, gap[~hard].max(), gap[hard].max(), tol, np.linalg.cond(Eb))
+
+
+def test_plain_c_caller_end_to_end(tmp_path):
+    """tests/c_abi/c_abi_smoke.c: a C99 program drives the C-ABI directly -- FE space, sweep, stencil residual of every
+    snapshot, H10 norms, rom_greedy, rom_project_h10, rom_pod -- and checks the identities listed in its header."""
+    import subprocess
+    from test_host_logic import _build_c_caller
+    exe, env = _build_c_caller(tmp_path)
+    r = subprocess.run([exe], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and out.rstrip().endswith("OK"), out
+

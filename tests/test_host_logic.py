@@ -468,3 +468,29 @@ def test_environment_switches_are_documented():
     launcher = {"ROMHC_LAUNCH_ID", "ROMHC_FORCE_DEVICE"}  # set / read by bench.py's launcher, not by the library
     assert read - dev_only <= doc, sorted(read - dev_only - doc)
     assert doc - launcher <= read, sorted(doc - launcher - read)
+
+
+def _build_c_caller(tmp_path):
+    """gcc -std=c99 build of tests/c_abi/c_abi_smoke.c against include/romhc.h and the in-tree libromhc.so."""
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    exe = str(tmp_path / "c_abi_smoke")
+    libdir = os.path.join(root, "romhighcontrast_amd", "csrc")
+    cmd = [gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "c_abi", "c_abi_smoke.c"), "-L", libdir, "-lromhc", "-lm", "-o", exe]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()
+    return exe, dict(os.environ, LD_LIBRARY_PATH=libdir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+
+
+def test_plain_c_caller_builds_against_the_header(tmp_path):
+    """include/romhc.h is a C header (no C++, no torch types): a C99 program that calls the sweep, the norms and the
+    single-call basis stage compiles with -Wall -Wextra -Werror, links against libromhc.so and starts; without a GPU it
+    is told so through rom_last_error() (the compute part of the same program is a -m gpu test)."""
+    exe, env = _build_c_caller(tmp_path)
+    r = subprocess.run([exe, "--symbols"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "libromhc version" in out and "rom_device_count ->" in out, out
+
