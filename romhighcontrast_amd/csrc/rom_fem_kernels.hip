@@ -209,7 +209,7 @@ __device__ inline void accumulate_klist_dma(const FemDev& f, int slot, const dou
   auto dma = [](unsigned lds_addr, const char* base, unsigned voff) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff),
                  "s"(x128_uniform(base))
-                 : "memory");
+                 : "memory", "m0");
   };
   auto issue = [&](int ch, unsigned slot_off) {
     const int p = ch >> 2, c = ch & 3;
@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
 #define X_DMA(LDS_, BASE_, VOFF_)                                                                                  \
   asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(LDS_)),   \
                "v"(VOFF_), "s"(x128_uniform(BASE_))                                                                \
-               : "memory")
+               : "memory", "m0")
   // the 4 loads of the segment under the cursor into half H_ of slot SLOT_, then the cursor moves on
 #define X_ISSUE_HALF(SLOT_, H_, MINE_)                                                                             \
   do {                                                                                                             \

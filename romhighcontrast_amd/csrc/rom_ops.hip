@@ -145,6 +145,50 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_wave(long long m, long lo
   }
 }
 
+// A/B switch (read once): the 64 x 64 register-staged engine for the thin shapes too
+static bool no_thin_gemm() {
+  static const bool off = getenv("ROMHC_NO_THIN_GEMM") != nullptr;
+  return off;
+}
+template <int MI>
+__global__ void k_gemm_nt_thin(long long m, long long n, long long K, long long kper, const double* __restrict__ A, long long lda,
+                               const double* __restrict__ B, long long ldb, double* __restrict__ part);  // (defined below)
+// thin A (m <= 64) against a long K: k_gemm_nt_thin over 128-row tiles of B x split-K, then the deterministic reduction
+static int launch_gemm_nt_thin(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
+                               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const char* prof_name) {
+  const long long tiles = (n + 127) / 128;
+  // one full round of the 768 resident workgroups (3 per CU), at least 512 columns of K per workgroup
+  long long splits = std::max<long long>(1, std::min<long long>((768 + tiles - 1) / tiles, k / 512));
+  long long kper = ((k + splits - 1) / splits + BK - 1) / BK * BK;
+  splits = (k + kper - 1) / kper;
+  double* part = nullptr;
+  ROM_TRY(rom_ctx_scratch(ctx, size_t(splits) * m * n, &part));
+  const dim3 grid{unsigned(tiles), 1u, unsigned(splits)};
+  {
+    static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;
+    char nm[64];
+    detail ? snprintf(nm, sizeof nm, "%s_thin_%lldx%lldx%lld_s%lld", prof_name, (long long)m, (long long)n, (long long)k, splits)
+           : snprintf(nm, sizeof nm, "%s", prof_name);
+    ROM_PROF(ctx, nm, 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(splits) * m * n));
+    switch ((m + 15) / 16) {
+      case 1: k_gemm_nt_thin<1><<<grid, 256, 0, ctx->stream>>>(m, n, k, kper, A, lda, B, ldb, part); break;
+      case 2: k_gemm_nt_thin<2><<<grid, 256, 0, ctx->stream>>>(m, n, k, kper, A, lda, B, ldb, part); break;
+      case 3: k_gemm_nt_thin<3><<<grid, 256, 0, ctx->stream>>>(m, n, k, kper, A, lda, B, ldb, part); break;
+      default: k_gemm_nt_thin<4><<<grid, 256, 0, ctx->stream>>>(m, n, k, kper, A, lda, B, ldb, part); break;
+    }
+  }
+  ROM_HIP(hipGetLastError());
+  {
+    ROM_PROF(ctx, "splitk_reduce", double(splits) * m * n, 8.0 * double(splits + 1) * m * n);
+    if (splits >= 16 && m * n <= 65536)
+      k_splitk_reduce_wave<<<unsigned((m * n + 3) / 4), 256, 0, ctx->stream>>>(m, n, int(splits), alpha, part, beta, C, ldc, 0);
+    else
+      k_splitk_reduce<<<unsigned((m * n + 255) / 256), 256, 0, ctx->stream>>>(m, n, int(splits), alpha, part, beta, C, ldc, 0);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
 int rom_launch_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const char* prof_name) {
   return rom_launch_gemm_nt_ex(ctx, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, prof_name, 0);
@@ -156,6 +200,9 @@ int rom_launch_gemm_nt_ex(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double 
                           const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const char* prof_name,
                           int lower_only) {
   if (m <= 0 || n <= 0) return ROM_OK;
+  if (!lower_only && m <= 64 && n >= 256 && k >= 2048 && size_t(lda) * 8 * 64 < (size_t(1) << 32) &&
+      size_t(ldb) * 8 * 128 < (size_t(1) << 32) && !no_thin_gemm())
+    return launch_gemm_nt_thin(ctx, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, prof_name);
   const long long nt = (m + 63) / 64;
   const long long tiles = lower_only ? nt * (nt + 1) / 2 : nt * ((n + 63) / 64);  // tiles that do work
   int splits = 1;
@@ -284,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_gram128(long long m, long long K, lo
 #define G_DMA(LDS_, BASE_, VOFF_)                                                                                   \
   asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(LDS_)),    \
                "v"(VOFF_), "s"(BASE_)                                                                               \
-               : "memory")
+               : "memory", "m0")
 #define G_ISSUE(SLOT_)                                                                                              \
   do {                                                                                                              \
     const unsigned sl_ = lds0 + unsigned(SLOT_) * G128_SLOT + unsigned(w) * 4096;                                   \
@@ -418,6 +465,278 @@ extern "C" int rom_gram(rom_ctx* ctx, int64_t m, int64_t k, rom_buf* A, size_t a
 }
 
 // ============================================================================================
+// THIN contractions against a snapshot block (round 3): one operand has at most 64 rows (sketches, modes, basis
+// vectors), the other is the (M, dim) block -- HBM bound: the block should stream through ONCE at the rate of a copy.
+// The 64 x 64 register-staged engine above reaches 2.4-3.0 TB/s on these shapes; the two kernels below take their
+// operand chunks by LDS-DMA like k_gram128 (no staging registers, 128-row / 128-column workgroup tiles: twice the bytes
+// in flight per instruction issued) and give a wave only the 16-row blocks of the thin operand that carry data
+// (MI = ceil(m / 16): the fp64 MFMA rate would bound a 64-row padded product at ~4.3 TB/s).
+// ============================================================================================
+#define T_DMA(LDS_, BASE_, VOFF_)                                                                                   \
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(LDS_)),    \
+               "v"(VOFF_), "s"(BASE_)                                                                               \
+               : "memory", "m0")
+
+// ---- NT: part[z][m][n] = A[m, Kz] B[n, Kz]^T, m <= 64, K snapshot-long (split over z) --------------------------------
+// Workgroup: all rows of A x 128 rows of B; wave w: B rows 32 w .. 32 w + 31, accumulators [MI][2].  Slot = {A: 64 rows x
+// 128 B | B: 128 rows x 128 B}, a row's eight 16-byte units at position u ^ ((row >> 1) & 7) (k_gram128's layout); two
+// slots, chunk ch + 1 in flight under the MFMAs of chunk ch.  Rows behind the operands are clamped (not stored).
+constexpr int TN_A = 64 * 128;              // bytes
+constexpr int TN_SLOT = TN_A + 128 * 128;   // 24,576 B; two slots: three workgroups per CU
+template <int MI>
+__global__ __launch_bounds__(256) void k_gemm_nt_thin(long long m, long long n, long long K, long long kper,
+                                                      const double* __restrict__ A, long long lda,
+                                                      const double* __restrict__ B, long long ldb, double* __restrict__ part) {
+  __shared__ __align__(16) char lds[2 * TN_SLOT];
+  const unsigned lds0 = unsigned(size_t((__attribute__((address_space(3))) char*)lds));
+  const long long c0 = blockIdx.x * 128LL;
+  const long long kbeg = blockIdx.z * kper, kend = std::min<long long>(K, kbeg + kper);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, kq = lane >> 4;
+  d4_t acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+  const int nfull = int((kend - kbeg) / BK), rem = int((kend - kbeg) % BK);
+  unsigned fa[4], fb[4];
+#pragma unroll
+  for (int kki = 0; kki < 4; ++kki) {
+    const unsigned uo = unsigned((((2 * kki) ^ (kq >> 1) ^ (fr >> 1)) << 4) + (kq & 1) * 8);
+    fa[kki] = unsigned(fr * 128) + uo;
+    fb[kki] = unsigned(TN_A + (w * 32 + fr) * 128) + uo;
+  }
+#define TN_FRAGS(SLOT_, KKI_, AF_, BF_)                                                                    \
+  do {                                                                                                     \
+    const char* pa_ = lds + (SLOT_) * TN_SLOT + fa[KKI_];                                                  \
+    const char* pb_ = lds + (SLOT_) * TN_SLOT + fb[KKI_];                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_) AF_[i_] = *reinterpret_cast<const double*>(pa_ + i_ * 2048); \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) BF_[j_] = *reinterpret_cast<const double*>(pb_ + j_ * 2048);  \
+  } while (0)
+  // DMA: 8 rows per instruction; wave w fetches A rows 16 w + 8 q (q < 2) and B rows 32 w + 8 q (q < 4)
+  unsigned voA[2], voB[4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int rl = 16 * w + 8 * q + (lane >> 3);
+    const long long ra = std::min<long long>(rl, m - 1);
+    voA[q] = unsigned(ra * lda * 8) + unsigned(((lane & 7) ^ ((rl >> 1) & 7)) * 16);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rl = 32 * w + 8 * q + (lane >> 3);
+    const long long rb = std::min<long long>(rl, n - 1 - c0);
+    voB[q] = unsigned(rb * ldb * 8) + unsigned(((lane & 7) ^ ((rl >> 1) & 7)) * 16);
+  }
+  const char* sA = reinterpret_cast<const char*>(A + kbeg);
+  const char* sB = reinterpret_cast<const char*>(B + c0 * ldb + kbeg);
+#define TN_ISSUE(SLOT_)                                                                                      \
+  do {                                                                                                       \
+    const unsigned sl_ = lds0 + unsigned(SLOT_) * TN_SLOT;                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) T_DMA(sl_ + unsigned(16 * w + 8 * q_) * 128u, sA, voA[q_]);        \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) T_DMA(sl_ + TN_A + unsigned(32 * w + 8 * q_) * 128u, sB, voB[q_]); \
+    sA += BK * 8;                                                                                            \
+    sB += BK * 8;                                                                                            \
+  } while (0)
+  if (nfull > 0) {
+    TN_ISSUE(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    double af[2][MI], bf[2][2];
+    TN_FRAGS(0, 0, af[0], bf[0]);
+    for (int ch = 0; ch < nfull; ++ch) {
+      const int slot = ch & 1;
+      if (ch + 1 < nfull) TN_ISSUE(slot ^ 1);  // (everybody left that slot at the barrier behind chunk ch - 1)
+#pragma unroll
+      for (int kki = 0; kki < 4; ++kki) {
+        const int pb = kki & 1;
+        if (kki < 3) TN_FRAGS(slot, kki + 1, af[pb ^ 1], bf[pb ^ 1]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][i], bf[pb][j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // chunk ch + 1 is in LDS for everybody
+      if (ch + 1 < nfull) TN_FRAGS(slot ^ 1, 0, af[0], bf[0]);
+    }
+  }
+#undef TN_ISSUE
+#undef TN_FRAGS
+  if (rem > 0) {
+    // the last columns of K (< 16), zero padded to one chunk, through registers: [A 64 x LDK | B 128 x LDK] doubles
+    double* st = reinterpret_cast<double*>(lds);
+    const int sk = threadIdx.x & 15, sr0 = threadIdx.x >> 4;
+    const long long k = kbeg + (long long)nfull * BK + sk;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const long long ra = sr0 + 16 * x;
+      st[ra * LDK + sk] = (ra < m && k < kend) ? A[ra * lda + k] : 0.0;
+    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const long long rb = c0 + sr0 + 16 * x;
+      st[64 * LDK + (sr0 + 16 * x) * LDK + sk] = (rb < n && k < kend) ? B[rb * ldb + k] : 0.0;
+    }
+    __syncthreads();
+    const double* pa = st + fr * LDK + kq;
+    const double* pb = st + 64 * LDK + (w * 32 + fr) * LDK + kq;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double af[MI], bf[2];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = pa[i * 16 * LDK + kk];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = pb[j * 16 * LDK + kk];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const long long r = i * 16 + (lane >> 4) + 4 * g;
+      if (r >= m) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const long long c = c0 + w * 32 + j * 16 + (lane & 15);
+        if (c < n) part[(blockIdx.z * m + r) * n + c] = acc[i][j][g];
+      }
+    }
+}
+
+// ---- NN: C[m, n0 .. n0 + 128) = alpha A[m, K] B[K, n] + beta C, m <= 64, n snapshot-long (>= 128).  The last tile is
+// shifted left to end at column n (no column of B beyond n is touched) and stores only the columns no other tile owns ----
+// Slot = {A: 64 rows x 16 k (the layout above) | B: 16 k-rows x 128 columns, a k-row = ONE DMA instruction (1 KB), rows
+// 1152 B apart so that the four k-rows a fragment read touches fall into different bank halves}.  Wave w: columns
+// 32 w .. 32 w + 31, accumulators [MI][2].  The last k-rows (K % 16) go through registers, zero padded.
+constexpr int TNN_BROW = 1024 + 128;               // bytes between the k-rows of the B part
+constexpr int TNN_SLOT = TN_A + 16 * TNN_BROW;     // 26,624 B; two slots: three workgroups per CU
+template <int MI>
+__global__ __launch_bounds__(256) void k_gemm_nn_thin(long long m, long long n, long long K, double alpha,
+                                                      const double* __restrict__ A, long long lda, const double* __restrict__ B,
+                                                      long long ldb, double beta, double* __restrict__ C, long long ldc) {
+  __shared__ __align__(16) char lds[2 * TNN_SLOT];
+  const unsigned lds0 = unsigned(size_t((__attribute__((address_space(3))) char*)lds));
+  const long long c_own = blockIdx.x * 128LL;                  // first column this workgroup stores
+  const long long c0 = std::min<long long>(c_own, n - 128);    // first column of its tile
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, kq = lane >> 4;
+  d4_t acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+  const int nfull = int(K / BK), rem = int(K % BK);
+  unsigned fa[4], fb[4];
+#pragma unroll
+  for (int kki = 0; kki < 4; ++kki) {
+    fa[kki] = unsigned(fr * 128) + unsigned((((2 * kki) ^ (kq >> 1) ^ (fr >> 1)) << 4) + (kq & 1) * 8);
+    fb[kki] = unsigned(TN_A + (4 * kki + kq) * TNN_BROW + (w * 32 + fr) * 8);
+  }
+#define TNN_FRAGS(SLOT_, KKI_, AF_, BF_)                                                                   \
+  do {                                                                                                     \
+    const char* pa_ = lds + (SLOT_) * TNN_SLOT + fa[KKI_];                                                 \
+    const char* pb_ = lds + (SLOT_) * TNN_SLOT + fb[KKI_];                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_) AF_[i_] = *reinterpret_cast<const double*>(pa_ + i_ * 2048); \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) BF_[j_] = *reinterpret_cast<const double*>(pb_ + j_ * 128);   \
+  } while (0)
+  unsigned voA[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int rl = 16 * w + 8 * q + (lane >> 3);
+    const long long ra = std::min<long long>(rl, m - 1);
+    voA[q] = unsigned(ra * lda * 8) + unsigned(((lane & 7) ^ ((rl >> 1) & 7)) * 16);
+  }
+  const unsigned voB = unsigned(lane) * 16u;  // lane -> columns 2 lane, 2 lane + 1 of the tile
+  const char* sA = reinterpret_cast<const char*>(A);
+  const char* sB = reinterpret_cast<const char*>(B + c0);
+  const size_t brow = size_t(ldb) * 8;
+#define TNN_ISSUE(SLOT_)                                                                                     \
+  do {                                                                                                       \
+    const unsigned sl_ = lds0 + unsigned(SLOT_) * TNN_SLOT;                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) T_DMA(sl_ + unsigned(16 * w + 8 * q_) * 128u, sA, voA[q_]);  \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                         \
+        T_DMA(sl_ + TN_A + unsigned(4 * w + q_) * unsigned(TNN_BROW), sB + size_t(4 * w + q_) * brow, voB);  \
+    sA += BK * 8;                                                                                            \
+    sB += BK * brow;                                                                                         \
+  } while (0)
+  if (nfull > 0) {
+    TNN_ISSUE(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    double af[2][MI], bf[2][2];
+    TNN_FRAGS(0, 0, af[0], bf[0]);
+    for (int ch = 0; ch < nfull; ++ch) {
+      const int slot = ch & 1;
+      if (ch + 1 < nfull) TNN_ISSUE(slot ^ 1);
+#pragma unroll
+      for (int kki = 0; kki < 4; ++kki) {
+        const int pb = kki & 1;
+        if (kki < 3) TNN_FRAGS(slot, kki + 1, af[pb ^ 1], bf[pb ^ 1]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][i], bf[pb][j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (ch + 1 < nfull) TNN_FRAGS(slot ^ 1, 0, af[0], bf[0]);
+    }
+  }
+#undef TNN_ISSUE
+#undef TNN_FRAGS
+  if (rem > 0) {
+    // [A 64 x LDK doubles | B 16 x 144 doubles]: the last k-rows, zero padded to one chunk
+    double* st = reinterpret_cast<double*>(lds);
+    double* stb = st + 64 * LDK;
+    const long long k0 = (long long)nfull * BK;
+    {
+      const int sk = threadIdx.x & 15, sr0 = threadIdx.x >> 4;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const long long ra = sr0 + 16 * x;
+        st[ra * LDK + sk] = (ra < m && sk < rem) ? A[ra * lda + k0 + sk] : 0.0;
+      }
+      const int cc = threadIdx.x & 127, kr0 = threadIdx.x >> 7;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const int kr = kr0 + 2 * x;
+        stb[kr * 144 + cc] = kr < rem ? B[(k0 + kr) * ldb + c0 + cc] : 0.0;
+      }
+    }
+    __syncthreads();
+    const double* pa = st + fr * LDK + kq;
+    const double* pb = stb + kq * 144 + w * 32 + fr;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double af[MI], bf[2];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = pa[i * 16 * LDK + kk];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = pb[kk * 144 + j * 16];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const long long r = i * 16 + (lane >> 4) + 4 * g;
+      if (r >= m) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const long long c = c0 + w * 32 + j * 16 + (lane & 15);
+        if (c < c_own) continue;
+        double* p = C + r * ldc + c;
+        *p = beta == 0.0 ? alpha * acc[i][j][g] : alpha * acc[i][j][g] + beta * *p;
+      }
+    }
+}
+#undef T_DMA
+
+// ============================================================================================
 // NN GEMM: C[m,n] = alpha * sum_k A[m,k] B[k,n] + beta C   (k small: the lift  c . basis)
 // ============================================================================================
 __global__ __launch_bounds__(256) void k_gemm_nn(long long m, long long n, long long K, double alpha,
@@ -472,9 +791,25 @@ __global__ __launch_bounds__(256) void k_gemm_nn(long long m, long long n, long 
 int rom_launch_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
   if (m <= 0 || n <= 0) return ROM_OK;
+  static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-shape names in the profile records
+  if (m <= 64 && n >= 1024 && k >= 128 && size_t(lda) * 8 * 64 < (size_t(1) << 32) && size_t(ldb) * 8 * 16 + 1024 < (size_t(1) << 32) &&
+      !no_thin_gemm()) {
+    // thin A against the rows of a snapshot-wide B
+    char nm[64];
+    detail ? snprintf(nm, sizeof nm, "gemm_nn_thin_%lldx%lldx%lld", (long long)m, (long long)n, (long long)k) : snprintf(nm, sizeof nm, "gemm_nn");
+    ROM_PROF(ctx, nm, 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(m) * n));
+    const dim3 grid{unsigned((n + 127) / 128)};
+    switch ((m + 15) / 16) {
+      case 1: k_gemm_nn_thin<1><<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc); break;
+      case 2: k_gemm_nn_thin<2><<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc); break;
+      case 3: k_gemm_nn_thin<3><<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc); break;
+      default: k_gemm_nn_thin<4><<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc); break;
+    }
+    ROM_HIP(hipGetLastError());
+    return ROM_OK;
+  }
   dim3 grid(unsigned((n + 63) / 64), unsigned((m + 63) / 64));
   {
-    static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-shape names in the profile records
     char nm[64];
     detail ? snprintf(nm, sizeof nm, "gemm_nn_%lldx%lldx%lld", (long long)m, (long long)n, (long long)k) : snprintf(nm, sizeof nm, "gemm_nn");
     ROM_PROF(ctx, nm, 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(m) * n));

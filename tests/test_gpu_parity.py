@@ -954,6 +954,36 @@ def test_repeated_sweeps_are_bit_identical(name):
             assert np.array_equal(out, ref), rep
 
 
+@pytest.mark.parametrize("kind,m,n,k", [("nt", 24, 1024, 65025), ("nt", 50, 300, 4099), ("nt", 1, 257, 2048),
+                                         ("nt", 64, 1000, 5007), ("nt", 17, 256, 2063), ("nt", 33, 513, 70001),
+                                         ("nn", 24, 65025, 1024), ("nn", 50, 4097, 300), ("nn", 3, 1029, 129),
+                                         ("nn", 64, 2000, 1013), ("nn", 16, 1024, 128), ("nn", 49, 262144, 50)])
+def test_thin_gemms_vs_numpy(kind, m, n, k):
+    """rom_gemm_nt / rom_gemm_nn with a thin operand against a snapshot-shaped block (the LDS-DMA kernels k_gemm_nt_thin /
+    k_gemm_nn_thin): odd leading dimensions, rows / columns / K that are no multiples of the tile, alpha and beta, every
+    count of 16-row blocks -- against float64 NumPy with the bound of a length-K dot product."""
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    rng = np.random.default_rng(m * 7 + n + k)
+    A = rng.standard_normal((m, k))
+    C0 = rng.standard_normal((m, n))
+    alpha, beta = -0.75, 0.5
+    if kind == "nt":
+        B = rng.standard_normal((n, k))
+        ref = alpha * (A @ B.T) + beta * C0
+    else:
+        B = rng.standard_normal((k, n))
+        ref = alpha * (A @ B) + beta * C0
+    Ad, Bd, Cd = ctx.upload(A), ctx.upload(B), ctx.upload(C0)
+    if kind == "nt":
+        ctx.gemm_nt(m, n, k, Ad, 0, k, Bd, 0, k, Cd, 0, n, alpha=alpha, beta=beta)
+    else:
+        ctx.gemm_nn(m, n, k, Ad, 0, k, Bd, 0, n, Cd, 0, n, alpha=alpha, beta=beta)
+    got = Cd.download(shape=(m, n))
+    scale = np.abs(alpha) * (np.abs(A) @ (np.abs(B.T) if kind == "nt" else np.abs(B))) + np.abs(beta * C0)
+    observed(f"thin gemm_{kind} {m}x{n}x{k}: |C - ref| / (|alpha| |A||B| + |beta C|)", np.abs(got - ref) / scale, 4e-16 * np.sqrt(k) + 1e-15)
+
+
 @pytest.mark.parametrize("M,D", [(512, 4096), (700, 5001), (1025, 4111), (640, 65025)])
 def test_gram_128_tiles_vs_numpy(api, M, D):
     """rom_gram on its 128 x 128 LDS-DMA path (M >= 512, D >= 4096): ragged last row tile, rows of odd length (8-byte
