@@ -207,7 +207,9 @@ int rom_launch_gemm_nt_ex(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double 
   const long long tiles = lower_only ? nt * (nt + 1) / 2 : nt * ((n + 63) / 64);  // tiles that do work
   int splits = 1;
   if (k >= 1024 && tiles < 512) {
-    splits = int(std::min<long long>((768 + tiles - 1) / tiles, (k + 511) / 512));
+    // (a handful of output tiles: the launch is one latency chain per workgroup -- 128 columns of K each instead of 512)
+    const long long kmin = tiles <= 4 ? 128 : 512;
+    splits = int(std::min<long long>((768 + tiles - 1) / tiles, (k + kmin - 1) / kmin));
     splits = std::max(splits, 1);
   }
   long long kper = ((k + splits - 1) / splits + BK - 1) / BK * BK;
