@@ -112,15 +112,16 @@ __global__ void k_mirror_lower(long long n, double* __restrict__ C, long long ld
   if (c > r) C[r * ldc + c] = C[c * ldc + r];
 }
 
+// (lower_only == 2: the partials are those of the TRANSPOSED product, C[c, r] receives element (r, c))
 __global__ void k_splitk_reduce(long long m, long long n, int splits, double alpha, const double* __restrict__ part,
                                 double beta, double* __restrict__ C, long long ldc, int lower_only) {
   long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (idx >= m * n) return;
-  if (lower_only && (idx % n) / 64 > (idx / n) / 64) return;
+  if (lower_only == 1 && (idx % n) / 64 > (idx / n) / 64) return;
   double s = 0.0;
   for (int z = 0; z < splits; ++z) s += part[z * m * n + idx];
   long long r = idx / n, c = idx % n;
-  double* p = C + r * ldc + c;
+  double* p = lower_only == 2 ? C + c * ldc + r : C + r * ldc + c;
   *p = beta == 0.0 ? alpha * s : alpha * s + beta * *p;
 }
 
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_wave(long long m, long lo
                                                             double* __restrict__ C, long long ldc, int lower_only) {
   const long long idx = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (idx >= m * n) return;
-  if (lower_only && (idx % n) / 64 > (idx / n) / 64) return;
+  if (lower_only == 1 && (idx % n) / 64 > (idx / n) / 64) return;
   const int lane = threadIdx.x & 63;
   // fixed order: lane l sums splits l, l + 64, ...; then the lanes are folded pairwise -- deterministic
   double s = 0.0;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_wave(long long m, long lo
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   if (lane == 0) {
     const long long r = idx / n, c = idx % n;
-    double* p = C + r * ldc + c;
+    double* p = lower_only == 2 ? C + c * ldc + r : C + r * ldc + c;
     *p = beta == 0.0 ? alpha * s : alpha * s + beta * *p;
   }
 }
@@ -154,8 +155,10 @@ template <int MI>
 __global__ void k_gemm_nt_thin(long long m, long long n, long long K, long long kper, const double* __restrict__ A, long long lda,
                                const double* __restrict__ B, long long ldb, double* __restrict__ part);  // (defined below)
 // thin A (m <= 64) against a long K: k_gemm_nt_thin over 128-row tiles of B x split-K, then the deterministic reduction
+// transposed != 0: (A, m, lda) is the THIN operand of C^T = A B^T, i.e. the caller's product is C (n x m) = B A^T
 static int launch_gemm_nt_thin(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A, int64_t lda,
-                               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const char* prof_name) {
+                               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const char* prof_name,
+                               int transposed = 0) {
   const long long tiles = (n + 127) / 128;
   // one full round of the 768 resident workgroups (3 per CU), at least 512 columns of K per workgroup
   long long splits = std::max<long long>(1, std::min<long long>((768 + tiles - 1) / tiles, k / 512));
@@ -181,9 +184,11 @@ static int launch_gemm_nt_thin(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, do
   {
     ROM_PROF(ctx, "splitk_reduce", double(splits) * m * n, 8.0 * double(splits + 1) * m * n);
     if (splits >= 16 && m * n <= 65536)
-      k_splitk_reduce_wave<<<unsigned((m * n + 3) / 4), 256, 0, ctx->stream>>>(m, n, int(splits), alpha, part, beta, C, ldc, 0);
+      k_splitk_reduce_wave<<<unsigned((m * n + 3) / 4), 256, 0, ctx->stream>>>(m, n, int(splits), alpha, part, beta, C, ldc,
+                                                                               transposed ? 2 : 0);
     else
-      k_splitk_reduce<<<unsigned((m * n + 255) / 256), 256, 0, ctx->stream>>>(m, n, int(splits), alpha, part, beta, C, ldc, 0);
+      k_splitk_reduce<<<unsigned((m * n + 255) / 256), 256, 0, ctx->stream>>>(m, n, int(splits), alpha, part, beta, C, ldc,
+                                                                              transposed ? 2 : 0);
   }
   ROM_HIP(hipGetLastError());
   return ROM_OK;
@@ -203,6 +208,9 @@ int rom_launch_gemm_nt_ex(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double 
   if (!lower_only && m <= 64 && n >= 256 && k >= 2048 && size_t(lda) * 8 * 64 < (size_t(1) << 32) &&
       size_t(ldb) * 8 * 128 < (size_t(1) << 32) && !no_thin_gemm())
     return launch_gemm_nt_thin(ctx, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, prof_name);
+  if (!lower_only && n <= 64 && m >= 256 && k >= 2048 && size_t(ldb) * 8 * 64 < (size_t(1) << 32) &&
+      size_t(lda) * 8 * 128 < (size_t(1) << 32) && !no_thin_gemm())  // thin B: the transposed product on the same kernel
+    return launch_gemm_nt_thin(ctx, n, m, k, alpha, B, ldb, A, lda, beta, C, ldc, prof_name, 1);
   const long long nt = (m + 63) / 64;
   const long long tiles = lower_only ? nt * (nt + 1) / 2 : nt * ((n + 63) / 64);  // tiles that do work
   int splits = 1;
@@ -622,6 +630,11 @@ __global__ __launch_bounds__(256) void k_gemm_nn_thin(long long m, long long n, 
   const unsigned lds0 = unsigned(size_t((__attribute__((address_space(3))) char*)lds));
   const long long c_own = blockIdx.x * 128LL;                  // first column this workgroup stores
   const long long c0 = std::min<long long>(c_own, n - 128);    // first column of its tile
+  // (grid.y > 1: A has more than 64 rows and a short K -- the lift  coefficients x basis : row tile blockIdx.y)
+  const long long r0 = blockIdx.y * 64LL;
+  A += r0 * lda;
+  C += r0 * ldc;
+  m = std::min<long long>(64, m - r0);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, kq = lane >> 4;
   d4_t acc[MI][2];
@@ -794,14 +807,14 @@ int rom_launch_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alp
                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
   if (m <= 0 || n <= 0) return ROM_OK;
   static const bool detail = getenv("ROMHC_PROF_DETAIL") != nullptr;  // per-shape names in the profile records
-  if (m <= 64 && n >= 1024 && k >= 128 && size_t(lda) * 8 * 64 < (size_t(1) << 32) && size_t(ldb) * 8 * 16 + 1024 < (size_t(1) << 32) &&
-      !no_thin_gemm()) {
-    // thin A against the rows of a snapshot-wide B
+  if ((m <= 64 ? k >= 128 : (k >= 16 && k <= 256)) && n >= 1024 && size_t(lda) * 8 * 64 < (size_t(1) << 32) &&
+      size_t(ldb) * 8 * 16 + 1024 < (size_t(1) << 32) && (m + 63) / 64 <= 65535 && !no_thin_gemm()) {
+    // thin A against the rows of a snapshot-wide B; or a tall A with a short K (the lift: output bound), in row tiles of 64
     char nm[64];
     detail ? snprintf(nm, sizeof nm, "gemm_nn_thin_%lldx%lldx%lld", (long long)m, (long long)n, (long long)k) : snprintf(nm, sizeof nm, "gemm_nn");
     ROM_PROF(ctx, nm, 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(m) * n));
-    const dim3 grid{unsigned((n + 127) / 128)};
-    switch ((m + 15) / 16) {
+    const dim3 grid{unsigned((n + 127) / 128), unsigned((m + 63) / 64)};
+    switch (m > 64 ? 4 : (m + 15) / 16) {
       case 1: k_gemm_nn_thin<1><<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc); break;
       case 2: k_gemm_nn_thin<2><<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc); break;
       case 3: k_gemm_nn_thin<3><<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc); break;

@@ -957,11 +957,14 @@ def test_repeated_sweeps_are_bit_identical(name):
 @pytest.mark.parametrize("kind,m,n,k", [("nt", 24, 1024, 65025), ("nt", 50, 300, 4099), ("nt", 1, 257, 2048),
                                          ("nt", 64, 1000, 5007), ("nt", 17, 256, 2063), ("nt", 33, 513, 70001),
                                          ("nn", 24, 65025, 1024), ("nn", 50, 4097, 300), ("nn", 3, 1029, 129),
-                                         ("nn", 64, 2000, 1013), ("nn", 16, 1024, 128), ("nn", 49, 262144, 50)])
+                                         ("nn", 64, 2000, 1013), ("nn", 16, 1024, 128), ("nn", 49, 262144, 50),
+                                         ("nt", 1000, 50, 4099), ("nt", 300, 1, 2048), ("nt", 257, 64, 5007),
+                                         ("nn", 1000, 4097, 50), ("nn", 130, 1029, 16), ("nn", 65, 2000, 256)])
 def test_thin_gemms_vs_numpy(kind, m, n, k):
     """rom_gemm_nt / rom_gemm_nn with a thin operand against a snapshot-shaped block (the LDS-DMA kernels k_gemm_nt_thin /
     k_gemm_nn_thin): odd leading dimensions, rows / columns / K that are no multiples of the tile, alpha and beta, every
-    count of 16-row blocks -- against float64 NumPy with the bound of a length-K dot product."""
+    count of 16-row blocks, the thin operand on either side (transposed product) and the tall-A / short-K lift -- against
+    float64 NumPy with the bound of a length-K dot product."""
     from romhighcontrast_amd import _ffi
     ctx = _ffi.get_context()
     rng = np.random.default_rng(m * 7 + n + k)
