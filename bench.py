@@ -352,7 +352,7 @@ def main():
             a_all_dev = ctx.upload(a_all.reshape(world * M, -1))
             replicate = (a_all_dev, U_all)
         be = sweep.GpuStepBackend(ctx, fem, a_dev, M, world, U_loc=U_loc, replicate=replicate)
-        Y_all = be.Y_all
+        stride = be.cstride  # what travels: the compact interface vectors
 
     def step():
         if not comm:
@@ -415,7 +415,7 @@ def main():
             peer = (rank + 1) % world  # expand a few rows of the NEXT rank's shard from the gathered vectors
             a_peer = ctx.upload(a_all[peer * M:peer * M + 4].reshape(4, -1))
             rows = ctx.alloc(4 * dim)
-            fem.expand(a_peer, 4, Y_all[(step_no[0] - 1) & 1], rows, y_row0=peer * M)
+            fem.expand(a_peer, 4, be.gathered_vectors((step_no[0] - 1) & 1, peer * M, 4), rows)
             chk = ctx.alloc(4 * dim)
             fem.solve_batch(a_peer, 4, chk)
             assert np.array_equal(rows.download(), chk.download())
@@ -482,8 +482,8 @@ def main():
         "config": {"workload": f"{label}: {blocks[0]}x{blocks[1]} blocks, N={N} "
                                f"({blocks[0] * N}x{blocks[1] * N} cells, dim {dim}), {M}-parameter sweep per GPU "
                                f"({world * M} total), SURVEY 8d parameters (seed {SEED})"
-                               + ((", RCCL all-gather each step of the snapshot block in FACTORED form: the interface "
-                                   f"vectors, {stride} doubles = {stride * 8} B per system, {M * stride * 8 / 1e6:.2f} MB sent per "
+                               + ((", RCCL all-gather each step of the snapshot block in FACTORED form: the compact interface "
+                                   f"vectors (the entries the expansion reads), {stride} doubles = {stride * 8} B per system, {M * stride * 8 / 1e6:.2f} MB sent per "
                                    "rank" + (" + expansion of the whole block into rows on every rank (the literal 8e row "
                                              "block, replicated)" if args.replicate else
                                              "; rows of the own shard materialised, any other row reproducible bit for bit "
@@ -496,7 +496,8 @@ def main():
         "event_ms_per_step": round(ev_ms / args.steps, 4),
         "profiled_pass_ms_per_step": round(wall_prof / args.steps * 1e3, 4),
         "rccl_ranks": rccl_ranks if comm else 0,
-        "exchange": ({"what": "interface vectors (factored snapshot block)", "doubles_per_system": stride,
+        "exchange": ({"what": "compact interface vectors (factored snapshot block; the nodal part is recomputed by the expansion)",
+                      "doubles_per_system": stride, "full_interface_vector_doubles": fem.reduced_stride,
                       "sent_bytes_per_rank_per_step": M * stride * 8, "received_bytes_per_rank_per_step": world * M * stride * 8,
                       "row_block_bytes_per_rank": M * dim * 8, "replicated_rows": bool(args.replicate)} if comm else None),
         "setup": {"setup_s": round(setup_s, 4),

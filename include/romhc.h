@@ -123,6 +123,13 @@ int rom_fem_reduced_layout(rom_fem* fem, int64_t* nodal_begin, int64_t* nodal_en
  * B, so Gram matrices, means and POD modes of snapshots can be formed from Y alone (every geometry whose
  * closed-form edges are all kept in compressed form, e.g. 2x2/N>=16, 3x3/N=171, 4x4/N=256). */
 int rom_fem_expansion_is_linear(rom_fem* fem, int* flag);
+/* Compact form for the exchange (the all-gather before the SVD): the entries of an interface vector outside
+ * its nodal part, rom_fem_compact_stride() doubles (272 of 784 at 256x256 / 2x2) -- all that has to travel, since the
+ * expansion recomputes the nodal part.  pack: Yc[c_row0+m] <- Y[y_row0+m]; unpack: the inverse (nodal part zeroed).
+ * Both only enqueue on the compute stream. */
+int rom_fem_compact_stride(rom_fem* fem, int64_t* stride);
+int rom_fem_pack_reduced_async(rom_fem* fem, rom_buf* Y, int64_t y_row0, int M, rom_buf* Yc, int64_t c_row0);
+int rom_fem_unpack_reduced_async(rom_fem* fem, rom_buf* Yc, int64_t c_row0, int M, rom_buf* Y, int64_t y_row0);
 int rom_solve_reduced_async(rom_fem* fem, rom_buf* a, int M, rom_buf* Y, int64_t y_row0);
 int rom_expand_batch_async(rom_fem* fem, rom_buf* a, int M, rom_buf* Y, int64_t y_row0, rom_buf* U, int64_t row0);
 /* flops / HBM bytes of the library's own algorithm for one snapshot solve, and the canonical

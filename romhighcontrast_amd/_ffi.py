@@ -64,6 +64,9 @@ PROTOTYPES = {
     "rom_fem_reduced_stride": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rom_fem_expansion_is_linear": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "rom_fem_reduced_layout": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "rom_fem_compact_stride": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rom_fem_pack_reduced_async": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64]),
+    "rom_fem_unpack_reduced_async": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64]),
     "rom_solve_reduced_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64]),
     "rom_expand_batch_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, _vp, C.c_int64]),
     "rom_solve_work": (C.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
@@ -425,6 +428,21 @@ class Fem:
         b, e = C.c_int64(0), C.c_int64(0)
         check(self.ctx.lib.rom_fem_reduced_layout(self.h, C.byref(b), C.byref(e)))
         return np.concatenate((np.arange(0, b.value), np.arange(e.value, self.reduced_stride)))
+
+    @property
+    def compact_stride(self) -> int:
+        """doubles per system of the COMPACT interface vector (the entries the expansion reads: what travels between ranks)"""
+        v = C.c_int64(0)
+        check(self.ctx.lib.rom_fem_compact_stride(self.h, C.byref(v)))
+        return v.value
+
+    def pack_reduced(self, Y: Buffer, M: int, Yc: Buffer, y_row0: int = 0, c_row0: int = 0):
+        """Yc[c_row0:c_row0+M] = the compact form of the interface vectors Y[y_row0:y_row0+M] (enqueued only)."""
+        check(self.ctx.lib.rom_fem_pack_reduced_async(self.h, Y.h, y_row0, M, Yc.h, c_row0))
+
+    def unpack_reduced(self, Yc: Buffer, M: int, Y: Buffer, c_row0: int = 0, y_row0: int = 0):
+        """The inverse of pack_reduced: full-stride vectors with a zero nodal part (expand() fills it) (enqueued only)."""
+        check(self.ctx.lib.rom_fem_unpack_reduced_async(self.h, Yc.h, c_row0, M, Y.h, y_row0))
 
     def solve_reduced(self, a: Buffer, M: int, Y: Buffer, y_row0: int = 0):
         """Stage 1 of the sweep (enqueued only): interface vectors of the M systems into Y[y_row0:y_row0+M]."""

@@ -316,6 +316,51 @@ extern "C" int rom_fem_reduced_layout(rom_fem* f, int64_t* nodal_begin, int64_t*
   return ROM_OK;
 }
 
+// ---- compact form of the interface vectors: what has to TRAVEL between ranks -------------------------------------------
+// The nodal part [nodal_begin, nodal_end) is an output of the expansion, so an exchange only needs the other
+// rom_fem_compact_stride() entries of a vector (272 of 784 at 256 x 256 / 2 x 2).  pack: Yc[c_row0 + m, :] = the entries
+// of Y[y_row0 + m, :] outside the nodal part, in order; unpack: the inverse (nodal part set to zero).  Both only enqueue.
+__global__ void k_pack_reduced(const double* __restrict__ Y, long long ystride, int nb, int ne, double* __restrict__ Yc, int kc) {
+  const double* y = Y + blockIdx.x * ystride;
+  double* yc = Yc + blockIdx.x * (long long)kc;
+  for (int c = threadIdx.x; c < kc; c += blockDim.x) yc[c] = y[c < nb ? c : c + (ne - nb)];
+}
+__global__ void k_unpack_reduced(const double* __restrict__ Yc, int kc, int nb, int ne, double* __restrict__ Y, long long ystride) {
+  double* y = Y + blockIdx.x * ystride;
+  const double* yc = Yc + blockIdx.x * (long long)kc;
+  for (int c = threadIdx.x; c < int(ystride); c += blockDim.x) y[c] = c < nb ? yc[c] : (c < ne ? 0.0 : yc[c - (ne - nb)]);
+}
+
+extern "C" int rom_fem_compact_stride(rom_fem* f, int64_t* stride) {
+  ROM_CHECK(f && stride, "rom_fem_compact_stride: null argument");
+  *stride = f->nGp - (f->xb0 - f->nGa);
+  return ROM_OK;
+}
+
+extern "C" int rom_fem_pack_reduced_async(rom_fem* f, rom_buf* Y, int64_t y_row0, int M, rom_buf* Yc, int64_t c_row0) {
+  ROM_CHECK(f && Y && Yc, "rom_fem_pack_reduced_async: null argument");
+  const int kc = f->nGp - (f->xb0 - f->nGa);
+  ROM_CHECK(M >= 0 && y_row0 >= 0 && c_row0 >= 0 && Y->n >= size_t(y_row0 + M) * f->nGp && Yc->n >= size_t(c_row0 + M) * kc,
+            "rom_fem_pack_reduced_async: buffers too small");
+  if (M == 0 || kc == 0) return ROM_OK;
+  ROM_HIP(hipSetDevice(f->ctx->device));
+  k_pack_reduced<<<M, 256, 0, f->ctx->stream>>>(Y->p + size_t(y_row0) * f->nGp, f->nGp, f->nGa, f->xb0, Yc->p + size_t(c_row0) * kc, kc);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+extern "C" int rom_fem_unpack_reduced_async(rom_fem* f, rom_buf* Yc, int64_t c_row0, int M, rom_buf* Y, int64_t y_row0) {
+  ROM_CHECK(f && Y && Yc, "rom_fem_unpack_reduced_async: null argument");
+  const int kc = f->nGp - (f->xb0 - f->nGa);
+  ROM_CHECK(M >= 0 && y_row0 >= 0 && c_row0 >= 0 && Y->n >= size_t(y_row0 + M) * f->nGp && Yc->n >= size_t(c_row0 + M) * kc,
+            "rom_fem_unpack_reduced_async: buffers too small");
+  if (M == 0 || f->nGp == 0) return ROM_OK;
+  ROM_HIP(hipSetDevice(f->ctx->device));
+  k_unpack_reduced<<<M, 256, 0, f->ctx->stream>>>(Yc->p + size_t(c_row0) * kc, kc, f->nGa, f->xb0, Y->p + size_t(y_row0) * f->nGp, f->nGp);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
 extern "C" int rom_fem_reduced_stride(rom_fem* f, int64_t* stride) {
   ROM_CHECK(f && stride, "rom_fem_reduced_stride: null argument");
   *stride = f->nGp;

@@ -75,19 +75,24 @@ def drain(backend):
 class GpuStepBackend:
     """libromhc realisation of the step protocol: rom_solve_reduced_async / rom_comm_allgather_async (RCCL over xGMI,
     on the context's communication stream) / rom_expand_batch_async, parameters resident in HBM.
+    What travels is the COMPACT form of the interface vectors (rom_fem_pack_reduced_async: the entries the expansion
+    reads, 272 of 784 doubles per system at 256 x 256 / 2 x 2 -- the nodal part is recomputed by whoever expands).
     `M` rows per rank; a rank whose shard is short (`m_valid` < M) pads its send buffer with zero vectors once."""
 
     def __init__(self, ctx, fem, a_dev, M, world, *, U_loc=None, replicate=None, m_valid=None):
         self.ctx, self.fem, self.a_dev, self.M, self.world = ctx, fem, a_dev, int(M), int(world)
         self.m_valid = self.M if m_valid is None else int(m_valid)
         self.stride = fem.reduced_stride
+        self.cstride = fem.compact_stride
         self.Y_loc = [ctx.alloc(max(self.M * self.stride, 1)) for _ in range(2)]
-        self.Y_all = [ctx.alloc(max(self.world * self.M * self.stride, 1)) for _ in range(2)]
+        self.Yc_loc = [ctx.alloc(max(self.M * self.cstride, 1)) for _ in range(2)]                 # send buffers
+        self.Yc_all = [ctx.alloc(max(self.world * self.M * self.cstride, 1)) for _ in range(2)]    # gathered
         if self.m_valid < self.M:
             for y in self.Y_loc:
                 y.fill(0.0)  # padding rows are gathered (and expanded by --replicate): they must hold finite numbers
         self.U_loc = U_loc if U_loc is not None else ctx.alloc(max(self.M * fem.dim, 1))
         self.replicate = replicate  # None, or (a_all_dev, U_all): also expand the gathered block on every rank
+        self.Y_all_full = ctx.alloc(self.world * self.M * self.stride) if replicate is not None else None
 
     def wait_slot(self, k):
         self.ctx.comm_wait_slot(k)
@@ -95,15 +100,24 @@ class GpuStepBackend:
     def solve_local(self, k):
         if self.m_valid:
             self.fem.solve_reduced(self.a_dev, self.m_valid, self.Y_loc[k])
+        self.fem.pack_reduced(self.Y_loc[k], self.M, self.Yc_loc[k])
 
     def allgather_async(self, k):
-        self.ctx.allgather_async(self.Y_loc[k], 0, self.Y_all[k], 0, self.M * self.stride, slot=k)
+        self.ctx.allgather_async(self.Yc_loc[k], 0, self.Yc_all[k], 0, self.M * self.cstride, slot=k)
+
+    def gathered_vectors(self, k, row0, rows, out=None):
+        """Full-stride interface vectors of the gathered rows [row0, row0 + rows) of slot k (the compute stream must
+        already wait for the collective: comm_wait / wait_slot)."""
+        out = out if out is not None else self.ctx.alloc(rows * self.stride)
+        self.fem.unpack_reduced(self.Yc_all[k], rows, out, c_row0=row0)
+        return out
 
     def expand(self, k):
         if self.replicate is not None:
             a_all_dev, U_all = self.replicate
             self.ctx.comm_wait(False)                                       # compute stream waits for the gathered vectors
-            self.fem.expand(a_all_dev, self.world * self.M, self.Y_all[k], U_all)   # the whole block as rows, on every rank
+            self.gathered_vectors(k, 0, self.world * self.M, out=self.Y_all_full)
+            self.fem.expand(a_all_dev, self.world * self.M, self.Y_all_full, U_all)   # the whole block as rows, on every rank
         elif self.m_valid:
             self.fem.expand(self.a_dev, self.m_valid, self.Y_loc[k], self.U_loc)    # rows of the own shard, while the vectors travel
 
@@ -216,8 +230,12 @@ class RcclSweep:
         def allgather(Y):
             if self.world == 1:
                 return Y
-            full = ctx.alloc(self.world * mp * stride)
-            ctx.allgather(Y, 0, full, 0, mp * stride)
+            # the compact form travels (the nodal part of a vector is an output of the expansion)
+            kc = fem.compact_stride
+            Yc, Yc_all, full = ctx.alloc(mp * kc), ctx.alloc(self.world * mp * kc), ctx.alloc(self.world * mp * stride)
+            fem.pack_reduced(Y, mp, Yc)
+            ctx.allgather(Yc, 0, Yc_all, 0, mp * kc)
+            fem.unpack_reduced(Yc_all, self.world * mp, full)
             return full
 
         Yall, M = sharded_sweep(a_all, self.world, self.rank, solve_local, allgather)

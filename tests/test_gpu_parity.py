@@ -924,6 +924,22 @@ def test_two_stage_sweep_is_bit_identical(api, blocks, N, M):
     fem.expand(ab, M, Y, U2, y_row0=3, row0=2)
     ctx.solve_status()
     assert np.array_equal(U2.download(shape=(M + 2, fem.dim))[2:], ref)
+    # the COMPACT form is what travels (rom_fem_pack_reduced_async / _unpack_): only the entries the expansion reads;
+    # unpacked into a fresh buffer (nodal part zero) it must expand to the same bits
+    kc = fem.compact_stride
+    cols = fem.reduced_inputs
+    assert kc == cols.size and kc <= stride
+    Yc = ctx.alloc(max((M + 1) * kc, 1))
+    Yc.fill(float("nan"))
+    fem.pack_reduced(Y, M, Yc, y_row0=3, c_row0=1)
+    assert np.array_equal(Yc.download(shape=(M + 1, kc))[1:], Y.download(shape=(M + 3, stride))[3:][:, cols])
+    Y3 = ctx.alloc(max((M + 2) * stride, 1))
+    Y3.fill(float("nan"))
+    fem.unpack_reduced(Yc, M, Y3, c_row0=1, y_row0=2)
+    U3 = ctx.alloc(M * fem.dim)
+    fem.expand(ab, M, Y3, U3, y_row0=2)
+    ctx.solve_status()
+    assert np.array_equal(U3.download(shape=(M, fem.dim)), ref)
 
 
 @pytest.mark.parametrize("name", ["b22", "b33", "b44"])

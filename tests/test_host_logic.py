@@ -319,10 +319,13 @@ def test_gpu_step_backend_follows_the_protocol():
             log.append(("status",))
 
     class Fem:
-        reduced_stride, dim = 10, 100
+        reduced_stride, compact_stride, dim = 10, 6, 100
 
         def solve_reduced(self, a, M, Y):
             log.append(("solve", M, Y.n))
+
+        def pack_reduced(self, Y, M, Yc):
+            log.append(("pack", M, Y.n, Yc.n))
 
         def expand(self, a, M, Y, U):
             log.append(("expand", M, Y.n, U.n))
@@ -333,7 +336,10 @@ def test_gpu_step_backend_follows_the_protocol():
     for s in range(3):
         assert sweep.run_step(be, s) == s % 2
     sweep.drain(be)
-    per_step = [("wait_slot", None), ("solve", 3, 40), ("allgather", 40, 80, 40, None), ("expand", 3, 40, 400)]
+    # the solve writes full-stride vectors (4 x 10), what is gathered is their compact form (4 x 6 -> 2 ranks x 4 x 6), all
+    # M rows of the shard (the padding row of the short shard included); the own rows are expanded from the full vectors
+    per_step = [("wait_slot", None), ("solve", 3, 40), ("pack", 4, 40, 24), ("allgather", 24, 48, 24, None),
+                ("expand", 3, 40, 400)]
     want = []
     for s in range(3):
         for rec in per_step:
