@@ -35,12 +35,10 @@ class ExpansionMap:
         self.K, self.dim = fem.reduced_stride, fem.dim
         self._ones = {}
         # the expansion only reads part of an interface vector (not the nodal edge blocks): all algebra below
-        # runs on those Kc "input" coordinates; Sel (K x Kc, 0/1) moves between the two
+        # runs on those Kc "input" coordinates -- the compact form that also travels between ranks
+        # (rom_fem_pack_reduced_async / rom_fem_unpack_reduced_async move between the two)
         self.inputs = fem.reduced_inputs
-        self.Kc = Kc = len(self.inputs)
-        sel = np.zeros((self.K, Kc))
-        sel[self.inputs, np.arange(Kc)] = 1.0
-        self.Sel = ctx.upload(sel)
+        self.Kc = Kc = fem.compact_stride
         Bt = self._basis_rows()
         self.S = ctx.alloc(Kc * Kc)
         ctx.gram(Kc, self.dim, Bt, 0, self.dim, self.S, 0, Kc)
@@ -57,13 +55,14 @@ class ExpansionMap:
         """(M, Kc) input coordinates of the interface vectors Y (M, K)."""
         Yc = self.ctx.alloc(max(M * self.Kc, 1))
         if M:
-            self.ctx.gemm_nn(M, self.Kc, self.K, Y, 0, self.K, self.Sel, 0, self.Kc, Yc, 0, self.Kc)
+            self.fem.pack_reduced(Y, M, Yc)
         return Yc
 
     def expand_compact(self, Wc, n, U, row0=0):
         """U[row0:row0+n] = expansion of n vectors given in input coordinates (n, Kc)."""
         W = self.ctx.alloc(max(n * self.K, 1))
-        self.ctx.gemm_nt(n, self.K, self.Kc, Wc, 0, self.Kc, self.Sel, 0, self.Kc, W, 0, self.K)
+        if n:
+            self.fem.unpack_reduced(Wc, n, W)
         self.expand_into(W, n, U, row0=row0)
 
     # ---- H^1_0 geometry of the snapshots in coordinates of the interface vectors ----------------------------
