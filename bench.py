@@ -13,9 +13,9 @@ parameters already resident in HBM and the (M, dim) fp64 snapshot block left in 
                   + POD of the 4096-snapshot block                                                     [configs[4]]
 
 With N > 1 (one process per GPU) every rank solves its own M-parameter shard (weak scaling: c2 at N=8 is config C3,
-8192 parameters) and the shards are exchanged with one RCCL all-gather per step, inside the timed region; the
-all-gather of step k runs on a communication stream and overlaps the solves of step k+1 (double buffered), the
-region ends when the last all-gather has landed.
+8192 parameters) and the shards are exchanged by RCCL all-gathers inside the timed region: the compact interface vectors
+of --exchange-every consecutive steps (default 8) travel in ONE collective on a communication stream, which overlaps the
+following steps (double buffered groups); the region ends when the last all-gather has landed.
 
 Launch: `python bench.py --gpus N` with no launcher environment starts the N ranks itself (fresh child processes
 with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; the parent never touches the GPU and never exec()s); under
@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--force-comm", action="store_true",
                     help="rehearsal: run the N>1 code path (RCCL communicator, all-gather of the interface vectors, "
                          "expansion of the gathered block) with one rank")
+    ap.add_argument("--exchange-every", type=int, default=8,
+                    help="N > 1: one all-gather per this many steps (the shards of a group travel together); 1 = every step")
     ap.add_argument("--replicate", action="store_true",
                     help="N>1: also expand the gathered factored block into snapshot rows on every rank (the literal "
                          "(M/G, dim) row block of SURVEY 8e, replicated)")
@@ -341,7 +343,7 @@ def main():
     # is what the POD consumes (romhighcontrast_amd/factored.py).  --replicate also expands the gathered block
     # on every rank (each rank then writes world x 528 MB per step); DESIGN.md section 7.
     stride = fem.reduced_stride
-    step_no = [0]
+    step_no, last_slot, every = [0], [0], 1
     if comm:
         # two buffer pairs: the all-gather of step k (communication stream) overlaps the expansion of step k and
         # the reduced solves of step k+1 (compute stream).  The loop itself is sweep.run_step -- the function the
@@ -351,19 +353,21 @@ def main():
             U_all = ctx.alloc(world * M * dim)
             a_all_dev = ctx.upload(a_all.reshape(world * M, -1))
             replicate = (a_all_dev, U_all)
-        be = sweep.GpuStepBackend(ctx, fem, a_dev, M, world, U_loc=U_loc, replicate=replicate)
+        every = 1 if args.replicate else max(1, int(args.exchange_every))
+        be = sweep.GpuStepBackend(ctx, fem, a_dev, M, world, U_loc=U_loc, replicate=replicate, every=every)
         stride = be.cstride  # what travels: the compact interface vectors
 
     def step():
         if not comm:
             fem.solve_batch(a_dev, M, U_loc, wait=False)  # enqueued only: no host round trip per step
             return
-        sweep.run_step(be, step_no[0])
+        last_slot[0] = sweep.run_step(be, step_no[0], every)
         step_no[0] += 1
 
     def drain():
         if comm:
-            sweep.drain(be)
+            sweep.drain(be, step_no[0], every)  # (sends the shards of a last, incomplete group)
+            step_no[0] = -(-step_no[0] // every) * every  # the next region starts a fresh group
         else:
             ctx.solve_status()  # waits for the compute stream; raises if any system was not positive definite
 
@@ -415,7 +419,8 @@ def main():
             peer = (rank + 1) % world  # expand a few rows of the NEXT rank's shard from the gathered vectors
             a_peer = ctx.upload(a_all[peer * M:peer * M + 4].reshape(4, -1))
             rows = ctx.alloc(4 * dim)
-            fem.expand(a_peer, 4, be.gathered_vectors((step_no[0] - 1) & 1, peer * M, 4), rows)
+            k_last = last_slot[0]  # the last step's shard is the last part of the last collective of its slot
+            fem.expand(a_peer, 4, be.gathered_vectors(k_last, peer, be.parts[k_last] - 1, 0, 4), rows)
             chk = ctx.alloc(4 * dim)
             fem.solve_batch(a_peer, 4, chk)
             assert np.array_equal(rows.download(), chk.download())
@@ -482,7 +487,7 @@ def main():
         "config": {"workload": f"{label}: {blocks[0]}x{blocks[1]} blocks, N={N} "
                                f"({blocks[0] * N}x{blocks[1] * N} cells, dim {dim}), {M}-parameter sweep per GPU "
                                f"({world * M} total), SURVEY 8d parameters (seed {SEED})"
-                               + ((", RCCL all-gather each step of the snapshot block in FACTORED form: the compact interface "
+                               + ((f", one RCCL all-gather per {every} step(s) of the snapshot block in FACTORED form: the compact interface "
                                    f"vectors (the entries the expansion reads), {stride} doubles = {stride * 8} B per system, {M * stride * 8 / 1e6:.2f} MB sent per "
                                    "rank" + (" + expansion of the whole block into rows on every rank (the literal 8e row "
                                              "block, replicated)" if args.replicate else
@@ -497,7 +502,7 @@ def main():
         "profiled_pass_ms_per_step": round(wall_prof / args.steps * 1e3, 4),
         "rccl_ranks": rccl_ranks if comm else 0,
         "exchange": ({"what": "compact interface vectors (factored snapshot block; the nodal part is recomputed by the expansion)",
-                      "doubles_per_system": stride, "full_interface_vector_doubles": fem.reduced_stride,
+                      "doubles_per_system": stride, "full_interface_vector_doubles": fem.reduced_stride, "steps_per_collective": every,
                       "sent_bytes_per_rank_per_step": M * stride * 8, "received_bytes_per_rank_per_step": world * M * stride * 8,
                       "row_block_bytes_per_rank": M * dim * 8, "replicated_rows": bool(args.replicate)} if comm else None),
         "setup": {"setup_s": round(setup_s, 4),

@@ -248,6 +248,12 @@ int rom_comm_allgather(rom_ctx* ctx, rom_buf* send, size_t send_off, rom_buf* re
  * compute stream (and the host if host_sync != 0) wait for the outstanding collectives */
 int rom_comm_allgather_async(rom_ctx* ctx, rom_buf* send, size_t send_off, rom_buf* recv, size_t recv_off,
                              size_t count, int slot /* 0|1: double-buffer slot of the send buffer */);
+/* The exchange of one step of a sharded sweep in ONE call: pack the interface vectors Y[y_row0 .. +M) of the own shard
+ * into their compact form (into `send`, M x rom_fem_compact_stride() doubles of scratch) and all-gather them into
+ * recv[recv_off ...] (nranks x M x compact stride) -- both on the communication stream, after everything enqueued so
+ * far on the compute stream, which is not blocked.  Slots as in rom_comm_allgather_async. */
+int rom_comm_allgather_packed_async(rom_fem* fem, rom_buf* Y, int64_t y_row0, int M, rom_buf* send, rom_buf* recv,
+                                    size_t recv_off, int slot);
 int rom_comm_wait(rom_ctx* ctx, int host_sync);
 /* compute stream waits for the collective last issued with `slot` (before its send buffer is rewritten) */
 int rom_comm_wait_slot(rom_ctx* ctx, int slot);

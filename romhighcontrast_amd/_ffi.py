@@ -67,6 +67,7 @@ PROTOTYPES = {
     "rom_fem_compact_stride": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rom_fem_pack_reduced_async": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64]),
     "rom_fem_unpack_reduced_async": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64]),
+    "rom_comm_allgather_packed_async": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_size_t, C.c_int]),
     "rom_solve_reduced_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64]),
     "rom_expand_batch_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, _vp, C.c_int64]),
     "rom_solve_work": (C.c_int, [_vp, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
@@ -443,6 +444,12 @@ class Fem:
     def unpack_reduced(self, Yc: Buffer, M: int, Y: Buffer, c_row0: int = 0, y_row0: int = 0):
         """The inverse of pack_reduced: full-stride vectors with a zero nodal part (expand() fills it) (enqueued only)."""
         check(self.ctx.lib.rom_fem_unpack_reduced_async(self.h, Yc.h, c_row0, M, Y.h, y_row0))
+
+    def allgather_packed_async(self, Y: Buffer, M: int, send: Buffer, recv: Buffer, recv_off: int = 0, slot: int = 0,
+                               y_row0: int = 0):
+        """Pack the M interface vectors Y[y_row0:] into `send` and all-gather them into `recv`, both on the
+        communication stream (the compute stream is not blocked); slots as Context.allgather_async."""
+        check(self.ctx.lib.rom_comm_allgather_packed_async(self.h, Y.h, y_row0, M, send.h, recv.h, recv_off, slot))
 
     def solve_reduced(self, a: Buffer, M: int, Y: Buffer, y_row0: int = 0):
         """Stage 1 of the sweep (enqueued only): interface vectors of the M systems into Y[y_row0:y_row0+M]."""

@@ -159,6 +159,46 @@ extern "C" int rom_comm_allgather_async(rom_ctx* ctx, rom_buf* send, size_t send
   ctx->slot_hi[slot][0] = send->p + send_off + count;
   ctx->slot_lo[slot][1] = recv->p + recv_off;
   ctx->slot_hi[slot][1] = recv->p + recv_off + count * size_t(ctx->nranks);
+  ctx->slot_lo[slot][2] = ctx->slot_hi[slot][2] = nullptr;
+  return ROM_OK;
+}
+
+// The step of a sharded sweep in one call: the interface vectors Y[y_row0 .. + M) of the own shard are packed into their
+// compact form (rom_fem_compact_stride() doubles each) and all-gathered -- BOTH on the communication stream, ordered after
+// everything enqueued so far on the compute stream, which goes straight on to the expansion (a pack kernel between the
+// reduced solves and the extension costs the compute stream 8 us per step at C2).  `send`: scratch for the packed shard
+// (M x compact stride), `recv`: nranks x M x compact stride from recv_off.  Slot semantics as rom_comm_allgather_async.
+extern "C" int rom_comm_allgather_packed_async(rom_fem* f, rom_buf* Y, int64_t y_row0, int M, rom_buf* send, rom_buf* recv,
+                                               size_t recv_off, int slot) {
+  ROM_CHECK(f && Y && send && recv, "rom_comm_allgather_packed_async: null argument");
+  rom_ctx* ctx = f->ctx;
+  ROM_CHECK(slot >= 0 && slot < 2, "rom_comm_allgather_packed_async: slot must be 0 or 1");
+  ROM_CHECK(ctx->comm, "rom_comm_allgather_packed_async: communicator not initialised (rom_comm_init)");
+  const size_t kc = size_t(f->nGp - (f->xb0 - f->nGa));
+  const size_t count = size_t(M) * kc;
+  ROM_CHECK(M >= 0 && y_row0 >= 0 && Y->n >= size_t(y_row0 + M) * f->nGp && send->n >= count &&
+                recv_off + count * size_t(ctx->nranks) <= recv->n,
+            "rom_comm_allgather_packed_async: buffers too small");
+  if (!ctx->comm_stream) {
+    ROM_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    ROM_HIP(hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) ROM_HIP(hipEventCreateWithFlags(&ctx->ev_slot[i], hipEventDisableTiming));
+  }
+  ROM_HIP(hipEventRecord(ctx->ev_comm, ctx->stream));
+  ROM_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm, 0));
+  ROM_TRY(rom_launch_pack_reduced(f, Y->p + size_t(y_row0) * f->nGp, send->p, M, ctx->comm_stream));
+  if (count)
+    ROM_NCCL(g_rccl.AllGather(send->p, recv->p + recv_off, count, NCCL_FLOAT64, (nccl_comm_t)ctx->comm, ctx->comm_stream));
+  ROM_HIP(hipEventRecord(ctx->ev_slot[slot], ctx->comm_stream));
+  ctx->slot_used[slot] = true;
+  ctx->slot_joined[slot] = false;
+  // (the slot's buffers: rom_buf_free waits for the slot when one of them is freed)
+  ctx->slot_lo[slot][0] = Y->p + size_t(y_row0) * f->nGp;
+  ctx->slot_hi[slot][0] = Y->p + size_t(y_row0 + M) * f->nGp;
+  ctx->slot_lo[slot][1] = recv->p + recv_off;
+  ctx->slot_hi[slot][1] = recv->p + recv_off + count * size_t(ctx->nranks);
+  ctx->slot_lo[slot][2] = send->p;
+  ctx->slot_hi[slot][2] = send->p + count;
   return ROM_OK;
 }
 
@@ -166,8 +206,16 @@ extern "C" int rom_comm_allgather_async(rom_ctx* ctx, rom_buf* send, size_t send
 // may then be overwritten by the next sweep step)
 extern "C" int rom_comm_wait_slot(rom_ctx* ctx, int slot) {
   ROM_CHECK(ctx && slot >= 0 && slot < 2, "rom_comm_wait_slot: bad arguments");
-  if (!ctx->comm_stream || !ctx->slot_used[slot]) return ROM_OK;
-  ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_slot[slot], 0));
+  if (!ctx->comm_stream || !ctx->slot_used[slot] || ctx->slot_joined[slot]) return ROM_OK;
+  // In the steady state of a sweep the collective of two steps ago finished long before the host gets here: then nothing
+  // needs to be enqueued -- a wait packet in the compute queue costs a kernel-to-kernel bubble even when its event is done.
+  const hipError_t q = hipEventQuery(ctx->ev_slot[slot]);
+  if (q == hipErrorNotReady) {
+    (void)hipGetLastError();  // (not an error: the collective is still in flight)
+    ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_slot[slot], 0));
+  } else {
+    ROM_HIP(q);
+  }
   ctx->slot_joined[slot] = true;
   return ROM_OK;
 }

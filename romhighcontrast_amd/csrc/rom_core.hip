@@ -296,7 +296,7 @@ extern "C" int rom_buf_free(rom_buf* b) {
     for (int s = 0; s < 2; ++s) {
       if (!c->slot_used[s] || c->slot_joined[s]) continue;
       bool touches = false;
-      for (int k = 0; k < 2; ++k) touches = touches || (c->slot_lo[s][k] < hi && lo < c->slot_hi[s][k]);
+      for (int k = 0; k < 3; ++k) touches = touches || (c->slot_lo[s][k] < hi && lo < c->slot_hi[s][k]);
       if (!touches) continue;
       ROM_HIP(hipSetDevice(c->device));
       ROM_HIP(hipStreamWaitEvent(c->stream, c->ev_slot[s], 0));

@@ -337,6 +337,15 @@ extern "C" int rom_fem_compact_stride(rom_fem* f, int64_t* stride) {
   return ROM_OK;
 }
 
+// (internal: the pack on a given stream -- rom_comm_allgather_packed_async runs it on the communication stream)
+int rom_launch_pack_reduced(rom_fem* f, const double* Y, double* Yc, int M, hipStream_t st) {
+  const int kc = f->nGp - (f->xb0 - f->nGa);
+  if (M <= 0 || kc <= 0) return ROM_OK;
+  k_pack_reduced<<<M, 256, 0, st>>>(Y, f->nGp, f->nGa, f->xb0, Yc, kc);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
 extern "C" int rom_fem_pack_reduced_async(rom_fem* f, rom_buf* Y, int64_t y_row0, int M, rom_buf* Yc, int64_t c_row0) {
   ROM_CHECK(f && Y && Yc, "rom_fem_pack_reduced_async: null argument");
   const int kc = f->nGp - (f->xb0 - f->nGa);

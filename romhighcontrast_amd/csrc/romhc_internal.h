@@ -83,8 +83,8 @@ struct rom_ctx {
   bool slot_used[2] = {false, false};
   // the device ranges the last collective of each slot reads and writes, and whether the compute stream has been
   // ordered behind that collective since (rom_comm_wait_slot / rom_comm_wait): rom_buf_free consults them
-  const double* slot_lo[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-  const double* slot_hi[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  const double* slot_lo[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // send, receive, packed scratch
+  const double* slot_hi[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   bool slot_joined[2] = {true, true};
   // kernels that need more than 64 KB of dynamic LDS must opt in once per DEVICE (a context is one device)
   bool lds_optin_reduced_solve = false, lds_optin_small_eig = false, lds_optin_pivchol = false;
@@ -290,3 +290,6 @@ int rom_launch_gemm_nt(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alp
 int rom_launch_gemm_nt_ex(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
                           int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
                           const char* prof_name, int lower_only);
+
+// pack of interface vectors into their compact form on stream `st` (rom_fem_solve.hip)
+int rom_launch_pack_reduced(rom_fem* f, const double* Y, double* Yc, int M, hipStream_t st);

@@ -49,44 +49,59 @@ def sharded_sweep(a_all, world: int, rank: int, solve_local, allgather, finish=N
 
 
 # ---- the double-buffered step loop of the N > 1 sweep ---------------------------------------------------------------------
-def run_step(backend, step_no: int) -> int:
-    """One step of the overlapped sweep; returns the buffer slot it used.  Two buffer pairs alternate: the all-gather of
-    step s (communication stream) overlaps the expansion of step s and the reduced solves of step s + 1 (compute stream),
-    so before slot k is rewritten the collective that last read it (step s - 2) must have finished.  `backend`:
-        wait_slot(k)        compute stream waits for the collective last issued with slot k (no-op if none)
-        solve_local(k)      this rank's shard -> interface vectors into the send buffer of slot k (a short shard is padded)
-        allgather_async(k)  send buffer of slot k -> gathered buffer of slot k, not blocking the compute stream
-        expand(k)           snapshot rows from the interface vectors of slot k (own shard, or all after waiting)
+def run_step(backend, step_no: int, every: int = 1) -> int:
+    """One step of the overlapped sweep; returns the buffer slot it used.  The exchange is issued once per GROUP of `every`
+    consecutive steps (one larger all-gather instead of `every` small ones: a cross-stream dependency costs the compute
+    stream ~25 us per step at C2, and xGMI prefers few large transfers); two buffer sets alternate between groups: the
+    all-gather of group g (communication stream) overlaps the expansions of its last step and the whole of group g + 1
+    (compute stream), so before a slot is rewritten the collective that last read it (group g - 2) must have finished.
+    `backend`:
+        wait_slot(k)            compute stream waits for the collective last issued with slot k (no-op if none)
+        solve_local(k, j)       this rank's shard of the group's step j -> interface vectors into part j of the send
+                                buffer of slot k (a short shard is padded)
+        allgather_async(k, n)   parts 0 .. n-1 of slot k's send buffer -> its gathered buffer, not blocking the compute stream
+        expand(k, j)            snapshot rows from the interface vectors of part j of slot k (own shard)
     bench.py drives GpuStepBackend with it; tests/test_host_logic.py drives a gloo stand-in through the SAME function
-    (two processes, even and ragged M, slot reuse over several steps)."""
-    k = step_no & 1
-    backend.wait_slot(k)
-    backend.solve_local(k)
-    backend.allgather_async(k)
-    backend.expand(k)
+    (two processes, even and ragged M, slot reuse over several groups, every = 1 and 3)."""
+    g, j = divmod(step_no, every)
+    k = g & 1
+    if j == 0:
+        backend.wait_slot(k)
+    backend.solve_local(k, j)
+    if j == every - 1:
+        backend.allgather_async(k, every)
+    backend.expand(k, j)
     return k
 
 
-def drain(backend):
-    """End of a timed region: everything enqueued by run_step has finished, the last all-gather has landed."""
+def drain(backend, steps_done=None, every: int = 1):
+    """End of a timed region: the shards of a last, incomplete group (steps_done % every of them) are sent, everything
+    enqueued by run_step has finished, the last all-gather has landed."""
+    if steps_done is not None and every > 1 and steps_done % every:
+        backend.allgather_async((steps_done // every) & 1, steps_done % every)
     backend.drain()
 
 
 class GpuStepBackend:
-    """libromhc realisation of the step protocol: rom_solve_reduced_async / rom_comm_allgather_async (RCCL over xGMI,
-    on the context's communication stream) / rom_expand_batch_async, parameters resident in HBM.
-    What travels is the COMPACT form of the interface vectors (rom_fem_pack_reduced_async: the entries the expansion
-    reads, 272 of 784 doubles per system at 256 x 256 / 2 x 2 -- the nodal part is recomputed by whoever expands).
-    `M` rows per rank; a rank whose shard is short (`m_valid` < M) pads its send buffer with zero vectors once."""
+    """libromhc realisation of the step protocol: rom_solve_reduced_async / rom_comm_allgather_packed_async (pack + RCCL
+    all-gather over xGMI, both on the context's communication stream) / rom_expand_batch_async, parameters resident in HBM.
+    What travels is the COMPACT form of the interface vectors (the entries the expansion reads, 272 of 784 doubles per
+    system at 256 x 256 / 2 x 2 -- the nodal part is recomputed by whoever expands), once per group of `every` steps.
+    `M` rows per rank and step; a rank whose shard is short (`m_valid` < M) pads its send buffer with zero vectors once.
+    Gathered layout of slot k after a collective of n parts: row (r * n + j) * M + m = rank r, part j, system m."""
 
-    def __init__(self, ctx, fem, a_dev, M, world, *, U_loc=None, replicate=None, m_valid=None):
+    def __init__(self, ctx, fem, a_dev, M, world, *, U_loc=None, replicate=None, m_valid=None, every=1):
         self.ctx, self.fem, self.a_dev, self.M, self.world = ctx, fem, a_dev, int(M), int(world)
+        self.every = int(every)
+        assert self.every >= 1 and (replicate is None or self.every == 1), "the replicated row block is exchanged every step"
         self.m_valid = self.M if m_valid is None else int(m_valid)
         self.stride = fem.reduced_stride
         self.cstride = fem.compact_stride
-        self.Y_loc = [ctx.alloc(max(self.M * self.stride, 1)) for _ in range(2)]
-        self.Yc_loc = [ctx.alloc(max(self.M * self.cstride, 1)) for _ in range(2)]                 # send buffers
-        self.Yc_all = [ctx.alloc(max(self.world * self.M * self.cstride, 1)) for _ in range(2)]    # gathered
+        rows = self.every * self.M
+        self.Y_loc = [ctx.alloc(max(rows * self.stride, 1)) for _ in range(2)]                   # full vectors of a group
+        self.Yc_loc = [ctx.alloc(max(rows * self.cstride, 1)) for _ in range(2)]                 # packed: send buffers
+        self.Yc_all = [ctx.alloc(max(self.world * rows * self.cstride, 1)) for _ in range(2)]    # gathered
+        self.parts = [0, 0]                                                                       # parts in the last collective of a slot
         if self.m_valid < self.M:
             for y in self.Y_loc:
                 y.fill(0.0)  # padding rows are gathered (and expanded by --replicate): they must hold finite numbers
@@ -97,29 +112,31 @@ class GpuStepBackend:
     def wait_slot(self, k):
         self.ctx.comm_wait_slot(k)
 
-    def solve_local(self, k):
+    def solve_local(self, k, j=0):
         if self.m_valid:
-            self.fem.solve_reduced(self.a_dev, self.m_valid, self.Y_loc[k])
-        self.fem.pack_reduced(self.Y_loc[k], self.M, self.Yc_loc[k])
+            self.fem.solve_reduced(self.a_dev, self.m_valid, self.Y_loc[k], y_row0=j * self.M)
 
-    def allgather_async(self, k):
-        self.ctx.allgather_async(self.Yc_loc[k], 0, self.Yc_all[k], 0, self.M * self.cstride, slot=k)
+    def allgather_async(self, k, n=1):
+        # pack + all-gather on the communication stream: the compute stream goes straight on to the expansion
+        self.fem.allgather_packed_async(self.Y_loc[k], n * self.M, self.Yc_loc[k], self.Yc_all[k], 0, slot=k)
+        self.parts[k] = n
 
-    def gathered_vectors(self, k, row0, rows, out=None):
-        """Full-stride interface vectors of the gathered rows [row0, row0 + rows) of slot k (the compute stream must
-        already wait for the collective: comm_wait / wait_slot)."""
+    def gathered_vectors(self, k, rank, part, row0, rows, out=None):
+        """Full-stride interface vectors of `rows` systems from `row0` of (rank, part) in the gathered buffer of slot k
+        (the compute stream must already wait for the collective: comm_wait / wait_slot)."""
         out = out if out is not None else self.ctx.alloc(rows * self.stride)
-        self.fem.unpack_reduced(self.Yc_all[k], rows, out, c_row0=row0)
+        self.fem.unpack_reduced(self.Yc_all[k], rows, out, c_row0=(rank * self.parts[k] + part) * self.M + row0)
         return out
 
-    def expand(self, k):
+    def expand(self, k, j=0):
         if self.replicate is not None:
             a_all_dev, U_all = self.replicate
             self.ctx.comm_wait(False)                                       # compute stream waits for the gathered vectors
-            self.gathered_vectors(k, 0, self.world * self.M, out=self.Y_all_full)
+            self.fem.unpack_reduced(self.Yc_all[k], self.world * self.M, self.Y_all_full)
             self.fem.expand(a_all_dev, self.world * self.M, self.Y_all_full, U_all)   # the whole block as rows, on every rank
         elif self.m_valid:
-            self.fem.expand(self.a_dev, self.m_valid, self.Y_loc[k], self.U_loc)    # rows of the own shard, while the vectors travel
+            # rows of the own shard, while the vectors travel
+            self.fem.expand(self.a_dev, self.m_valid, self.Y_loc[k], self.U_loc, y_row0=j * self.M)
 
     def drain(self):
         self.ctx.solve_status()  # waits for the compute stream; raises if any system was not positive definite

@@ -194,12 +194,14 @@ class GlooBackend:
     It enforces the protocol's ordering rules instead of trusting them: a send buffer may only be rewritten after the
     collective that reads it has been waited for, a gathered buffer only read after its collective has been waited for."""
 
-    def __init__(self):
-        self.Y_loc = [np.full((mp, g.dim), np.nan) for _ in range(2)]
-        self.Y_all = [np.full((world * mp, g.dim), np.nan) for _ in range(2)]
+    def __init__(self, every):
+        self.every = every
+        self.Y_loc = [np.full((every * mp, g.dim), np.nan) for _ in range(2)]
+        self.Y_all = [np.full((world * every * mp, g.dim), np.nan) for _ in range(2)]
         self.work = [None, None]
         self.in_flight = [False, False]
-        self.step_of_slot = [None, None]
+        self.parts = [0, 0]
+        self.steps_of_slot = [[], []]
         self.expanded = []
         self.step = 0
 
@@ -212,54 +214,69 @@ class GlooBackend:
             self.work[k] = None
         self.in_flight[k] = False
 
-    def solve_local(self, k):
+    def solve_local(self, k, j):
         assert not self.in_flight[k], f"slot {k} rewritten while its all-gather is in flight"
-        self.Y_loc[k][:] = 0.0         # a short shard is padded with zero vectors
+        if j == 0:
+            self.steps_of_slot[k] = []
+        part = self.Y_loc[k][j * mp:(j + 1) * mp]
+        part[:] = 0.0                  # a short shard is padded with zero vectors
         if hi > lo:
-            self.Y_loc[k][:hi - lo] = ro.generate_solutions(g, self.params(self.step)[lo:hi])
-        self.step_of_slot[k] = self.step
+            part[:hi - lo] = ro.generate_solutions(g, self.params(self.step)[lo:hi])
+        self.steps_of_slot[k].append(self.step)
 
-    def allgather_async(self, k):
-        assert not self.in_flight[k]
-        self.work[k] = dist.all_gather_into_tensor(torch.from_numpy(self.Y_all[k]), torch.from_numpy(self.Y_loc[k]), async_op=True)
+    def allgather_async(self, k, n):
+        assert not self.in_flight[k] and n == len(self.steps_of_slot[k])
+        self.work[k] = dist.all_gather_into_tensor(torch.from_numpy(self.Y_all[k][:world * n * mp]),
+                                                   torch.from_numpy(self.Y_loc[k][:n * mp]), async_op=True)
         self.in_flight[k] = True
+        self.parts[k] = n
 
-    def expand(self, k):
-        self.expanded.append((self.step, self.Y_loc[k][:hi - lo].copy()))   # rows of the own shard
+    def expand(self, k, j):
+        self.expanded.append((self.step, self.Y_loc[k][j * mp:j * mp + hi - lo].copy()))   # rows of the own shard
         self.step += 1
 
     def drain(self):
         for k in range(2):
             self.wait_slot(k)
 
+    def check_gathered(self, k):
+        """slot k's last collective, once waited for: rank r, part j = rows [r mp, ...) of the unsharded sweep of that step"""
+        self.wait_slot(k)
+        n = self.parts[k]
+        for jpart, st in enumerate(self.steps_of_slot[k][:n]):
+            ref = ro.generate_solutions(g, self.params(st))
+            for r in range(world):
+                rlo, rhi = sweep.shard_bounds(M, world, r)
+                got = self.Y_all[k][(r * n + jpart) * mp:(r * n + jpart + 1) * mp]
+                assert np.array_equal(got[:rhi - rlo], ref[rlo:rhi]), f"step {st}: gathered shard of rank {r} differs"
+                assert not got[rhi - rlo:].any(), "padding rows of a short shard must be zero"
 
-be = GlooBackend()
-steps = 7
-for s in range(steps):
-    k = sweep.run_step(be, s)
-    assert k == s % 2
-    if s >= 1:
-        # the PREVIOUS step's gathered block (other slot) must be complete and equal to the unsharded sweep once waited for
-        kp = (s - 1) % 2
-        be.wait_slot(kp)
-        ref = ro.generate_solutions(g, be.params(s - 1))
-        assert np.array_equal(be.Y_all[kp][:M], ref), f"step {s - 1}: gathered block differs from the unsharded sweep"
-        assert not be.Y_all[kp][M:].any(), "padding rows of a short shard must be zero"
-sweep.drain(be)
-kl = (steps - 1) % 2
-assert np.array_equal(be.Y_all[kl][:M], ro.generate_solutions(g, be.params(steps - 1)))
-assert [st for st, _ in be.expanded] == list(range(steps))
-for st, rows in be.expanded:
-    assert np.array_equal(rows, ro.generate_solutions(g, be.params(st))[lo:hi])
-# the protocol check itself must bite: rewriting a slot without waiting is refused
-be.allgather_async(0)
-try:
-    be.solve_local(0)
-    raise SystemExit("missing wait was not detected")
-except AssertionError:
-    pass
-sweep.drain(be)
-dist.barrier()
+
+for every in (1, 3):
+    be = GlooBackend(every)
+    steps = 7
+    for s in range(steps):
+        k = sweep.run_step(be, s, every)
+        assert k == (s // every) % 2
+        if s % every == every - 1 and s >= every:
+            be.check_gathered(k ^ 1)   # the PREVIOUS group's gathered block (other slot): complete and equal to the sweep
+    sweep.drain(be, steps, every)      # (7 steps in groups of 3: the last group has one shard)
+    kl = ((steps - 1) // every) % 2
+    assert be.parts[kl] == (steps % every or every)
+    be.check_gathered(kl)
+    assert [st for st, _ in be.expanded] == list(range(steps))
+    for st, rows in be.expanded:
+        assert np.array_equal(rows, ro.generate_solutions(g, be.params(st))[lo:hi])
+    # the protocol check itself must bite: rewriting a slot without waiting is refused
+    be.steps_of_slot[0] = [0]
+    be.allgather_async(0, 1)
+    try:
+        be.solve_local(0, 0)
+        raise SystemExit("missing wait was not detected")
+    except AssertionError:
+        pass
+    sweep.drain(be)
+    dist.barrier()
 dist.destroy_process_group()
 print("OK", rank)
 '''
@@ -268,10 +285,10 @@ print("OK", rank)
 @pytest.mark.parametrize("M", [8, 7])
 def test_step_loop_two_ranks_gloo(tmp_path, M):
     """The double-buffered step loop bench.py runs for N > 1 (sweep.run_step: wait-before-rewrite, solve, asynchronous
-    all-gather, expansion, slot alternation) driven by two processes through a gloo stand-in for the RCCL calls: over 7
-    steps (each slot reused three times) with different parameters per step, for an even and a ragged M, the gathered
-    block of every step equals the unsharded sweep (the reference's map over all parameters,
-    src/lib/SolutionsManagers.py:51,64-68)."""
+    all-gather once per group of steps, expansion, slot alternation) driven by two processes through a gloo stand-in for
+    the RCCL calls: over 7 steps with different parameters per step, exchanged every step and in groups of 3 (the last
+    group incomplete), for an even and a ragged M, the gathered shards of every step equal the unsharded sweep (the
+    reference's map over all parameters, src/lib/SolutionsManagers.py:51,64-68)."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -321,30 +338,42 @@ def test_gpu_step_backend_follows_the_protocol():
     class Fem:
         reduced_stride, compact_stride, dim = 10, 6, 100
 
-        def solve_reduced(self, a, M, Y):
-            log.append(("solve", M, Y.n))
+        def solve_reduced(self, a, M, Y, y_row0=0):
+            log.append(("solve", M, Y.n, y_row0))
 
-        def pack_reduced(self, Y, M, Yc):
-            log.append(("pack", M, Y.n, Yc.n))
+        def allgather_packed_async(self, Y, M, send, recv, recv_off, slot=0):
+            log.append(("pack+allgather", M, Y.n, send.n, recv.n, slot))
 
-        def expand(self, a, M, Y, U):
-            log.append(("expand", M, Y.n, U.n))
+        def expand(self, a, M, Y, U, y_row0=0):
+            log.append(("expand", M, Y.n, U.n, y_row0))
 
     be = sweep.GpuStepBackend(Ctx(), Fem(), "a", 4, 2, m_valid=3)
     assert log == [("fill", 40, 0.0), ("fill", 40, 0.0)]
     del log[:]
     for s in range(3):
         assert sweep.run_step(be, s) == s % 2
-    sweep.drain(be)
+    sweep.drain(be, 3, 1)
     # the solve writes full-stride vectors (4 x 10), what is gathered is their compact form (4 x 6 -> 2 ranks x 4 x 6), all
     # M rows of the shard (the padding row of the short shard included); the own rows are expanded from the full vectors
-    per_step = [("wait_slot", None), ("solve", 3, 40), ("pack", 4, 40, 24), ("allgather", 24, 48, 24, None),
-                ("expand", 3, 40, 400)]
+    per_step = [("wait_slot", None), ("solve", 3, 40, 0), ("pack+allgather", 4, 40, 24, 48, None), ("expand", 3, 40, 400, 0)]
     want = []
     for s in range(3):
         for rec in per_step:
             want.append(tuple(s % 2 if v is None else v for v in rec))
     assert log == want + [("status",), ("comm_wait", True)], log
+    # groups of 3 steps: one wait and one collective per group, the parts of a group side by side in the slot's buffers
+    # (3 x 4 x 10 full vectors, 3 x 4 x 6 packed, 2 ranks x 3 x 4 x 6 gathered); 4 steps: the last group sends one part
+    del log[:]
+    be = sweep.GpuStepBackend(Ctx(), Fem(), "a", 4, 2, every=3)
+    for s in range(4):
+        assert sweep.run_step(be, s, 3) == (s // 3) % 2
+    sweep.drain(be, 4, 3)
+    assert log == [("wait_slot", 0), ("solve", 4, 120, 0), ("expand", 4, 120, 400, 0),
+                   ("solve", 4, 120, 4), ("expand", 4, 120, 400, 4),
+                   ("solve", 4, 120, 8), ("pack+allgather", 12, 120, 72, 144, 0), ("expand", 4, 120, 400, 8),
+                   ("wait_slot", 1), ("solve", 4, 120, 0), ("expand", 4, 120, 400, 0),
+                   ("pack+allgather", 4, 120, 72, 144, 1), ("status",), ("comm_wait", True)], log
+    assert be.parts == [3, 1]
 
 
 def test_parameter_sampler_matches_reference():
