@@ -1218,6 +1218,24 @@ def test_rccl_single_rank_allgather(api):
         sm32 = SM.SolutionsManagerFEM((2, 2), 32)             # (compressed edges: linear expansion)
         fs = sweep.RcclSweep(sm32, 0, 1).generate_factored(a)  # the gathered block left in factored form
         assert fs.M == 5 and np.array_equal(fs.rows().numpy(), sm32.generate_solutions(a))
+        # the step loop of bench.py on the real backend: compact vectors, one collective per group of 2 steps, 5 steps (the
+        # last group incomplete); every gathered shard must expand to the rows of a plain sweep, bit for bit
+        fem, M = sm32._fem, 5
+        a_dev = ctx.upload(np.ascontiguousarray(a).reshape(M, -1))
+        ref = sm32.generate_solutions(a)
+        be = sweep.GpuStepBackend(ctx, fem, a_dev, M, 1, every=2)
+        assert be.cstride < be.stride
+        for step in range(5):
+            k = sweep.run_step(be, step, 2)
+        sweep.drain(be, 5, 2)
+        assert be.parts == [1, 2] and k == 0
+        assert np.array_equal(be.U_loc.download(shape=(M, fem.dim)), ref)
+        for slot, part in ((0, 0), (1, 0), (1, 1)):
+            Yfull = be.gathered_vectors(slot, 0, part, 0, M)
+            rows = ctx.alloc(M * fem.dim)
+            fem.expand(a_dev, M, Yfull, rows)
+            ctx.solve_status()
+            assert np.array_equal(rows.download(shape=(M, fem.dim)), ref), (slot, part)
     finally:
         ctx.comm_destroy()
 
