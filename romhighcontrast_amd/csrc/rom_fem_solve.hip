@@ -254,8 +254,10 @@ static int solve_batch_impl(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t r
   // (under per-kernel profiling the sweep stays on one stream: an event bracket then times its kernel alone)
   const int want = ctx->profile ? 1 : ctx->n_streams > 0 ? ctx->n_streams : (f->fused1 && !f->sw_no_fused ? 1 : 2);
   const int nsub = std::max(1, std::min(want, (M + 255) / 256));
-  ROM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-  for (int s = 1; s < nsub; ++s) ROM_HIP(hipStreamWaitEvent(ctx->aux[s - 1], ctx->ev_fork, 0));
+  if (nsub > 1) {  // (no marker packet in the compute queue when the sweep stays on one stream: it costs a kernel-to-kernel bubble)
+    ROM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    for (int s = 1; s < nsub; ++s) ROM_HIP(hipStreamWaitEvent(ctx->aux[s - 1], ctx->ev_fork, 0));
+  }
   for (int m0 = 0; m0 < M; m0 += Mc_max) {
     const int Mchunk = std::min(Mc_max, M - m0);
     const int per = ((Mchunk + nsub - 1) / nsub + 63) / 64 * 64;
@@ -280,8 +282,10 @@ static int solve_batch_impl(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t r
         ROM_HIP(hipEventRecord(ctx->ev_join[s - 1], ctx->aux[s - 1]));
         ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[s - 1], 0));
       }
-      ROM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-      for (int s = 1; s < nsub; ++s) ROM_HIP(hipStreamWaitEvent(ctx->aux[s - 1], ctx->ev_fork, 0));
+      if (nsub > 1) {
+        ROM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        for (int s = 1; s < nsub; ++s) ROM_HIP(hipStreamWaitEvent(ctx->aux[s - 1], ctx->ev_fork, 0));
+      }
     }
   }
   for (int s = 1; s < nsub; ++s) {
