@@ -640,6 +640,10 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   const double* am = a + size_t(m) * f.kblk;
   double* ym = f.y + size_t(m) * f.nGp;
   const TileDesc& d = f.desc[0];
+  // the alignment gaps of the interface vector are read (against zero table entries) by the extension: they must hold
+  // finite numbers whatever buffer the caller handed in -- zeroed here, ahead of every other store of this wave to its
+  // vector, instead of by a memset launch in front of every sweep
+  for (int i = lane; i < f.nGp; i += 64) ym[i] = 0.0;
   // Assembly in the MFMA accumulator layout of the Cholesky below: element g of block q = (ib, jb), ib >= jb, is
   // (row 16 ib + 4 g + (lane >> 4), column 16 jb + (lane & 15)).  The host lists the (term, block) pairs whose
   // rectangle and block intersect (57 at 2x2 / N=128); a pair is exactly four loads, so a ring of PAIR_RING

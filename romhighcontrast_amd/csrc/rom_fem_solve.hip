@@ -385,7 +385,8 @@ extern "C" int rom_fem_reduced_stride(rom_fem* f, int64_t* stride) {
 extern "C" int rom_solve_reduced_async(rom_fem* f, rom_buf* a, int M, rom_buf* Y, int64_t y_row0) {
   ROM_CHECK(f && Y, "rom_solve_reduced_async: null argument");
   ROM_CHECK(M >= 0 && y_row0 >= 0 && Y->n >= size_t(y_row0 + M) * f->nGp, "rom_solve_reduced_async: Y too small");
-  if (M > 0 && f->nGp > 0)  // padding slots are read against zero table entries: they must hold finite numbers
+  // padding slots are read against zero table entries: they must hold finite numbers (k_solve1 zeroes its vector itself)
+  if (M > 0 && f->nGp > 0 && !(f->fused1 && !f->sw_no_fused))
     ROM_HIP(hipMemsetAsync(Y->p + size_t(y_row0) * f->nGp, 0, size_t(M) * f->nGp * sizeof(double), f->ctx->stream));
   return solve_batch_impl(f, a, M, nullptr, 0, false, Y, y_row0, 1);
 }
