@@ -237,6 +237,18 @@ def pick_device(local_rank: int, local_world: int, ndev: int) -> int:
                      "required (RCCL refuses two ranks on one device)")
 
 
+def gathered_rows_ok(ctx, fem, be, a_all, rank, world, M, dim, k_last) -> bool:
+    """A few rows of the NEXT rank's shard, expanded from the vectors the last collective of slot `k_last` gathered, against a
+    plain local sweep of the same parameters (bit for bit)."""
+    peer = (rank + 1) % world
+    a_peer = ctx.upload(a_all[peer * M:peer * M + 4].reshape(4, -1))
+    rows = ctx.alloc(4 * dim)
+    fem.expand(a_peer, 4, be.gathered_vectors(k_last, peer, be.parts[k_last] - 1, 0, 4), rows)
+    chk = ctx.alloc(4 * dim)
+    fem.solve_batch(a_peer, 4, chk)
+    return bool(np.array_equal(rows.download(), chk.download()))
+
+
 def pod_accounting(M, dim, r):
     """Flops of a POD by the Gram route that are USEFUL work (SURVEY 8d without its 10 M^3 'eigh' term, which the
     subspace iteration never executes): the symmetric half of ONE Gram matrix + the lift of r modes."""
@@ -257,6 +269,11 @@ def main():
     ap.add_argument("--no-extras", "--no-pod", dest="no_extras", action="store_true",
                     help="only the sweep line: no POD / greedy / API-rate legs")
     ap.add_argument("--no-pod-c3", action="store_true", help="c2: skip the POD of the 8192-snapshot C3 block")
+    ap.add_argument("--preroll", type=float, default=0.25,
+                    help="seconds of untimed steps in front of the first timed region (on top of --warmup): the part reaches "
+                         "its steady clocks only after ~0.2 s of work, and a region of 100 C2 steps is 25 ms")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="c2 on one GPU: skip the compact C4 / C5 legs (sweep, dominant kernel, greedy n = 50, C5 POD)")
     ap.add_argument("--force-comm", action="store_true",
                     help="rehearsal: run the N>1 code path (RCCL communicator, all-gather of the interface vectors, "
                          "expansion of the gathered block) with one rank")
@@ -374,6 +391,41 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
+    exchange_note = None
+    if comm and not args.replicate:
+        # Pre-flight of the grouped exchange: the warm-up above has just sent full groups and, whenever
+        # warmup % every != 0, a last partial one.  A peer's rows expanded from the gathered vectors must equal a plain local
+        # sweep of the same parameters bit for bit; if they do not with groups of `every` steps, the run falls back to one
+        # collective per step (and says so in its line) instead of timing a broken path.
+        ok = gathered_rows_ok(ctx, fem, be, a_all, rank, world, M, dim, last_slot[0])
+        ok_all = int(round(float(ctx.allreduce_host([1.0 if ok else 0.0], "sum")[0]))) == world
+        if not ok_all and every > 1:
+            exchange_note = f"grouped exchange (every {every} steps) failed its bit-identity pre-flight: fell back to every step"
+            print("bench.py: " + exchange_note, file=sys.stderr)
+            every = 1
+            be = sweep.GpuStepBackend(ctx, fem, a_dev, M, world, U_loc=U_loc, replicate=None, every=1)
+            step_no[0] = 0
+            for _ in range(max(1, args.warmup)):
+                step()
+            drain()
+            ok = gathered_rows_ok(ctx, fem, be, a_all, rank, world, M, dim, last_slot[0])
+            ok_all = int(round(float(ctx.allreduce_host([1.0 if ok else 0.0], "sum")[0]))) == world
+        assert ok_all, "the gathered interface vectors do not reproduce the peer's rows"
+    # untimed, time-based pre-roll: `steps` / `warmup` stay what the caller passed; the regions below then agree to ~1 %
+    # (BENCH_r03: five regions falling 0.296 -> 0.263 ms per step behind 5 warm-up steps = 1.4 ms of work)
+    preroll_steps = 0
+    if args.preroll > 0:
+        t_pre = time.perf_counter()
+        while True:
+            for _ in range(max(1, every) * 4):
+                step()
+            drain()
+            preroll_steps += max(1, every) * 4
+            done = time.perf_counter() - t_pre >= args.preroll
+            if comm:
+                done = float(ctx.allreduce_host([1.0 if done else 0.0], "max")[0]) > 0.5  # (every rank takes the same decision)
+            if done:
+                break
     walls, evs = [], []
     for _ in range(max(1, args.repeats)):
         barrier()
@@ -416,14 +468,8 @@ def main():
             for off in probe:
                 assert U_all.download(1, offset=rank * M * dim + off)[0] == ref.download(1, offset=off)[0]
         else:
-            peer = (rank + 1) % world  # expand a few rows of the NEXT rank's shard from the gathered vectors
-            a_peer = ctx.upload(a_all[peer * M:peer * M + 4].reshape(4, -1))
-            rows = ctx.alloc(4 * dim)
-            k_last = last_slot[0]  # the last step's shard is the last part of the last collective of its slot
-            fem.expand(a_peer, 4, be.gathered_vectors(k_last, peer, be.parts[k_last] - 1, 0, 4), rows)
-            chk = ctx.alloc(4 * dim)
-            fem.solve_batch(a_peer, 4, chk)
-            assert np.array_equal(rows.download(), chk.download())
+            # (the last step's shard is the last part of the last collective of its slot)
+            assert gathered_rows_ok(ctx, fem, be, a_all, rank, world, M, dim, last_slot[0])
             for off in probe:
                 assert U_loc.download(1, offset=off)[0] == ref.download(1, offset=off)[0]
     if rank != 0:
@@ -498,13 +544,17 @@ def main():
         "repeats": {"regions": len(walls), "ms_per_step": [round(x, 4) for x in ms_all], "min_ms_per_step": round(min(ms_all), 4),
                     "median_ms_per_step": round(ms_all[med], 4), "max_ms_per_step": round(max(ms_all), 4),
                     "note": "each region = exactly `steps` steps between barriers; value / ms_per_step are the median region's"},
+        "preroll": {"seconds": args.preroll, "steps": preroll_steps,
+                    "note": "untimed steps in front of the first region, on top of `warmup` (clocks settle after ~0.2 s of work)"},
         "event_ms_per_step": round(ev_ms / args.steps, 4),
         "profiled_pass_ms_per_step": round(wall_prof / args.steps * 1e3, 4),
         "rccl_ranks": rccl_ranks if comm else 0,
         "exchange": ({"what": "compact interface vectors (factored snapshot block; the nodal part is recomputed by the expansion)",
                       "doubles_per_system": stride, "full_interface_vector_doubles": fem.reduced_stride, "steps_per_collective": every,
                       "sent_bytes_per_rank_per_step": M * stride * 8, "received_bytes_per_rank_per_step": world * M * stride * 8,
-                      "row_block_bytes_per_rank": M * dim * 8, "replicated_rows": bool(args.replicate)} if comm else None),
+                      "row_block_bytes_per_rank": M * dim * 8, "replicated_rows": bool(args.replicate),
+                      "preflight": exchange_note or "a peer's rows expanded from the gathered vectors equal a local sweep bit for bit "
+                                                    "(checked after the warm-up, whose last group is partial when warmup % every != 0, and again after the run)"} if comm else None),
         "setup": {"setup_s": round(setup_s, 4),
                   "solves_per_sec_incl_setup_one_sweep": round(M / (setup_s + wall / args.steps), 1),
                   "note": "setup_s = SolutionsManagerFEM(...) = rom_fem_create (parameter-independent tables, once per FE "
@@ -540,6 +590,13 @@ def main():
             "note": "USEFUL flops (symmetric half of ONE Gram matrix M(M+1)dim + lift 2 r M dim; no eigh term) over the wall "
                     "time of ONE rom_pod call incl. the download of the modes; the executed flops and the Gram kernel's own "
                     "rate are in the `" + pod_key + "` record"}
+        if pod_key == "pod_c3" and "pod" in out:
+            p1 = out["pod"]  # the metric's own 1-GPU geometry: 1024 x 65 025
+            out["roofline"]["secondary"]["at_1gpu_geometry"] = {
+                "workload": f"{p1['modes']}-mode POD of the {p1['M']} x {p1['dim']} block (C2: what ONE GPU holds)",
+                "achieved": round(p1["gflops"] * 1e-3, 2), "unit": "TFLOP/s", "frac": round(p1["gflops"] * 1e-3 / FP64_MATRIX_PEAK_TFLOPS, 4),
+                "seconds": p1["seconds"], "resolved_modes": p1.get("resolved_modes"),
+                "note": "same accounting; at this size the Gram kernel is a sixth of the call, the rest small dense problems and launches"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blocks, N, a_loc, budget_s=cfg["cpu_budget_s"], label=label,
                                            min_solves=2 if args.config == "c5" else 4)
@@ -560,6 +617,15 @@ def main():
                                        "sigma_1": float(sv[0]), "kind": "reference call",
                                        "sample": f"numpy.linalg.svd of the centred first {Ms} snapshots (the SVD inside "
                                                  f"sklearn PCA, src/lib/ReducedBasis.py:196), all LAPACK threads of the host"}
+    if world == 1 and not args.no_extras and args.config == "c2" and not custom and not args.no_other_configs:
+        # the two other single-GPU workloads of SURVEY 8d, compact, in the SAME line (the driver runs `python bench.py`)
+        U_loc.free()
+        a_dev.free()
+        for other in ("c4", "c5"):
+            try:
+                out[other] = other_config_leg(ctx, dev, other)
+            except Exception as e:  # (a leg must never cost the headline line)
+                out[other] = {"error": f"{type(e).__name__}: {e}"}
     if comm:
         ctx.comm_destroy()
         sweep.cleanup_rendezvous(rank)
@@ -683,7 +749,7 @@ def extras_pod_c2(out, args, ctx, sm, fem, a_dev, U_loc, M, dim, blocks):
         del X3, U3, G3
 
 
-def extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim):
+def extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim, factored_too=True):
     """C4: greedy reduced basis to n=50 on the 1024-parameter training set, both modes (src/lib/ReducedBasis.py:112-139),
     on snapshot rows (what a caller of the reference API has) and on the factored block."""
     from romhighcontrast_amd.lib import ReducedBasis as RB
@@ -703,7 +769,7 @@ def extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim):
         rec[f"rows_{tag}"] = {"seconds": round(t, 4), "tflops_algorithmic": round(fl / t * 1e-12, 2),
                               "max_rel_error_at_n": {str(k): float(e[k - 1]) for k in (1, 2, 5, 10, 20, 30, 40, 50) if k <= n},
                               "first_picks": rb.picks[:10]}
-    if fem.expansion_is_linear:
+    if fem.expansion_is_linear and factored_too:
         from romhighcontrast_amd import factored
         Yf = ctx.alloc(M * fem.reduced_stride)
         fem.solve_reduced(a_dev, M, Yf)
@@ -719,7 +785,75 @@ def extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim):
     out["greedy"] = rec
 
 
-def extras_pod_c5(out, ctx, sm, fem, a_dev, U_loc, M, dim):
+def other_config_leg(ctx, dev, config):
+    """Compact run of another single-GPU workload (C4 / C5) for the default line: sweep rate (median of 3 regions behind a
+    pre-roll), per-kernel HIP events of one pass, dominant kernel against its roofline, and the workload's basis stage
+    (C4: greedy n = 50 in both modes on rows; C5: 50-mode POD of the rows).  `python bench.py --config c4|c5` has the
+    full legs (factored forms, CPU baselines, API rates)."""
+    from romhighcontrast_amd.lib.SolutionsManagers import SolutionsManagerFEM
+    cfg = CONFIGS[config]
+    blocks, N, M = cfg["blocks"], cfg["N"], cfg["M"]
+    steps = 20 if config == "c4" else 4
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    sm = SolutionsManagerFEM(blocks, N, device=dev)
+    ctx.synchronize()
+    setup_s = time.perf_counter() - t0
+    fem, dim = sm._fem, sm.vspace_dim
+    a_loc = workload_parameters(config, blocks, M)
+    a_dev = ctx.upload(a_loc.reshape(M, -1))
+    U = ctx.alloc(M * dim)
+    for _ in range(2):
+        fem.solve_batch(a_dev, M, U, wait=False)
+    ctx.solve_status()
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.2:
+        fem.solve_batch(a_dev, M, U, wait=False)
+        ctx.solve_status()
+    walls = []
+    for _ in range(3):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fem.solve_batch(a_dev, M, U, wait=False)
+        ctx.solve_status()
+        walls.append(time.perf_counter() - t0)
+    wall = sorted(walls)[1]
+    ctx.profile_reset()
+    ctx.profile(True)
+    for _ in range(steps):
+        fem.solve_batch(a_dev, M, U, wait=False)
+    ctx.solve_status()
+    ctx.profile(False)
+    prof = ctx.profile_report()
+    kernels = {k: {"ms_per_step": round(v["total_ms"] / steps, 4), "launches_per_step": v["launches"] / steps,
+                   "tflops": round(v["flops"] / v["total_ms"] * 1e-9, 2) if v["total_ms"] > 0 else 0.0,
+                   "frac": round(v["flops"] / v["total_ms"] * 1e-9 / FP64_MATRIX_PEAK_TFLOPS, 4) if v["total_ms"] > 0 and v["flops"] > 0 else None}
+               for k, v in prof.items() if v["launches"]}
+    dom = max(prof, key=lambda k: prof[k]["total_ms"])
+    d = prof[dom]
+    ach = d["flops"] / d["total_ms"] * 1e-9
+    rec = {"workload": f"{cfg['label']}: {blocks[0]}x{blocks[1]} blocks, N={N}, dim {dim}, {M}-parameter sweep (SURVEY 8d parameters, seed {SEED})",
+           "value": round(M * steps / wall, 1), "unit": "solves/s", "steps": steps, "ms_per_step": round(wall / steps * 1e3, 4),
+           "regions_ms_per_step": [round(w / steps * 1e3, 4) for w in walls], "setup_s": round(setup_s, 3),
+           "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / FP64_MATRIX_PEAK_TFLOPS, 4), "avg_launch_ms": round(d["total_ms"] / d["launches"], 5)},
+           "kernels": kernels,
+           "note": "compact leg of the default run: the timed regions run the sweep as the library does by default (two concurrent "
+                   "sub-batches), `kernels` is one extra pass on ONE stream with every launch bracketed by HIP events"}
+    sub = {}
+    if config == "c4":
+        extras_greedy_c4(sub, ctx, sm, fem, a_loc, a_dev, U, M, dim, factored_too=False)
+        rec["greedy"] = sub["greedy"]
+    else:
+        extras_pod_c5(sub, ctx, sm, fem, a_dev, U, M, dim, factored_too=False)
+        rec["pod"] = sub["pod"]
+        rec["pod"]["frac_of_matrix_peak"] = round(rec["pod"]["gflops"] * 1e-3 / FP64_MATRIX_PEAK_TFLOPS, 4)
+    del U, a_dev, sm, fem
+    return rec
+
+
+def extras_pod_c5(out, ctx, sm, fem, a_dev, U_loc, M, dim, factored_too=True):
     """C5: POD of the 4096 x 1 046 529 block (src/lib/ReducedBasis.py:189-200), rows and factored."""
     from romhighcontrast_amd.lib.ReducedBasis import pod_modes
     from romhighcontrast_amd.lib.SolutionsManagers import DeviceArray
@@ -739,7 +873,7 @@ def extras_pod_c5(out, ctx, sm, fem, a_dev, U_loc, M, dim):
                   **getattr(pod_modes, "last_info", {}),
                   "note": "gflops = useful flops (symmetric half of ONE Gram + lift, no eigh term) over the wall time of pod_modes"}
     del X
-    if fem.expansion_is_linear:
+    if fem.expansion_is_linear and factored_too:
         from romhighcontrast_amd import factored
         Yf = ctx.alloc(M * fem.reduced_stride)
         fem.solve_reduced(a_dev, M, Yf)
