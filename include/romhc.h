@@ -217,9 +217,16 @@ int rom_greedy(rom_fem* fem, rom_buf* U, int64_t u_row0, int M, rom_buf* a, cons
  * matrix + subspace iteration for the modes above 1e-5 sigma_1, deflation + randomised range finder below, Rayleigh-
  * Ritz over the collected modes; modes below 1e-13 sigma_1 do not exist in fp64 data and are completed with
  * orthonormal directions of singular value 0.  info_host (8 doubles or NULL): resolved modes, completed modes, Gram
- * passes, sketch passes, executed flops, useful flops (M(M+1)dim + 2 n M dim), subspace iterations, 0. */
+ * passes, sketch passes, executed flops, useful flops (M(M+1)dim + 2 n M dim), subspace iterations, stop reason (0: all n
+ * modes resolved; 1: the spectrum reached the floor -- the completed modes are not determined by the data; 2: a pass
+ * accepted nothing although the floor was not reached -- modes above it may be missing). */
 int rom_pod(rom_ctx* ctx, rom_buf* X, int64_t x_row0, int M, int64_t dim, int n, int center, rom_buf* V, int64_t v_row0,
             double* sigma_host, double* info_host);
+/* the same with the floor chosen by the caller: modes with sigma <= rel_floor * sigma_1 are not looked for (every sketch
+ * pass over the block buys four orders of magnitude; a reduced basis that is used to 1e-10 does not need the last ones).
+ * rel_floor <= 1e-13 is rom_pod. */
+int rom_pod_ex(rom_ctx* ctx, rom_buf* X, int64_t x_row0, int M, int64_t dim, int n, int center, double rel_floor, rom_buf* V,
+               int64_t v_row0, double* sigma_host, double* info_host);
 /* n nearly orthonormal rows of V -> orthonormal rows, each as close as possible to what it was: V <- (V V^T)^(-1/2) V */
 int rom_symmetric_orthonormalize(rom_ctx* ctx, rom_buf* V, int64_t v_row0, int n, int64_t dim);
 /* rows V[v_row0+found .. +found+rest) <- deterministic pseudo-random directions, orthonormal and orthogonal to the

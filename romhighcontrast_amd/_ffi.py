@@ -92,6 +92,7 @@ PROTOTYPES = {
     "rom_orthonormalize_rows": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp, C.c_int64]),
     "rom_greedy": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rom_pod": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp]),
+    "rom_pod_ex": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, _vp, C.c_int64, _vp, _vp]),
     "rom_symmetric_orthonormalize": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64]),
     "rom_complete_orthonormal": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int64]),
     "rom_small_eig_host": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]),
@@ -268,14 +269,15 @@ class Context:
     def orthonormalize_rows(self, X: "Buffer", n, dim, Q: "Buffer", x_row0=0, q_row0=0):
         check(self.lib.rom_orthonormalize_rows(self.h, X.h, x_row0, n, dim, Q.h, q_row0))
 
-    def pod(self, X: "Buffer", M, dim, n, V: "Buffer", center=True, x_row0=0, v_row0=0):
-        """rom_pod: X is overwritten.  Returns (sigma (n,), info dict)."""
+    def pod(self, X: "Buffer", M, dim, n, V: "Buffer", center=True, x_row0=0, v_row0=0, rel_floor=0.0):
+        """rom_pod / rom_pod_ex: X is overwritten.  Returns (sigma (n,), info dict)."""
         sigma, info = np.zeros(max(n, 1)), np.zeros(8)
-        check(self.lib.rom_pod(self.h, X.h, x_row0, M, dim, n, 1 if center else 0, V.h, v_row0, sigma.ctypes.data,
-                               info.ctypes.data))
+        check(self.lib.rom_pod_ex(self.h, X.h, x_row0, M, dim, n, 1 if center else 0, float(rel_floor), V.h, v_row0,
+                                  sigma.ctypes.data, info.ctypes.data))
         keys = ("resolved_modes", "completed_modes", "gram_passes", "sketch_passes")
         d = {k: int(info[i]) for i, k in enumerate(keys)}
-        d.update(executed_flops=float(info[4]), useful_flops=float(info[5]), subspace_iterations=int(info[6]))
+        d.update(executed_flops=float(info[4]), useful_flops=float(info[5]), subspace_iterations=int(info[6]),
+                 stop_reason=("filled", "floor", "budget")[int(info[7])])
         return sigma[:n], d
 
     def symmetric_orthonormalize(self, V: "Buffer", n, dim, v_row0=0):
@@ -322,6 +324,9 @@ class Context:
         return v
 
 
+D2H_BYTES = [0]  # bytes copied from device buffers to the host through Buffer.download (tests assert on it)
+
+
 class Buffer:
     """fp64 device buffer owned by the library; freed on garbage collection."""
 
@@ -339,6 +344,7 @@ class Buffer:
 
     def download(self, n=None, offset=0, shape=None) -> np.ndarray:
         n = self.n - offset if n is None else int(n)
+        D2H_BYTES[0] += 8 * n
         out = _pinned_array(self.ctx.lib, n) if n * 8 >= PINNED_DOWNLOAD_BYTES else None
         if out is None:
             out = np.empty(n, dtype=np.float64)

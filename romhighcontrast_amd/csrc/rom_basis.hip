@@ -1370,10 +1370,13 @@ int sketched_modes(rom_ctx* ctx, const double* X, int M, int64_t dim, const doub
 // center != 0: subtract the column means first (sklearn PCA.fit).  V: (n, dim) rows = modes, sign convention of
 // sklearn's svd_flip(u_based_decision=False); sigma_host: n singular values (0 for completed modes);
 // info_host (8 doubles, may be null): resolved modes, completed modes, Gram passes, sketch passes, executed flops,
-// useful flops, subspace iterations, 0.
-extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t dim, int n, int center, rom_buf* Vb,
-                       int64_t v_row0, double* sigma_host, double* info_host) {
+// useful flops, subspace iterations, stop reason (0 filled, 1 floor reached, 2 budget).
+// rel_floor: modes with sigma <= rel_floor * sigma_1 are not looked for (<= 0 or below the fp64 noise floor of the snapshots,
+// 1e-13: that floor -- what a full LAPACK SVD of the block resolves)
+extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t dim, int n, int center, double rel_floor,
+                          rom_buf* Vb, int64_t v_row0, double* sigma_host, double* info_host) {
   ROM_CHECK(ctx && Xb && Vb && (sigma_host || n == 0), "rom_pod: null argument");
+  const double floor_rel = rel_floor > NOISE_FLOOR ? rel_floor : NOISE_FLOOR;
   ROM_CHECK(M >= 1 && dim >= 1 && n >= 0 && x_row0 >= 0 && v_row0 >= 0, "rom_pod: bad sizes");
   ROM_CHECK(n <= std::min<int64_t>(M, dim), "rom_pod: %d modes requested from a %d x %lld block", n, M, (long long)dim);
   ROM_CHECK(n + 12 <= SE_MAX, "rom_pod: at most %d modes", SE_MAX - 12);
@@ -1398,7 +1401,10 @@ extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t
     info.executed += 2.0 * take * M * double(dim);
     return ROM_OK;
   };
-  const int passes = 12;
+  // the sketch passes run until the request is filled or the spectrum has reached the floor; the budget below only guards
+  // against a pass that makes no progress (every pass accepts at least one mode or ends the loop)
+  const int passes = n + 2;
+  bool at_floor_stop = false;
   if (n > 0) {
     Tmp G, W, fac;
     ROM_TRY(G.get(ctx, size_t(M) * M));
@@ -1435,20 +1441,27 @@ extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t
     // a pass accepts modes over four orders of magnitude -- a dozen of them in a spectrum that decays like the snapshot
     // blocks' do -- so it asks for at most 16 (+ 8 of oversampling): the thin products scale with b, the small dense
     // problems with b^3; a spectrum that decays more slowly takes more passes
-    const int want = std::min(n - found, 16);
+    // (a request with hundreds of modes left asks for more per pass: 16 per pass would be n / 16 passes over the block)
+    const int want = std::min(n - found, std::max(16, (n - found) / 4));
     const int bmax = int(std::min<int64_t>(std::min<int64_t>(M, dim), want + 8));
     ROM_TRY(Vs.get(ctx, size_t(bmax) * dim));
     ROM_TRY(sketched_modes(ctx, X, M, dim, V, Bt, found, want, p, Vs, ss, b, info));
     info.sketch_passes += 1;
     int take = 0;
-    while (take < std::min(b, want) && ss[take] > SKETCH_ACCEPT * ss[0] && ss[take] > NOISE_FLOOR * sigma_1) ++take;
-    if (take == 0) break;
+    while (take < std::min(b, want) && ss[take] > SKETCH_ACCEPT * ss[0] && ss[take] > floor_rel * sigma_1) ++take;
+    if (take == 0) {
+      at_floor_stop = b == 0 || ss[0] <= floor_rel * sigma_1;
+      break;
+    }
     ROM_HIP(hipMemcpyAsync(V + size_t(found) * dim, Vs.p(), size_t(take) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     ROM_TRY(orthonormalize_against(ctx, V, found, take, dim));
-    const bool at_floor = take < b && ss[take] <= NOISE_FLOOR * sigma_1;
+    const bool at_floor = take < b && ss[take] <= floor_rel * sigma_1;
     ROM_TRY(deflate(found, take));
     found += take;
-    if (at_floor) break;  // the spectrum has reached the noise floor: nothing left to find
+    if (at_floor) {  // the spectrum has reached the floor: nothing left to find
+      at_floor_stop = true;
+      break;
+    }
   }
   if (found) {
     // Rayleigh-Ritz on the collected subspace: X ~ B V  ->  the SVD of B orders / rotates the modes
@@ -1482,7 +1495,14 @@ extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t
     info_host[4] = info.executed;
     info_host[5] = double(M) * (M + 1) * double(dim) + 2.0 * n * M * double(dim);
     info_host[6] = info.eig_iterations;
-    info_host[7] = 0.0;
+    // why the call stopped short of n modes: 0 request filled, 1 the spectrum reached the floor (the completed modes are
+    // not determined by the data), 2 no accepted mode in a pass / pass budget (modes above the floor may be missing)
+    info_host[7] = found >= n ? 0.0 : (at_floor_stop || sigma_1 == 0.0 ? 1.0 : 2.0);
   }
   return ROM_OK;
+}
+
+extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t dim, int n, int center, rom_buf* Vb,
+                       int64_t v_row0, double* sigma_host, double* info_host) {
+  return rom_pod_ex(ctx, Xb, x_row0, M, dim, n, center, 0.0, Vb, v_row0, sigma_host, info_host);
 }

@@ -211,7 +211,10 @@ class ReducedBasisRandom(BaseReducedBasis):
         return self
 
 
-def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True):
+_pod_warned = set()
+
+
+def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, rel_floor=0.0, download=True):
     """Leading ``n`` right singular vectors / singular values of the (M, dim) snapshot block: one C call (rom_pod).
 
     MFMA Gram matrix ``G = Xc Xc^T`` -> leading eigenpairs by subspace iteration (projected problems by a one-workgroup
@@ -223,19 +226,31 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True):
     basis is completed with orthonormalised pseudo-random directions (singular value 0, seeded by the number of
     resolved modes: deterministic), so the rows returned are always orthonormal.  Rows follow scikit-learn's
     ``svd_flip(u_based_decision=False)`` sign convention (the PCA call at src/lib/ReducedBasis.py:196).  X is
-    overwritten.  ``pod_modes.last_info``: flop accounting and pass counts of the call."""
+    overwritten.  ``pod_modes.last_info``: flop accounting and pass counts of the call.  ``rel_floor``: do not look for
+    modes below that fraction of sigma_1 (rom_pod_ex; default: the fp64 noise floor of the block, 1e-13).
+    ``download=False`` returns the modes as a DeviceArray."""
     M, dim = X.rows, X.dim
     n = min(n, M, dim)
     V = ctx.alloc(max(n * dim, 1))
-    sig, info = ctx.pod(X.buf, M, dim, n, V, center=center)
+    sig, info = ctx.pod(X.buf, M, dim, n, V, center=center, rel_floor=rel_floor)
     pod_modes.last_info = info
     pod_modes.resolved = info["resolved_modes"]
     if info["completed_modes"]:
-        warning(f"POD: {info['completed_modes']} of the {n} requested modes lie below the fp64 noise floor of the snapshot "
-                f"block (sigma < 1e-13 sigma_1); completed with orthonormal directions of zero singular value")
+        floor = max(rel_floor, 1e-13)
+        if info["stop_reason"] == "budget":
+            msg = (f"POD: {info['completed_modes']} of the {n} requested modes were NOT found although the spectrum had not "
+                   f"reached the floor ({floor:g} sigma_1): a sketch pass accepted nothing; completed with orthonormal "
+                   "directions of zero singular value")
+        else:
+            msg = (f"POD: {info['completed_modes']} of the {n} requested modes lie below the floor of the snapshot block (sigma < "
+                   f"{floor:g} sigma_1" + ("" if rel_floor > 1e-13 else ": fp64 noise of the data") + "); completed with "
+                   "orthonormal directions of zero singular value")
+        if msg not in _pod_warned:  # (once per process and message: a bench calls this a dozen times on the same block)
+            _pod_warned.add(msg)
+            warning(msg)
     if n == 0:
-        return np.zeros((0, dim)), sig
-    return V.download(n * dim, shape=(n, dim)), sig
+        return (np.zeros((0, dim)) if download else DeviceArray(V, 0, dim)), sig
+    return (V.download(n * dim, shape=(n, dim)) if download else DeviceArray(V, n, dim)), sig
 
 
 class ReducedBasisPCA(BaseReducedBasis):
@@ -263,7 +278,25 @@ class ReducedBasisPCA(BaseReducedBasis):
             super().set(basis=np.vstack((lead, comps))[:n], a=np.vstack((a2train[lead_idx], a2train[~has_inf]))[:n])
             return self
         if isinstance(solutions2train, DeviceArray):
-            solutions2train = solutions2train.numpy()
+            # the training block is resident in HBM: the INFINIT_A snapshots are peeled off BY INDEX on the device
+            # (get_starting_basis, :153-164, does it on host rows), the pool is gathered into the private copy that rom_pod
+            # overwrites, and only the basis rows ever cross PCIe
+            Ud, a2 = solutions2train, np.asarray(a2train)
+            ctx, dim = sm._ctx, Ud.dim
+            has_inf = (a2 == INFINIT_A).reshape(len(a2), -1).sum(axis=1) > 0
+            pool_idx = np.flatnonzero(~has_inf)
+            lead_idx = np.flatnonzero(has_inf) if self.add_inf_solutions else np.zeros(0, dtype=np.int64)
+            X = ctx.alloc(max(len(pool_idx) * dim, 1)).gather_rows_from(Ud.buf, pool_idx, dim)
+            comps, sigma = pod_modes(ctx, DeviceArray(X, len(pool_idx), dim), n, center=True)
+            self.singular_values_ = sigma
+            self.resolved_modes_ = pod_modes.resolved
+            if lead_idx.size:
+                lead = DeviceArray(ctx.alloc(lead_idx.size * dim).gather_rows_from(Ud.buf, lead_idx, dim), lead_idx.size, dim).numpy()
+            else:
+                lead = np.empty((0, dim))
+            super().set(basis=np.vstack((lead, comps))[:n], a=np.vstack((a2[lead_idx].reshape((-1,) + a2.shape[1:]), a2[pool_idx]))[:n])
+            warning("PCA method has not been adapted for inverse parameter estimation, the a coefficients are not correct.")
+            return self
         basis, a, solutions2train, a2train = get_starting_basis(solutions2train, a2train, self.add_inf_solutions)
         ctx = sm._ctx
         X = _as_device(ctx, np.array(solutions2train, dtype=np.float64), sm.vspace_dim)  # private copy

@@ -418,6 +418,86 @@ def test_pod_small_modes_vs_lapack(api):
         assert np.abs(c[:k].T @ c[:k] - Vt[:k].T @ Vt[:k]).max() < 1e-8, name
 
 
+def test_pod_slowly_decaying_spectrum_many_modes(api):
+    """a request of hundreds of modes from a spectrum that decays slowly -- 320 modes over 12 orders of
+    magnitude, 195 of them below the reach of the Gram matrix -- must be FILLED by the sketch passes (the round-3 loop gave
+    up after 12 passes of 16 modes and completed the rest with sigma = 0 under a warning that blamed the data), every
+    singular value against LAPACK, and the call must say why it stopped.  The floor of rom_pod_ex cuts the same request
+    short on purpose: the modes above it are unchanged, the rest is completed and the stop reason says 'floor'."""
+    SM, RB = api
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    rng = np.random.default_rng(11)
+    M, dim, n = 512, 3000, 320
+    Q1, _ = np.linalg.qr(rng.standard_normal((M, M)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((dim, M)))
+    s = 10.0 ** (-np.arange(M) / 27.0)
+    Xh = (Q1 * s) @ Q2.T
+    sv = np.linalg.svd(Xh, compute_uv=False)
+    X = ctx.upload(Xh)
+    comps, sig = RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), n, center=False)
+    info = RB.pod_modes.last_info
+    assert info["resolved_modes"] == n and info["completed_modes"] == 0 and info["stop_reason"] == "filled", info
+    assert info["sketch_passes"] >= 3, info
+    # (a singular value is determined to ~50 eps sigma_1 absolutely -- LAPACK's own error and the rounding of the test matrix:
+    # 7e-3 of the smallest one requested)
+    observed("POD, 320 modes over 12 orders: singular values vs LAPACK (relative, beyond 1e-14 sigma_1)",
+             np.maximum(np.abs(sig - sv[:n]) - 1e-14 * sv[0], 0.0) / sv[:n], 1e-3)
+    lead = sv[:n] > 1e-6 * sv[0]
+    observed("POD, 320 modes: singular values above 1e-6 sigma_1 (relative)", np.abs(sig[lead] / sv[:n][lead] - 1), 1e-9)
+    observed("POD, 320 modes: orthonormality of the rows", np.abs(comps @ comps.T - np.eye(n)), 1e-9)
+    # the same request with a floor at 1e-8 sigma_1
+    X = ctx.upload(Xh)
+    comps_f, sig_f = RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), n, center=False, rel_floor=1e-8)
+    info_f = RB.pod_modes.last_info
+    k = info_f["resolved_modes"]
+    above = int((sv > 1e-8 * sv[0]).sum())
+    assert info_f["stop_reason"] == "floor" and info_f["completed_modes"] == n - k and above - 2 <= k <= above + 2, (info_f, above)
+    assert info_f["sketch_passes"] < info["sketch_passes"]
+    # (the modes a pass accepts last are its least converged ones -- the power step weighs a direction with sigma^3 -- and a
+    # later pass would have refined them through the final Rayleigh-Ritz step: next to the cut the values are good to 1e-2)
+    far = sv[:k] > 1e-6 * sv[0]
+    observed("POD with rel_floor = 1e-8: singular values above 1e-6 sigma_1 vs LAPACK (relative)", np.abs(sig_f[:k][far] / sv[:k][far] - 1), 1e-9)
+    observed("POD with rel_floor = 1e-8: singular values between the floor and 1e-6 sigma_1 (relative)",
+             np.abs(sig_f[:k][~far] / sv[:k][~far] - 1), 5e-2)
+    assert np.all(sig_f[k:] == 0.0)
+    observed("POD with rel_floor = 1e-8: orthonormality of resolved + completed rows", np.abs(comps_f @ comps_f.T - np.eye(n)), 1e-9)
+
+
+def test_pca_class_from_a_device_block_stays_on_the_device(api):
+    """ReducedBasisPCA.build (src/lib/ReducedBasis.py:189-200) on a DeviceArray at the size of config C3 (8192 x 65 025,
+    4.3 GB): the INFINIT_A snapshots are peeled off by index on the device, the pool is gathered into rom_pod's private
+    copy, and only basis rows cross PCIe -- the bytes that leave the device through Buffer.download are counted.  The
+    basis equals the one from the building blocks (pod_modes on the gathered pool behind the peeled rows)."""
+    SM, RB = api
+    from romhighcontrast_amd import _ffi
+    sm = SM.SolutionsManagerFEM((2, 2), 128)
+    ctx, dim = sm._ctx, sm.vspace_dim
+    M, n = 8192, 50
+    a = 10.0 ** np.random.default_rng(20240807).uniform(0, 2, size=(M, 2, 2))
+    inf_rows = [5, 4000, 8191]
+    for k, r in enumerate(inf_rows):
+        a[r].flat[k] = RB.INFINIT_A
+    Ud = sm.generate_solutions_device(a)
+    before = _ffi.D2H_BYTES[0]
+    rb = RB.ReducedBasisPCA(add_inf_solutions=True).build(n, sm, Ud, a)
+    moved = _ffi.D2H_BYTES[0] - before
+    assert moved <= (n + len(inf_rows) + 2) * dim * 8, f"{moved} bytes left the device; the block is {M * dim * 8}"
+    assert rb.basis.shape == (n, dim) and np.array_equal(np.asarray(rb.a[:3]), a[inf_rows])
+    # the same from the building blocks
+    pool_idx = np.setdiff1d(np.arange(M), inf_rows)
+    X = ctx.alloc(len(pool_idx) * dim).gather_rows_from(Ud.buf, pool_idx, dim)
+    comps, sig = RB.pod_modes(ctx, SM.DeviceArray(X, len(pool_idx), dim), n)
+    lead = SM.DeviceArray(ctx.alloc(3 * dim).gather_rows_from(Ud.buf, np.array(inf_rows), dim), 3, dim).numpy()
+    assert np.array_equal(rb.basis, np.vstack((lead, comps))[:n])
+    assert np.array_equal(rb.singular_values_, sig)
+    # and the peeled rows are what the reference's own peel-off takes from host rows (a small subsample of the block)
+    sub = np.array(sorted(set(inf_rows) | set(range(0, M, 1024))))
+    lead_h, lead_a, pool_h, pool_a = RB.get_starting_basis(SM.DeviceArray(ctx.alloc(len(sub) * dim).gather_rows_from(Ud.buf, sub, dim),
+                                                                       len(sub), dim).numpy(), a[sub], True)
+    assert np.array_equal(lead_h, lead) and np.array_equal(lead_a, a[inf_rows])
+
+
 def SolutionsManagerFEM_cached(SM, blocks, N):
     return SM.SolutionsManagerFEM(blocks, N)
 
