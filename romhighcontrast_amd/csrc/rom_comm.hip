@@ -4,6 +4,7 @@
 // src/lib/SolutionsManagers.py:51); the sweep shards contiguously over the GPUs of a node and the
 // (M/G, dim) fp64 shards are exchanged once with ncclAllGather before the basis stage.
 // librccl.so.1 is dlopen()ed on first use so that single-GPU runs carry no RCCL dependency.
+#include <algorithm>
 #include <dlfcn.h>
 
 #include <cstring>
@@ -132,6 +133,25 @@ extern "C" int rom_comm_allgather(rom_ctx* ctx, rom_buf* send, size_t send_off, 
   return ROM_OK;
 }
 
+// Ranges a slot's outstanding collective(s) touch.  A slot that is issued again before the compute stream has been ordered
+// behind its previous collective keeps the UNION of the old and the new ranges: the slot's event is recorded again behind
+// the new collective (the communication stream runs them in order), so one wait covers both, and rom_buf_free must go on
+// seeing the buffers of the earlier one.
+static void slot_ranges(rom_ctx* ctx, int slot, const double* const lo[3], const double* const hi[3]) {
+  const bool merge = ctx->slot_used[slot] && !ctx->slot_joined[slot];
+  for (int k = 0; k < 3; ++k) {
+    if (merge && ctx->slot_lo[slot][k] != ctx->slot_hi[slot][k] && lo[k] != hi[k]) {
+      ctx->slot_lo[slot][k] = std::min(ctx->slot_lo[slot][k], lo[k]);
+      ctx->slot_hi[slot][k] = std::max(ctx->slot_hi[slot][k], hi[k]);
+    } else if (!merge || lo[k] != hi[k]) {
+      ctx->slot_lo[slot][k] = lo[k];
+      ctx->slot_hi[slot][k] = hi[k];
+    }
+  }
+  ctx->slot_used[slot] = true;
+  ctx->slot_joined[slot] = false;
+}
+
 // Overlapped form: the collective runs on the context's communication stream, ordered after everything
 // enqueued so far on the compute stream; the compute stream is NOT blocked, so the next sweep step can
 // run while the shards travel over xGMI.  rom_comm_wait() makes the compute stream (and the host, if
@@ -153,13 +173,11 @@ extern "C" int rom_comm_allgather_async(rom_ctx* ctx, rom_buf* send, size_t send
   ROM_NCCL(g_rccl.AllGather(send->p + send_off, recv->p + recv_off, count, NCCL_FLOAT64, (nccl_comm_t)ctx->comm,
                             ctx->comm_stream));
   ROM_HIP(hipEventRecord(ctx->ev_slot[slot], ctx->comm_stream));
-  ctx->slot_used[slot] = true;
-  ctx->slot_joined[slot] = false;
-  ctx->slot_lo[slot][0] = send->p + send_off;
-  ctx->slot_hi[slot][0] = send->p + send_off + count;
-  ctx->slot_lo[slot][1] = recv->p + recv_off;
-  ctx->slot_hi[slot][1] = recv->p + recv_off + count * size_t(ctx->nranks);
-  ctx->slot_lo[slot][2] = ctx->slot_hi[slot][2] = nullptr;
+  {
+    const double* lo[3] = {send->p + send_off, recv->p + recv_off, nullptr};
+    const double* hi[3] = {send->p + send_off + count, recv->p + recv_off + count * size_t(ctx->nranks), nullptr};
+    slot_ranges(ctx, slot, lo, hi);
+  }
   return ROM_OK;
 }
 
@@ -190,15 +208,11 @@ extern "C" int rom_comm_allgather_packed_async(rom_fem* f, rom_buf* Y, int64_t y
   if (count)
     ROM_NCCL(g_rccl.AllGather(send->p, recv->p + recv_off, count, NCCL_FLOAT64, (nccl_comm_t)ctx->comm, ctx->comm_stream));
   ROM_HIP(hipEventRecord(ctx->ev_slot[slot], ctx->comm_stream));
-  ctx->slot_used[slot] = true;
-  ctx->slot_joined[slot] = false;
-  // (the slot's buffers: rom_buf_free waits for the slot when one of them is freed)
-  ctx->slot_lo[slot][0] = Y->p + size_t(y_row0) * f->nGp;
-  ctx->slot_hi[slot][0] = Y->p + size_t(y_row0 + M) * f->nGp;
-  ctx->slot_lo[slot][1] = recv->p + recv_off;
-  ctx->slot_hi[slot][1] = recv->p + recv_off + count * size_t(ctx->nranks);
-  ctx->slot_lo[slot][2] = send->p;
-  ctx->slot_hi[slot][2] = send->p + count;
+  {  // (the slot's buffers: rom_buf_free waits for the slot when one of them is freed)
+    const double* lo[3] = {Y->p + size_t(y_row0) * f->nGp, recv->p + recv_off, send->p};
+    const double* hi[3] = {Y->p + size_t(y_row0 + M) * f->nGp, recv->p + recv_off + count * size_t(ctx->nranks), send->p + count};
+    slot_ranges(ctx, slot, lo, hi);
+  }
   return ROM_OK;
 }
 

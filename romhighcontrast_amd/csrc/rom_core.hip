@@ -298,8 +298,10 @@ extern "C" int rom_buf_free(rom_buf* b) {
       bool touches = false;
       for (int k = 0; k < 3; ++k) touches = touches || (c->slot_lo[s][k] < hi && lo < c->slot_hi[s][k]);
       if (!touches) continue;
-      ROM_HIP(hipSetDevice(c->device));
-      ROM_HIP(hipStreamWaitEvent(c->stream, c->ev_slot[s], 0));
+      // (an error here must neither leak the block nor return it to the cache unordered: fall back to the host waiting for
+      // the whole communication stream)
+      if (hipSetDevice(c->device) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_slot[s], 0) != hipSuccess)
+        hipStreamSynchronize(c->comm_stream);
       c->slot_joined[s] = true;
     }
   }

@@ -188,7 +188,8 @@ def exchange_unique_id(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
     """Rank 0 creates the id and publishes it atomically through a file unique to this launch
     (MASTER_ADDR/PORT + run id, or + parent pid and its start time); the other ranks poll for it.  A file written more
     than STALE_MARGIN_S before this process started is a leftover of a launch that died before its cleanup (same port,
-    same name): it is ignored, rank 0 of THIS launch replaces it."""
+    same name): it is ignored, rank 0 of THIS launch replaces it -- except under ROMHC_LAUNCH_ID, whose file name no other
+    launch can have."""
     path = rendezvous_path()
     if rank == 0:
         uid = make_id()
@@ -198,7 +199,10 @@ def exchange_unique_id(rank: int, make_id, timeout_s: float = 120.0) -> bytes:
         os.replace(tmp, path)
         return uid
     t0 = time.time()
-    not_before = _own_start_time() - STALE_MARGIN_S
+    # ROMHC_LAUNCH_ID is a fresh uuid per launch (bench.py's launcher): no other launch ever wrote this file, so its age
+    # says nothing -- a rank that a wrapper starts a minute after rank 0 must still take it.  A run id the
+    # user chose (--rdzv-id) or the parent-process fallback can meet a leftover of an earlier launch: there the age counts.
+    not_before = 0.0 if os.environ.get("ROMHC_LAUNCH_ID") else _own_start_time() - STALE_MARGIN_S
     while time.time() - t0 < timeout_s:
         try:
             if os.stat(path).st_mtime >= not_before:

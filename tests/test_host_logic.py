@@ -148,7 +148,18 @@ def test_rendezvous_key_and_stale_files(tmp_path, monkeypatch):
     assert "job42" in named and str(os.getppid()) not in os.path.basename(named).split("job42")[1]
     monkeypatch.setenv("ROMHC_LAUNCH_ID", "abc")
     assert "abc" in sweep.rendezvous_path() and "job42" not in sweep.rendezvous_path()
-    # a stale file (another launch's id, written long before this process started) is ignored until rank 0 replaces it
+    # a launch named by ROMHC_LAUNCH_ID (a fresh uuid per launch) takes its file whatever its age: a rank that a wrapper
+    # starts long after rank 0 published must not time out
+    path = sweep.rendezvous_path()
+    with open(path, "wb") as f:
+        f.write(bytes(range(128)))
+    old = time.time() - 3600.0
+    os.utime(path, (old, old))
+    assert sweep.exchange_unique_id(1, None, timeout_s=2.0) == bytes(range(128))
+    os.remove(path)
+    # under a name the user chose (or the parent-process fallback) a stale file -- another launch's id, written long before
+    # this process started -- is ignored until rank 0 replaces it
+    monkeypatch.delenv("ROMHC_LAUNCH_ID")
     path = sweep.rendezvous_path()
     with open(path, "wb") as f:
         f.write(b"\xff" * 128)
