@@ -24,69 +24,13 @@ import os
 import sys
 
 import numpy as np
-import scipy.sparse.linalg as spla
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import rom_oracle as ro  # noqa: E402
 
-LD = np.longdouble
-
-
-def edge_weights(g, a):
-    """diag / east / north of the oracle (fp64, exactly what every solver is given) -> edge weights in long double:
-    w_e[r,c] couples (r,c)-(r,c+1), w_n[r,c] couples (r,c)-(r+1,c), w_b[r,c] = diag + sum of off-diagonals = the weight
-    of the edges to boundary vertices."""
-    d, e, n = ro.stencil_arrays(g, a)
-    d, e, n = d.astype(LD), e.astype(LD), n.astype(LD)
-    wb = d.copy()
-    wb[:, :-1] += e
-    wb[:, 1:] += e
-    wb[:-1, :] += n
-    wb[1:, :] += n
-    return -e, -n, wb
-
-
-def residual_ld(g, we, wn, wb, B, x):
-    """b - A x in long double, edge form."""
-    X = x.reshape(g.nr, g.nc)
-    Ax = wb * X
-    dh = X[:, :-1] - X[:, 1:]
-    Ax[:, :-1] += we * dh
-    Ax[:, 1:] -= we * dh
-    dv = X[:-1, :] - X[1:, :]
-    Ax[:-1, :] += wn * dv
-    Ax[1:, :] -= wn * dv
-    return (B.astype(LD).reshape(g.nr, g.nc) - Ax).ravel()
-
-
-def h10_ld(g, v):
-    V = v.reshape(g.nr, g.nc)
-    s = (V[:, 0] ** 2).sum() + (V[:, -1] ** 2).sum() + (V[0, :] ** 2).sum() + (V[-1, :] ** 2).sum()
-    s += ((V[:, :-1] - V[:, 1:]) ** 2).sum() + ((V[:-1, :] - V[1:, :]) ** 2).sum()
-    return np.sqrt(s)
-
-
-def referee(blocks, N, a, max_steps=12):
-    g = ro.Geometry(blocks, N)
-    B = ro.load_vector(g)
-    lu = spla.splu(ro.assemble_csc(g, a))
-    x0 = lu.solve(B)
-    we, wn, wb = edge_weights(g, a)
-    x = x0.astype(LD)
-    hist = []
-    for k in range(max_steps):
-        r = residual_ld(g, we, wn, wb, B, x)
-        dx = lu.solve(np.asarray(r, dtype=np.float64)).astype(LD)
-        rel = float(h10_ld(g, dx) / h10_ld(g, x))
-        hist.append(rel)
-        x = x + dx
-        print(f"  step {k}: |dx|/|x| (H10) = {rel:.3e}", flush=True)
-        if rel < 1e-17 or (k > 0 and rel > 0.5 * hist[-2]):
-            break
-    truth = np.asarray(x, dtype=np.float64)            # nearest fp64 vector to the long-double solution
-    err_superlu = float(h10_ld(g, x0.astype(LD) - x) / h10_ld(g, x))
-    return g, truth, x0, err_superlu, hist
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from referee import LD, h10_ld, referee  # noqa: E402
 
 
 def main():
@@ -120,6 +64,21 @@ def main():
                     f"{name}_err_ref_lsq_vs_truth": e_lsq, f"{name}_err_ref_lsqsparse_vs_truth": e_sp,
                     f"{name}_history": np.array(hist)})
     np.savez_compressed(os.path.join(out, "referee_g4_floating.npz"), **rec)
+    # fixture g8: the rows of the experiment's training set that have blocks at INFINIT_A ((2,2)/N=6: no floating block, but
+    # kappa ~ 1e11): the truth of every such row and the distance of the reference's own row from it
+    z = np.load(os.path.join(out, "g8_experiment.npz"), allow_pickle=True)
+    a8 = z["a"]
+    rows = np.flatnonzero((a8 == 1e10).reshape(len(a8), -1).any(axis=1))
+    truths, e_ref, e_slu = [], [], []
+    for r in rows:
+        g, truth, x0, err, hist = referee((2, 2), 6, a8[r], verbose=False)
+        tl = truth.astype(LD)
+        truths.append(truth)
+        e_slu.append(err)
+        e_ref.append(float(h10_ld(g, z["solutions"][r].astype(LD) - tl) / h10_ld(g, tl)))
+    print("g8 INFINIT_A rows", rows.tolist(), "reference vs truth", np.array(e_ref), "SuperLU vs truth", np.array(e_slu))
+    np.savez_compressed(os.path.join(out, "referee_g8_inf.npz"), rows=rows, truth=np.array(truths),
+                        err_ref_vs_truth=np.array(e_ref), err_superlu_vs_truth=np.array(e_slu))
 
 
 if __name__ == "__main__":

@@ -23,7 +23,6 @@ pytestmark = pytest.mark.gpu
 
 SNAP_TOL = 1e-11
 FLOATING_FACTOR = 2.0   # floating rows: GPU-vs-truth <= this x max(reference lsq, lsqsparse vs truth)
-FLOATING_TOL = 5e-5     # floating rows without a referee fixture (g8: (2,2)/N=6 with INFINIT_A blocks)
 
 
 @pytest.fixture(scope="module")
@@ -727,15 +726,15 @@ def test_full_size_c2_properties(api):
         r = Y.download(dim) - sm.B_total
         u = row.download(dim)
         # ||r||_inf relative to ||diag(A) u||_inf
-        assert np.abs(r).max() < 1e-11 * np.abs(u).max() * 4 * a[m].max()
+        observed(f"C2: stencil residual of row {m}, ||A u - B||_inf / ||diag(A) u||_inf", np.abs(r).max() / (np.abs(u).max() * 4 * a[m].max()), 1e-11)
     # linearity in 1/a: u(2a) = u(a)/2 exactly up to roundoff
     U2 = sm.generate_solutions_device(2.0 * a[:8]).numpy()
-    U1 = Ud.numpy()[:8] if False else np.stack([Ud.buf.download(dim, offset=i * dim) for i in range(8)])
-    assert np.max(np.abs(2.0 * U2 - U1)) < 1e-12 * np.abs(U1).max()
+    U1 = np.stack([Ud.buf.download(dim, offset=i * dim) for i in range(8)])
+    observed("C2: homogeneity, max |2 u(2a) - u(a)| / max |u|", np.max(np.abs(2.0 * U2 - U1)) / np.abs(U1).max(), 1e-12)
     # symmetry: swapping the two block columns mirrors the solution left-right
     am = a[:4][:, :, ::-1]
     Um = sm.generate_solutions(am).reshape(4, 255, 255)[:, :, ::-1].reshape(4, -1)
-    assert np.max(np.abs(Um - U1[:4])) < 1e-11 * np.abs(U1).max()
+    observed("C2: mirror symmetry, max |u(a mirrored) mirrored - u(a)| / max |u|", np.max(np.abs(Um - U1[:4])) / np.abs(U1).max(), 1e-11)
     # three rows against the SuperLU oracle
     g = ro.Geometry((2, 2), 128)
     idx = [0, 511, 1023]
@@ -743,7 +742,7 @@ def test_full_size_c2_properties(api):
     Ug = np.stack([Ud.buf.download(dim, offset=i * dim) for i in idx])
     observed("C2: rows 0, 511, 1023 vs SuperLU oracle (rel H10)", relh10(g, Ug, Uo), SNAP_TOL)
     # norms on the device agree with the oracle's on the same vectors
-    np.testing.assert_allclose(sm.H10norm(Ud)[idx], ro.H10norm(g, Ug), rtol=1e-12)
+    observed("C2: H10 norms on the device vs the oracle's on the same rows (relative)", np.abs(sm.H10norm(Ud)[idx] / ro.H10norm(g, Ug) - 1), 1e-12)
 
 
 def test_full_size_c3_workload(api):
@@ -810,6 +809,28 @@ def _oracle_rows(args):
     g = ro.Geometry(blocks, N)
     B = ro.load_vector(g)
     return np.stack([ro.solve_one(g, a, B, "lsqsparse") for a in rows])
+
+
+def _refereed_rows(args):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from referee import referee
+    blocks, N, rows = args
+    out = [referee(blocks, N, a, verbose=False) for a in rows]
+    return np.stack([o[2] for o in out]), np.stack([o[1] for o in out])
+
+
+def refereed_rows_parallel(blocks, N, a, workers=2):
+    """(SuperLU rows, refined-truth rows) of the parameters `a`, one factorisation each, in FRESH processes (spawn)."""
+    import multiprocessing as mp
+    workers = max(1, min(workers, len(a)))
+    with mp.get_context("spawn").Pool(workers) as pool:
+        parts = pool.map(_refereed_rows, [(blocks, N, a[i::workers]) for i in range(workers)])
+    slu, tru = np.empty((len(a), parts[0][0].shape[1])), np.empty((len(a), parts[0][0].shape[1]))
+    for i, (p0, p1) in enumerate(parts):
+        slu[i::workers], tru[i::workers] = p0, p1
+    return slu, tru
 
 
 def oracle_sweep_parallel(blocks, N, a, workers=8):
@@ -943,19 +964,24 @@ def test_full_size_c5_workload(api):
         fem.stencil_apply(row, 1, Y, a_one=a[m].ravel())
         res = Y.download(dim) - sm.B_total
         u = row.download(dim)
-        assert np.abs(res).max() < 1e-11 * np.abs(u).max() * 4 * a[m].max()
+        observed(f"C5: stencil residual of row {m}, ||A u - B||_inf / ||diag(A) u||_inf", np.abs(res).max() / (np.abs(u).max() * 4 * a[m].max()), 1e-11)
     u0 = Ud.buf.download(dim, offset=0).reshape(1023, 1023)
-    assert np.abs(u0 - u0[::-1, :]).max() < 1e-12 * u0.max() and np.abs(u0 - u0.T).max() < 1e-12 * u0.max()
+    observed("C5: symmetries of the unit-coefficient solution (up-down, transpose), relative to max u",
+             max(np.abs(u0 - u0[::-1, :]).max(), np.abs(u0 - u0.T).max()) / u0.max(), 1e-12)
     u1, u2 = Ud.buf.download(dim, offset=dim), Ud.buf.download(dim, offset=2 * dim)
-    assert np.abs(7.0 * u1 - u2).max() < 1e-12 * np.abs(u2).max()
+    observed("C5: homogeneity, max |7 u(7a) - u(a)| / max |u|", np.abs(7.0 * u1 - u2).max() / np.abs(u2).max(), 1e-12)
     g = ro.Geometry(blocks, N)
     idx = [5, M - 1]
-    Uo = oracle_sweep_parallel(blocks, N, a[idx], workers=2)
+    Uo, Ut = refereed_rows_parallel(blocks, N, a[idx], workers=2)
     Ug = np.stack([Ud.buf.download(dim, offset=i * dim) for i in idx])
     observed("C5: rows 5, 4095 vs SuperLU oracle (rel H10)", relh10(g, Ug, Uo), SNAP_TOL)
+    # (how much of that distance is the oracle's own: SuperLU + refinement with long-double edge-form residuals = the truth)
+    observed("C5: rows 5, 4095 vs the refined truth (rel H10)", relh10(g, Ug, Ut), SNAP_TOL)
+    observed("C5: (for the record) SuperLU oracle vs the refined truth on those rows (rel H10)", relh10(g, Uo, Ut), 1e-9)
     h1 = sm.H10norm(Ud)
-    assert np.all(h1 > 0) and abs(h1[2] / h1[1] - 7.0) < 1e-11
-    np.testing.assert_allclose(h1[idx], ro.H10norm(g, Ug), rtol=1e-11)
+    assert np.all(h1 > 0)
+    observed("C5: homogeneity of the H10 norms, |h1(a) / h1(7a) - 7|", abs(h1[2] / h1[1] - 7.0), 1e-11)
+    observed("C5: H10 norms on the device vs the oracle's on the same rows (relative)", np.abs(h1[idx] / ro.H10norm(g, Ug) - 1), 1e-11)
     # POD of the full block: rows vs interface vectors
     Yf = ctx.alloc(M * fem.reduced_stride)
     fem.solve_reduced(ctx.upload(a.reshape(M, -1)), M, Yf)
@@ -967,9 +993,9 @@ def test_full_size_c5_workload(api):
     del X
     big = sig_r > 1e-6 * sig_r[0]
     assert big.sum() >= 20
-    np.testing.assert_allclose(sig_f[big], sig_r[big], rtol=1e-7)
-    assert np.abs(np.abs(np.sum(modes_f[big] * modes_r[big], axis=1)) - 1.0).max() < 1e-6
-    assert np.abs(modes_r[big] @ modes_r[big].T - np.eye(int(big.sum()))).max() < 1e-9
+    observed("C5 POD: singular values > 1e-6 sigma_1, rows vs factored (relative)", np.abs(sig_f[big] / sig_r[big] - 1), 1e-7)
+    observed("C5 POD: |<mode_rows, mode_factored>| - 1 for those modes", np.abs(np.abs(np.sum(modes_f[big] * modes_r[big], axis=1)) - 1.0), 1e-6)
+    observed("C5 POD: orthonormality of those rows", np.abs(modes_r[big] @ modes_r[big].T - np.eye(int(big.sum()))), 1e-9)
     # a 256-row subsample against LAPACK on the host (the SVD inside sklearn's PCA, src/lib/ReducedBasis.py:196)
     Ms = 256
     Xs = Ud.buf.download(Ms * dim, shape=(Ms, dim))
@@ -1356,7 +1382,15 @@ def test_g8_experiment_statistics(api):
     # rows with INFINIT_A blocks: kappa ~ 1e11 (reference self-consistency ~1e-6); the rest to 1e-11
     err = relh10(g, data["solutions"], z["solutions"])
     hard = (a == RB.INFINIT_A).any(axis=(1, 2))
-    assert err[~hard].max() < SNAP_TOL and err[hard].max() < FLOATING_TOL
+    # Every row to the snapshot bound, the INFINIT_A ones included: at (2,2) every block touches the Dirichlet boundary, the
+    # 1e10 blocks simply clamp their edges, and the extended-precision referee (tests/golden/referee_g8_inf.npz) puts the
+    # reference's own rows within 1e-15 of the truth -- so do ours (round 3 kept 5e-5 here for want of that fixture).
+    observed("g8: snapshots vs the reference's, ordinary parameters (rel H10)", err[~hard], SNAP_TOL)
+    observed("g8: snapshots vs the reference's, INFINIT_A parameters (rel H10)", err[hard], SNAP_TOL)
+    r8 = load_golden("referee_g8_inf.npz")
+    assert np.array_equal(r8["rows"], np.flatnonzero(hard))
+    observed("g8: INFINIT_A rows vs the refined truth (rel H10; the reference's own: <= 9.4e-16)",
+             relh10(g, np.asarray(data["solutions"])[hard], r8["truth"]), 1e-14)
     for b in builders:
         key = b.name.replace(" ", "_").replace("$", "").replace("\\", "").replace("^", "").replace("{", "").replace("}", "")
         assert str(z["name_" + key]) == b.name
@@ -1369,8 +1403,18 @@ def test_g8_experiment_statistics(api):
                 ref = z[f"err_{key}_{n}_{f}"]
                 observed(f"g8 {key} n={n} {f}: error records vs reference, ordinary parameters (BASELINE: 1e-10)",
                          np.abs(getattr(e, f) - ref)[~hard], 1e-10)
-                observed(f"g8 {key} n={n} {f}: error records vs reference, INFINIT_A parameters",
-                         np.abs(getattr(e, f) - ref)[hard], 1e-4)
+                # INFINIT_A test parameters: the projection is taken in the unit-coefficient inner product (well conditioned:
+                # BASELINE bound); the Galerkin ROM solves (C A(a) C^T) c = C B with a = 1e10 blocks, whose condition number
+                # reaches 1e10 once the basis holds a snapshot that lives in such a block -- two exact implementations (the
+                # reference's own pair included) then differ by cond x eps in the coefficients and in the error record
+                tol_f = 1e-10
+                if f == "forward_modeling":
+                    Qb = np.linalg.qr(np.asarray(data[b.name]["basis"].basis)[:n].T)[0].T
+                    conds = [np.linalg.cond(Qb @ ro.stencil_apply(g, am, Qb).T) for am in a[hard]]
+                    tol_f = max(1e-10, 1e-14 * max(conds))
+                observed(f"g8 {key} n={n} {f}: error records vs reference, INFINIT_A parameters (bound {tol_f:.1e}"
+                         + (" = 1e-14 cond(C A(a) C^T)" if tol_f > 1e-10 else ": BASELINE") + ")",
+                         np.abs(getattr(e, f) - ref)[hard], tol_f)
             # state estimation (src/lib/ReducedBasis.py:65-70) and the two parameter estimators (:72-86,
             # src/lib/Estimators.py:24-37): a least-squares fit through the (points x n) matrix E of basis values.
             # Bases that hold INFINIT_A snapshots make E nearly rank deficient (cond(E) up to 5e12 in this fixture),
@@ -1385,8 +1429,8 @@ def test_g8_experiment_statistics(api):
                 assert got.shape == ref.shape, (b.name, n, f)
                 scale = max(1.0, np.abs(ref).max())
                 gap = np.abs(got - ref).reshape(len(ref), -1).max(axis=1) / scale   # per test parameter
-                assert gap[~hard].max() <= tol and gap[hard].max() <= max(tol, 1e-4), \
-                    (b.name, n, f, gap[~hard].max(), gap[hard].max(), tol, np.linalg.cond(Eb))
+                observed(f"g8 {key} n={n} {f}: records vs reference, all parameters (bound = max(1e-9, 1e-13 cond(E)), cond(E) = {np.linalg.cond(Eb):.1e})",
+                         gap, tol)
 
 
 def test_plain_c_caller_end_to_end(tmp_path):
