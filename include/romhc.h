@@ -227,6 +227,24 @@ int rom_pod(rom_ctx* ctx, rom_buf* X, int64_t x_row0, int M, int64_t dim, int n,
  * rel_floor <= 1e-13 is rom_pod. */
 int rom_pod_ex(rom_ctx* ctx, rom_buf* X, int64_t x_row0, int M, int64_t dim, int n, int center, double rel_floor, rom_buf* V,
                int64_t v_row0, double* sigma_host, double* info_host);
+/* ---- the basis stage on a snapshot block held in FACTORED form ---------------------------------------------------------
+ * A sweep gathered from several GPUs exists on every rank as interface vectors, not as rows (rom_comm_allgather_packed_
+ * async); when rom_fem_expansion_is_linear() the rows are U = Y B^T with a fixed B, so the builders below work on the
+ * (M, Kc) block of COMPACT interface vectors (Kc = rom_fem_compact_stride(); rom_fem_pack_reduced_async makes them) and
+ * never form a row except the basis vectors they return.  Same reference bodies as the row calls above
+ * (src/lib/ReducedBasis.py:112-139, :189-200); same contracts, same picks / modes up to rounding.
+ * rom_fem_energy_map builds (once per FE space, cached on the fem) the geometry of the snapshots in those coordinates:
+ * parts 1 = H^1_0 inner product (norms, greedy), 2 = the block forms u^T A_b v and the load functional (Galerkin greedy),
+ * 4 = Euclidean inner product (POD); the other calls build what they need themselves.  k_h10 / k_l2 (may be NULL): ranks. */
+int rom_fem_energy_map(rom_fem* fem, int parts, int* k_h10, int* k_l2);
+/* H10norm (src/lib/SolutionsManagers.py:56-58) of M snapshots from their compact interface vectors Yc[c_row0 ...] */
+int rom_h10norm_factored(rom_fem* fem, rom_buf* Yc, int64_t c_row0, int M, double* out_host);
+/* rom_greedy on compact interface vectors (M x Kc); a: M x nrb*ncb parameters (mode 1) */
+int rom_greedy_factored(rom_fem* fem, rom_buf* Yc, int64_t c_row0, int M, rom_buf* a, const double* h1norm_host, int mode,
+                        int n, int64_t* picks_out, double* max_err_out);
+/* rom_pod on compact interface vectors (M x Kc, not modified): V[v_row0 ...] receives the n modes as ROWS (n x dim) */
+int rom_pod_factored(rom_fem* fem, rom_buf* Yc, int64_t c_row0, int M, int n, int center, rom_buf* V, int64_t v_row0,
+                     double* sigma_host, double* info_host);
 /* n nearly orthonormal rows of V -> orthonormal rows, each as close as possible to what it was: V <- (V V^T)^(-1/2) V */
 int rom_symmetric_orthonormalize(rom_ctx* ctx, rom_buf* V, int64_t v_row0, int n, int64_t dim);
 /* rows V[v_row0+found .. +found+rest) <- deterministic pseudo-random directions, orthonormal and orthogonal to the

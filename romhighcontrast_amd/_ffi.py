@@ -92,6 +92,10 @@ PROTOTYPES = {
     "rom_orthonormalize_rows": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, _vp, C.c_int64]),
     "rom_greedy": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rom_pod": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp]),
+    "rom_fem_energy_map": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rom_h10norm_factored": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp]),
+    "rom_greedy_factored": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rom_pod_factored": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp, _vp]),
     "rom_pod_ex": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, _vp, C.c_int64, _vp, _vp]),
     "rom_symmetric_orthonormalize": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int64]),
     "rom_complete_orthonormal": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int64]),
@@ -182,6 +186,7 @@ class Context:
         h = _vp()
         check(self.lib.rom_init(device, C.byref(h)))
         self.h = h
+        self.has_comm = False
         self.device = device
 
     # -- buffers ---------------------------------------------------------------------------
@@ -302,8 +307,10 @@ class Context:
 
     def comm_init(self, uid: bytes, rank: int, nranks: int):
         check(self.lib.rom_comm_init(self.h, uid, len(uid), rank, nranks))
+        self.has_comm = True
 
     def comm_destroy(self):
+        self.has_comm = False
         check(self.lib.rom_comm_destroy(self.h))
 
     def allgather(self, send: "Buffer", send_off, recv: "Buffer", recv_off, count):
@@ -501,6 +508,37 @@ class Fem:
         check(self.ctx.lib.rom_greedy(self.h, U.h, u_row0, M, a.h if a is not None else None, h1.ctypes.data,
                                       1 if galerkin else 0, n, picks.ctypes.data, errs.ctypes.data))
         return [int(p) for p in picks[:n]], [float(e) for e in errs[:n]]
+
+    # -- basis stage on compact interface vectors (factored snapshot blocks: rom_factored.hip) --------------
+    def energy_map(self, parts=7):
+        """rom_fem_energy_map: build / cache the geometry of the snapshots in interface-vector coordinates (1: H^1_0,
+        2: Galerkin forms, 4: Euclidean).  Returns the ranks (k_h10, k_l2)."""
+        k1, k2 = C.c_int(0), C.c_int(0)
+        check(self.ctx.lib.rom_fem_energy_map(self.h, int(parts), C.byref(k1), C.byref(k2)))
+        return k1.value, k2.value
+
+    def h10norm_factored(self, Yc: Buffer, M: int, c_row0=0) -> np.ndarray:
+        out = np.empty(max(M, 1))
+        check(self.ctx.lib.rom_h10norm_factored(self.h, Yc.h, c_row0, M, out.ctypes.data))
+        return out[:M]
+
+    def greedy_factored(self, Yc: Buffer, M: int, a: Buffer | None, h1norm, galerkin: bool, n: int, c_row0=0):
+        """rom_greedy_factored: (picks list, max relative errors list)."""
+        h1 = _host(np.broadcast_to(np.asarray(h1norm, dtype=np.float64), (M,)))
+        picks, errs = np.zeros(max(n, 1), dtype=np.int64), np.zeros(max(n, 1))
+        check(self.ctx.lib.rom_greedy_factored(self.h, Yc.h, c_row0, M, a.h if a is not None else None, h1.ctypes.data,
+                                               1 if galerkin else 0, n, picks.ctypes.data, errs.ctypes.data))
+        return [int(p) for p in picks[:n]], [float(e) for e in errs[:n]]
+
+    def pod_factored(self, Yc: Buffer, M: int, n: int, V: Buffer, center=True, c_row0=0, v_row0=0):
+        """rom_pod_factored: modes as rows into V.  Returns (sigma (n,), info dict)."""
+        sigma, info = np.zeros(max(n, 1)), np.zeros(8)
+        check(self.ctx.lib.rom_pod_factored(self.h, Yc.h, c_row0, M, n, 1 if center else 0, V.h, v_row0, sigma.ctypes.data,
+                                            info.ctypes.data))
+        keys = ("resolved_modes", "completed_modes", "gram_passes", "sketch_passes")
+        d = {k: int(info[i]) for i, k in enumerate(keys)}
+        d.update(executed_flops=float(info[4]), subspace_iterations=int(info[6]), stop_reason=("filled", "floor", "budget")[int(info[7])])
+        return sigma[:n], d
 
     def evaluate_points(self, U: Buffer, K: int, ix, iy, tx, ty, row0=0) -> np.ndarray:
         ix = np.ascontiguousarray(ix, dtype=np.int32)

@@ -1,0 +1,54 @@
+// Pieces of the basis stage shared by rom_basis.hip and rom_factored.hip (internal).
+#pragma once
+#include <algorithm>
+
+#include "rom_ops.h"
+
+namespace {
+
+// ---- temporaries from the context's caching allocator ---------------------------------------------------------------
+struct Tmp {
+  rom_buf* b = nullptr;
+  Tmp() = default;
+  Tmp(const Tmp&) = delete;
+  Tmp& operator=(const Tmp&) = delete;
+  ~Tmp() { release(); }
+  void release() {
+    if (b) rom_buf_free(b);
+    b = nullptr;
+  }
+  int get(rom_ctx* ctx, size_t n) {
+    release();
+    return rom_buf_alloc(ctx, std::max<size_t>(n, 1), &b);
+  }
+  double* p() const { return b->p; }
+  operator double*() const { return b->p; }
+};
+
+int read_status(rom_ctx* ctx, const char* who) {
+  int status = 0;
+  ROM_HIP(hipMemcpyAsync(&status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  if (status) {
+    rom_set_error("%s: reduced matrix not positive definite", who);
+    return ROM_ERR_NOT_SPD;
+  }
+  return ROM_OK;
+}
+
+int download(rom_ctx* ctx, const double* d, double* h, size_t n) {
+  if (n == 0) return ROM_OK;
+  ROM_HIP(hipMemcpyAsync(h, d, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  return ROM_OK;
+}
+
+}  // namespace
+
+// kernels of rom_basis.hip that the factored greedy launches as well
+__global__ void kb_greedy_select(int M, const double* __restrict__ err2, const double* __restrict__ extra2,
+                                 const double* __restrict__ h1, int it, int* __restrict__ picks, double* __restrict__ maxerr);
+__global__ void kb_grow_ahat(double* __restrict__ Ahat, int k, int ld, int j, const double* __restrict__ col,
+                             const int* __restrict__ degenerate, int it);
+__global__ void kb_galerkin_gap(int M, int n, const double* __restrict__ P, const double* __restrict__ c, double* __restrict__ extra2);
+__global__ void kb_ints_to_doubles(const int* __restrict__ src, double* __restrict__ dst, int n);

@@ -290,6 +290,7 @@ extern "C" int rom_fem_destroy(rom_fem* f) {
                   f->d_ditem_k, f->d_dmat, f->d_scb};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  rom_factored_map_free(f->fmap);
   delete f;
   return ROM_OK;
 }

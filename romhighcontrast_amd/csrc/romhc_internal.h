@@ -276,6 +276,7 @@ struct rom_fem {
   std::vector<int> ranks;        // compressed size of every active edge (elimination order)
   // work accounting
   double flops_solve = 0, bytes_solve = 0;
+  void* fmap = nullptr;          // rom_factored_map: geometry of the snapshots in interface-vector coordinates (rom_factored.hip)
   // factor workspace (grown on demand)
   double* d_L = nullptr;
   double* d_invL = nullptr;
@@ -291,5 +292,6 @@ int rom_launch_gemm_nt_ex(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double 
                           int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
                           const char* prof_name, int lower_only);
 
+void rom_factored_map_free(void* map);  // (rom_factored.hip)
 // pack of interface vectors into their compact form on stream `st` (rom_fem_solve.hip)
 int rom_launch_pack_reduced(rom_fem* f, const double* Y, double* Yc, int M, hipStream_t st);

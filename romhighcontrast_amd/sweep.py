@@ -249,13 +249,16 @@ class RcclSweep:
             return Y
 
         def allgather(Y):
-            if self.world == 1:
-                return Y
-            # the compact form travels (the nodal part of a vector is an output of the expansion)
+            # the compact form travels (the nodal part of a vector is an output of the expansion).  One rank takes the same
+            # path -- pack, the collective whenever the context has a communicator, unpack -- so that a single-GPU run
+            # exercises what every rank of an N-GPU job runs (world = 1 used to return Y untouched)
             kc = fem.compact_stride
             Yc, Yc_all, full = ctx.alloc(mp * kc), ctx.alloc(self.world * mp * kc), ctx.alloc(self.world * mp * stride)
             fem.pack_reduced(Y, mp, Yc)
-            ctx.allgather(Yc, 0, Yc_all, 0, mp * kc)
+            if self.world > 1 or ctx.has_comm:
+                ctx.allgather(Yc, 0, Yc_all, 0, mp * kc)
+            else:
+                Yc_all.copy_from(Yc, mp * kc)
             fem.unpack_reduced(Yc_all, self.world * mp, full)
             return full
 

@@ -46,8 +46,8 @@ if fem.expansion_is_linear:
     _, t = T(lambda: (fem.solve_reduced(ctx.upload(a.reshape(M, -1)), M, Y), ctx.solve_status()))
     print(f"reduced solves (interface vectors, K = {K}): {t*1e3:.2f} ms")
     fs = factored.FactoredSnapshots(sm, Y, M)
-    _, t = T(lambda: fs.map.energy_coordinates())
-    print(f"energy coordinates of the FE space (once): {t:.2f} s, k' = {fs.map.energy_coordinates()[0].shape[1]}")
+    _, t = T(lambda: fs.map.build(3))
+    print(f"energy map of the FE space (once): {t:.2f} s, ranks = {fs.map.build(3)}")
     h1f, t = T(lambda: factored.h10norm_factored(fs))
     print(f"H10 norms from the interface vectors: {t*1e3:.2f} ms, max rel diff to the stencil norms {np.abs(h1f / h1 - 1).max():.1e}")
     for mode in (RB.GREEDY_FOR_H10, RB.GREEDY_FOR_GALERKIN):
