@@ -631,11 +631,14 @@ __global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
 //   rank-4 blocked Cholesky (panel in row-per-lane form, trailing update on MFMA) with the forward substitution
 //   carried along -> back substitution on registers ->
 //   coefficient blocks for the extension (what k_coef does on the general path).
+// LDS 23,040 B (round 4; 40,448 before): the block sums of the assembly (20 KB), then the factor PACKED by rows (row r at
+// r (r + 1) / 2: 16.6 KB instead of a 64 x 66 square), then the weighted unknowns of the coefficient blocks share one area
 __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restrict__ a) {
-  __shared__ __align__(16) double Ls[64 * LDC];
-  __shared__ __align__(16) double Pn[64 * 4];  // one 64 x 4 panel of the Cholesky
+  __shared__ __align__(16) double Ls[40 * 64];  // assembly: the ten lower blocks [block][g][lane]; Cholesky on: L packed by rows
+  __shared__ __align__(16) double Pn[64 * 4];   // one 64 x 4 panel of the Cholesky
   __shared__ double zs[64];
-  __shared__ double wz[DENSE_GROUPS_MAX * 64];
+  double* const wz = Ls;                        // (the factor is dead once its columns sit in registers)
+  static_assert(DENSE_GROUPS_MAX * 64 <= 40 * 64 && 64 * 65 / 2 <= 40 * 64, "the shared area holds each of its three tenants");
   const int m = blockIdx.x, lane = threadIdx.x;
   const double* am = a + size_t(m) * f.kblk;
   double* ym = f.y + size_t(m) * f.nGp;
@@ -651,8 +654,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   // else hides the latency).  The pairs are sorted by block; a block's sum is kept in four registers and
   // stored to an LDS copy of the blocks when its last pair is done (the target block of a pair is a run-time
   // index, which registers cannot have).
-  double* Cl = Ls;  // the ten lower blocks during the assembly, [block][g][lane] (Ls is not needed before the Cholesky)
-  static_assert(40 * 64 <= 64 * LDC, "block copy must fit in the tile buffer");
+  double* Cl = Ls;  // the ten lower blocks during the assembly, [block][g][lane] (the factor is not needed before the Cholesky)
   const int l16 = lane & 15, l4 = lane >> 4;
   const int nterm = d.t1 - d.t0;
   const double mycoef = lane < nterm ? term_coef(f.terms[d.t0 + lane], am) : 0.0;  // lane t: weight of term t
@@ -781,8 +783,12 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
     // (c) the factorised panel: operand array for the MFMAs and the columns of L for the back substitution
     *reinterpret_cast<double2*>(&Pn[lane * 4]) = double2{v[0], v[1]};
     *reinterpret_cast<double2*>(&Pn[lane * 4 + 2]) = double2{v[2], v[3]};
-    *reinterpret_cast<double2*>(&Ls[lane * LDC + c0]) = double2{v[0], v[1]};
-    *reinterpret_cast<double2*>(&Ls[lane * LDC + c0 + 2]) = double2{v[2], v[3]};
+    {  // row `lane` of L, packed: only the entries on / below the diagonal exist
+      double* lrow = Ls + lane * (lane + 1) / 2 + c0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (c0 + k <= lane) lrow[k] = v[k];
+    }
     __builtin_amdgcn_wave_barrier();
     // (d) trailing update C[ib][jb'] -= Lp[ib] Lp[jb']^T for the blocks right of / below the panel
     if (p < 15) {
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   // chain x_j = y_j / L_jj ; y_i -= L_ji x_j (i < j) runs on registers and readlane broadcasts only.
   double lcol[64];
 #pragma unroll
-  for (int j = 0; j < 64; ++j) lcol[j] = Ls[j * LDC + lane];
+  for (int j = 0; j < 64; ++j) lcol[j] = Ls[j * (j + 1) / 2 + lane];  // L[j][lane] for lane <= j (beyond: another row's entry, never used)
 #pragma unroll
   for (int j = 63; j >= 0; --j) {
     const double xj = readlane_f64(y, j) * readlane_f64(myrs, j);
