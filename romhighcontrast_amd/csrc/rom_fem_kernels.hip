@@ -149,7 +149,8 @@ __device__ inline void tile_from_acc(double* Cb, const Acc& acc, const STile& st
 }
 
 // LDS carve-up of the factor kernels: B staging (2 buffers) | union { A staging (2 buffers), C tile }
-constexpr int FACT_LDS_DOUBLES = 2 * STAGE_DOUBLES + TILE_DOUBLES;  // 6528 doubles = 52,224 B -> 3 WG / CU
+constexpr int LDK8 = 10;                                        // row stride of a staged [64][8] chunk (16-byte aligned rows)
+constexpr int FACT_LDS_DOUBLES = TILE_DOUBLES + 64 * LDK8;      // C tile | one 8-wide chunk of invL: 4864 doubles = 38,912 B -> 4 WG / CU
 
 // acc += sum over the k-list of `slot` of L[slotA] * L[slotB]^T
 // a pointer that is the same in every lane, in scalar registers whatever the compiler thinks of it
@@ -168,12 +169,16 @@ __device__ inline unsigned long long x128_uniform(unsigned long long v) {
 // equal at C4, 2-3 % slower at C5).  A chunk = 16 k of both tiles =
 // {A 64 rows x 128 B | B 64 rows x 128 B}; one DMA instruction writes 64 lanes x 16 B back to back = 8 rows, the eight
 // 16-byte units of a row stored at position u ^ ((row >> 1) & 7) (conflict-free fragment reads without padding); wave w
-// fetches rows 16 w .. 16 w + 15 of both operands (4 instructions per chunk).  Three slots: chunks ch + 1 and ch + 2 are
-// in flight under the 16 MFMAs per wave of chunk ch, one barrier per chunk behind a counted s_waitcnt (vmcnt retires in
-// order: at most the 4 loads of the younger chunk may still be out).  `lds`: TD_LDS_BYTES; ends with a barrier (the
-// area may be reused right after).
+// fetches rows 16 w .. 16 w + 15 of both operands (4 instructions per chunk); one barrier per chunk.  `lds`: TD_LDS_BYTES;
+// ends with a barrier (the area may be reused right after).  (Rounds 2-3: three slots, chunks ch + 1 and ch + 2 in flight
+// behind a counted s_waitcnt vmcnt(4).)
+// Round 4: TWO slots (chunk ch + 1 in flight under chunk ch, plain vmcnt(0) in front of the barrier).  The third slot bought
+// its deeper prefetch with 16 KB of LDS per workgroup: with two, a diagonal-update workgroup needs 33.8 KB and a panel
+// workgroup 39.4 KB -- FOUR of them per CU instead of three, and these kernels live on resident workgroups
+// (profiles/r03_overlap_and_chunk_probes.txt: -19 % from three to two).
 constexpr int TD_SLOT = 2 * 64 * 128;     // bytes
-constexpr int TD_LDS_BYTES = 3 * TD_SLOT;  // 49,152
+constexpr int TD_NSLOT = 2;
+constexpr int TD_LDS_BYTES = TD_NSLOT * TD_SLOT;  // 32,768
 template <class FP>
 __device__ inline void accumulate_klist_dma(const FemDev& f, int slot, const double* Lm, FP active, Acc& acc, char* lds,
                                             const WavePos& wp) {
@@ -223,14 +228,12 @@ __device__ inline void accumulate_klist_dma(const FemDev& f, int slot, const dou
     dma(sl + 8192, bb, vo[0]);
     dma(sl + 8192 + 1024, bb, vo[1]);
   };
-  unsigned s_cur = 0, s_nxt = TD_SLOT, s_far = 2 * TD_SLOT;  // slots of chunks ch, ch + 1, ch + 2
+  unsigned s_cur = 0, s_nxt = TD_SLOT;  // slots of chunks ch, ch + 1
   issue(0, s_cur);
-  if (n > 1) issue(1, s_nxt);
   for (int ch = 0; ch < n; ++ch) {
-    // chunk ch has landed for everybody, and everybody has left the slot of chunk ch - 1 (= that of chunk ch + 2)
-    if (ch + 1 < n) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (ch + 2 < n) issue(ch + 2, s_far);
+    // chunk ch has landed for everybody, and everybody has left the slot of chunk ch - 1 (= that of chunk ch + 1)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ch + 1 < n) issue(ch + 1, s_nxt);
     if (active(ch)) {
       const char* sp = lds + s_cur;
       double af[2][2], bf[2][2];
@@ -257,8 +260,7 @@ __device__ inline void accumulate_klist_dma(const FemDev& f, int slot, const dou
     }
     const unsigned t = s_cur;
     s_cur = s_nxt;
-    s_nxt = s_far;
-    s_far = t;
+    s_nxt = t;
   }
   __syncthreads();
 }
@@ -416,8 +418,7 @@ __global__ __launch_bounds__(256) void k_back_pre(FemDev f, const double* __rest
 template <int NS>
 __device__ inline void diag_update_body(const FemDev& f, const double* __restrict__ am0, int m0, int nsys, int slot, double* lds,
                                         double* coef) {
-  double* Cb = lds;  // the C tile aliases the whole staging area (used after the k-loop only)
-  static_assert(TILE_DOUBLES <= STAGE_TOTAL, "C tile must fit in the staging area");
+  double* Cb = lds;  // the C tile aliases the DMA slots (used after the k-loop only)
   const WavePos wp;
   const TileDesc& d = f.desc[slot];
   STile st[NS];
@@ -439,9 +440,9 @@ __device__ inline void diag_update_body(const FemDev& f, const double* __restric
 // NS = 2: two systems per workgroup (one pass over the term tables for both)
 template <int NS>
 __global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __restrict__ a, int slot, int Mc) {
-  __shared__ __align__(16) double lds[TD_LDS_BYTES / 8];  // 48 KB: three workgroups per CU
+  __shared__ __align__(16) double lds[TILE_DOUBLES];  // 33.8 KB (the two DMA slots alias the C tile): four workgroups per CU
   __shared__ double coef[NS * COEF_MAX];
-  static_assert(STAGE_TOTAL * 8 <= TD_LDS_BYTES, "the tile fits");
+  static_assert(TD_LDS_BYTES <= TILE_DOUBLES * 8, "the DMA slots fit under the tile");
   const int m0 = blockIdx.x * NS;
   diag_update_body<NS>(f, a + size_t(m0) * f.kblk, m0, min(NS, Mc - m0), slot, lds, coef);
 }
@@ -862,8 +863,8 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
 template <int NS>
 __device__ inline void panel_body(const FemDev& f, const double* __restrict__ am0, int m0, int nsys, int j, int ent, double* lds,
                                   double* yj, double* coef) {
-  double* stB = lds;
-  double* Cb = lds + 2 * STAGE_DOUBLES;
+  double* Cb = lds;                  // (the DMA slots of the k loop alias it)
+  double* stB = lds + TILE_DOUBLES;  // one 8-wide chunk of invL_jj
   const int slot = f.colrow[ent];
   const int ti = f.colti[ent];
   const WavePos wp;
@@ -886,10 +887,32 @@ __device__ inline void panel_body(const FemDev& f, const double* __restrict__ am
 
     // X = C * invL_jj^T
     acc_zero(acc);
-    const double* I = f.invL + (size_t(m) * f.T + j) * 4096 + stage_row() * 64 + stage_seg();
+    // (8-wide chunks of invL through ONE 5 KB staging buffer: 16 barriers instead of 5, and 13 KB less LDS per workgroup)
+    const double* I = f.invL + (size_t(m) * f.T + j) * 4096 + (t >> 2) * 64 + (t & 3) * 2;
     const int kmax = (wp.wc + 1) * 32;  // invL[c][k] = 0 for k > c
-    gemm_loop_Atile(Cb, 4, [&](int ch, double* v) { load4_aligned(I + ch * BK, v); },
-                    [&](int ch) { return ch * BK < kmax; }, acc, stB, wp);
+    {
+      const int fr = wp.lane & 15, kq = wp.lane >> 4;
+      double2 vb = *reinterpret_cast<const double2*>(I);
+      for (int ch = 0; ch < 8; ++ch) {
+        *reinterpret_cast<double2*>(stB + (t >> 2) * LDK8 + (t & 3) * 2) = vb;
+        __syncthreads();
+        if (ch + 1 < 8) vb = *reinterpret_cast<const double2*>(I + (ch + 1) * 8);
+        if (ch * 8 < kmax) {
+          const double* pa = Cb + (wp.wr * 32 + fr) * LDC + ch * 8 + kq;
+          const double* pb = stB + (wp.wc * 32 + fr) * LDK8 + kq;
+#pragma unroll
+          for (int kk = 0; kk < 8; kk += 4) {
+            const double a0 = pa[kk], a1 = pa[16 * LDC + kk];
+            const double b0 = pb[kk], b1 = pb[16 * LDK8 + kk];
+            acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.c[0][0], 0, 0, 0);
+            acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.c[0][1], 0, 0, 0);
+            acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.c[1][0], 0, 0, 0);
+            acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.c[1][1], 0, 0, 0);
+          }
+        }
+        __syncthreads();
+      }
+    }
 
     double* Lout = Lm + size_t(slot) * 4096;
 #pragma unroll
@@ -931,7 +954,7 @@ __device__ inline void panel_block(int b, int nrows, int Mc, int& m, int& row) {
 // update -- 20 % -- but not here: C4 0.69 ms either way, C5 7 % slower; profiles/r02_tile_cholesky_probes.txt)
 template <int NS>
 __global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc) {
-  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];  // (+ yj = 52,736 B: three workgroups per CU)
+  __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];  // (+ yj = 39,424 B: four workgroups per CU)
   __shared__ double yj[64];
   double* coef = lds;  // NS * COEF_MAX term weights: only the assembly reads them, before the k loop writes the area
   int mp, row;

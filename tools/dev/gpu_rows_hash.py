@@ -1,0 +1,12 @@
+import sys, hashlib
+sys.path.insert(0, ".")
+import numpy as np
+from romhighcontrast_amd import _ffi
+ctx = _ffi.get_context(0)
+for blocks, N, M in (((3, 3), 171, 64), ((4, 4), 64, 40), ((2, 3), 40, 20)):
+    a = 10.0 ** np.random.default_rng(N).uniform(0, 6, size=(M, blocks[0] * blocks[1]))
+    fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)
+    U = ctx.alloc(M * fem.dim)
+    fem.solve_batch(ctx.upload(a), M, U)
+    h = hashlib.sha256(U.download().tobytes()).hexdigest()[:16]
+    print(blocks, N, M, h)
