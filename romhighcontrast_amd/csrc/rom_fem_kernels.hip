@@ -86,11 +86,19 @@ struct STile {
 
 
 // NS systems (consecutive rows of `a`) are assembled from ONE pass over the tables: the assembly costs what it reads
-// (profiles/r02_tile_cholesky_probes.txt), and the tables are the same for every system.  coef: NS * COEF_MAX doubles.
+// (profiles/r02_tile_cholesky_probes.txt), and the tables are the same for every system.
+// coef: LDS, NS * COEF_MAX doubles of term weights + TERM_DESC_DOUBLES of term descriptors.
+// Round 4: the loop used to fetch a term's descriptor from global memory (the same 36 bytes in every thread), test it, and
+// only then ask for the table rows -- two dependent memory round trips per term, ~10 terms per tile: 20 of the 27 us a panel
+// workgroup of column 0 lives (per-column times, profiles/r04_tile_cholesky.txt).  Now the descriptors of a pass are staged
+// in LDS next to the weights (one coalesced load), every thread walks ITS intersecting terms, and the rows of the next one
+// are in flight while the current one is added.  Same terms in the same order per entry: the tiles are bit-identical.
+constexpr int TERM_DESC_DOUBLES = COEF_MAX * 3 / 2;  // 3 ints per term: table, rows lo | hi << 16, columns lo | hi << 16
 template <int NS>
 __device__ inline void s_tile_load(STile (&st)[NS], const TileDesc& d, const FemDev& f, const double* __restrict__ am0,
                                    int nsys, double* coef) {
   const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
+  int* desc = reinterpret_cast<int*>(coef + NS * COEF_MAX);
 #pragma unroll
   for (int q = 0; q < NS; ++q)
 #pragma unroll
@@ -99,27 +107,47 @@ __device__ inline void s_tile_load(STile (&st)[NS], const TileDesc& d, const Fem
     const int nt = min(COEF_MAX, d.t1 - tb);
     __syncthreads();
     if (int(threadIdx.x) < nt) {
+      const GenTerm g = f.terms[tb + threadIdx.x];
 #pragma unroll
-      for (int q = 0; q < NS; ++q)
-        coef[q * COEF_MAX + threadIdx.x] = term_coef(f.terms[tb + threadIdx.x], am0 + size_t(q < nsys ? q : 0) * f.kblk);
+      for (int q = 0; q < NS; ++q) coef[q * COEF_MAX + threadIdx.x] = term_coef(g, am0 + size_t(q < nsys ? q : 0) * f.kblk);
+      desc[3 * threadIdx.x] = g.tab;
+      desc[3 * threadIdx.x + 1] = int(g.r_lo) | int(g.r_hi) << 16;
+      desc[3 * threadIdx.x + 2] = int(g.c_lo) | int(g.c_hi) << 16;
     }
     __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-      const GenTerm& g = f.terms[tb + t];
-      if (r < g.r_lo || r >= g.r_hi || c0 >= g.c_hi || c0 + 16 <= g.c_lo) continue;
-      const double2* src = reinterpret_cast<const double2*>(f.pool + size_t(g.tab) * 4096 + r * 64 + c0);
+    // this thread's next term at or behind t whose rectangle meets its 1 x 16 strip (nt: none)
+    auto next_term = [&](int t) {
+      for (; t < nt; ++t) {
+        const int rr = desc[3 * t + 1], cc = desc[3 * t + 2];
+        if (r >= (rr & 0xffff) && r < (rr >> 16) && c0 < (cc >> 16) && c0 + 16 > (cc & 0xffff)) break;
+      }
+      return t;
+    };
+    auto fetch = [&](int t, double2 (&w)[8]) {
+      const double2* src = reinterpret_cast<const double2*>(f.pool + size_t(desc[3 * t]) * 4096 + r * 64 + c0);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) w[x] = src[x];  // tables are zero outside their rectangle: no masks needed
+    };
+    double2 wa[8], wb[8];
+    int ta = next_term(0);
+    if (ta < nt) fetch(ta, wa);
+    while (ta < nt) {
+      const int tn = next_term(ta + 1);
+      if (tn < nt) fetch(tn, wb);
       double cf[NS];
 #pragma unroll
-      for (int q = 0; q < NS; ++q) cf[q] = coef[q * COEF_MAX + t];
+      for (int q = 0; q < NS; ++q) cf[q] = coef[q * COEF_MAX + ta];
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
-        const double2 w = src[x];  // tables are zero outside their rectangle: no masks needed
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-          st[q].v[2 * x] += cf[q] * w.x;
-          st[q].v[2 * x + 1] += cf[q] * w.y;
+          st[q].v[2 * x] += cf[q] * wa[x].x;
+          st[q].v[2 * x + 1] += cf[q] * wa[x].y;
         }
       }
+#pragma unroll
+      for (int x = 0; x < 8; ++x) wa[x] = wb[x];
+      ta = tn;
     }
   }
   if (d.diag && r >= d.ndr) {
@@ -439,9 +467,9 @@ __device__ inline void diag_update_body(const FemDev& f, const double* __restric
 }
 // NS = 2: two systems per workgroup (one pass over the term tables for both)
 template <int NS>
-__global__ __launch_bounds__(256) void k_diag_update(FemDev f, const double* __restrict__ a, int slot, int Mc) {
+__global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void k_diag_update(FemDev f, const double* __restrict__ a, int slot, int Mc) {
   __shared__ __align__(16) double lds[TILE_DOUBLES];  // 33.8 KB (the two DMA slots alias the C tile): four workgroups per CU
-  __shared__ double coef[NS * COEF_MAX];
+  __shared__ double coef[NS * COEF_MAX + TERM_DESC_DOUBLES];
   static_assert(TD_LDS_BYTES <= TILE_DOUBLES * 8, "the DMA slots fit under the tile");
   const int m0 = blockIdx.x * NS;
   diag_update_body<NS>(f, a + size_t(m0) * f.kblk, m0, min(NS, Mc - m0), slot, lds, coef);
@@ -953,7 +981,7 @@ __device__ inline void panel_block(int b, int nrows, int Mc, int& m, int& row) {
 // (NS = 2, a workgroup doing its row tile for two systems with one pass over the term tables, pays in the diagonal
 // update -- 20 % -- but not here: C4 0.69 ms either way, C5 7 % slower; profiles/r02_tile_cholesky_probes.txt)
 template <int NS>
-__global__ __launch_bounds__(256) void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc) {
+__global__ __launch_bounds__(256, 4) void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc) {  // (<= 128 VGPRs: four waves per SIMD)
   __shared__ __align__(16) double lds[FACT_LDS_DOUBLES];  // (+ yj = 39,424 B: four workgroups per CU)
   __shared__ double yj[64];
   double* coef = lds;  // NS * COEF_MAX term weights: only the assembly reads them, before the k loop writes the area
