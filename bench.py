@@ -512,8 +512,9 @@ def main():
     # PMC-measured memory-side traffic of the dominant kernel, if a summary of separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command is committed
     cfg_sizes = {"c2": ((2, 2), 128, 1024), "c4": ((3, 3), 171, 1024), "c5": ((4, 4), 256, 4096)}
-    pmc_files = {"c2": ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"), "c4": ("r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json"),
-                 "c5": ("r03_pmc_traffic_c5.json", "r02_pmc_traffic_c5.json")}
+    pmc_files = {"c2": ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"),
+                 "c4": ("r04_pmc_traffic_c4.json", "r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json"),
+                 "c5": ("r04_pmc_traffic_c5.json", "r03_pmc_traffic_c5.json", "r02_pmc_traffic_c5.json")}
     for pmc_name in pmc_files.get(args.config, ()):
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc_path) and (blocks, N, M) == cfg_sizes[args.config]:

@@ -1,4 +1,4 @@
-"""Per-kernel HIP-event times (rom_profile_*) of the basis-stage calls: rom_pod at C2 / C3 / C5 size (`pod [M]`, `pod5`), rom_greedy at C4 size in both modes (`greedy`), or `all`.  Also the program the round-3 rocprofv3 --kernel-trace --stats summary of the basis stage was taken from (REPS=1 keeps it short)."""
+"""Per-kernel HIP-event times (rom_profile_*) of the basis-stage calls: rom_pod at C2 / C3 / C5 size (`pod [M]`, `pod5`), rom_greedy at C4 size in both modes (`greedy`), the factored builders at C4 size (`factored`), or `all`.  Also the program the round-3 rocprofv3 --kernel-trace --stats summary of the basis stage was taken from (REPS=1 keeps it short)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -52,6 +52,43 @@ if which in ("greedy", "all"):
             w = time.perf_counter() - t0
         ctx.profile(False)
         report(ctx, f"rom_greedy {mode} n=50", w)
+if which in ("factored", "all"):
+    # the same builders on the block held in factored form (rom_greedy_factored / rom_pod_factored, round 4)
+    from romhighcontrast_amd import factored
+    sm = SM.SolutionsManagerFEM((3, 3), 171)
+    ctx, fem, dim = sm._ctx, sm._fem, sm.vspace_dim
+    M = 1024
+    a = bench.workload_parameters("c4", (3, 3), M)
+    Yf = ctx.alloc(M * fem.reduced_stride)
+    fem.solve_reduced(ctx.upload(a.reshape(M, -1)), M, Yf)
+    ctx.solve_status()
+    fs = factored.FactoredSnapshots(sm, Yf, M)
+    t0 = time.perf_counter()
+    ranks = fs.map.build(7)
+    ctx.synchronize()
+    print(f"rom_fem_energy_map(7) at 3x3 / N=171: {(time.perf_counter() - t0) * 1e3:.1f} ms, ranks {ranks}, Kc = {fs.map.Kc}")
+    h1 = factored.h10norm_factored(fs)
+    for mode in (RB.GREEDY_FOR_H10, RB.GREEDY_FOR_GALERKIN):
+        for rep in range(2):
+            ctx.synchronize()
+            if rep == 1:
+                ctx.profile_reset(); ctx.profile(True)
+            t0 = time.perf_counter()
+            RB.ReducedBasisGreedy(mode).build(50, sm, fs, a, h1)
+            ctx.synchronize()
+            w = time.perf_counter() - t0
+        ctx.profile(False)
+        report(ctx, f"rom_greedy_factored {mode} n=50", w)
+    for rep in range(2):
+        ctx.synchronize()
+        if rep == 1:
+            ctx.profile_reset(); ctx.profile(True)
+        t0 = time.perf_counter()
+        factored.pod_modes_factored(fs, 50)
+        ctx.synchronize()
+        w = time.perf_counter() - t0
+    ctx.profile(False)
+    report(ctx, "rom_pod_factored 1024 x 262144 (C4 block), 50 modes", w)
 if which == "pod5":
     sm = SM.SolutionsManagerFEM((4, 4), 256)
     ctx, dim = sm._ctx, sm.vspace_dim
