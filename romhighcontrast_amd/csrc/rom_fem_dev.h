@@ -13,6 +13,13 @@ struct FemDev {
   const double* pool;  // 64x64 tables of the tile terms
   const int* pairs;    // single-tile solve: (term, block) pairs of the assembly, two ints each
   int npairs;          // multiple of 64 (no-op padded), followed by 64 more no-ops
+  // k_solve1 (four systems per workgroup, the blocks dealt to its four waves): wave w walks pairs wp0[w] .. wp0[w + 1] - 1
+  const double* pool_acc;  // their 16x16 table pieces, 256 doubles each, in accumulator layout [g pair][lane][2] (+ zero pieces behind the end)
+  const int* wmeta;        // term | q << 8 | (last pair of block q) << 16 per pair (+ 128 no-ops behind the end)
+  int wp0[5];
+  int s1_t0, s1_nterm, s1_ndr;  // the single tile's terms and unknowns (desc[0], by value)
+  const int* s1_items;    // flat records of the dense items: {group, position, nv, b0, b1, voff[4] + k, vblk[4], vu0[4], vu1[4], -} (24 ints)
+  const int* s1_citems;   // ... of the coefficient items: {position | code << 28, source, b0, b1}; code 0 dense product's, 1 one over (a_b0 + a_b1), 2 copy, 3 zero
   const GenTerm* terms;
   const double* Bt;    // back substitution tables of the closed-form edges
   const double* P;     // expansion tables of the active edges
@@ -71,6 +78,11 @@ constexpr int COEF_MAX = 64;   // term weights cached in LDS per pass
 #define PAIR_RING_ 8
 #endif
 constexpr int PAIR_RING = PAIR_RING_;  // (term, block) pairs in flight in the single-tile assembly
+// k_solve1's dynamic LDS: the term weights of its four systems, four per-wave areas
+constexpr int S1_COEF_BYTES = 4 * COEF_MAX * 8, S1_WAVE_BYTES = (40 * 64 + 64 * 4 + 64 + 64) * 8;
+constexpr int S1_ITEM_PASSES = 4;  // coefficient items (64 per pass) whose descriptors k_solve1 reads ahead of its Cholesky
+constexpr int S1_DENSE_BYTES = 64 * 64 * 8;  // the matrix of the dense product of the tail (64 x ndi, ndi <= 64)
+constexpr int S1_LDS_BYTES = S1_COEF_BYTES + 4 * S1_WAVE_BYTES + S1_DENSE_BYTES;
 constexpr int DENSE_GROUPS_MAX = 8;  // closed-form edges whose coefficient blocks k_solve1 builds
 
 // row of H0 that holds the extension from side s evaluated at interior vertex (i,j), 1-based
@@ -95,7 +107,7 @@ __global__ void k_back_pre(FemDev f, const double* __restrict__ a, int Mc);
 template <int NS>
 __global__ void k_diag_update(FemDev f, const double* __restrict__ a, int slot, int Mc);
 __global__ void k_diag_factor(FemDev f, int slot, int j);
-__global__ void k_solve1(FemDev f, const double* __restrict__ a);
+__global__ void k_solve1(FemDev f, const double* __restrict__ a, int Mc);
 template <int NS>
 __global__ void k_factor_panel(FemDev f, const double* __restrict__ a, int j, int Mc);
 __global__ void k_backsolve(FemDev f);

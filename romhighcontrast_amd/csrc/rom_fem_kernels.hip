@@ -493,6 +493,102 @@ __device__ inline double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// k_solve1 keeps its factor packed by rows in whole panels of four columns: rows 4 g .. 4 g + 3 have 4 (g + 1) entries each
+__device__ __host__ constexpr int s1_lrow(int r) { return 8 * (r >> 2) * ((r >> 2) + 1) + (r & 3) * 4 * ((r >> 2) + 1); }
+
+// One 64 x 4 panel of the blocked Cholesky of k_solve1 / k_diag_factor, in row-per-lane form (row r of the panel at
+// Pn[4 r]; c0 = its first column): on return v = row `lane` of L in these columns, y / myrs carry the forward substitution.
+// Round 4: every lane factorises the 4 x 4 diagonal block for itself (LDS broadcast reads of rows c0 .. c0 + 3, fetched
+// beside its own row) instead of receiving pivots and multipliers through v_readlane one column at a time -- 14
+// cross-lane broadcasts per panel, each at the end of a dependent chain (31 k of a wave's 82 k cycles), become straight
+// VALU code.  Same operations on the same numbers in the same order as the broadcast form: same bits.
+__device__ inline void chol_panel_rows(const double* Pn, int lane, int c0, double (&v)[4], double& y, double& myrs, bool& bad) {
+  {
+    const double2 v01 = *reinterpret_cast<const double2*>(&Pn[lane * 4]);
+    const double2 v23 = *reinterpret_cast<const double2*>(&Pn[lane * 4 + 2]);
+    v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
+  }
+  const double a00 = Pn[c0 * 4];
+  const double2 r1 = *reinterpret_cast<const double2*>(&Pn[(c0 + 1) * 4]);
+  const double2 r2 = *reinterpret_cast<const double2*>(&Pn[(c0 + 2) * 4]);
+  double a22 = Pn[(c0 + 2) * 4 + 2];
+  const double2 r3a = *reinterpret_cast<const double2*>(&Pn[(c0 + 3) * 4]);
+  const double2 r3b = *reinterpret_cast<const double2*>(&Pn[(c0 + 3) * 4 + 2]);
+  const double a10 = r1.x, a20 = r2.x, a30 = r3a.x;
+  double a11 = r1.y, a21 = r2.y, a31 = r3a.y, a32 = r3b.x, a33 = r3b.y;
+  const double y0 = readlane_f64(y, c0);
+  double y1 = readlane_f64(y, c0 + 1), y2 = readlane_f64(y, c0 + 2), y3 = readlane_f64(y, c0 + 3);
+  // column c0
+  bad = bad || !(a00 > 0.0);
+  const double rs0 = rsqrt_newton(a00);
+  const double l10 = a10 * rs0, l20 = a20 * rs0, l30 = a30 * rs0;
+  a11 -= l10 * l10; a21 -= l20 * l10; a31 -= l30 * l10;
+  a22 -= l20 * l20; a32 -= l30 * l20; a33 -= l30 * l30;
+  const double yd0 = y0 * rs0;
+  y1 -= l10 * yd0; y2 -= l20 * yd0; y3 -= l30 * yd0;
+  {
+    const double l = lane >= c0 ? v[0] * rs0 : 0.0;  // L[lane][c0]
+    v[0] = l;
+    if (lane == c0) {
+      y = yd0;
+      myrs = rs0;
+    } else if (lane > c0) {
+      y -= l * yd0;
+    }
+    v[1] -= l * l10; v[2] -= l * l20; v[3] -= l * l30;
+  }
+  // column c0 + 1
+  bad = bad || !(a11 > 0.0);
+  const double rs1 = rsqrt_newton(a11);
+  const double l21 = a21 * rs1, l31 = a31 * rs1;
+  a22 -= l21 * l21; a32 -= l31 * l21; a33 -= l31 * l31;
+  const double yd1 = y1 * rs1;
+  y2 -= l21 * yd1; y3 -= l31 * yd1;
+  {
+    const double l = lane >= c0 + 1 ? v[1] * rs1 : 0.0;
+    v[1] = l;
+    if (lane == c0 + 1) {
+      y = yd1;
+      myrs = rs1;
+    } else if (lane > c0 + 1) {
+      y -= l * yd1;
+    }
+    v[2] -= l * l21; v[3] -= l * l31;
+  }
+  // column c0 + 2
+  bad = bad || !(a22 > 0.0);
+  const double rs2 = rsqrt_newton(a22);
+  const double l32 = a32 * rs2;
+  a33 -= l32 * l32;
+  const double yd2 = y2 * rs2;
+  y3 -= l32 * yd2;
+  {
+    const double l = lane >= c0 + 2 ? v[2] * rs2 : 0.0;
+    v[2] = l;
+    if (lane == c0 + 2) {
+      y = yd2;
+      myrs = rs2;
+    } else if (lane > c0 + 2) {
+      y -= l * yd2;
+    }
+    v[3] -= l * l32;
+  }
+  // column c0 + 3
+  bad = bad || !(a33 > 0.0);
+  const double rs3 = rsqrt_newton(a33);
+  const double yd3 = y3 * rs3;
+  {
+    const double l = lane >= c0 + 3 ? v[3] * rs3 : 0.0;
+    v[3] = l;
+    if (lane == c0 + 3) {
+      y = yd3;
+      myrs = rs3;
+    } else if (lane > c0 + 3) {
+      y -= l * yd3;
+    }
+  }
+}
+
 // Diagonal tile j, steps 2 and 3 in one kernel on the matrix cores (one wave per system, LDS 36 KB: all 1024 systems
 // of a step resident at once):
 //   rank-4 blocked right-looking Cholesky of the tile held in MFMA accumulator layout (the scheme of k_solve1: a
@@ -532,29 +628,7 @@ __device__ inline void diag_factor_body(const FemDev& f, int m, int slot, int j,
     }
     __builtin_amdgcn_wave_barrier();
     double v[4];
-    {
-      const double2 v01 = *reinterpret_cast<const double2*>(&Pn[lane * 4]);
-      const double2 v23 = *reinterpret_cast<const double2*>(&Pn[lane * 4 + 2]);
-      v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int jc = c0 + k;
-      const double dj = readlane_f64(v[k], jc);
-      bad = bad || !(dj > 0.0);
-      const double rs = rsqrt_newton(dj);
-      const double l = lane >= jc ? v[k] * rs : 0.0;  // L[lane][jc]
-      v[k] = l;
-      const double yj = readlane_f64(y, jc) * rs;
-      if (lane == jc) {
-        y = yj;
-        myrs = rs;
-      } else if (lane > jc) {
-        y -= l * yj;
-      }
-#pragma unroll
-      for (int kk = k + 1; kk < 4; ++kk) v[kk] -= l * readlane_f64(l, c0 + kk);
-    }
+    chol_panel_rows(Pn, lane, c0, v, y, myrs, bad);
     __builtin_amdgcn_wave_barrier();
     *reinterpret_cast<double2*>(&Pn[lane * 4]) = double2{v[0], v[1]};
     *reinterpret_cast<double2*>(&Pn[lane * 4 + 2]) = double2{v[2], v[3]};
@@ -656,77 +730,231 @@ __global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
 
 // Whole reduced solve of a system whose reduced matrix is ONE tile (e.g. 2x2 blocks at N = 128: 2 x 31
 // compressed unknowns + the cross point), one wave per system, nothing but the solution leaves the CU:
-//   assemble the lower 16x16 blocks in MFMA accumulator layout (term by term, double buffered) ->
+//   assemble the lower 16x16 blocks in MFMA accumulator layout (term by term) ->
 //   rank-4 blocked Cholesky (panel in row-per-lane form, trailing update on MFMA) with the forward substitution
 //   carried along -> back substitution on registers ->
 //   coefficient blocks for the extension (what k_coef does on the general path).
-// LDS 23,040 B (round 4; 40,448 before): the block sums of the assembly (20 KB), then the factor PACKED by rows (row r at
-// r (r + 1) / 2: 16.6 KB instead of a 64 x 66 square), then the weighted unknowns of the coefficient blocks share one area
-__global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restrict__ a) {
-  __shared__ __align__(16) double Ls[40 * 64];  // assembly: the ten lower blocks [block][g][lane]; Cholesky on: L packed by rows
-  __shared__ __align__(16) double Pn[64 * 4];   // one 64 x 4 panel of the Cholesky
-  __shared__ double zs[64];
-  double* const wz = Ls;                        // (the factor is dead once its columns sit in registers)
-  static_assert(DENSE_GROUPS_MAX * 64 <= 40 * 64 && 64 * 65 / 2 <= 40 * 64, "the shared area holds each of its three tenants");
-  const int m = blockIdx.x, lane = threadIdx.x;
+// Round 4: FOUR systems per workgroup (one per wave), and the assembly is split BY BLOCKS instead of by systems.  Every
+// system adds up the same (term, block) table pieces with its own weights; with a wave per system each wave pulled all
+// 117 KB of them through the CU's load path for itself (25 k of a wave's 82 k cycles: 39 GB/s per CU with 64 KB in flight;
+// sharing the pieces through an LDS ring moved the same bytes through the LDS instead and got 12 k).  Now wave w adds up
+// ITS blocks (a quarter of the pairs, balanced by the host) for all four systems: a piece is fetched once per workgroup
+// (two 16-byte loads per lane -- the pieces are stored in accumulator layout, [g pair][lane][2], in the order the waves
+// walk them: no index to wait for), multiplied by four weights, and the finished block sums go to the LDS area of the
+// system they belong to.  A block's sum runs over the same pairs in the same order as before: same bits.
+// LDS (dynamic): term weights of the four systems | per wave: the block sums of the assembly (20 KB), then the factor PACKED
+// by rows (s1_lrow), then the weighted unknowns of the coefficient blocks in the same area; a panel; z
+__global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restrict__ a, int Mc) {
+  extern __shared__ __align__(16) char s1_dyn[];
+  const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  double* const coefs = reinterpret_cast<double*>(s1_dyn);  // [system][term]
+  const double* const Dl = reinterpret_cast<const double*>(s1_dyn + S1_COEF_BYTES + 4 * S1_WAVE_BYTES);  // the matrix of the dense product, 64 x ndi
+  double* const Ls = reinterpret_cast<double*>(s1_dyn + S1_COEF_BYTES + w * S1_WAVE_BYTES);  // assembly: the ten lower blocks [block][g][lane]; Cholesky on: L packed by rows
+  double* const Pn = Ls + 40 * 64;  // one 64 x 4 panel of the Cholesky
+  double* const zs = Pn + 64 * 4;
+  double* const aL = zs + 64;       // the system's block coefficients a_m[0 .. kblk)
+  double* const wz = Ls;            // (the factor is dead once its columns sit in registers)
+  static_assert(DENSE_GROUPS_MAX * 64 <= 40 * 64 && 8 * 16 * 17 <= 40 * 64, "the shared area holds each of its three tenants");
+  static_assert(S1_WAVE_BYTES == (40 * 64 + 64 * 4 + 64 + 64) * 8 && S1_COEF_BYTES == 4 * 64 * 8, "LDS areas");
+  const int m_raw = 4 * int(blockIdx.x) + w;
+  const bool live = m_raw < Mc;  // (the last workgroup may have waves without a system: they fetch and wait with the others, then leave)
+  const int m = live ? m_raw : Mc - 1;
   const double* am = a + size_t(m) * f.kblk;
   double* ym = f.y + size_t(m) * f.nGp;
-  const TileDesc& d = f.desc[0];
-  // the alignment gaps of the interface vector are read (against zero table entries) by the extension: they must hold
-  // finite numbers whatever buffer the caller handed in -- zeroed here, ahead of every other store of this wave to its
-  // vector, instead of by a memset launch in front of every sweep
-  for (int i = lane; i < f.nGp; i += 64) ym[i] = 0.0;
+#ifdef ROMHC_SOLVE1_STAMPS
+  unsigned long long stamp[10];
+#define S1_STAMP(i) stamp[i] = __builtin_readcyclecounter()
+  S1_STAMP(0);
+#else
+#define S1_STAMP(i)
+#endif
+#ifdef ROMHC_SOLVE1_PANEL_STAMPS
+  unsigned long long pt_last = 0, pt_sum[4] = {0, 0, 0, 0}, qt[6] = {0, 0, 0, 0, 0, 0};
+#define S1_QT(i) qt[i] = __builtin_readcyclecounter()
+#define S1_PT(i)                                                      \
+  do {                                                                \
+    const unsigned long long t_ = __builtin_readcyclecounter();       \
+    pt_sum[i] += t_ - pt_last;                                        \
+    pt_last = t_;                                                     \
+  } while (0)
+#else
+#define S1_PT(i)
+#define S1_QT(i)
+#endif
+// LDS traffic of ONE wave needs no barrier (a wave's LDS instructions execute in order); this keeps the compiler in line
+#define S1_WAVE_SYNC()                                   \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_wave_barrier();                     \
+  } while (0)
   // Assembly in the MFMA accumulator layout of the Cholesky below: element g of block q = (ib, jb), ib >= jb, is
   // (row 16 ib + 4 g + (lane >> 4), column 16 jb + (lane & 15)).  The host lists the (term, block) pairs whose
-  // rectangle and block intersect (57 at 2x2 / N=128); a pair is exactly four loads, so a ring of PAIR_RING
-  // pairs keeps 4 * PAIR_RING loads in flight with statically known wait counts (one wave per SIMD: nothing
-  // else hides the latency).  The pairs are sorted by block; a block's sum is kept in four registers and
-  // stored to an LDS copy of the blocks when its last pair is done (the target block of a pair is a run-time
-  // index, which registers cannot have).
-  double* Cl = Ls;  // the ten lower blocks during the assembly, [block][g][lane] (the factor is not needed before the Cholesky)
+  // rectangle and block intersect (57 at 2x2 / N=128), block by block, and deals the blocks to the four waves; a
+  // pair is exactly two loads, so a ring of PAIR_RING pairs keeps 2 * PAIR_RING loads in flight with statically known
+  // wait counts.  The sums of a block (one per system) are kept in registers and stored to the LDS copy of the blocks
+  // of their system when the block's last pair is done (the target block of a pair is a run-time index, which registers
+  // cannot have).
   const int l16 = lane & 15, l4 = lane >> 4;
-  const int nterm = d.t1 - d.t0;
-  const double mycoef = lane < nterm ? term_coef(f.terms[d.t0 + lane], am) : 0.0;  // lane t: weight of term t
-#pragma unroll
-  for (int x = 0; x < 40; ++x) Cl[x * 64 + lane] = 0.0;
+  // The matrix of the dense product of the tail (64 x ndi doubles, the same for every system) goes to LDS once per
+  // workgroup, by LDS-DMA, before anything else: it lands while the assembly runs, and the barrier behind the assembly
+  // publishes it.  (Each wave used to pull its own copy through the load path AFTER the back substitution: 64 eight-byte
+  // loads per lane at the 40 GB/s per CU that path gives such loads, 7 k cycles.)
   {
-    const int2* pairs = reinterpret_cast<const int2*>(f.pairs);  // (element offset of the block in the pool, term | q << 8)
-    const double* pbase = f.pool + l4 * 64 + l16;
-    double v[PAIR_RING][4];
-    double acc4[4] = {0.0, 0.0, 0.0, 0.0};
-    int2 mine = pairs[lane];  // lane i holds pair i of the current group of 64 (the list is padded with no-ops)
-    auto issue = [&](int2 pr_lane, int i, double (&dst)[4]) {
-      const double* pb = pbase + __builtin_amdgcn_readlane(pr_lane.x, i);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) dst[g] = pb[g * 256];  // rows 4 g + l4 of the block
+    const unsigned d0 = unsigned(size_t((__attribute__((address_space(3))) char*)s1_dyn)) + unsigned(S1_COEF_BYTES + 4 * S1_WAVE_BYTES);
+    const int nchunk = (f.ndi + 1) >> 1;  // kilobytes (the host pads the matrix to whole ones)
+    const char* src = reinterpret_cast<const char*>(f.dmat);
+    for (int c = w; c < nchunk; c += 4)
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane(d0 + unsigned(c) * 1024u)),
+                   "v"(unsigned(lane) * 16u), "s"(x128_uniform(src + size_t(c) * 1024))
+                   : "memory", "m0");
+  }
+  RhsTerm rt;
+  double gvec, rcoef;
+  int4 irec[6], crec[S1_ITEM_PASSES];
+  int wd[DENSE_GROUPS_MAX], xr_first;
+  int2 sc_b;
+  {
+    const int p0 = f.wp0[w], np = f.wp0[w + 1] - p0;  // this wave's pairs: pieces p0 .. of pool_acc, metas p0 .. of wmeta
+    const double2* pbase = reinterpret_cast<const double2*>(f.pool_acc) + size_t(p0) * 128 + lane;
+    double2 v[PAIR_RING][2];
+    auto issue = [&](int i, double2 (&dst)[2]) {
+      dst[0] = pbase[size_t(i) * 128];       // g = 0, 1
+      dst[1] = pbase[size_t(i) * 128 + 64];  // g = 2, 3
     };
+    // Everything that depends on nothing is asked for at once, the small things first (a wave's loads return in order):
+    // the system's coefficients, the descriptors of the terms (lane t: term t) and of the rhs terms, the metas, then the
+    // first PAIR_RING pieces.  The coefficients are parked in LDS: what used to be chains of dependent global loads
+    // (descriptor -> a_m[block] -> divide, 6 k + 7 k cycles at the head of the kernel and of the rhs) are LDS reads.
+    const double a_l = lane < f.kblk ? am[lane] : 1.0;
+    const GenTerm gt = f.terms[f.s1_t0 + min(lane, f.s1_nterm - 1)];
+    rt = f.rhs[min(lane, max(f.nrhs, 1) - 1)];
+    gvec = f.g[lane];
+    int mine = f.wmeta[p0 + lane];  // lane i holds the meta of pair i of the current group of 64
+    // ... and the records of the tail (flat, one per lane and item: rom_fem_setup.hip), which wait in registers
+    {
+      const int4* ir = reinterpret_cast<const int4*>(f.s1_items) + size_t(min(lane, max(f.ndi, 1) - 1)) * 6;
 #pragma unroll
-    for (int u = 0; u < PAIR_RING; ++u) issue(mine, u, v[u]);
-    for (int base = 0; base < f.npairs; base += 64) {
-      const int2 cur = mine;
-      const int2 nxt = pairs[base + 64 + lane];  // (the list carries 64 extra no-ops behind its end)
+      for (int x = 0; x < 6; ++x) irec[x] = ir[x];
 #pragma unroll
-      for (int i = 0; i < 64; ++i) {
-        const int u = i % PAIR_RING;
-        const int meta = __builtin_amdgcn_readlane(cur.y, i);  // term | q << 8 | (last pair of block q) << 16
-        const double cf = readlane_f64(mycoef, meta & 0xff);
+      for (int r = 0; r < S1_ITEM_PASSES; ++r) crec[r] = reinterpret_cast<const int4*>(f.s1_citems)[min(lane + 64 * r, max(f.ncoef, 1) - 1)];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc4[g] += cf * v[u][g];
-        if (meta >> 16) {  // the pairs are sorted by block: its sum is complete
-          double* dst = Cl + ((meta >> 8) & 0xff) * 256 + lane;
+      for (int g = 0; g < DENSE_GROUPS_MAX; ++g) wd[g] = g < f.ndg ? f.dweight[g * 64 + lane] : -2;
+      xr_first = lane < f.ncross ? f.xred[lane] : 0;
+      sc_b = lane < f.nsc ? reinterpret_cast<const int2*>(f.scb)[lane] : int2{0, 0};
+    }
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            dst[g * 64] = acc4[g];
-            acc4[g] = 0.0;
+    for (int u = 0; u < PAIR_RING; ++u) issue(u, v[u]);
+#pragma unroll
+    for (int x = 0; x < 40; ++x) Ls[x * 64 + lane] = 0.0;
+    aL[lane] = a_l;
+    S1_WAVE_SYNC();
+    coefs[w * 64 + lane] = lane < f.s1_nterm ? term_coef(gt, aL) : 0.0;  // lane t: weight of term t
+    rcoef = lane < f.nrhs ? (rt.kind == 0 ? aL[rt.b0] / (aL[rt.e0] + aL[rt.e1]) : 0.5) : 0.0;  // lane t: weight of rhs term t
+    __syncthreads();  // every system's weights are there; every system's block area is zeroed
+    double cf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) cf[s] = coefs[s * 64 + lane];
+    double acc4[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc4[s][g] = 0.0;
+    double* const Cl0 = reinterpret_cast<double*>(s1_dyn + S1_COEF_BYTES) + lane;  // system s: + s * (S1_WAVE_BYTES / 8)
+    S1_STAMP(1);
+    for (int base = 0; base < np; base += 64) {
+      const int cur = mine;
+      const int nxt = f.wmeta[p0 + base + 64 + lane];  // (the list carries 128 no-ops behind its end)
+      const int cnt = min(64, np - base);  // (a multiple of PAIR_RING: the host pads every wave's list with no-ops)
+#pragma unroll
+      for (int i0 = 0; i0 < 64; i0 += PAIR_RING) {  // (unrolled: straight-line code keeps the compiler's wait counts exact)
+        if (i0 >= cnt) break;
+#pragma unroll
+        for (int u = 0; u < PAIR_RING; ++u) {
+          const int i = i0 + u;
+          const int meta = __builtin_amdgcn_readlane(cur, i);  // term | q << 8 | (last pair of block q) << 16
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double c = readlane_f64(cf[s], meta & 0xff);
+            acc4[s][0] = __builtin_fma(c, v[u][0].x, acc4[s][0]);
+            acc4[s][1] = __builtin_fma(c, v[u][0].y, acc4[s][1]);
+            acc4[s][2] = __builtin_fma(c, v[u][1].x, acc4[s][2]);
+            acc4[s][3] = __builtin_fma(c, v[u][1].y, acc4[s][3]);
           }
+          if (meta >> 16) {  // the pairs are sorted by block: its sums are complete
+            double* dst = Cl0 + ((meta >> 8) & 0xff) * 256;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                dst[s * (S1_WAVE_BYTES / 8) + g * 64] = acc4[s][g];
+                acc4[s][g] = 0.0;
+              }
+          }
+          issue(base + i + PAIR_RING, v[u]);
         }
-        if (i + PAIR_RING < 64) issue(cur, i + PAIR_RING, v[u]);
-        else issue(nxt, i + PAIR_RING - 64, v[u]);
       }
       mine = nxt;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's share of the dense product's matrix has landed)
+    __syncthreads();  // the four waves' blocks are in every system's area
   }
-  __builtin_amdgcn_wave_barrier();
+  double* Cl = Ls;  // the ten lower blocks of this wave's system, [block][g][lane]
+  if (!live) return;  // (no workgroup-wide barrier below)
+  S1_STAMP(2);
+  // the alignment gaps of the interface vector are read (against zero table entries) by the extension: they must hold
+  // finite numbers whatever buffer the caller handed in -- zeroed here, ahead of every other store of this wave to its
+  // vector (a wave's stores to one address stay in order), instead of by a memset launch in front of every sweep
+  for (int i = lane; i < f.nGp; i += 64) ym[i] = 0.0;
+  // Everything of the tail that does not depend on the solution is done (or asked for) HERE, ahead of the Cholesky, whose
+  // 30 k cycles hide its memory round trips: the scalar block, the weights of the dense groups, this lane's item of the
+  // dense product with its 64 matrix entries, the descriptors of the coefficient items.  (Was: 13 k cycles of dependent
+  // loads and divides behind the back substitution.)  Same expressions on the same numbers: same bits.
+  S1_QT(0);
+  if (lane < f.nsc) ym[f.spos0 + lane] = sc_b.y >= 0 ? 1.0 / (aL[sc_b.x] + aL[sc_b.y]) : (1.0 / (double(f.N) * double(f.N))) / aL[sc_b.x];
+  for (int i = lane + 64; i < f.nsc; i += 64) {
+    const int b0 = f.scb[2 * i], b1 = f.scb[2 * i + 1];
+    ym[f.spos0 + i] = b1 >= 0 ? 1.0 / (aL[b0] + aL[b1]) : (1.0 / (double(f.N) * double(f.N))) / aL[b0];
+  }
+  S1_QT(1);
+  double wgt[DENSE_GROUPS_MAX];
+#pragma unroll
+  for (int g = 0; g < DENSE_GROUPS_MAX; ++g) {
+    wgt[g] = 0.0;
+    if (g < f.ndg) {
+      const DenseGroup& dg = f.dgroups[g];
+      wgt[g] = wd[g] >= 0 ? aL[wd[g]] : (wd[g] == -1 ? (aL[dg.b0] + aL[dg.b1]) / 2 : 0.0);
+    }
+  }
+  S1_QT(2);
+  const bool has_it = lane < f.ndi;  // this lane's item of the first pass of the dense product
+  const int it_g = irec[0].x, it_pos = irec[0].y, it_nv = irec[0].z;
+  double it_den = 1.0, it_cv[4] = {0.0, 0.0, 0.0, 0.0}, it_vv[4] = {0.0, 0.0, 0.0, 0.0};
+  if (has_it) {
+    const int voff[4] = {irec[1].y, irec[1].z, irec[1].w, irec[2].x}, vblk[4] = {irec[2].y, irec[2].z, irec[2].w, irec[3].x};
+    const int vu0[4] = {irec[3].y, irec[3].z, irec[3].w, irec[4].x}, vu1[4] = {irec[4].y, irec[4].z, irec[4].w, irec[5].x};
+    it_den = aL[irec[0].w] + aL[irec[1].x];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (v < it_nv) {
+        it_cv[v] = aL[vblk[v]] / (aL[vu0[v]] + aL[vu1[v]]);
+        it_vv[v] = f.vec[voff[v]];
+      }
+    S1_QT(3);
+  }
+  S1_QT(4);
+  // coefficient items of the first S1_ITEM_PASSES passes: constants go out now, copies of the solution are remembered
+  int ci_dst[S1_ITEM_PASSES], ci_src[S1_ITEM_PASSES];
+#pragma unroll
+  for (int r = 0; r < S1_ITEM_PASSES; ++r) {
+    ci_src[r] = -1;
+    ci_dst[r] = crec[r].x & 0xfffffff;
+    if (lane + 64 * r < f.ncoef) {
+      const int code = crec[r].x >> 28;
+      if (code == 2) ci_src[r] = crec[r].y;
+      else if (code != 0) ym[ci_dst[r]] = code == 1 ? 1.0 / (aL[crec[r].z] + aL[crec[r].w]) : 0.0;
+    }
+  }
+  S1_STAMP(3);
   d4_t C[4][4];
   {
     int q = 0;
@@ -744,26 +972,24 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int R = 16 * ib + 4 * g + l4, Cc = 16 * jb + l16;
-        if (R >= d.ndr || Cc >= d.ndr) C[ib][jb][g] = R == Cc ? 1.0 : 0.0;  // padding unknowns: identity
+        if (R >= f.s1_ndr || Cc >= f.s1_ndr) C[ib][jb][g] = R == Cc ? 1.0 : 0.0;  // padding unknowns: identity
       }
-  // rhs of the reduced system (k_rhs)
-  double y = f.g[lane];
+  // rhs of the reduced system (k_rhs): y = g + sum_t weight_t * (vector t placed at its rows), the terms in their order
+  double y = gvec;
   for (int t0 = 0; t0 < f.nrhs; t0 += 8) {  // eight terms at a time: their vector loads are in flight together
     double rv[8];
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
       rv[x] = 0.0;
       if (t0 + x < f.nrhs) {
-        const RhsTerm& rt = f.rhs[t0 + x];
-        if (lane >= rt.pos && lane < rt.pos + rt.len) rv[x] = f.vec[rt.voff + lane - rt.pos];
+        const int pos = __builtin_amdgcn_readlane(rt.pos, t0 + x), len = __builtin_amdgcn_readlane(rt.len, t0 + x);
+        const int voff = __builtin_amdgcn_readlane(rt.voff, t0 + x);
+        if (lane >= pos && lane < pos + len) rv[x] = f.vec[voff + lane - pos];
       }
     }
 #pragma unroll
     for (int x = 0; x < 8; ++x)
-      if (t0 + x < f.nrhs) {
-        const RhsTerm& rt = f.rhs[t0 + x];
-        y += (rt.kind == 0 ? am[rt.b0] / (am[rt.e0] + am[rt.e1]) : 0.5) * rv[x];
-      }
+      if (t0 + x < f.nrhs) y += readlane_f64(rcoef, t0 + x) * rv[x];
   }
   // Blocked right-looking Cholesky, 16 panels of 4 columns.  A panel goes through LDS into row-per-lane form
   // (lane r holds its 4 entries), is factorised there with readlane broadcasts -- the forward substitution of y
@@ -772,6 +998,10 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   // of ~120 broadcast reads + 240 FMAs per lane in the column-by-column form.
   bool bad = false;
   double myrs = 0.0;
+  S1_STAMP(4);
+#ifdef ROMHC_SOLVE1_PANEL_STAMPS
+  pt_last = __builtin_readcyclecounter();
+#endif
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
     const int jb = p >> 2, co = 4 * (p & 3), c0 = 4 * p;
@@ -783,42 +1013,22 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
         for (int g = 0; g < 4; ++g) Pn[(16 * ib + 4 * g + l4) * 4 + (l16 - co)] = C[ib][jb][g];
     }
     __builtin_amdgcn_wave_barrier();
+    S1_PT(0);
     // (b) row-per-lane: lane r holds A[r][c0 .. c0+3]
     double v[4];
-    {
-      const double2 v01 = *reinterpret_cast<const double2*>(&Pn[lane * 4]);
-      const double2 v23 = *reinterpret_cast<const double2*>(&Pn[lane * 4 + 2]);
-      v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int j = c0 + k;
-      const double dj = readlane_f64(v[k], j);
-      bad = bad || !(dj > 0.0);
-      const double rs = rsqrt_newton(dj);
-      const double l = lane >= j ? v[k] * rs : 0.0;  // L[lane][j]
-      v[k] = l;
-      const double yj = readlane_f64(y, j) * rs;
-      if (lane == j) {
-        y = yj;
-        myrs = rs;
-      } else if (lane > j) {
-        y -= l * yj;
-      }
-#pragma unroll
-      for (int kk = k + 1; kk < 4; ++kk) v[kk] -= l * readlane_f64(l, c0 + kk);
-    }
+    chol_panel_rows(Pn, lane, c0, v, y, myrs, bad);
     __builtin_amdgcn_wave_barrier();
+    S1_PT(1);
     // (c) the factorised panel: operand array for the MFMAs and the columns of L for the back substitution
     *reinterpret_cast<double2*>(&Pn[lane * 4]) = double2{v[0], v[1]};
     *reinterpret_cast<double2*>(&Pn[lane * 4 + 2]) = double2{v[2], v[3]};
-    {  // row `lane` of L, packed: only the entries on / below the diagonal exist
-      double* lrow = Ls + lane * (lane + 1) / 2 + c0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (c0 + k <= lane) lrow[k] = v[k];
+    if ((lane >> 2) >= p) {  // row `lane` of L, packed in whole panels: rows 4 g .. 4 g + 3 hold panels 0 .. g (zeros right of the diagonal)
+      double* lrow = Ls + s1_lrow(lane) + c0;
+      *reinterpret_cast<double2*>(lrow) = double2{v[0], v[1]};
+      *reinterpret_cast<double2*>(lrow + 2) = double2{v[2], v[3]};
     }
     __builtin_amdgcn_wave_barrier();
+    S1_PT(2);
     // (d) trailing update C[ib][jb'] -= Lp[ib] Lp[jb']^T for the blocks right of / below the panel
     if (p < 15) {
       double frag[4];
@@ -831,14 +1041,16 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
           C[ib][jb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag[ib], frag[jb2], C[ib][jb2], 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
+    S1_PT(3);
   }
   if (bad && lane == 0) atomicOr(f.status, 1);
-  __syncthreads();
+  S1_WAVE_SYNC();
+  S1_STAMP(5);
   // back substitution x = L^-T y.  Column `lane` of L is fetched from LDS in one batch (conflict free), then the
   // chain x_j = y_j / L_jj ; y_i -= L_ji x_j (i < j) runs on registers and readlane broadcasts only.
   double lcol[64];
 #pragma unroll
-  for (int j = 0; j < 64; ++j) lcol[j] = Ls[j * (j + 1) / 2 + lane];  // L[j][lane] for lane <= j (beyond: another row's entry, never used)
+  for (int j = 0; j < 64; ++j) lcol[j] = Ls[s1_lrow(j) + lane];  // L[j][lane] for lane <= j (beyond: padding or another row's entry, never used)
 #pragma unroll
   for (int j = 63; j >= 0; --j) {
     const double xj = readlane_f64(y, j) * readlane_f64(myrs, j);
@@ -847,42 +1059,59 @@ __global__ __launch_bounds__(64) void k_solve1(FemDev f, const double* __restric
   }
   ym[lane] = y;
   zs[lane] = y;
-  __syncthreads();
+  S1_WAVE_SYNC();
+  S1_STAMP(6);
   // coefficient blocks + nodal copy of the cross points (what k_coef does on the general path).  The blocks of
   // the closed-form edges are one dense product here: out[it] = sum_j D[j][it] * (w_g(j) z_j), D = all their
   // matrices side by side (64 x items, coalesced in `it`), w_g(j) the weight of source j for group g.
-  for (int x = lane; x < f.ncross; x += 64) ym[f.xb0 + x] = zs[f.xred[x]];
-  for (int i = lane; i < f.nsc; i += 64) {
-    const int b0 = f.scb[2 * i], b1 = f.scb[2 * i + 1];
-    ym[f.spos0 + i] = b1 >= 0 ? 1.0 / (am[b0] + am[b1]) : (1.0 / (double(f.N) * double(f.N))) / am[b0];
-  }
-  for (int idx = lane; idx < f.ndg * 64; idx += 64) {
-    const DenseGroup& dg = f.dgroups[idx >> 6];
-    const int wd = f.dweight[idx];
-    const double wgt = wd >= 0 ? am[wd] : (wd == -1 ? (am[dg.b0] + am[dg.b1]) / 2 : 0.0);
-    wz[idx] = wgt * zs[idx & 63];
-  }
-  __syncthreads();
-  for (int it = lane; it < f.ndi; it += 64) {
-    const int g = f.ditem_group[it], k = f.ditem_k[it];
-    const DenseGroup& dg = f.dgroups[g];
-    const double* D = f.dmat + it;
-    const double* wg = wz + g * 64;
-    double dv[64];
+  if (lane < f.ncross) ym[f.xb0 + lane] = zs[xr_first];
+  for (int x = lane + 64; x < f.ncross; x += 64) ym[f.xb0 + x] = zs[f.xred[x]];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) dv[j] = D[size_t(j) * f.ndi];  // all 64 coalesced loads in flight at once
+  for (int g = 0; g < DENSE_GROUPS_MAX; ++g)
+    if (g < f.ndg) wz[g * 64 + lane] = wgt[g] * y;  // (y = z_lane)
+  S1_WAVE_SYNC();
+  S1_STAMP(7);
+  if (has_it) {
+    const double* wg = wz + it_g * 64;
+    const double* D = Dl + lane;
     double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) acc += dv[j] * wg[j];
-    for (int v = 0; v < dg.nv; ++v) acc += am[dg.vblk[v]] / (am[dg.vu0[v]] + am[dg.vu1[v]]) * f.vec[dg.voff[v] + k];
-    ym[dg.cpos + k] = acc / (am[dg.b0] + am[dg.b1]);
+    for (int j = 0; j < 64; ++j) acc += D[j * f.ndi] * wg[j];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (v < it_nv) acc += it_cv[v] * it_vv[v];
+    ym[it_pos] = acc / it_den;
   }
-  for (int it = lane; it < f.ncoef; it += 64) {
+#pragma unroll
+  for (int r = 0; r < S1_ITEM_PASSES; ++r)
+    if (ci_src[r] >= 0) ym[ci_dst[r]] = zs[ci_src[r]];
+  for (int it = lane + 64 * S1_ITEM_PASSES; it < f.ncoef; it += 64) {
     const CoefGroup& cg = f.groups[f.item_group[it]];
     const int k = f.item_k[it];
     if (cg.kind == 1 && k < cg.r) continue;  // done above
-    ym[cg.cpos + k] = k == cg.r ? 1.0 / (am[cg.b0] + am[cg.b1]) : (k < cg.r ? zs[cg.zpos + k] : 0.0);
+    ym[cg.cpos + k] = k == cg.r ? 1.0 / (aL[cg.b0] + aL[cg.b1]) : (k < cg.r ? zs[cg.zpos + k] : 0.0);
   }
+#ifdef ROMHC_SOLVE1_STAMPS
+  S1_STAMP(8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  S1_STAMP(9);
+  S1_WAVE_SYNC();
+#pragma unroll
+  for (int k = 0; k < 10; ++k)
+    if (lane == k) ym[k] = double(stamp[k] - stamp[0]);  // (dev build: the vector's first entries carry the stamps)
+#ifdef ROMHC_SOLVE1_PANEL_STAMPS
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (lane == 10 + k) ym[10 + k] = double(pt_sum[k]);
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    if (lane == 14 + k) ym[14 + k] = double(qt[k] - stamp[2]);
+#endif
+#endif
+#undef S1_STAMP
+#undef S1_PT
+#undef S1_QT
+#undef S1_WAVE_SYNC
 }
 
 // Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;

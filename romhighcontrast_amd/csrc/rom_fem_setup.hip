@@ -21,7 +21,7 @@ FemDev make_dev(const rom_fem* f) {
   FemDev d;
   d.nrb = f->nrb; d.ncb = f->ncb; d.N = f->N; d.n1 = f->n1; d.n1p = f->n1p; d.nr = f->nr; d.nc = f->nc;
   d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.nexp = f->nexp; d.ncross = f->ncross;
-  d.xb0 = f->xb0; d.pool = f->d_pool; d.pairs = f->d_pairs; d.npairs = f->npairs; d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
+  d.xb0 = f->xb0; d.pool = f->d_pool; d.pairs = f->d_pairs; d.npairs = f->npairs; d.pool_acc = f->d_pool_acc; d.wmeta = f->d_wmeta; d.s1_items = f->d_s1_items; d.s1_citems = f->d_s1_citems; for (int i = 0; i < 5; ++i) d.wp0[i] = f->wp0[i]; d.s1_t0 = d.s1_nterm = d.s1_ndr = 0; if (f->fused1 && !f->desc.empty()) { d.s1_t0 = f->desc[0].t0; d.s1_nterm = f->desc[0].t1 - f->desc[0].t0; d.s1_ndr = f->desc[0].ndr; } d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
   d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.scb = f->d_scb; d.spos0 = f->spos0; d.nsc = f->nsc;
   d.sblk0 = f->spos0 + f->n_all_edges; d.groups = f->d_groups; d.cm = f->d_cm; d.item_group = f->d_item_group;
   d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.dgroups = f->d_dgroups; d.dweight = f->d_dweight;
@@ -286,7 +286,7 @@ extern "C" int rom_fem_destroy(rom_fem* f) {
   void* ptrs[] = {f->d_A0, f->d_G, f->d_Gs, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
                   f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
                   f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred, f->d_groups, f->d_cm,
-                  f->d_item_group, f->d_item_k, f->d_pairs, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
+                  f->d_item_group, f->d_item_k, f->d_pairs, f->d_pool_acc, f->d_wmeta, f->d_s1_items, f->d_s1_citems, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
                   f->d_ditem_k, f->d_dmat, f->d_scb};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -958,6 +958,47 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         if (pairs.size() > first) pairs.back() |= 1 << 16;  // last pair of this block
       }
   }
+  // k_solve1 runs four systems per workgroup and deals the BLOCKS to its four waves (largest first, to the wave with the
+  // fewest pairs so far); wave w walks pairs wp0[w] .. wp0[w + 1] - 1 of `wmeta`, whose table pieces lie in the same order in
+  // `pool_acc`: piece = the 16 x 16 block of the pair's table in the accumulator layout of its consumer,
+  // [g pair h][lane][e] = table(16 ib + 4 (2 h + e) + (lane >> 4), 16 jb + (lane & 15))
+  std::vector<double> pool_acc;
+  std::vector<int> wmeta;
+  if (f->fused1) {
+    const int npr = int(pairs.size() / 2);
+    std::vector<std::vector<int>> of_block(10), of_wave(4);
+    for (int i = 0; i < npr; ++i) of_block[(pairs[2 * i + 1] >> 8) & 0xff].push_back(i);
+    std::vector<int> order(10), load(4, 0);
+    for (int q = 0; q < 10; ++q) order[q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return of_block[x].size() > of_block[y].size(); });
+    std::vector<std::vector<int>> blocks_of(4);
+    for (int q : order) {
+      const int w = int(std::min_element(load.begin(), load.end()) - load.begin());
+      blocks_of[w].push_back(q);
+      load[w] += int(of_block[q].size());
+    }
+    for (int w = 0; w < 4; ++w) {
+      std::sort(blocks_of[w].begin(), blocks_of[w].end());
+      f->wp0[w] = int(wmeta.size());
+      for (int q : blocks_of[w])
+        for (int i : of_block[q]) {
+          wmeta.push_back(pairs[2 * i + 1]);
+          const size_t o = pool_acc.size();
+          pool_acc.resize(o + 256);
+          for (int h = 0; h < 2; ++h)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 2; ++e)
+                pool_acc[o + h * 128 + lane * 2 + e] = pool[size_t(pairs[2 * i]) + size_t(4 * (2 * h + e) + (lane >> 4)) * TB + (lane & 15)];
+        }
+      while ((int(wmeta.size()) - f->wp0[w]) % PAIR_RING) {  // the walk goes PAIR_RING pairs at a time: no-ops (weight 0) on zero pieces
+        wmeta.push_back(COEF_MAX - 1);
+        pool_acc.resize(pool_acc.size() + 256, 0.0);
+      }
+    }
+    f->wp0[4] = int(wmeta.size());
+    wmeta.resize(wmeta.size() + 128, COEF_MAX - 1);        // no-ops (the walk reads its metas 64 at a time, one group ahead)
+    pool_acc.resize(pool_acc.size() + 2 * PAIR_RING * 256, 0.0);  // the fetches that run ahead of the walk
+  }
   f->npairs = int((pairs.size() / 2 + 63) / 64 * 64);
   // no-op padding: term slot COEF_MAX - 1 is never a real term (its weight is 0), block 0 of the first table
   while (int(pairs.size() / 2) < f->npairs + 64) { pairs.push_back(0); pairs.push_back(COEF_MAX - 1); }
@@ -1035,9 +1076,9 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         dgroups.push_back(dg);
       }
     const int ndi = int(ditem_group.size());
-    std::vector<double> dmat(size_t(TB) * std::max(ndi, 1), 0.0);
+    std::vector<double> dmat(size_t(TB) * std::max(ndi, 1) + 128, 0.0);  // (+ 1 KB: k_solve1 copies it to LDS in whole kilobytes)
     dweight.assign(dgroups.size() * TB, -2);
-    bool ok = f->fused1 && int(dgroups.size()) <= DENSE_GROUPS_MAX;
+    bool ok = f->fused1 && int(dgroups.size()) <= DENSE_GROUPS_MAX && rhs_terms.size() <= 64 && nrb * ncb <= 64 && ndi <= 64;  // (k_solve1: a lane per rhs term / per block coefficient)
     for (size_t dgi = 0; dgi < dgroups.size() && ok; ++dgi) {
       const CoefGroup& cg = groups[dsrc[dgi].first];
       for (int t = 0; t < cg.nterm && ok; ++t) {
@@ -1060,6 +1101,31 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
     f->ndi = f->fused1 ? ndi : 0;
     ROM_TRY(upload(ctx->stream, &f->d_dgroups, dgroups));
     ROM_TRY(upload(ctx->stream, &f->d_dweight, dweight));
+    // k_solve1 reads one FLAT record per item and lane (every level of indirection is a memory round trip a lone wave waits
+    // out): dense item = {group, position, nv, b0, b1, voff[4] + k, vblk[4], vu0[4], vu1[4], pad} (24 ints);
+    // coefficient item = {position | code << 28, source, b0, b1}, code 0 = the dense product's, 1 = 1 / (a_b0 + a_b1),
+    // 2 = copy of the solution, 3 = zero
+    std::vector<int> s1_items(size_t(std::max(ndi, 1)) * 24, 0), s1_citems(size_t(std::max(f->ncoef, 1)) * 4, 0);
+    if (f->fused1) {
+      for (int it = 0; it < ndi; ++it) {
+        const DenseGroup& dg = dgroups[ditem_group[it]];
+        int* r = &s1_items[size_t(it) * 24];
+        r[0] = ditem_group[it]; r[1] = dg.cpos + ditem_k[it]; r[2] = dg.nv; r[3] = dg.b0; r[4] = dg.b1;
+        for (int v = 0; v < 4; ++v) {
+          r[5 + v] = v < dg.nv ? dg.voff[v] + ditem_k[it] : 0;
+          r[9 + v] = v < dg.nv ? dg.vblk[v] : 0; r[13 + v] = v < dg.nv ? dg.vu0[v] : 0; r[17 + v] = v < dg.nv ? dg.vu1[v] : 0;
+        }
+      }
+      for (int it = 0; it < f->ncoef; ++it) {
+        const CoefGroup& cg = groups[item_group[it]];
+        const int k = item_k[it];
+        const int code = cg.kind == 1 && k < cg.r ? 0 : k == cg.r ? 1 : k < cg.r ? 2 : 3;
+        int* r = &s1_citems[size_t(it) * 4];
+        r[0] = (cg.cpos + k) | code << 28; r[1] = cg.zpos + k; r[2] = cg.b0; r[3] = cg.b1;
+      }
+    }
+    ROM_TRY(upload(ctx->stream, &f->d_s1_items, s1_items));
+    ROM_TRY(upload(ctx->stream, &f->d_s1_citems, s1_citems));
     ROM_TRY(upload(ctx->stream, &f->d_ditem_group, ditem_group));
     ROM_TRY(upload(ctx->stream, &f->d_ditem_k, ditem_k));
     ROM_TRY(upload(ctx->stream, &f->d_dmat, dmat));
@@ -1230,6 +1296,10 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   ROM_TRY(upload(ctx->stream, &f->d_pool, pool));
   ROM_TRY(upload(ctx->stream, &f->d_terms, terms));
   ROM_TRY(upload(ctx->stream, &f->d_pairs, pairs));
+  ROM_TRY(upload(ctx->stream, &f->d_pool_acc, pool_acc));
+  ROM_TRY(upload(ctx->stream, &f->d_wmeta, wmeta));
+  if (f->fused1)  // (the attribute belongs to the kernel as loaded on this device; setting it again is harmless)
+    ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve1), hipFuncAttributeMaxDynamicSharedMemorySize, S1_LDS_BYTES));
   f->nrhs = int(rhs_terms.size());
   ROM_TRY(upload(ctx->stream, &f->d_rhs, rhs_terms));
   ROM_TRY(upload(ctx->stream, &f->d_pre, pre_edges));

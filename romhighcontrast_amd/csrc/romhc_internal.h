@@ -226,6 +226,11 @@ struct rom_fem {
   double* d_pool = nullptr;  // 64x64 tables of the tile terms
   int* d_pairs = nullptr;    // (term, block) pairs of the single-tile assembly
   int npairs = 0;
+  double* d_pool_acc = nullptr;  // k_solve1: the pairs' table pieces in accumulator layout, in the order its four waves walk them
+  int* d_wmeta = nullptr;        // ... and their metas; wave w walks wp0[w] .. wp0[w + 1] - 1 (rom_fem_dev.h)
+  int wp0[5] = {};
+  int* d_s1_items = nullptr;   // k_solve1: flat records of the dense items (24 ints) and of the coefficient items (4 ints), rom_fem_setup.hip
+  int* d_s1_citems = nullptr;
   int* d_kptr = nullptr;     // nslots+1
   int* d_kpair = nullptr;    // 2*entries (slotA, slotB)
   int* d_colptr = nullptr;   // T+1 : rows below the diagonal in column j
