@@ -769,8 +769,7 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
 #define S1_STAMP(i)
 #endif
 #ifdef ROMHC_SOLVE1_PANEL_STAMPS
-  unsigned long long pt_last = 0, pt_sum[4] = {0, 0, 0, 0}, qt[6] = {0, 0, 0, 0, 0, 0};
-#define S1_QT(i) qt[i] = __builtin_readcyclecounter()
+  unsigned long long pt_last = 0, pt_sum[4] = {0, 0, 0, 0};
 #define S1_PT(i)                                                      \
   do {                                                                \
     const unsigned long long t_ = __builtin_readcyclecounter();       \
@@ -779,7 +778,6 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
   } while (0)
 #else
 #define S1_PT(i)
-#define S1_QT(i)
 #endif
 // LDS traffic of ONE wave needs no barrier (a wave's LDS instructions execute in order); this keeps the compiler in line
 #define S1_WAVE_SYNC()                                   \
@@ -909,13 +907,11 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
   // 30 k cycles hide its memory round trips: the scalar block, the weights of the dense groups, this lane's item of the
   // dense product with its 64 matrix entries, the descriptors of the coefficient items.  (Was: 13 k cycles of dependent
   // loads and divides behind the back substitution.)  Same expressions on the same numbers: same bits.
-  S1_QT(0);
   if (lane < f.nsc) ym[f.spos0 + lane] = sc_b.y >= 0 ? 1.0 / (aL[sc_b.x] + aL[sc_b.y]) : (1.0 / (double(f.N) * double(f.N))) / aL[sc_b.x];
   for (int i = lane + 64; i < f.nsc; i += 64) {
     const int b0 = f.scb[2 * i], b1 = f.scb[2 * i + 1];
     ym[f.spos0 + i] = b1 >= 0 ? 1.0 / (aL[b0] + aL[b1]) : (1.0 / (double(f.N) * double(f.N))) / aL[b0];
   }
-  S1_QT(1);
   double wgt[DENSE_GROUPS_MAX];
 #pragma unroll
   for (int g = 0; g < DENSE_GROUPS_MAX; ++g) {
@@ -925,7 +921,6 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
       wgt[g] = wd[g] >= 0 ? aL[wd[g]] : (wd[g] == -1 ? (aL[dg.b0] + aL[dg.b1]) / 2 : 0.0);
     }
   }
-  S1_QT(2);
   const bool has_it = lane < f.ndi;  // this lane's item of the first pass of the dense product
   const int it_g = irec[0].x, it_pos = irec[0].y, it_nv = irec[0].z;
   double it_den = 1.0, it_cv[4] = {0.0, 0.0, 0.0, 0.0}, it_vv[4] = {0.0, 0.0, 0.0, 0.0};
@@ -939,9 +934,7 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
         it_cv[v] = aL[vblk[v]] / (aL[vu0[v]] + aL[vu1[v]]);
         it_vv[v] = f.vec[voff[v]];
       }
-    S1_QT(3);
   }
-  S1_QT(4);
   // coefficient items of the first S1_ITEM_PASSES passes: constants go out now, copies of the solution are remembered
   int ci_dst[S1_ITEM_PASSES], ci_src[S1_ITEM_PASSES];
 #pragma unroll
@@ -1103,14 +1096,10 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (lane == 10 + k) ym[10 + k] = double(pt_sum[k]);
-#pragma unroll
-  for (int k = 0; k < 5; ++k)
-    if (lane == 14 + k) ym[14 + k] = double(qt[k] - stamp[2]);
 #endif
 #endif
 #undef S1_STAMP
 #undef S1_PT
-#undef S1_QT
 #undef S1_WAVE_SYNC
 }
 

@@ -15,7 +15,7 @@ fem = _ffi.Fem(ctx, 2, 2, 128)
 a = 10.0 ** np.random.default_rng(20240807).uniform(0, 2, size=(M, 4))
 ab = ctx.upload(a)
 Y = ctx.alloc(M * fem.reduced_stride)
-names = ["prologue", "stream", "zero y", "rhs+load C", "cholesky", "back subst", "weights", "dense product", "drain"]
+names = ["prologue", "assembly", "tail data ahead", "rhs+load C", "cholesky", "back subst", "weights", "dense product + items", "drain"]
 for rep in range(3):
     fem.solve_reduced(ab, M, Y)
     ctx.solve_status()
@@ -27,9 +27,8 @@ for rep in range(3):
     st = y[:, :10]
     d = np.diff(st, axis=1)
     print(f"rep {rep}: kernel {ms * 1e3:.1f} us; wave total {st[:, 9].mean():.0f} cycles (min {st[:, 9].min():.0f} max {st[:, 9].max():.0f});"
-          f" panels: acc->Pn {y[:, 13].mean():.0f} rows+chain {y[:, 10].mean():.0f} write back {y[:, 11].mean():.0f} frags+MFMA {y[:, 12].mean():.0f}")
+          f" panels (-DROMHC_SOLVE1_PANEL_STAMPS): wait for the update + acc->Pn {y[:, 10].mean():.0f} rows+chain {y[:, 11].mean():.0f} write back {y[:, 12].mean():.0f} frags + MFMA issue {y[:, 13].mean():.0f}")
     print("   " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, d.mean(axis=0))))
-    print("   after the stream: " + " ".join(f"{v:.0f}" for v in y[:, 14:19].mean(axis=0)))
     if M > 1024:
         for lo in range(0, M, 1024):
             dd = np.diff(st[lo:lo + 1024], axis=1).mean(axis=0)
