@@ -935,6 +935,21 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
   slot_terms.clear();
   smalls.clear();
+  if (getenv("ROMHC_VERBOSE")) {  // what the assembly of the tiles reads: 128-byte strips (one thread-row x 16 columns) that meet a term's rectangle
+    double strips = 0, tiles_diag = 0, tiles_sub = 0, nterm = 0;
+    for (const TileDesc& d : f->desc) {
+      (d.ti == d.tj ? tiles_diag : tiles_sub) += 1;
+      for (int t = d.t0; t < d.t1; ++t) {
+        const GenTerm& g = terms[t];
+        nterm += 1;
+        for (int r = g.r_lo; r < g.r_hi; ++r)
+          for (int c0 = 0; c0 < 64; c0 += 16)
+            if (c0 < g.c_hi && c0 + 16 > g.c_lo) strips += 1;
+      }
+    }
+    fprintf(stderr, "romhc:   tile assembly: %.0f diagonal + %.0f sub-diagonal tiles, %.0f terms, %.1f KB of table strips per system and sweep\n",
+            tiles_diag, tiles_sub, nterm, strips * 128 / 1024);
+  }
   // the whole reduced solve in one wave (k_solve1) if the reduced matrix is a single tile; its assembly walks
   // the (term, 16x16 block) pairs whose rectangle and block intersect
   f->fused1 = T == 1 && f->desc[0].t1 - f->desc[0].t0 < COEF_MAX && f->nGa == TB;
