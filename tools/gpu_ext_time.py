@@ -7,6 +7,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from romhighcontrast_amd import _ffi
 
+if os.environ.get('ROMHC_LIB'):
+    _ffi.load_library(os.path.abspath(os.environ['ROMHC_LIB']))  # (dev: a variant build)
 ctx = _ffi.get_context(0)
 NB, N, M = int(os.environ.get("NB", "2")), int(os.environ.get("N", "128")), int(os.environ.get("M", "1024"))
 reps, inner = int(os.environ.get("REPS", "7")), int(os.environ.get("INNER", "20"))
