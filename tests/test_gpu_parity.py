@@ -1011,6 +1011,39 @@ def test_full_size_c5_workload(api):
     np.testing.assert_allclose(sig_s[keep], sv[:30][keep], rtol=1e-7)
 
 
+@pytest.mark.parametrize("blocks,N", [((2, 2), 128), ((2, 2), 100), ((2, 2), 64)])
+def test_single_tile_solve_does_not_depend_on_its_batch(api, blocks, N):
+    """The single-tile reduced solve (k_solve1) runs four systems per workgroup, one per wave, and its waves share the
+    assembly: a system's interface vector -- hence its snapshot row -- must not depend on which systems share its
+    workgroup, on its place in it, or on waves of the last workgroup having no system.  Batches of 1, 2, 3, 5, 7 systems
+    and a permuted batch against one sweep of all of them, bit for bit; the rows also against the oracle."""
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)
+    if fem.n_tiles != 1:
+        pytest.skip("this geometry does not take the single-tile path")
+    k = blocks[0] * blocks[1]
+    M = 18
+    a = 10.0 ** np.random.default_rng(N).uniform(0, 4, size=(M, k))
+    U = ctx.alloc(M * fem.dim)
+    fem.solve_batch(ctx.upload(a), M, U)
+    ref = U.download(shape=(M, fem.dim))
+    lo = 0
+    for n in (1, 2, 3, 5, 7):
+        Us = ctx.alloc(n * fem.dim)
+        fem.solve_batch(ctx.upload(a[lo:lo + n]), n, Us)
+        assert np.array_equal(Us.download(shape=(n, fem.dim)), ref[lo:lo + n]), f"batch of {n} systems from row {lo}"
+        lo += n
+    perm = np.random.default_rng(1).permutation(M)
+    Up = ctx.alloc(M * fem.dim)
+    fem.solve_batch(ctx.upload(a[perm]), M, Up)
+    assert np.array_equal(Up.download(shape=(M, fem.dim)), ref[perm])
+    g = ro.Geometry(blocks, N)
+    rows = [0, 7, M - 1]
+    Uo = ro.generate_solutions(g, a[rows].reshape(len(rows), *blocks), "lsqsparse")
+    observed(f"single-tile path {blocks} N={N}: rows vs the SuperLU oracle (rel H10)", (ro.H10norm(g, ref[rows] - Uo) / ro.H10norm(g, Uo)).max(), SNAP_TOL)
+
+
 @pytest.mark.parametrize("blocks,N,M", [((2, 2), 128, 200), ((3, 3), 20, 70), ((1, 2), 6, 5), ((2, 2), 16, 130), ((1, 1), 8, 3)])
 def test_two_stage_sweep_is_bit_identical(api, blocks, N, M):
     """rom_solve_reduced_async + rom_expand_batch_async (the factored form that travels between GPUs) must
