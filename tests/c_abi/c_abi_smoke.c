@@ -8,6 +8,9 @@
  *   - the greedy's first pick is row 0 with relative error exactly 1.0, its errors are non-increasing;
  *   - a picked snapshot is reproduced by its own projection (relative H^1_0 error < 1e-11);
  *   - POD modes are orthonormal and sigma_0 >= sigma_1 > 0.
+ *   - (2 x 2 blocks, N = 48, where snapshots are a linear image of their interface vectors) the basis stage on the factored
+ *     block agrees with the one on rows: rom_h10norm_factored with rom_h10norm (1e-11), rom_greedy_factored with rom_greedy
+ *     (same picks, errors to 1e-10), rom_pod_factored with rom_pod (singular values to 1e-9 sigma_0).
  * (the parity tests proper -- against the oracle -- are tests/test_gpu_parity.py) */
 #include <math.h>
 #include <stdio.h>
@@ -124,6 +127,59 @@ int main(int argc, char** argv) {
 
   printf("C-ABI smoke: %d snapshots of dim %lld, picks %lld %lld %lld, errors %.3e %.3e %.3e, sigma %.6e %.6e\n", M, (long long)dim,
          (long long)picks[0], (long long)picks[1], (long long)picks[2], err[0], err[1], err[2], sigma[0], sigma[1]);
+
+  /* ---- the same basis stage on the FACTORED block: interface vectors instead of rows (what a multi-GPU sweep leaves on
+   * every rank).  A geometry whose expansion is linear (edges kept in compressed form): 2 x 2 blocks, N = 48. */
+  {
+    enum { N2 = 48, M2 = 6 };
+    rom_fem* fem2 = NULL;
+    CK(rom_fem_create(ctx, NRB, NCB, N2, &fem2));
+    int lin = 0, nr2, nc2, ni2, nt2;
+    int64_t dim2, ky, kc;
+    CK(rom_fem_expansion_is_linear(fem2, &lin));
+    CK(rom_fem_dims(fem2, &nr2, &nc2, &dim2, &ni2, &nt2));
+    CK(rom_fem_reduced_stride(fem2, &ky));
+    CK(rom_fem_compact_stride(fem2, &kc));
+    REQUIRE(lin == 1 && kc > 0 && kc <= ky, "expansion linear %d, strides %lld / %lld", lin, (long long)ky, (long long)kc);
+    double a2[M2 * K];
+    for (int m = 0; m < M2; ++m)
+      for (int k = 0; k < K; ++k) a2[m * K + k] = 1.0 + 9.0 * fabs(sin(2.0 + 5.0 * m + 3.0 * k));
+    rom_buf *a2_d, *U2, *Y2, *Yc, *V2, *X2, *V3;
+    CK(rom_buf_alloc(ctx, M2 * K, &a2_d));
+    CK(rom_buf_alloc(ctx, (size_t)M2 * dim2, &U2));
+    CK(rom_buf_alloc(ctx, (size_t)M2 * ky, &Y2));
+    CK(rom_buf_alloc(ctx, (size_t)M2 * kc, &Yc));
+    CK(rom_buf_alloc(ctx, (size_t)NMODES * dim2, &V2));
+    CK(rom_buf_alloc(ctx, (size_t)M2 * dim2, &X2));
+    CK(rom_buf_alloc(ctx, (size_t)NMODES * dim2, &V3));
+    CK(rom_buf_upload(a2_d, 0, a2, M2 * K));
+    CK(rom_solve_batch(fem2, a2_d, M2, U2, 0));
+    CK(rom_solve_reduced_async(fem2, a2_d, M2, Y2, 0));
+    CK(rom_solve_status(ctx));
+    CK(rom_fem_pack_reduced_async(fem2, Y2, 0, M2, Yc, 0));
+    int k_h10 = 0, k_l2 = 0;
+    CK(rom_fem_energy_map(fem2, 1 | 4, &k_h10, &k_l2));
+    REQUIRE(k_h10 > 0 && k_h10 <= kc && k_l2 > 0 && k_l2 <= kc, "ranks of the energy map: %d, %d of %lld", k_h10, k_l2, (long long)kc);
+    double hr[M2], hf[M2];
+    CK(rom_h10norm(fem2, U2, 0, NULL, 0, M2, hr));
+    CK(rom_h10norm_factored(fem2, Yc, 0, M2, hf));
+    for (int m = 0; m < M2; ++m) REQUIRE(fabs(hf[m] - hr[m]) <= 1e-11 * hr[m], "H10 norm of snapshot %d: %.15g from rows, %.15g factored", m, hr[m], hf[m]);
+    int64_t pr[NPICK], pf[NPICK];
+    double er[NPICK], ef[NPICK];
+    CK(rom_greedy(fem2, U2, 0, M2, NULL, hr, 0, NPICK, pr, er));
+    CK(rom_greedy_factored(fem2, Yc, 0, M2, NULL, hf, 0, NPICK, pf, ef));
+    for (int i = 0; i < NPICK; ++i)
+      REQUIRE(pr[i] == pf[i] && fabs(er[i] - ef[i]) <= 1e-10, "greedy step %d: row %lld (error %.3e) on rows, %lld (%.3e) factored", i, (long long)pr[i], er[i], (long long)pf[i], ef[i]);
+    double sr[NMODES], sf[NMODES];
+    CK(rom_buf_copy(X2, 0, U2, 0, (size_t)M2 * dim2));
+    CK(rom_pod(ctx, X2, 0, M2, dim2, NMODES, 1, V2, 0, sr, NULL));
+    CK(rom_pod_factored(fem2, Yc, 0, M2, NMODES, 1, V3, 0, sf, NULL));
+    for (int i = 0; i < NMODES; ++i) REQUIRE(fabs(sr[i] - sf[i]) <= 1e-9 * sr[0], "singular value %d: %.15g on rows, %.15g factored", i, sr[i], sf[i]);
+    printf("factored stage: %d snapshots of dim %lld from %lld-double interface vectors, energy ranks %d / %d, picks %lld %lld %lld, sigma %.6e %.6e\n",
+           M2, (long long)dim2, (long long)kc, k_h10, k_l2, (long long)pf[0], (long long)pf[1], (long long)pf[2], sf[0], sf[1]);
+    rom_buf_free(V3); rom_buf_free(X2); rom_buf_free(V2); rom_buf_free(Yc); rom_buf_free(Y2); rom_buf_free(U2); rom_buf_free(a2_d);
+    CK(rom_fem_destroy(fem2));
+  }
   free(B); free(r); free(u);
   rom_buf_free(X); rom_buf_free(C); rom_buf_free(P); rom_buf_free(V); rom_buf_free(AU); rom_buf_free(U); rom_buf_free(a_d);
   CK(rom_fem_destroy(fem));

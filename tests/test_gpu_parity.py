@@ -1473,7 +1473,9 @@ def test_g8_experiment_statistics(api):
 
 def test_plain_c_caller_end_to_end(tmp_path):
     """tests/c_abi/c_abi_smoke.c: a C99 program drives the C-ABI directly -- FE space, sweep, stencil residual of every
-    snapshot, H10 norms, rom_greedy, rom_project_h10, rom_pod -- and checks the identities listed in its header."""
+    snapshot, H10 norms, rom_greedy, rom_project_h10, rom_pod, and (round 4) the same basis stage on the factored block:
+    rom_fem_energy_map, rom_h10norm_factored, rom_greedy_factored, rom_pod_factored against the row calls -- and checks the
+    identities listed in its header."""
     import subprocess
     from test_host_logic import _build_c_caller
     exe, env = _build_c_caller(tmp_path)
