@@ -79,7 +79,7 @@ constexpr int COEF_MAX = 64;   // term weights cached in LDS per pass
 #endif
 constexpr int PAIR_RING = PAIR_RING_;  // (term, block) pairs in flight in the single-tile assembly
 // k_solve1's dynamic LDS: the term weights of its four systems, four per-wave areas
-constexpr int S1_COEF_BYTES = 4 * COEF_MAX * 8, S1_WAVE_BYTES = (40 * 64 + 64 * 4 + 64 + 64) * 8;
+constexpr int S1_COEF_BYTES = 4 * COEF_MAX * 8, S1_WAVE_BYTES = (40 * 64 + 64 * 4 + 64 + 64 + 3 * 64 * 4) * 8;
 constexpr int S1_ITEM_PASSES = 4;  // coefficient items (64 per pass) whose descriptors k_solve1 reads ahead of its Cholesky
 constexpr int S1_DENSE_BYTES = 64 * 64 * 8;  // the matrix of the dense product of the tail (64 x ndi, ndi <= 64)
 constexpr int S1_LDS_BYTES = S1_COEF_BYTES + 4 * S1_WAVE_BYTES + S1_DENSE_BYTES;

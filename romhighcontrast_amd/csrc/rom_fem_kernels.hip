@@ -502,24 +502,17 @@ __device__ __host__ constexpr int s1_lrow(int r) { return 8 * (r >> 2) * ((r >> 
 // beside its own row) instead of receiving pivots and multipliers through v_readlane one column at a time -- 14
 // cross-lane broadcasts per panel, each at the end of a dependent chain (31 k of a wave's 82 k cycles), become straight
 // VALU code.  Same operations on the same numbers in the same order as the broadcast form: same bits.
-__device__ inline void chol_panel_rows(const double* Pn, int lane, int c0, double (&v)[4], double& y, double& myrs, bool& bad) {
-  {
-    const double2 v01 = *reinterpret_cast<const double2*>(&Pn[lane * 4]);
-    const double2 v23 = *reinterpret_cast<const double2*>(&Pn[lane * 4 + 2]);
-    v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
-  }
-  const double a00 = Pn[c0 * 4];
-  const double2 r1 = *reinterpret_cast<const double2*>(&Pn[(c0 + 1) * 4]);
-  const double2 r2 = *reinterpret_cast<const double2*>(&Pn[(c0 + 2) * 4]);
-  double a22 = Pn[(c0 + 2) * 4 + 2];
-  const double2 r3a = *reinterpret_cast<const double2*>(&Pn[(c0 + 3) * 4]);
-  const double2 r3b = *reinterpret_cast<const double2*>(&Pn[(c0 + 3) * 4 + 2]);
-  const double a10 = r1.x, a20 = r2.x, a30 = r3a.x;
-  double a11 = r1.y, a21 = r2.y, a31 = r3a.y, a32 = r3b.x, a33 = r3b.y;
+// A non-positive (or NaN) pivot shows in its 1 / sqrt: lane j's myrs = 1 / L_jj is then not a finite positive number, and
+// every later one is NaN.  (Tested once, behind the factorisation: an or-chain over the 64 pivots kept them all alive.)
+__device__ inline bool chol_pivots_bad(double myrs) {
+  return __builtin_amdgcn_ballot_w64(!(myrs > 0.0 && myrs < 1.0e300)) != 0;
+}
+// (the arithmetic; a00 .. a33: the lower triangle of the panel's 4 x 4 diagonal block, the same numbers in every lane)
+__device__ inline void chol_panel_core(int lane, int c0, double (&v)[4], double& y, double& myrs, double a00, double a10,
+                                       double a11, double a20, double a21, double a22, double a30, double a31, double a32, double a33) {
   const double y0 = readlane_f64(y, c0);
   double y1 = readlane_f64(y, c0 + 1), y2 = readlane_f64(y, c0 + 2), y3 = readlane_f64(y, c0 + 3);
   // column c0
-  bad = bad || !(a00 > 0.0);
   const double rs0 = rsqrt_newton(a00);
   const double l10 = a10 * rs0, l20 = a20 * rs0, l30 = a30 * rs0;
   a11 -= l10 * l10; a21 -= l20 * l10; a31 -= l30 * l10;
@@ -538,7 +531,6 @@ __device__ inline void chol_panel_rows(const double* Pn, int lane, int c0, doubl
     v[1] -= l * l10; v[2] -= l * l20; v[3] -= l * l30;
   }
   // column c0 + 1
-  bad = bad || !(a11 > 0.0);
   const double rs1 = rsqrt_newton(a11);
   const double l21 = a21 * rs1, l31 = a31 * rs1;
   a22 -= l21 * l21; a32 -= l31 * l21; a33 -= l31 * l31;
@@ -556,7 +548,6 @@ __device__ inline void chol_panel_rows(const double* Pn, int lane, int c0, doubl
     v[2] -= l * l21; v[3] -= l * l31;
   }
   // column c0 + 2
-  bad = bad || !(a22 > 0.0);
   const double rs2 = rsqrt_newton(a22);
   const double l32 = a32 * rs2;
   a33 -= l32 * l32;
@@ -574,7 +565,6 @@ __device__ inline void chol_panel_rows(const double* Pn, int lane, int c0, doubl
     v[3] -= l * l32;
   }
   // column c0 + 3
-  bad = bad || !(a33 > 0.0);
   const double rs3 = rsqrt_newton(a33);
   const double yd3 = y3 * rs3;
   {
@@ -587,6 +577,26 @@ __device__ inline void chol_panel_rows(const double* Pn, int lane, int c0, doubl
       y -= l * yd3;
     }
   }
+}
+__device__ inline void chol_panel_rows(const double* Pn, int lane, int c0, double (&v)[4], double& y, double& myrs) {
+  {
+    const double2 v01 = *reinterpret_cast<const double2*>(&Pn[lane * 4]);
+    const double2 v23 = *reinterpret_cast<const double2*>(&Pn[lane * 4 + 2]);
+    v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
+  }
+  const double a00 = Pn[c0 * 4];
+  const double2 r1 = *reinterpret_cast<const double2*>(&Pn[(c0 + 1) * 4]);
+  const double2 r2 = *reinterpret_cast<const double2*>(&Pn[(c0 + 2) * 4]);
+  const double a22 = Pn[(c0 + 2) * 4 + 2];
+  const double2 r3a = *reinterpret_cast<const double2*>(&Pn[(c0 + 3) * 4]);
+  const double2 r3b = *reinterpret_cast<const double2*>(&Pn[(c0 + 3) * 4 + 2]);
+  chol_panel_core(lane, c0, v, y, myrs, a00, r1.x, r1.y, r2.x, r2.y, a22, r3a.x, r3a.y, r3b.x, r3b.y);
+}
+// the same with the panel already in registers (v: row `lane`); the diagonal block comes from its four lanes
+__device__ inline void chol_panel_regs(int lane, int c0, double (&v)[4], double& y, double& myrs) {
+  chol_panel_core(lane, c0, v, y, myrs, readlane_f64(v[0], c0), readlane_f64(v[0], c0 + 1), readlane_f64(v[1], c0 + 1),
+                  readlane_f64(v[0], c0 + 2), readlane_f64(v[1], c0 + 2), readlane_f64(v[2], c0 + 2), readlane_f64(v[0], c0 + 3),
+                  readlane_f64(v[1], c0 + 3), readlane_f64(v[2], c0 + 3), readlane_f64(v[3], c0 + 3));
 }
 
 // Diagonal tile j, steps 2 and 3 in one kernel on the matrix cores (one wave per system, LDS 36 KB: all 1024 systems
@@ -615,7 +625,6 @@ __device__ inline void diag_factor_body(const FemDev& f, int m, int slot, int j,
         C[ib][jb][g] = Lt[max(R, Cc) * 64 + min(R, Cc)];
       }
   double y = f.y[size_t(m) * f.nGp + j * 64 + lane];
-  bool bad = false;
   double myrs = 0.0;
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
@@ -628,7 +637,7 @@ __device__ inline void diag_factor_body(const FemDev& f, int m, int slot, int j,
     }
     __builtin_amdgcn_wave_barrier();
     double v[4];
-    chol_panel_rows(Pn, lane, c0, v, y, myrs, bad);
+    chol_panel_rows(Pn, lane, c0, v, y, myrs);
     __builtin_amdgcn_wave_barrier();
     *reinterpret_cast<double2*>(&Pn[lane * 4]) = double2{v[0], v[1]};
     *reinterpret_cast<double2*>(&Pn[lane * 4 + 2]) = double2{v[2], v[3]};
@@ -647,7 +656,7 @@ __device__ inline void diag_factor_body(const FemDev& f, int m, int slot, int j,
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (bad && lane == 0) atomicOr(f.status, 1);
+  if (chol_pivots_bad(myrs) && lane == 0) atomicOr(f.status, 1);
   f.y[size_t(m) * f.nGp + j * 64 + lane] = y;
   rinv[lane] = myrs;  // 1 / L[lane][lane]
   __builtin_amdgcn_wave_barrier();
@@ -729,35 +738,47 @@ __global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
 
 
 // Whole reduced solve of a system whose reduced matrix is ONE tile (e.g. 2x2 blocks at N = 128: 2 x 31
-// compressed unknowns + the cross point), one wave per system, nothing but the solution leaves the CU:
+// compressed unknowns + the cross point); nothing but the interface vector leaves the CU:
 //   assemble the lower 16x16 blocks in MFMA accumulator layout (term by term) ->
 //   rank-4 blocked Cholesky (panel in row-per-lane form, trailing update on MFMA) with the forward substitution
 //   carried along -> back substitution on registers ->
 //   coefficient blocks for the extension (what k_coef does on the general path).
-// Round 4: FOUR systems per workgroup (one per wave), and the assembly is split BY BLOCKS instead of by systems.  Every
-// system adds up the same (term, block) table pieces with its own weights; with a wave per system each wave pulled all
-// 117 KB of them through the CU's load path for itself (25 k of a wave's 82 k cycles: 39 GB/s per CU with 64 KB in flight;
-// sharing the pieces through an LDS ring moved the same bytes through the LDS instead and got 12 k).  Now wave w adds up
-// ITS blocks (a quarter of the pairs, balanced by the host) for all four systems: a piece is fetched once per workgroup
-// (two 16-byte loads per lane -- the pieces are stored in accumulator layout, [g pair][lane][2], in the order the waves
-// walk them: no index to wait for), multiplied by four weights, and the finished block sums go to the LDS area of the
-// system they belong to.  A block's sum runs over the same pairs in the same order as before: same bits.
-// LDS (dynamic): term weights of the four systems | per wave: the block sums of the assembly (20 KB), then the factor PACKED
-// by rows (s1_lrow), then the weighted unknowns of the coefficient blocks in the same area; a panel; z
-__global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restrict__ a, int Mc) {
+// Round 4: FOUR systems per workgroup, TWO waves per system, and every piece of the kernel moved to where it waits least.
+//  * Assembly split BY BLOCKS instead of by systems.  Every system adds up the same (term, block) table pieces with its own
+//    weights; with a wave per system each wave pulled all 117 KB of them through the CU's load path for itself (25 k of a
+//    wave's 82 k cycles: 39 GB/s per CU with 64 KB in flight; sharing the pieces through an LDS ring moved the same bytes
+//    through the LDS instead and got 12 k).  Now factor wave w adds up ITS blocks (a quarter of the pairs, balanced by the
+//    host) for all four systems: a piece is fetched once per workgroup (two 16-byte loads per lane -- the pieces are stored
+//    in accumulator layout, [g pair][lane][2], in the order the waves walk them: no index to wait for), multiplied by four
+//    weights, and the finished block sums go to the LDS area of the system they belong to.  A block's sum runs over the
+//    same pairs in the same order as before: same bits.
+//  * Waves 0 .. 3 ("factor" waves, one per system): weights, their share of the assembly, the rhs, the factorisation of the
+//    Cholesky's panels in row form with the forward substitution, the back substitution.  Waves 4 .. 7 ("update" waves,
+//    one per system): everything that does not sit on that chain -- they hold the accumulators of the Cholesky, do its
+//    MFMAs and layout changes while the factor wave factorises, fetch the descriptors of the tail and compute what of it
+//    does not depend on the solution while the assembly runs, and build the coefficient blocks once the solution is there.
+//    One instruction stream did all of this in turn before (59 k cycles a system; the Cholesky alone 29 k at ~270
+//    instructions per panel, issue-bound: software pipelining inside ONE wave changed nothing).
+// LDS (dynamic): term weights of the four systems | per system: the block sums of the assembly (20 KB), then the factor PACKED
+// by rows (s1_lrow), then the weighted unknowns of the coefficient blocks in the same area; two panels; z; a; two panels on
+// their way from the accumulators to row form | the matrix of the dense product of the tail
+__global__ __launch_bounds__(512) void k_solve1(FemDev f, const double* __restrict__ a, int Mc) {
   extern __shared__ __align__(16) char s1_dyn[];
-  const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6), w = w8 & 3, lane = threadIdx.x & 63;
+  const bool upd = w8 >= 4;  // the system's update wave
   double* const coefs = reinterpret_cast<double*>(s1_dyn);  // [system][term]
   const double* const Dl = reinterpret_cast<const double*>(s1_dyn + S1_COEF_BYTES + 4 * S1_WAVE_BYTES);  // the matrix of the dense product, 64 x ndi
   double* const Ls = reinterpret_cast<double*>(s1_dyn + S1_COEF_BYTES + w * S1_WAVE_BYTES);  // assembly: the ten lower blocks [block][g][lane]; Cholesky on: L packed by rows
-  double* const Pn = Ls + 40 * 64;  // one 64 x 4 panel of the Cholesky
+  double* const Pn = Ls + 40 * 64;  // the 64 x 4 panel of the even steps of the Cholesky
   double* const zs = Pn + 64 * 4;
   double* const aL = zs + 64;       // the system's block coefficients a_m[0 .. kblk)
-  double* const wz = Ls;            // (the factor is dead once its columns sit in registers)
+  double* const Pn1 = aL + 64;      // the panel of the odd steps (the update wave reads one while the other is written)
+  double* const PnB = Pn1 + 64 * 4; // two 64 x 4 panels on their way from the accumulators to row form
+  double* const wz = Ls;            // (the factor is dead once the back substitution is through)
   static_assert(DENSE_GROUPS_MAX * 64 <= 40 * 64 && 8 * 16 * 17 <= 40 * 64, "the shared area holds each of its three tenants");
-  static_assert(S1_WAVE_BYTES == (40 * 64 + 64 * 4 + 64 + 64) * 8 && S1_COEF_BYTES == 4 * 64 * 8, "LDS areas");
+  static_assert(S1_WAVE_BYTES == (40 * 64 + 64 * 4 + 64 + 64 + 3 * 64 * 4) * 8 && S1_COEF_BYTES == 4 * 64 * 8, "LDS areas");
   const int m_raw = 4 * int(blockIdx.x) + w;
-  const bool live = m_raw < Mc;  // (the last workgroup may have waves without a system: they fetch and wait with the others, then leave)
+  const bool live = m_raw < Mc;  // (the last workgroup may hold waves without a system: they walk along -- the barriers count them -- and store nothing)
   const int m = live ? m_raw : Mc - 1;
   const double* am = a + size_t(m) * f.kblk;
   double* ym = f.y + size_t(m) * f.nGp;
@@ -768,31 +789,181 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
 #else
 #define S1_STAMP(i)
 #endif
-#ifdef ROMHC_SOLVE1_PANEL_STAMPS
-  unsigned long long pt_last = 0, pt_sum[4] = {0, 0, 0, 0};
-#define S1_PT(i)                                                      \
-  do {                                                                \
-    const unsigned long long t_ = __builtin_readcyclecounter();       \
-    pt_sum[i] += t_ - pt_last;                                        \
-    pt_last = t_;                                                     \
-  } while (0)
-#else
-#define S1_PT(i)
-#endif
 // LDS traffic of ONE wave needs no barrier (a wave's LDS instructions execute in order); this keeps the compiler in line
 #define S1_WAVE_SYNC()                                   \
   do {                                                   \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
     __builtin_amdgcn_wave_barrier();                     \
   } while (0)
-  // Assembly in the MFMA accumulator layout of the Cholesky below: element g of block q = (ib, jb), ib >= jb, is
-  // (row 16 ib + 4 g + (lane >> 4), column 16 jb + (lane & 15)).  The host lists the (term, block) pairs whose
-  // rectangle and block intersect (57 at 2x2 / N=128), block by block, and deals the blocks to the four waves; a
-  // pair is exactly two loads, so a ring of PAIR_RING pairs keeps 2 * PAIR_RING loads in flight with statically known
-  // wait counts.  The sums of a block (one per system) are kept in registers and stored to the LDS copy of the blocks
-  // of their system when the block's last pair is done (the target block of a pair is a run-time index, which registers
-  // cannot have).
+// a workgroup barrier behind this wave's LDS traffic
+#define S1_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
   const int l16 = lane & 15, l4 = lane >> 4;
+
+  if (upd) {
+    // ================= the update wave of system w =================
+    // the flat records of the tail (one per lane and item: rom_fem_setup.hip) are asked for first and wait in registers
+    int4 irec[6], crec[S1_ITEM_PASSES];
+    int wd[DENSE_GROUPS_MAX];
+    {
+      const int4* ir = reinterpret_cast<const int4*>(f.s1_items) + size_t(min(lane, max(f.ndi, 1) - 1)) * 6;
+#pragma unroll
+      for (int x = 0; x < 6; ++x) irec[x] = ir[x];
+#pragma unroll
+      for (int r = 0; r < S1_ITEM_PASSES; ++r) crec[r] = reinterpret_cast<const int4*>(f.s1_citems)[min(lane + 64 * r, max(f.ncoef, 1) - 1)];
+#pragma unroll
+      for (int g = 0; g < DENSE_GROUPS_MAX; ++g) wd[g] = g < f.ndg ? f.dweight[g * 64 + lane] : -2;
+    }
+    const int xr_first = lane < f.ncross ? f.xred[lane] : 0;
+    const int2 sc_b = lane < f.nsc ? reinterpret_cast<const int2*>(f.scb)[lane] : int2{0, 0};
+    __syncthreads();  // (1) weights, zeroed block areas, and the system's coefficients aL
+    // Everything of the tail that does not depend on the solution, while the factor waves assemble.
+    // The alignment gaps of the interface vector are read (against zero table entries) by the extension: they must hold
+    // finite numbers whatever buffer the caller handed in -- zeroed here, ahead of every other store of this wave to its
+    // vector (a wave's stores to one address stay in order; ALL stores to the vector are this wave's), instead of by a
+    // memset launch in front of every sweep
+    if (live)
+      for (int i = lane; i < f.nGp; i += 64) ym[i] = 0.0;
+    if (live && lane < f.nsc) ym[f.spos0 + lane] = sc_b.y >= 0 ? 1.0 / (aL[sc_b.x] + aL[sc_b.y]) : (1.0 / (double(f.N) * double(f.N))) / aL[sc_b.x];
+    for (int i = lane + 64; live && i < f.nsc; i += 64) {
+      const int b0 = f.scb[2 * i], b1 = f.scb[2 * i + 1];
+      ym[f.spos0 + i] = b1 >= 0 ? 1.0 / (aL[b0] + aL[b1]) : (1.0 / (double(f.N) * double(f.N))) / aL[b0];
+    }
+    double wgt[DENSE_GROUPS_MAX];
+#pragma unroll
+    for (int g = 0; g < DENSE_GROUPS_MAX; ++g) {
+      wgt[g] = 0.0;
+      if (g < f.ndg) {
+        const DenseGroup& dg = f.dgroups[g];
+        wgt[g] = wd[g] >= 0 ? aL[wd[g]] : (wd[g] == -1 ? (aL[dg.b0] + aL[dg.b1]) / 2 : 0.0);
+      }
+    }
+    const bool has_it = lane < f.ndi;  // this lane's item of the first pass of the dense product
+    const int it_g = irec[0].x, it_pos = irec[0].y, it_nv = irec[0].z;
+    double it_den = 1.0, it_cv[4] = {0.0, 0.0, 0.0, 0.0}, it_vv[4] = {0.0, 0.0, 0.0, 0.0};
+    if (has_it) {
+      const int voff[4] = {irec[1].y, irec[1].z, irec[1].w, irec[2].x}, vblk[4] = {irec[2].y, irec[2].z, irec[2].w, irec[3].x};
+      const int vu0[4] = {irec[3].y, irec[3].z, irec[3].w, irec[4].x}, vu1[4] = {irec[4].y, irec[4].z, irec[4].w, irec[5].x};
+      it_den = aL[irec[0].w] + aL[irec[1].x];
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (v < it_nv) {
+          it_cv[v] = aL[vblk[v]] / (aL[vu0[v]] + aL[vu1[v]]);
+          it_vv[v] = f.vec[voff[v]];
+        }
+    }
+    // coefficient items of the first S1_ITEM_PASSES passes: constants go out now, copies of the solution are remembered
+    int ci_dst[S1_ITEM_PASSES], ci_src[S1_ITEM_PASSES];
+#pragma unroll
+    for (int r = 0; r < S1_ITEM_PASSES; ++r) {
+      ci_src[r] = -1;
+      ci_dst[r] = crec[r].x & 0xfffffff;
+      if (lane + 64 * r < f.ncoef) {
+        const int code = crec[r].x >> 28;
+        if (code == 2) ci_src[r] = crec[r].y;
+        else if (code != 0 && live) ym[ci_dst[r]] = code == 1 ? 1.0 / (aL[crec[r].z] + aL[crec[r].w]) : 0.0;
+      }
+    }
+    __syncthreads();  // (2) the block sums are complete
+    // ---- the accumulators of the Cholesky: the ten lower blocks in MFMA accumulator layout
+    d4_t C[4][4];
+    {
+      int q = 0;
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb <= ib; ++jb, ++q)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int R = 16 * ib + 4 * g + l4, Cc = 16 * jb + l16;
+            const double x = Ls[(q * 4 + g) * 64 + lane];
+            C[ib][jb][g] = (R >= f.s1_ndr || Cc >= f.s1_ndr) ? (R == Cc ? 1.0 : 0.0) : x;  // padding unknowns: identity
+          }
+    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) PnB[x * 64 + lane] = 0.0;
+    S1_BARRIER();  // (3) the block sums have been read: the factor may move into their place
+#ifdef ROMHC_SOLVE1_PANEL_STAMPS
+    unsigned long long uwait = 0;
+    const unsigned long long ut0 = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+    for (int p = 0; p < 15; ++p) {
+      const int jb = p >> 2;
+      {  // the columns of panel p + 1 as the accumulators have them (updates of the panels before p) -> row form via LDS
+        const int p1 = p + 1, jb1 = p1 >> 2, co1 = 4 * (p1 & 3);
+        double* dstp = PnB + (p1 & 1) * 256;
+        if ((l16 >> 2) == (p1 & 3)) {
+#pragma unroll
+          for (int ib = jb1; ib < 4; ++ib)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dstp[(16 * ib + 4 * g + l4) * 4 + (l16 - co1)] = C[ib][jb1][g];
+        }
+      }
+#ifdef ROMHC_SOLVE1_PANEL_STAMPS
+      { const unsigned long long t0_ = __builtin_readcyclecounter(); S1_BARRIER(); uwait += __builtin_readcyclecounter() - t0_; }
+#else
+      S1_BARRIER();  // panel p is factorised and in LDS; the base of panel p + 1 is in LDS
+#endif
+      const double* Pp = (p & 1) ? Pn1 : Pn;
+      double frag[4];
+#pragma unroll
+      for (int x = jb; x < 4; ++x) frag[x] = Pp[(16 * x + l16) * 4 + l4];  // same map for A (row, k) and B (k, col)
+#pragma unroll
+      for (int jb2 = jb; jb2 < 4; ++jb2)
+#pragma unroll
+        for (int ib = jb2; ib < 4; ++ib)
+          C[ib][jb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag[ib], frag[jb2], C[ib][jb2], 0, 0, 0);
+    }
+#ifdef ROMHC_SOLVE1_PANEL_STAMPS
+    const unsigned long long ut1 = __builtin_readcyclecounter();
+#endif
+    S1_BARRIER();  // (4) the solution z is in LDS
+    if (!live) return;
+    // ---- coefficient blocks + nodal copy of the cross points (what k_coef does on the general path).  The blocks of
+    // the closed-form edges are one dense product here: out[it] = sum_j D[j][it] * (w_g(j) z_j), D = all their
+    // matrices side by side (64 x items, in LDS since the start of the kernel), w_g(j) the weight of source j for group g.
+    const double z = zs[lane];
+    ym[lane] = z;
+    if (lane < f.ncross) ym[f.xb0 + lane] = zs[xr_first];
+    for (int x = lane + 64; x < f.ncross; x += 64) ym[f.xb0 + x] = zs[f.xred[x]];
+#pragma unroll
+    for (int g = 0; g < DENSE_GROUPS_MAX; ++g)
+      if (g < f.ndg) wz[g * 64 + lane] = wgt[g] * z;
+    S1_WAVE_SYNC();
+    if (has_it) {
+      const double* wg = wz + it_g * 64;
+      const double* D = Dl + lane;
+      double acc = 0.0;
+#pragma unroll 1
+      for (int j0 = 0; j0 < 64; j0 += 16) {  // (16 at a time: the whole column in flight at once costs 256 registers)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc += D[(j0 + j) * f.ndi] * wg[j0 + j];
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (v < it_nv) acc += it_cv[v] * it_vv[v];
+      ym[it_pos] = acc / it_den;
+    }
+#pragma unroll
+    for (int r = 0; r < S1_ITEM_PASSES; ++r)
+      if (ci_src[r] >= 0) ym[ci_dst[r]] = zs[ci_src[r]];
+    for (int it = lane + 64 * S1_ITEM_PASSES; it < f.ncoef; it += 64) {
+      const CoefGroup& cg = f.groups[f.item_group[it]];
+      const int k = f.item_k[it];
+      if (cg.kind == 1 && k < cg.r) continue;  // done above
+      ym[cg.cpos + k] = k == cg.r ? 1.0 / (aL[cg.b0] + aL[cg.b1]) : (k < cg.r ? zs[cg.zpos + k] : 0.0);
+    }
+#ifdef ROMHC_SOLVE1_STAMPS
+    if (lane < 12) ym[lane] = PnB[lane];  // (dev build: the factor wave's stamps, parked in LDS, replace the first unknowns)
+#ifdef ROMHC_SOLVE1_PANEL_STAMPS
+    if (lane == 12) ym[12] = double(uwait);
+    if (lane == 13) ym[13] = double(ut1 - ut0);
+#endif
+#endif
+    return;
+  }
+
+  // ================= the factor wave of system w =================
   // The matrix of the dense product of the tail (64 x ndi doubles, the same for every system) goes to LDS once per
   // workgroup, by LDS-DMA, before anything else: it lands while the assembly runs, and the barrier behind the assembly
   // publishes it.  (Each wave used to pull its own copy through the load path AFTER the back substitution: 64 eight-byte
@@ -806,11 +977,15 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
                    "v"(unsigned(lane) * 16u), "s"(x128_uniform(src + size_t(c) * 1024))
                    : "memory", "m0");
   }
+  // Assembly in the MFMA accumulator layout of the Cholesky below: element g of block q = (ib, jb), ib >= jb, is
+  // (row 16 ib + 4 g + (lane >> 4), column 16 jb + (lane & 15)).  The host lists the (term, block) pairs whose
+  // rectangle and block intersect (57 at 2x2 / N=128), block by block, and deals the blocks to the four factor waves; a
+  // pair is exactly two loads, so a ring of PAIR_RING pairs keeps 2 * PAIR_RING loads in flight with statically known
+  // wait counts.  The sums of a block (one per system) are kept in registers and stored to the LDS copy of the blocks
+  // of their system when the block's last pair is done (the target block of a pair is a run-time index, which registers
+  // cannot have).
   RhsTerm rt;
   double gvec, rcoef;
-  int4 irec[6], crec[S1_ITEM_PASSES];
-  int wd[DENSE_GROUPS_MAX], xr_first;
-  int2 sc_b;
   {
     const int p0 = f.wp0[w], np = f.wp0[w + 1] - p0;  // this wave's pairs: pieces p0 .. of pool_acc, metas p0 .. of wmeta
     const double2* pbase = reinterpret_cast<const double2*>(f.pool_acc) + size_t(p0) * 128 + lane;
@@ -828,18 +1003,6 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
     rt = f.rhs[min(lane, max(f.nrhs, 1) - 1)];
     gvec = f.g[lane];
     int mine = f.wmeta[p0 + lane];  // lane i holds the meta of pair i of the current group of 64
-    // ... and the records of the tail (flat, one per lane and item: rom_fem_setup.hip), which wait in registers
-    {
-      const int4* ir = reinterpret_cast<const int4*>(f.s1_items) + size_t(min(lane, max(f.ndi, 1) - 1)) * 6;
-#pragma unroll
-      for (int x = 0; x < 6; ++x) irec[x] = ir[x];
-#pragma unroll
-      for (int r = 0; r < S1_ITEM_PASSES; ++r) crec[r] = reinterpret_cast<const int4*>(f.s1_citems)[min(lane + 64 * r, max(f.ncoef, 1) - 1)];
-#pragma unroll
-      for (int g = 0; g < DENSE_GROUPS_MAX; ++g) wd[g] = g < f.ndg ? f.dweight[g * 64 + lane] : -2;
-      xr_first = lane < f.ncross ? f.xred[lane] : 0;
-      sc_b = lane < f.nsc ? reinterpret_cast<const int2*>(f.scb)[lane] : int2{0, 0};
-    }
 #pragma unroll
     for (int u = 0; u < PAIR_RING; ++u) issue(u, v[u]);
 #pragma unroll
@@ -848,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
     S1_WAVE_SYNC();
     coefs[w * 64 + lane] = lane < f.s1_nterm ? term_coef(gt, aL) : 0.0;  // lane t: weight of term t
     rcoef = lane < f.nrhs ? (rt.kind == 0 ? aL[rt.b0] / (aL[rt.e0] + aL[rt.e1]) : 0.5) : 0.0;  // lane t: weight of rhs term t
-    __syncthreads();  // every system's weights are there; every system's block area is zeroed
+    __syncthreads();  // (1) every system's weights are there; every system's block area is zeroed
     double cf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) cf[s] = coefs[s * 64 + lane];
@@ -894,79 +1057,21 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
       mine = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's share of the dense product's matrix has landed)
-    __syncthreads();  // the four waves' blocks are in every system's area
+    __syncthreads();  // (2) the four waves' blocks are in every system's area
   }
-  double* Cl = Ls;  // the ten lower blocks of this wave's system, [block][g][lane]
-  if (!live) return;  // (no workgroup-wide barrier below)
   S1_STAMP(2);
-  // the alignment gaps of the interface vector are read (against zero table entries) by the extension: they must hold
-  // finite numbers whatever buffer the caller handed in -- zeroed here, ahead of every other store of this wave to its
-  // vector (a wave's stores to one address stay in order), instead of by a memset launch in front of every sweep
-  for (int i = lane; i < f.nGp; i += 64) ym[i] = 0.0;
-  // Everything of the tail that does not depend on the solution is done (or asked for) HERE, ahead of the Cholesky, whose
-  // 30 k cycles hide its memory round trips: the scalar block, the weights of the dense groups, this lane's item of the
-  // dense product with its 64 matrix entries, the descriptors of the coefficient items.  (Was: 13 k cycles of dependent
-  // loads and divides behind the back substitution.)  Same expressions on the same numbers: same bits.
-  if (lane < f.nsc) ym[f.spos0 + lane] = sc_b.y >= 0 ? 1.0 / (aL[sc_b.x] + aL[sc_b.y]) : (1.0 / (double(f.N) * double(f.N))) / aL[sc_b.x];
-  for (int i = lane + 64; i < f.nsc; i += 64) {
-    const int b0 = f.scb[2 * i], b1 = f.scb[2 * i + 1];
-    ym[f.spos0 + i] = b1 >= 0 ? 1.0 / (aL[b0] + aL[b1]) : (1.0 / (double(f.N) * double(f.N))) / aL[b0];
-  }
-  double wgt[DENSE_GROUPS_MAX];
+  double nv[4];  // the current panel of the Cholesky in row form (row `lane`), all updates applied
+  {  // panel 0 straight from the block sums: row r = lane sits in block (r >> 4, 0), element g = (r >> 2) & 3
+    const int ib = lane >> 4;
+    const double* src = Ls + ((ib * (ib + 1) / 2) * 4 + ((lane >> 2) & 3)) * 64 + (lane & 3) * 16;
+    const double2 x0 = *reinterpret_cast<const double2*>(src), x1 = *reinterpret_cast<const double2*>(src + 2);
+    nv[0] = x0.x; nv[1] = x0.y; nv[2] = x1.x; nv[3] = x1.y;
 #pragma unroll
-  for (int g = 0; g < DENSE_GROUPS_MAX; ++g) {
-    wgt[g] = 0.0;
-    if (g < f.ndg) {
-      const DenseGroup& dg = f.dgroups[g];
-      wgt[g] = wd[g] >= 0 ? aL[wd[g]] : (wd[g] == -1 ? (aL[dg.b0] + aL[dg.b1]) / 2 : 0.0);
-    }
+    for (int k = 0; k < 4; ++k)  // padding unknowns: identity
+      if (lane >= f.s1_ndr || k >= f.s1_ndr) nv[k] = lane == k ? 1.0 : 0.0;
   }
-  const bool has_it = lane < f.ndi;  // this lane's item of the first pass of the dense product
-  const int it_g = irec[0].x, it_pos = irec[0].y, it_nv = irec[0].z;
-  double it_den = 1.0, it_cv[4] = {0.0, 0.0, 0.0, 0.0}, it_vv[4] = {0.0, 0.0, 0.0, 0.0};
-  if (has_it) {
-    const int voff[4] = {irec[1].y, irec[1].z, irec[1].w, irec[2].x}, vblk[4] = {irec[2].y, irec[2].z, irec[2].w, irec[3].x};
-    const int vu0[4] = {irec[3].y, irec[3].z, irec[3].w, irec[4].x}, vu1[4] = {irec[4].y, irec[4].z, irec[4].w, irec[5].x};
-    it_den = aL[irec[0].w] + aL[irec[1].x];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-      if (v < it_nv) {
-        it_cv[v] = aL[vblk[v]] / (aL[vu0[v]] + aL[vu1[v]]);
-        it_vv[v] = f.vec[voff[v]];
-      }
-  }
-  // coefficient items of the first S1_ITEM_PASSES passes: constants go out now, copies of the solution are remembered
-  int ci_dst[S1_ITEM_PASSES], ci_src[S1_ITEM_PASSES];
-#pragma unroll
-  for (int r = 0; r < S1_ITEM_PASSES; ++r) {
-    ci_src[r] = -1;
-    ci_dst[r] = crec[r].x & 0xfffffff;
-    if (lane + 64 * r < f.ncoef) {
-      const int code = crec[r].x >> 28;
-      if (code == 2) ci_src[r] = crec[r].y;
-      else if (code != 0) ym[ci_dst[r]] = code == 1 ? 1.0 / (aL[crec[r].z] + aL[crec[r].w]) : 0.0;
-    }
-  }
+  S1_BARRIER();  // (3) the block sums have been read (by this wave and by the update wave): the factor may move in
   S1_STAMP(3);
-  d4_t C[4][4];
-  {
-    int q = 0;
-#pragma unroll
-    for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-      for (int jb = 0; jb <= ib; ++jb, ++q)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) C[ib][jb][g] = Cl[(q * 4 + g) * 64 + lane];
-  }
-#pragma unroll
-  for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-    for (int jb = 0; jb <= ib; ++jb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int R = 16 * ib + 4 * g + l4, Cc = 16 * jb + l16;
-        if (R >= f.s1_ndr || Cc >= f.s1_ndr) C[ib][jb][g] = R == Cc ? 1.0 : 0.0;  // padding unknowns: identity
-      }
   // rhs of the reduced system (k_rhs): y = g + sum_t weight_t * (vector t placed at its rows), the terms in their order
   double y = gvec;
   for (int t0 = 0; t0 < f.nrhs; t0 += 8) {  // eight terms at a time: their vector loads are in flight together
@@ -984,123 +1089,82 @@ __global__ __launch_bounds__(256) void k_solve1(FemDev f, const double* __restri
     for (int x = 0; x < 8; ++x)
       if (t0 + x < f.nrhs) y += readlane_f64(rcoef, t0 + x) * rv[x];
   }
-  // Blocked right-looking Cholesky, 16 panels of 4 columns.  A panel goes through LDS into row-per-lane form
-  // (lane r holds its 4 entries), is factorised there with readlane broadcasts -- the forward substitution of y
-  // rides along -- and goes back through LDS as the A and B operand of v_mfma_f64_16x16x4_f64 (K = 4 is exactly
-  // one panel) for the rank-4 update of the trailing blocks: 8 LDS fragment reads + <= 10 MFMAs per panel instead
-  // of ~120 broadcast reads + 240 FMAs per lane in the column-by-column form.
-  bool bad = false;
+  // Blocked right-looking Cholesky, 16 panels of 4 columns, on the system's two waves.  This wave keeps the current panel
+  // in row form (nv) and factorises it (chol_panel_regs: every lane factorises the 4 x 4 diagonal block for itself; the
+  // forward substitution of y rides along); the update wave holds the accumulators, applies the rank-4 updates to them
+  // with MFMAs (K = 4 is exactly one panel) and hands the NEXT panel's columns over in row form as the panels BEFORE the
+  // current one left them (`base`) -- this wave applies the current panel's update to them itself, on the vector pipe,
+  // k in the order of the matrix instruction (same bits as the all-MFMA form).  One barrier per panel: factorised panel
+  // and base are in LDS.
   double myrs = 0.0;
-  S1_STAMP(4);
 #ifdef ROMHC_SOLVE1_PANEL_STAMPS
-  pt_last = __builtin_readcyclecounter();
+  unsigned long long fwait = 0;
 #endif
+  S1_STAMP(4);
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
-    const int jb = p >> 2, co = 4 * (p & 3), c0 = 4 * p;
-    // (a) panel columns out of the accumulators
-    if ((l16 >> 2) == (p & 3)) {
-#pragma unroll
-      for (int ib = jb; ib < 4; ++ib)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) Pn[(16 * ib + 4 * g + l4) * 4 + (l16 - co)] = C[ib][jb][g];
+    const int c0 = 4 * p;
+    chol_panel_regs(lane, c0, nv, y, myrs);
+    {  // the factorised panel: operand array of the update wave's MFMAs ...
+      double* Pp = (p & 1) ? Pn1 : Pn;
+      *reinterpret_cast<double2*>(&Pp[lane * 4]) = double2{nv[0], nv[1]};
+      *reinterpret_cast<double2*>(&Pp[lane * 4 + 2]) = double2{nv[2], nv[3]};
     }
-    __builtin_amdgcn_wave_barrier();
-    S1_PT(0);
-    // (b) row-per-lane: lane r holds A[r][c0 .. c0+3]
-    double v[4];
-    chol_panel_rows(Pn, lane, c0, v, y, myrs, bad);
-    __builtin_amdgcn_wave_barrier();
-    S1_PT(1);
-    // (c) the factorised panel: operand array for the MFMAs and the columns of L for the back substitution
-    *reinterpret_cast<double2*>(&Pn[lane * 4]) = double2{v[0], v[1]};
-    *reinterpret_cast<double2*>(&Pn[lane * 4 + 2]) = double2{v[2], v[3]};
-    if ((lane >> 2) >= p) {  // row `lane` of L, packed in whole panels: rows 4 g .. 4 g + 3 hold panels 0 .. g (zeros right of the diagonal)
+    if ((lane >> 2) >= p) {  // ... and row `lane` of L, packed in whole panels: rows 4 g .. 4 g + 3 hold panels 0 .. g (zeros right of the diagonal)
       double* lrow = Ls + s1_lrow(lane) + c0;
-      *reinterpret_cast<double2*>(lrow) = double2{v[0], v[1]};
-      *reinterpret_cast<double2*>(lrow + 2) = double2{v[2], v[3]};
+      *reinterpret_cast<double2*>(lrow) = double2{nv[0], nv[1]};
+      *reinterpret_cast<double2*>(lrow + 2) = double2{nv[2], nv[3]};
     }
-    __builtin_amdgcn_wave_barrier();
-    S1_PT(2);
-    // (d) trailing update C[ib][jb'] -= Lp[ib] Lp[jb']^T for the blocks right of / below the panel
     if (p < 15) {
-      double frag[4];
+#ifdef ROMHC_SOLVE1_PANEL_STAMPS
+      { const unsigned long long t0_ = __builtin_readcyclecounter(); S1_BARRIER(); fwait += __builtin_readcyclecounter() - t0_; }
+#else
+      S1_BARRIER();
+#endif
+      const double* bp = PnB + ((p + 1) & 1) * 256 + lane * 4;
+      const double2 b01 = *reinterpret_cast<const double2*>(bp), b23 = *reinterpret_cast<const double2*>(bp + 2);
+      double nn[4] = {b01.x, b01.y, b23.x, b23.y};
 #pragma unroll
-      for (int x = jb; x < 4; ++x) frag[x] = Pn[(16 * x + l16) * 4 + l4];  // same map for A (row, k) and B (k, col)
+      for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int jb2 = jb; jb2 < 4; ++jb2)
+        for (int k = 0; k < 4; ++k) nn[kk] = __builtin_fma(-nv[k], readlane_f64(nv[k], c0 + 4 + kk), nn[kk]);
 #pragma unroll
-        for (int ib = jb2; ib < 4; ++ib)
-          C[ib][jb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag[ib], frag[jb2], C[ib][jb2], 0, 0, 0);
+      for (int kk = 0; kk < 4; ++kk) nv[kk] = nn[kk];
     }
-    __builtin_amdgcn_wave_barrier();
-    S1_PT(3);
   }
-  if (bad && lane == 0) atomicOr(f.status, 1);
+  if (chol_pivots_bad(myrs) && live && lane == 0) atomicOr(f.status, 1);
   S1_WAVE_SYNC();
   S1_STAMP(5);
-  // back substitution x = L^-T y.  Column `lane` of L is fetched from LDS in one batch (conflict free), then the
+  // back substitution x = L^-T y.  Column `lane` of L is fetched from LDS in batches (conflict free), then the
   // chain x_j = y_j / L_jj ; y_i -= L_ji x_j (i < j) runs on registers and readlane broadcasts only.
-  double lcol[64];
 #pragma unroll
-  for (int j = 0; j < 64; ++j) lcol[j] = Ls[s1_lrow(j) + lane];  // L[j][lane] for lane <= j (beyond: padding or another row's entry, never used)
+  for (int h = 1; h >= 0; --h) {  // (in two halves: 64 registers of L at a time)
+    double lcol[32];
 #pragma unroll
-  for (int j = 63; j >= 0; --j) {
-    const double xj = readlane_f64(y, j) * readlane_f64(myrs, j);
-    if (lane == j) y = xj;
-    else if (lane < j) y -= lcol[j] * xj;
+    for (int j = 0; j < 32; ++j) lcol[j] = Ls[s1_lrow(32 * h + j) + lane];  // L[j][lane] for lane <= j (beyond: padding or another row's entry, never used)
+#pragma unroll
+    for (int j = 31; j >= 0; --j) {
+      const int jj = 32 * h + j;
+      const double xj = readlane_f64(y, jj) * readlane_f64(myrs, jj);
+      if (lane == jj) y = xj;
+      else if (lane < jj) y -= lcol[j] * xj;
+    }
   }
-  ym[lane] = y;
   zs[lane] = y;
-  S1_WAVE_SYNC();
   S1_STAMP(6);
-  // coefficient blocks + nodal copy of the cross points (what k_coef does on the general path).  The blocks of
-  // the closed-form edges are one dense product here: out[it] = sum_j D[j][it] * (w_g(j) z_j), D = all their
-  // matrices side by side (64 x items, coalesced in `it`), w_g(j) the weight of source j for group g.
-  if (lane < f.ncross) ym[f.xb0 + lane] = zs[xr_first];
-  for (int x = lane + 64; x < f.ncross; x += 64) ym[f.xb0 + x] = zs[f.xred[x]];
-#pragma unroll
-  for (int g = 0; g < DENSE_GROUPS_MAX; ++g)
-    if (g < f.ndg) wz[g * 64 + lane] = wgt[g] * y;  // (y = z_lane)
-  S1_WAVE_SYNC();
-  S1_STAMP(7);
-  if (has_it) {
-    const double* wg = wz + it_g * 64;
-    const double* D = Dl + lane;
-    double acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) acc += D[j * f.ndi] * wg[j];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-      if (v < it_nv) acc += it_cv[v] * it_vv[v];
-    ym[it_pos] = acc / it_den;
-  }
-#pragma unroll
-  for (int r = 0; r < S1_ITEM_PASSES; ++r)
-    if (ci_src[r] >= 0) ym[ci_dst[r]] = zs[ci_src[r]];
-  for (int it = lane + 64 * S1_ITEM_PASSES; it < f.ncoef; it += 64) {
-    const CoefGroup& cg = f.groups[f.item_group[it]];
-    const int k = f.item_k[it];
-    if (cg.kind == 1 && k < cg.r) continue;  // done above
-    ym[cg.cpos + k] = k == cg.r ? 1.0 / (aL[cg.b0] + aL[cg.b1]) : (k < cg.r ? zs[cg.zpos + k] : 0.0);
-  }
 #ifdef ROMHC_SOLVE1_STAMPS
-  S1_STAMP(8);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  S1_STAMP(9);
-  S1_WAVE_SYNC();
 #pragma unroll
-  for (int k = 0; k < 10; ++k)
-    if (lane == k) ym[k] = double(stamp[k] - stamp[0]);  // (dev build: the vector's first entries carry the stamps)
+  for (int k = 0; k < 7; ++k)
+    if (lane == k) PnB[k] = double(stamp[k] - stamp[0]);  // (dev build: the update wave stores them in place of the first unknowns)
+  if (lane >= 7 && lane < 12) PnB[lane] = 0.0;
 #ifdef ROMHC_SOLVE1_PANEL_STAMPS
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (lane == 10 + k) ym[10 + k] = double(pt_sum[k]);
+  if (lane == 10) PnB[10] = double(fwait);
 #endif
 #endif
+  S1_BARRIER();  // (4) the solution z is in LDS: the update wave builds the coefficient blocks
 #undef S1_STAMP
-#undef S1_PT
 #undef S1_WAVE_SYNC
+#undef S1_BARRIER
 }
 
 // Sub-diagonal tiles of column j: C = S_ij - sum_k L_ik L_jk^T ; L_ij = C invL_jj^T ;

@@ -105,7 +105,7 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
   const bool fused1 = f->fused1 && !f->sw_no_fused;  // the whole reduced solve in one wave-per-system kernel
   if (f->nGp > 0 && fused1 && (stages & 1)) {
     ROM_PROF(ctx, "solve1", Mc * (262144 / 3.0 + 3 * 4096.0), Mc * 8.0 * 4096 * 3);
-    k_solve1<<<(Mc + 3) / 4, 256, S1_LDS_BYTES, st>>>(d, am, Mc);  // four systems per workgroup
+    k_solve1<<<(Mc + 3) / 4, 512, S1_LDS_BYTES, st>>>(d, am, Mc);  // four systems per workgroup, two waves each
   }
   if (f->nGp > 0 && !fused1 && (stages & 1)) {
     {

@@ -15,7 +15,7 @@ fem = _ffi.Fem(ctx, 2, 2, 128)
 a = 10.0 ** np.random.default_rng(20240807).uniform(0, 2, size=(M, 4))
 ab = ctx.upload(a)
 Y = ctx.alloc(M * fem.reduced_stride)
-names = ["prologue", "assembly", "tail data ahead", "rhs+load C", "cholesky", "back subst", "weights", "dense product + items", "drain"]
+names = ["prologue", "assembly", "panel 0 + barrier", "rhs", "cholesky", "back subst", "-", "-", "-"]
 for rep in range(3):
     fem.solve_reduced(ab, M, Y)
     ctx.solve_status()
@@ -26,8 +26,8 @@ for rep in range(3):
     y = Y.download(M * fem.reduced_stride).reshape(M, -1)
     st = y[:, :10]
     d = np.diff(st, axis=1)
-    print(f"rep {rep}: kernel {ms * 1e3:.1f} us; wave total {st[:, 9].mean():.0f} cycles (min {st[:, 9].min():.0f} max {st[:, 9].max():.0f});"
-          f" panels (-DROMHC_SOLVE1_PANEL_STAMPS): wait for the update + acc->Pn {y[:, 10].mean():.0f} rows+chain {y[:, 11].mean():.0f} write back {y[:, 12].mean():.0f} frags + MFMA issue {y[:, 13].mean():.0f}")
+    print(f"rep {rep}: kernel {ms * 1e3:.1f} us; wave total {st[:, 6].mean():.0f} cycles (min {st[:, 6].min():.0f} max {st[:, 6].max():.0f});"
+          f" Cholesky (-DROMHC_SOLVE1_PANEL_STAMPS): factor wave waits at the panel barriers {y[:, 10].mean():.0f}; update wave: loop {y[:, 13].mean():.0f}, of it waiting {y[:, 12].mean():.0f}")
     print("   " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, d.mean(axis=0))))
     if M > 1024:
         for lo in range(0, M, 1024):
