@@ -1692,6 +1692,13 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
 #ifndef ROMHC_EPI_PRIO
 #define ROMHC_EPI_PRIO 3
 #endif
+// Cache policy of the row stores (probe builds: -DX128_STORE_POLICY='" nt"' / '" sc1"').  Plain write-back stores it is: the
+// pieces of a mesh row that neighbouring tiles write meet in L2 and leave it as whole lines -- streaming stores ("nt") cost
+// 10 % of the kernel, write-through ("sc1", "sc0 sc1") 46 % -- although they would spare the 5.8 us every kernel boundary
+// behind this kernel spends writing back the 32 MB of dirty lines it leaves in the eight L2s (profiles/r04_extend_lines_probes.txt)
+#ifndef X128_STORE_POLICY
+#define X128_STORE_POLICY ""
+#endif
   // The epilogue runs at raised wave priority: while one workgroup of a CU stores and the other multiplies, neither
   // makes full progress (tools/mfma_store_overlap.hip, `waves`); letting the stores go first shortens that phase
   // (C2: 0.234 -> 0.220 ms; the other way round, priority to the k loop: 0.243 ms; priority to the prologue as
@@ -1754,15 +1761,15 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
         const double2_u pr = double2_u{odd ? got : x0, odd ? x1 : got};
         const unsigned long long m16 = x128_uniform(k16[hp] & in), m8 = x128_uniform(k8[hp] & in), m8b = x128_uniform(k8b[hp] & in);
         unsigned long long sv;
-        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx4 %2, %3, off\n\ts_mov_b64 exec, %0"
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx4 %2, %3, off" X128_STORE_POLICY "\n\ts_mov_b64 exec, %0"
                      : "=&s"(sv)
                      : "s"(m16), "v"(sp[hp]), "v"(pr));
         if (m8 != 0)  // (uniform: only the wave that holds the end of a mesh row has such lanes)
-          asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx2 %2, %3, off\n\ts_mov_b64 exec, %0"
+          asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx2 %2, %3, off" X128_STORE_POLICY "\n\ts_mov_b64 exec, %0"
                        : "=&s"(sv)
                        : "s"(m8), "v"(sp[hp]), "v"(pr.x));
         if (FLAT && m8b != 0)
-          asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx2 %2, %3, off\n\ts_mov_b64 exec, %0"
+          asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx2 %2, %3, off" X128_STORE_POLICY "\n\ts_mov_b64 exec, %0"
                        : "=&s"(sv)
                        : "s"(m8b), "v"(sp[hp] + d1[hp]), "v"(pr.y));
         sp[hp] += step;
