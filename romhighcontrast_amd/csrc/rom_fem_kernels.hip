@@ -815,7 +815,30 @@ __global__ __launch_bounds__(512) void k_solve1(FemDev f, const double* __restri
     }
     const int xr_first = lane < f.ncross ? f.xred[lane] : 0;
     const int2 sc_b = lane < f.nsc ? reinterpret_cast<const int2*>(f.scb)[lane] : int2{0, 0};
+    const RhsTerm rt = f.rhs[min(lane, max(f.nrhs, 1) - 1)];  // lane t: rhs term t
+    const double gvec = f.g[lane];
     __syncthreads();  // (1) weights, zeroed block areas, and the system's coefficients aL
+    {  // rhs of the reduced system (k_rhs): y = g + sum_t weight_t * (vector t placed at its rows), the terms in their order;
+       // parked in LDS for the factor wave (it needs it with the first panel, and has the assembly to do meanwhile)
+      const double rcoef = lane < f.nrhs ? (rt.kind == 0 ? aL[rt.b0] / (aL[rt.e0] + aL[rt.e1]) : 0.5) : 0.0;  // lane t: weight of rhs term t
+      double y = gvec;
+      for (int t0 = 0; t0 < f.nrhs; t0 += 8) {  // eight terms at a time: their vector loads are in flight together
+        double rv[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          rv[x] = 0.0;
+          if (t0 + x < f.nrhs) {
+            const int pos = __builtin_amdgcn_readlane(rt.pos, t0 + x), len = __builtin_amdgcn_readlane(rt.len, t0 + x);
+            const int voff = __builtin_amdgcn_readlane(rt.voff, t0 + x);
+            if (lane >= pos && lane < pos + len) rv[x] = f.vec[voff + lane - pos];
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+          if (t0 + x < f.nrhs) y += readlane_f64(rcoef, t0 + x) * rv[x];
+      }
+      zs[lane] = y;
+    }
     // Everything of the tail that does not depend on the solution, while the factor waves assemble.
     // The alignment gaps of the interface vector are read (against zero table entries) by the extension: they must hold
     // finite numbers whatever buffer the caller handed in -- zeroed here, ahead of every other store of this wave to its
@@ -984,8 +1007,6 @@ __global__ __launch_bounds__(512) void k_solve1(FemDev f, const double* __restri
   // wait counts.  The sums of a block (one per system) are kept in registers and stored to the LDS copy of the blocks
   // of their system when the block's last pair is done (the target block of a pair is a run-time index, which registers
   // cannot have).
-  RhsTerm rt;
-  double gvec, rcoef;
   {
     const int p0 = f.wp0[w], np = f.wp0[w + 1] - p0;  // this wave's pairs: pieces p0 .. of pool_acc, metas p0 .. of wmeta
     const double2* pbase = reinterpret_cast<const double2*>(f.pool_acc) + size_t(p0) * 128 + lane;
@@ -995,13 +1016,10 @@ __global__ __launch_bounds__(512) void k_solve1(FemDev f, const double* __restri
       dst[1] = pbase[size_t(i) * 128 + 64];  // g = 2, 3
     };
     // Everything that depends on nothing is asked for at once, the small things first (a wave's loads return in order):
-    // the system's coefficients, the descriptors of the terms (lane t: term t) and of the rhs terms, the metas, then the
-    // first PAIR_RING pieces.  The coefficients are parked in LDS: what used to be chains of dependent global loads
+    // the system's coefficients, the descriptors of the terms (lane t: term t), the metas, then the first PAIR_RING pieces.  The coefficients are parked in LDS: what used to be chains of dependent global loads
     // (descriptor -> a_m[block] -> divide, 6 k + 7 k cycles at the head of the kernel and of the rhs) are LDS reads.
     const double a_l = lane < f.kblk ? am[lane] : 1.0;
     const GenTerm gt = f.terms[f.s1_t0 + min(lane, f.s1_nterm - 1)];
-    rt = f.rhs[min(lane, max(f.nrhs, 1) - 1)];
-    gvec = f.g[lane];
     int mine = f.wmeta[p0 + lane];  // lane i holds the meta of pair i of the current group of 64
 #pragma unroll
     for (int u = 0; u < PAIR_RING; ++u) issue(u, v[u]);
@@ -1010,7 +1028,6 @@ __global__ __launch_bounds__(512) void k_solve1(FemDev f, const double* __restri
     aL[lane] = a_l;
     S1_WAVE_SYNC();
     coefs[w * 64 + lane] = lane < f.s1_nterm ? term_coef(gt, aL) : 0.0;  // lane t: weight of term t
-    rcoef = lane < f.nrhs ? (rt.kind == 0 ? aL[rt.b0] / (aL[rt.e0] + aL[rt.e1]) : 0.5) : 0.0;  // lane t: weight of rhs term t
     __syncthreads();  // (1) every system's weights are there; every system's block area is zeroed
     double cf[4];
 #pragma unroll
@@ -1072,23 +1089,7 @@ __global__ __launch_bounds__(512) void k_solve1(FemDev f, const double* __restri
   }
   S1_BARRIER();  // (3) the block sums have been read (by this wave and by the update wave): the factor may move in
   S1_STAMP(3);
-  // rhs of the reduced system (k_rhs): y = g + sum_t weight_t * (vector t placed at its rows), the terms in their order
-  double y = gvec;
-  for (int t0 = 0; t0 < f.nrhs; t0 += 8) {  // eight terms at a time: their vector loads are in flight together
-    double rv[8];
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      rv[x] = 0.0;
-      if (t0 + x < f.nrhs) {
-        const int pos = __builtin_amdgcn_readlane(rt.pos, t0 + x), len = __builtin_amdgcn_readlane(rt.len, t0 + x);
-        const int voff = __builtin_amdgcn_readlane(rt.voff, t0 + x);
-        if (lane >= pos && lane < pos + len) rv[x] = f.vec[voff + lane - pos];
-      }
-    }
-#pragma unroll
-    for (int x = 0; x < 8; ++x)
-      if (t0 + x < f.nrhs) y += readlane_f64(rcoef, t0 + x) * rv[x];
-  }
+  double y = zs[lane];  // the rhs of the reduced system, built by the update wave while the assembly ran
   // Blocked right-looking Cholesky, 16 panels of 4 columns, on the system's two waves.  This wave keeps the current panel
   // in row form (nv) and factorises it (chol_panel_regs: every lane factorises the 4 x 4 diagonal block for itself; the
   // forward substitution of y rides along); the update wave holds the accumulators, applies the rank-4 updates to them
