@@ -77,9 +77,14 @@ __device__ inline double term_coef(const GenTerm& g, const double* __restrict__ 
   }
 }
 
-// This thread's share of the assembled tile: row (t >> 2), 16 consecutive columns starting at
-// (t & 3) * 16.  Every table is read with 16-byte loads, 128 contiguous bytes per thread and table; the
-// values wait in registers while the MFMA k-loop runs.
+// This thread's share of the assembled tile (round 4): lane l of wave w holds, for x = 0 .. 7, the two entries
+// (row 16 w + 2 x + (l >> 5), columns 2 (l & 31), + 1): v[2 x], v[2 x + 1].  One load instruction of the wave then reads
+// two whole rows of a table = ONE contiguous kilobyte (eight cache lines), and the wave's 16 rows take eight of them.
+// (Before: a thread owned 16 consecutive columns of one row and read them with eight 16-byte loads; every instruction
+// of the wave touched 64 different cache lines for 16 bytes each.  The coalesced share takes the same time -- the assembly,
+// 8 % of a C4 step, is a chain of memory round trips with two terms in flight, not line traffic: profiles/r04_tile_cholesky.txt
+// -- but leaves k_factor_panel without register spills.)
+// The values wait in registers while the MFMA k-loop runs.
 struct STile {
   double v[16];
 };
@@ -88,16 +93,17 @@ struct STile {
 // NS systems (consecutive rows of `a`) are assembled from ONE pass over the tables: the assembly costs what it reads
 // (profiles/r02_tile_cholesky_probes.txt), and the tables are the same for every system.
 // coef: LDS, NS * COEF_MAX doubles of term weights + TERM_DESC_DOUBLES of term descriptors.
-// Round 4: the loop used to fetch a term's descriptor from global memory (the same 36 bytes in every thread), test it, and
-// only then ask for the table rows -- two dependent memory round trips per term, ~10 terms per tile: 20 of the 27 us a panel
-// workgroup of column 0 lives (per-column times, profiles/r04_tile_cholesky.txt).  Now the descriptors of a pass are staged
-// in LDS next to the weights (one coalesced load), every thread walks ITS intersecting terms, and the rows of the next one
-// are in flight while the current one is added.  Same terms in the same order per entry: the tiles are bit-identical.
+// The descriptors of a pass are staged in LDS next to the weights (one coalesced load); every WAVE walks the terms whose
+// rectangle meets its band of 16 rows (a uniform walk), fetches only the row pairs inside the rectangle, and the rows of
+// the next term are in flight while the current one is added.  Same terms in the same order per entry as ever: the tiles
+// are bit-identical (entries outside a term's rectangle are zero in its table: adding them or not is the same).
 constexpr int TERM_DESC_DOUBLES = COEF_MAX * 3 / 2;  // 3 ints per term: table, rows lo | hi << 16, columns lo | hi << 16
 template <int NS>
 __device__ inline void s_tile_load(STile (&st)[NS], const TileDesc& d, const FemDev& f, const double* __restrict__ am0,
                                    int nsys, double* coef) {
-  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
+  const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6), l = threadIdx.x & 63;
+  const int band = 16 * w;                   // this wave's rows: band .. band + 15
+  const int rb = band + (l >> 5), cu = 2 * (l & 31);  // the lane's row at x = 0 (row of x: rb + 2 x) and its first column
   int* desc = reinterpret_cast<int*>(coef + NS * COEF_MAX);
 #pragma unroll
   for (int q = 0; q < NS; ++q)
@@ -115,46 +121,65 @@ __device__ inline void s_tile_load(STile (&st)[NS], const TileDesc& d, const Fem
       desc[3 * threadIdx.x + 2] = int(g.c_lo) | int(g.c_hi) << 16;
     }
     __syncthreads();
-    // this thread's next term at or behind t whose rectangle meets its 1 x 16 strip (nt: none)
+    // the wave's next term at or behind t whose rows meet its band (nt: none)
     auto next_term = [&](int t) {
       for (; t < nt; ++t) {
-        const int rr = desc[3 * t + 1], cc = desc[3 * t + 2];
-        if (r >= (rr & 0xffff) && r < (rr >> 16) && c0 < (cc >> 16) && c0 + 16 > (cc & 0xffff)) break;
+        const int rr = __builtin_amdgcn_readfirstlane(desc[3 * t + 1]);
+        if (band < (rr >> 16) && band + 16 > (rr & 0xffff)) break;
       }
       return t;
     };
-    auto fetch = [&](int t, double2 (&w)[8]) {
-      const double2* src = reinterpret_cast<const double2*>(f.pool + size_t(desc[3 * t]) * 4096 + r * 64 + c0);
+    // row pairs (band + 2 x, + 1) of term t inside its rectangle: bit x of the mask; their kilobytes are fetched
+    auto fetch = [&](int t, double2 (&wv)[8]) -> int {
+      const int rr = __builtin_amdgcn_readfirstlane(desc[3 * t + 1]);
+      const int lo = rr & 0xffff, hi = rr >> 16;
+      const double2* src = reinterpret_cast<const double2*>(f.pool + size_t(__builtin_amdgcn_readfirstlane(desc[3 * t])) * 4096 + rb * 64 + cu);
+      int mask = 0;
 #pragma unroll
-      for (int x = 0; x < 8; ++x) w[x] = src[x];  // tables are zero outside their rectangle: no masks needed
+      for (int x = 0; x < 8; ++x)
+        if (band + 2 * x + 2 > lo && band + 2 * x < hi) {  // (uniform)
+          wv[x] = src[x * 64];  // tables are zero outside their rectangle: no lane masks needed
+          mask |= 1 << x;
+        }
+      return mask;
     };
     double2 wa[8], wb[8];
-    int ta = next_term(0);
-    if (ta < nt) fetch(ta, wa);
+    int ta = next_term(0), ma = 0;
+    if (ta < nt) ma = fetch(ta, wa);
     while (ta < nt) {
       const int tn = next_term(ta + 1);
-      if (tn < nt) fetch(tn, wb);
+      int mb = 0;
+      if (tn < nt) mb = fetch(tn, wb);
       double cf[NS];
 #pragma unroll
       for (int q = 0; q < NS; ++q) cf[q] = coef[q * COEF_MAX + ta];
 #pragma unroll
-      for (int x = 0; x < 8; ++x) {
+      for (int x = 0; x < 8; ++x)
+        if (ma >> x & 1) {
 #pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          st[q].v[2 * x] += cf[q] * wa[x].x;
-          st[q].v[2 * x + 1] += cf[q] * wa[x].y;
+          for (int q = 0; q < NS; ++q) {
+            st[q].v[2 * x] += cf[q] * wa[x].x;
+            st[q].v[2 * x + 1] += cf[q] * wa[x].y;
+          }
         }
-      }
 #pragma unroll
       for (int x = 0; x < 8; ++x) wa[x] = wb[x];
       ta = tn;
+      ma = mb;
     }
   }
-  if (d.diag && r >= d.ndr) {
+  if (d.diag) {
 #pragma unroll
-    for (int q = 0; q < NS; ++q)
+    for (int x = 0; x < 8; ++x) {
+      const int r = rb + 2 * x;
+      if (r >= d.ndr) {
 #pragma unroll
-      for (int x = 0; x < 16; ++x) st[q].v[x] = (c0 + x == r) ? 1.0 : 0.0;  // padding unknowns: identity
+        for (int q = 0; q < NS; ++q) {
+          st[q].v[2 * x] = cu == r ? 1.0 : 0.0;  // padding unknowns: identity
+          st[q].v[2 * x + 1] = cu + 1 == r ? 1.0 : 0.0;
+        }
+      }
+    }
   }
   __syncthreads();  // (`coef` may alias memory the caller writes next)
 }
@@ -162,9 +187,10 @@ __device__ inline void s_tile_load(STile (&st)[NS], const TileDesc& d, const Fem
 // C(LDS tile) = S_tile - acc
 __device__ inline void tile_from_acc(double* Cb, const Acc& acc, const STile& st, const WavePos& wp) {
   {
-    double2* dst = reinterpret_cast<double2*>(Cb + (threadIdx.x >> 2) * LDC + (threadIdx.x & 3) * 16);
+    const int l = threadIdx.x & 63;  // (the share of s_tile_load: rows 16 w + 2 x + (l >> 5), columns 2 (l & 31), + 1)
+    double* dst = Cb + (16 * (threadIdx.x >> 6) + (l >> 5)) * LDC + 2 * (l & 31);
 #pragma unroll
-    for (int x = 0; x < 8; ++x) dst[x] = double2{st.v[2 * x], st.v[2 * x + 1]};
+    for (int x = 0; x < 8; ++x) *reinterpret_cast<double2*>(dst + 2 * x * LDC) = double2{st.v[2 * x], st.v[2 * x + 1]};
   }
   __syncthreads();
 #pragma unroll
