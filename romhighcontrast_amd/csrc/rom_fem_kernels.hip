@@ -61,6 +61,12 @@ __global__ void k_repack_table(const double* __restrict__ G, int ld, int nseg, i
 }
 
 
+__device__ inline double readlane_f64(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // ============================================================================================
 // reduced-system tile assembly
 // ============================================================================================
@@ -193,6 +199,107 @@ __device__ inline void tile_from_acc(double* Cb, const Acc& acc, const STile& st
     for (int x = 0; x < 8; ++x) *reinterpret_cast<double2*>(dst + 2 * x * LDC) = double2{st.v[2 * x], st.v[2 * x + 1]};
   }
   __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Cb[acc_row(wp, i, g) * LDC + acc_col(wp, j)] -= acc.c[i][j][g];
+  __syncthreads();
+}
+
+// The same assembly as a STREAM (round 4): S_tile for NS systems straight into LDS tiles T[q] (64 x LDC).
+// s_tile_load walks a tile's ~10 terms with two terms in flight -- a chain of memory round trips that is 8 % of a C4 step
+// (profiles/r04_tile_cholesky.txt) and cannot be deepened: the tile itself sits in 32 of the 128 registers four resident
+// workgroups per CU allow.  Here the host has flattened, per tile and wave, the (row pair, term) pieces that wave needs
+// (FemDev::alist: element offset of the piece in the pool | meta = x + (term << 8) + (last piece of position x) << 16; a piece =
+// 8 rows x 16 columns of a table = eight whole cache lines, position x = one of the 2 x 4 such pieces of the wave's 16 rows),
+// sorted by position, the terms of a position in their order: a ring of TILE_RING kilobytes is in flight whatever term
+// they belong to, a position's sum lives in two registers per system and goes to LDS when its last piece is in, and the
+// tile never occupies registers.  Weights: lane t holds the weight of term t (two registers for up to 128 terms), fetched
+// with v_readlane.  Every entry adds up the same products in the same order as s_tile_load: same bits.
+// Called by all 256 threads; ends with a barrier (the tiles are complete and visible).
+constexpr int TILE_RING = 8;
+template <int NS>
+__device__ inline void s_tile_to_lds(double* const (&T)[NS], int slot, const TileDesc& d, const FemDev& f, const double* __restrict__ am0, int nsys) {
+  const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6), l = threadIdx.x & 63;
+  const int band = 16 * w, rsub = l >> 3, csub = 2 * (l & 7);  // piece x = 4 pr + cs: rows band + 8 pr + rsub, columns 16 cs + csub, + 1
+  const int e0 = f.aoff[slot * 4 + w], ne = f.aoff[slot * 4 + w + 1] - e0;  // this wave's pieces (a multiple of TILE_RING: padded with no-ops)
+  const int2* ent = reinterpret_cast<const int2*>(f.alist) + e0;
+  const double2* pool2 = reinterpret_cast<const double2*>(f.pool) + rsub * 32 + (l & 7);  // (a piece: 8 rows x 16 columns = eight whole cache lines)
+  double2 v[TILE_RING];
+  int2 mine = ent[l];  // lane i: piece i of the current group of 64 (the list carries 128 no-ops behind its end)
+  auto issue = [&](int2 e_lane, int i, double2& dst) { dst = pool2[__builtin_amdgcn_readlane(e_lane.x, i) >> 1]; };
+#pragma unroll
+  for (int u = 0; u < TILE_RING; ++u) issue(mine, u, v[u]);
+  // weights of the terms, lane t: terms t and 64 + t
+  const int nt = d.t1 - d.t0;
+  double c0[NS], c1[NS];
+  {
+    const GenTerm g0 = f.terms[d.t0 + min(l, nt - 1)], g1 = f.terms[d.t0 + min(64 + l, nt - 1)];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      const double* am = am0 + size_t(q < nsys ? q : 0) * f.kblk;
+      c0[q] = l < nt ? term_coef(g0, am) : 0.0;
+      c1[q] = 64 + l < nt ? term_coef(g1, am) : 0.0;
+    }
+  }
+  // rows that no term touches stay zero
+#pragma unroll
+  for (int q = 0; q < NS; ++q)
+    for (int i = threadIdx.x; i < 64 * LDC / 2; i += 256) reinterpret_cast<double2*>(T[q])[i] = double2{0.0, 0.0};
+  __syncthreads();
+  double2 acc[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) acc[q] = double2{0.0, 0.0};
+  for (int base = 0; base < ne; base += 64) {
+    const int2 cur = mine;
+    const int2 nxt = ent[base + 64 + l];
+    const int cnt = min(64, ne - base);
+#pragma unroll
+    for (int i0 = 0; i0 < 64; i0 += TILE_RING) {  // (unrolled: straight-line code keeps the compiler's wait counts exact)
+      if (i0 >= cnt) break;
+#pragma unroll
+      for (int u = 0; u < TILE_RING; ++u) {
+        const int i = i0 + u;
+        const int meta = __builtin_amdgcn_readlane(cur.y, i);  // x | term << 8 | (last piece of row pair x) << 16 | no-op << 17
+        const int t = (meta >> 8) & 0xff;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          double c = t < 64 ? readlane_f64(c0[q], t) : readlane_f64(c1[q], t - 64);
+          if (meta >> 17) c = 0.0;
+          acc[q].x = __builtin_fma(c, v[u].x, acc[q].x);
+          acc[q].y = __builtin_fma(c, v[u].y, acc[q].y);
+        }
+        if ((meta >> 16) & 1) {  // the pieces are sorted by row pair: its sum is complete
+          const int x = meta & 0xff, row = band + 8 * (x >> 2) + rsub, col = 16 * (x & 3) + csub;
+#pragma unroll
+          for (int q = 0; q < NS; ++q) {
+            *reinterpret_cast<double2*>(T[q] + row * LDC + col) = acc[q];
+            acc[q] = double2{0.0, 0.0};
+          }
+        }
+        if (i + TILE_RING < 64) issue(cur, i + TILE_RING, v[u]);
+        else issue(nxt, i + TILE_RING - 64, v[u]);
+      }
+    }
+    mine = nxt;
+  }
+  if (d.diag) {  // padding unknowns: identity
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int r = band + 8 * (x >> 2) + rsub, c = 16 * (x & 3) + csub;
+      if (r >= d.ndr) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<double2*>(T[q] + r * LDC + c) = double2{c == r ? 1.0 : 0.0, c + 1 == r ? 1.0 : 0.0};
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// T (LDS tile holding S) -= acc
+__device__ inline void tile_minus_acc(double* Cb, const Acc& acc, const WavePos& wp) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -472,12 +579,37 @@ __global__ __launch_bounds__(256) void k_back_pre(FemDev f, const double* __rest
 template <int NS>
 __device__ inline void diag_update_body(const FemDev& f, const double* __restrict__ am0, int m0, int nsys, int slot, double* lds,
                                         double* coef) {
-  double* Cb = lds;  // the C tile aliases the DMA slots (used after the k-loop only)
   const WavePos wp;
   const TileDesc& d = f.desc[slot];
+  const bool lower = !(wp.wr == 0 && wp.wc == 1);
+  if (d.t1 - d.t0 <= 128) {
+    // the k-loops first (their DMA slots alias the first tile), then ONE pass over the tables assembles S for all NS systems
+    // straight into their LDS tiles, minus the accumulators, out
+    Acc acc[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      acc_zero(acc[q]);
+      if (q >= nsys) continue;
+      if (q > 0) __syncthreads();  // (the previous k-loop's slots)
+      accumulate_klist_dma(f, slot, f.L + size_t(m0 + q) * f.nslots * 4096, [&](int) { return lower; }, acc[q], reinterpret_cast<char*>(lds), wp);
+    }
+    __syncthreads();
+    double* T[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) T[q] = lds + q * TILE_DOUBLES;
+    s_tile_to_lds<NS>(T, slot, d, f, am0, nsys);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      if (q >= nsys) break;
+      tile_minus_acc(T[q], acc[q], wp);
+      double* Lout = f.L + (size_t(m0 + q) * f.nslots + slot) * 4096;
+      for (int idx = threadIdx.x; idx < 4096; idx += 256) Lout[idx] = T[q][(idx >> 6) * LDC + (idx & 63)];
+    }
+    return;
+  }
+  double* Cb = lds;  // the C tile aliases the DMA slots (used after the k-loop only)
   STile st[NS];
   s_tile_load<NS>(st, d, f, am0, nsys, coef);  // (the values wait in registers)
-  const bool lower = !(wp.wr == 0 && wp.wc == 1);
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     if (q >= nsys) break;
@@ -494,7 +626,7 @@ __device__ inline void diag_update_body(const FemDev& f, const double* __restric
 // NS = 2: two systems per workgroup (one pass over the term tables for both)
 template <int NS>
 __global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void k_diag_update(FemDev f, const double* __restrict__ a, int slot, int Mc) {
-  __shared__ __align__(16) double lds[TILE_DOUBLES];  // 33.8 KB (the two DMA slots alias the C tile): four workgroups per CU
+  __shared__ __align__(16) double lds[NS * TILE_DOUBLES];  // 33.8 KB per system (the two DMA slots alias the first tile): NS = 1: four workgroups per CU
   __shared__ double coef[NS * COEF_MAX + TERM_DESC_DOUBLES];
   static_assert(TD_LDS_BYTES <= TILE_DOUBLES * 8, "the DMA slots fit under the tile");
   const int m0 = blockIdx.x * NS;
@@ -513,11 +645,6 @@ __device__ inline double rsqrt_newton(double d) {
   return y;
 }
 
-__device__ inline double readlane_f64(double v, int lane) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
 
 // k_solve1 keeps its factor packed by rows in whole panels of four columns: rows 4 g .. 4 g + 3 have 4 (g + 1) entries each
 __device__ __host__ constexpr int s1_lrow(int r) { return 8 * (r >> 2) * ((r >> 2) + 1) + (r & 3) * 4 * ((r >> 2) + 1); }
@@ -1207,8 +1334,9 @@ __device__ inline void panel_body(const FemDev& f, const double* __restrict__ am
   const WavePos wp;
   const TileDesc& d = f.desc[slot];
   const int t = threadIdx.x;
+  const bool stream = NS == 1 && d.t1 - d.t0 <= 128;  // (the assembly as a stream of kilobytes behind the k-loop: s_tile_to_lds)
   STile st[NS];
-  s_tile_load<NS>(st, d, f, am0, nsys, coef);
+  if (!stream) s_tile_load<NS>(st, d, f, am0, nsys, coef);
   static_assert(TD_LDS_BYTES <= FACT_LDS_DOUBLES * 8, "the DMA slots alias the staging area and the C tile");
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
@@ -1220,7 +1348,14 @@ __device__ inline void panel_body(const FemDev& f, const double* __restrict__ am
     Acc acc;
     acc_zero(acc);
     accumulate_klist_dma(f, slot, Lm, [](int) { return true; }, acc, reinterpret_cast<char*>(lds), wp);
-    tile_from_acc(Cb, acc, st[q], wp);
+    if (stream) {
+      __syncthreads();  // (the k-loop's slots)
+      double* T[1] = {Cb};
+      s_tile_to_lds<1>(T, slot, d, f, am0 + size_t(q) * f.kblk, 1);
+      tile_minus_acc(Cb, acc, wp);
+    } else {
+      tile_from_acc(Cb, acc, st[q], wp);
+    }
 
     // X = C * invL_jj^T
     acc_zero(acc);

@@ -21,7 +21,7 @@ FemDev make_dev(const rom_fem* f) {
   FemDev d;
   d.nrb = f->nrb; d.ncb = f->ncb; d.N = f->N; d.n1 = f->n1; d.n1p = f->n1p; d.nr = f->nr; d.nc = f->nc;
   d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.nexp = f->nexp; d.ncross = f->ncross;
-  d.xb0 = f->xb0; d.pool = f->d_pool; d.pairs = f->d_pairs; d.npairs = f->npairs; d.pool_acc = f->d_pool_acc; d.wmeta = f->d_wmeta; d.s1_items = f->d_s1_items; d.s1_citems = f->d_s1_citems; for (int i = 0; i < 5; ++i) d.wp0[i] = f->wp0[i]; d.s1_t0 = d.s1_nterm = d.s1_ndr = 0; if (f->fused1 && !f->desc.empty()) { d.s1_t0 = f->desc[0].t0; d.s1_nterm = f->desc[0].t1 - f->desc[0].t0; d.s1_ndr = f->desc[0].ndr; } d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
+  d.xb0 = f->xb0; d.pool = f->d_pool; d.alist = f->d_alist; d.aoff = f->d_aoff; d.pairs = f->d_pairs; d.npairs = f->npairs; d.pool_acc = f->d_pool_acc; d.wmeta = f->d_wmeta; d.s1_items = f->d_s1_items; d.s1_citems = f->d_s1_citems; for (int i = 0; i < 5; ++i) d.wp0[i] = f->wp0[i]; d.s1_t0 = d.s1_nterm = d.s1_ndr = 0; if (f->fused1 && !f->desc.empty()) { d.s1_t0 = f->desc[0].t0; d.s1_nterm = f->desc[0].t1 - f->desc[0].t0; d.s1_ndr = f->desc[0].ndr; } d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
   d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.scb = f->d_scb; d.spos0 = f->spos0; d.nsc = f->nsc;
   d.sblk0 = f->spos0 + f->n_all_edges; d.groups = f->d_groups; d.cm = f->d_cm; d.item_group = f->d_item_group;
   d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.dgroups = f->d_dgroups; d.dweight = f->d_dweight;
@@ -286,7 +286,7 @@ extern "C" int rom_fem_destroy(rom_fem* f) {
   void* ptrs[] = {f->d_A0, f->d_G, f->d_Gs, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
                   f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
                   f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred, f->d_groups, f->d_cm,
-                  f->d_item_group, f->d_item_k, f->d_pairs, f->d_pool_acc, f->d_wmeta, f->d_s1_items, f->d_s1_citems, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
+                  f->d_item_group, f->d_item_k, f->d_pairs, f->d_alist, f->d_aoff, f->d_pool_acc, f->d_wmeta, f->d_s1_items, f->d_s1_citems, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
                   f->d_ditem_k, f->d_dmat, f->d_scb};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -935,6 +935,39 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   }
   slot_terms.clear();
   smalls.clear();
+  // The assembly of a tile as a stream of kilobytes (s_tile_to_lds): wave w of a workgroup owns rows 16 w .. 16 w + 15 as
+  // 2 x 4 positions of 8 rows x 16 columns; per tile slot and wave, the (position x, term) pieces that meet the term's
+  // rectangle, sorted by position, the terms of a position in their order; padded to whole rings with no-ops, 128 no-ops behind the end.
+  std::vector<int> alist, aoff;
+  {
+    const int RING = 8;
+    for (size_t sl = 0; sl < f->desc.size(); ++sl) {
+      const TileDesc& d = f->desc[sl];
+      for (int w = 0; w < 4; ++w) {
+        aoff.push_back(int(alist.size() / 2));
+        if (d.t1 - d.t0 > 128) continue;  // (such a tile takes the register path)
+        for (int x = 0; x < 8; ++x) {  // position x = 4 pr + cs: rows 16 w + 8 pr .. + 7, columns 16 cs .. + 15
+          const int r0 = 16 * w + 8 * (x >> 2), c0 = 16 * (x & 3);
+          const size_t first = alist.size();
+          for (int t = d.t0; t < d.t1; ++t) {
+            const GenTerm& g = terms[t];
+            if (!(r0 + 8 > g.r_lo && r0 < g.r_hi && c0 + 16 > g.c_lo && c0 < g.c_hi)) continue;
+            alist.push_back(int(size_t(g.tab) * 4096 + size_t(r0) * TB + c0));
+            alist.push_back(x | (t - d.t0) << 8);
+          }
+          if (alist.size() > first) alist.back() |= 1 << 16;  // last piece of this position
+        }
+        while ((alist.size() / 2 - size_t(aoff.back())) % RING) { alist.push_back(0); alist.push_back(1 << 17); }
+      }
+    }
+    aoff.push_back(int(alist.size() / 2));
+    for (int i = 0; i < 128; ++i) { alist.push_back(0); alist.push_back(1 << 17); }
+    if (getenv("ROMHC_VERBOSE")) {
+      size_t real = 0;
+      for (size_t i = 1; i < alist.size(); i += 2) real += (alist[i] >> 17) ? 0 : 1;
+      fprintf(stderr, "romhc:   tile assembly as a stream: %zu KB per system and sweep in pieces of 8 rows x 16 columns\n", real);
+    }
+  }
   if (getenv("ROMHC_VERBOSE")) {  // what the assembly of the tiles reads: 128-byte strips (one thread-row x 16 columns) that meet a term's rectangle
     double strips = 0, tiles_diag = 0, tiles_sub = 0, nterm = 0;
     for (const TileDesc& d : f->desc) {
@@ -1311,6 +1344,8 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   ROM_TRY(upload(ctx->stream, &f->d_pool, pool));
   ROM_TRY(upload(ctx->stream, &f->d_terms, terms));
   ROM_TRY(upload(ctx->stream, &f->d_pairs, pairs));
+  ROM_TRY(upload(ctx->stream, &f->d_alist, alist));
+  ROM_TRY(upload(ctx->stream, &f->d_aoff, aoff));
   ROM_TRY(upload(ctx->stream, &f->d_pool_acc, pool_acc));
   ROM_TRY(upload(ctx->stream, &f->d_wmeta, wmeta));
   if (f->fused1)  // (the attribute belongs to the kernel as loaded on this device; setting it again is harmless)

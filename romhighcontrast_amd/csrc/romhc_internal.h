@@ -225,6 +225,8 @@ struct rom_fem {
   GenTerm* d_terms = nullptr;
   double* d_pool = nullptr;  // 64x64 tables of the tile terms
   int* d_pairs = nullptr;    // (term, block) pairs of the single-tile assembly
+  int* d_alist = nullptr;    // tile assembly as a stream: pieces per tile slot and wave (rom_fem_dev.h)
+  int* d_aoff = nullptr;
   int npairs = 0;
   double* d_pool_acc = nullptr;  // k_solve1: the pairs' table pieces in accumulator layout, in the order its four waves walk them
   int* d_wmeta = nullptr;        // ... and their metas; wave w walks wp0[w] .. wp0[w + 1] - 1 (rom_fem_dev.h)
