@@ -13,6 +13,7 @@ struct FemDev {
   const double* pool;  // 64x64 tables of the tile terms
   const int* alist;    // tile assembly as a stream (s_tile_to_lds): per tile slot and wave, pieces {element offset of a row pair's kilobyte in the pool, x | term << 8 | last << 16 | no-op << 17}
   const int* aoff;     // 4 * slots + 1 offsets into it (in pieces)
+  int tile_stream;     // 0: tiles are assembled in registers (s_tile_load; ROMHC_NO_TILE_STREAM, and any tile of more than 128 terms)
   const int* pairs;    // single-tile solve: (term, block) pairs of the assembly, two ints each
   int npairs;          // multiple of 64 (no-op padded), followed by 64 more no-ops
   // k_solve1 (four systems per workgroup, the blocks dealt to its four waves): wave w walks pairs wp0[w] .. wp0[w + 1] - 1

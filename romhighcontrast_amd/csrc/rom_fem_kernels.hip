@@ -582,7 +582,7 @@ __device__ inline void diag_update_body(const FemDev& f, const double* __restric
   const WavePos wp;
   const TileDesc& d = f.desc[slot];
   const bool lower = !(wp.wr == 0 && wp.wc == 1);
-  if (d.t1 - d.t0 <= 128) {
+  if (f.tile_stream && d.t1 - d.t0 <= 128) {
     // the k-loops first (their DMA slots alias the first tile), then ONE pass over the tables assembles S for all NS systems
     // straight into their LDS tiles, minus the accumulators, out
     Acc acc[NS];
@@ -1334,7 +1334,7 @@ __device__ inline void panel_body(const FemDev& f, const double* __restrict__ am
   const WavePos wp;
   const TileDesc& d = f.desc[slot];
   const int t = threadIdx.x;
-  const bool stream = NS == 1 && d.t1 - d.t0 <= 128;  // (the assembly as a stream of kilobytes behind the k-loop: s_tile_to_lds)
+  const bool stream = NS == 1 && f.tile_stream && d.t1 - d.t0 <= 128;  // (the assembly as a stream of kilobytes behind the k-loop: s_tile_to_lds)
   STile st[NS];
   if (!stream) s_tile_load<NS>(st, d, f, am0, nsys, coef);
   static_assert(TD_LDS_BYTES <= FACT_LDS_DOUBLES * 8, "the DMA slots alias the staging area and the C tile");

@@ -21,7 +21,7 @@ FemDev make_dev(const rom_fem* f) {
   FemDev d;
   d.nrb = f->nrb; d.ncb = f->ncb; d.N = f->N; d.n1 = f->n1; d.n1p = f->n1p; d.nr = f->nr; d.nc = f->nc;
   d.nGp = f->nGp; d.nGa = f->nGa; d.npre = f->npre; d.nrhs = f->nrhs; d.nexp = f->nexp; d.ncross = f->ncross;
-  d.xb0 = f->xb0; d.pool = f->d_pool; d.alist = f->d_alist; d.aoff = f->d_aoff; d.pairs = f->d_pairs; d.npairs = f->npairs; d.pool_acc = f->d_pool_acc; d.wmeta = f->d_wmeta; d.s1_items = f->d_s1_items; d.s1_citems = f->d_s1_citems; for (int i = 0; i < 5; ++i) d.wp0[i] = f->wp0[i]; d.s1_t0 = d.s1_nterm = d.s1_ndr = 0; if (f->fused1 && !f->desc.empty()) { d.s1_t0 = f->desc[0].t0; d.s1_nterm = f->desc[0].t1 - f->desc[0].t0; d.s1_ndr = f->desc[0].ndr; } d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
+  d.xb0 = f->xb0; d.pool = f->d_pool; d.alist = f->d_alist; d.aoff = f->d_aoff; d.tile_stream = f->sw_no_tile_stream ? 0 : 1; d.pairs = f->d_pairs; d.npairs = f->npairs; d.pool_acc = f->d_pool_acc; d.wmeta = f->d_wmeta; d.s1_items = f->d_s1_items; d.s1_citems = f->d_s1_citems; for (int i = 0; i < 5; ++i) d.wp0[i] = f->wp0[i]; d.s1_t0 = d.s1_nterm = d.s1_ndr = 0; if (f->fused1 && !f->desc.empty()) { d.s1_t0 = f->desc[0].t0; d.s1_nterm = f->desc[0].t1 - f->desc[0].t0; d.s1_ndr = f->desc[0].ndr; } d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
   d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.scb = f->d_scb; d.spos0 = f->spos0; d.nsc = f->nsc;
   d.sblk0 = f->spos0 + f->n_all_edges; d.groups = f->d_groups; d.cm = f->d_cm; d.item_group = f->d_item_group;
   d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.dgroups = f->d_dgroups; d.dweight = f->d_dweight;
@@ -1395,6 +1395,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   f->sw_no_ext128 = getenv("ROMHC_NO_EXT128") != nullptr;
   f->sw_no_fold = getenv("ROMHC_NO_FOLD_EXPAND") != nullptr;
   f->sw_no_tile_pairs = getenv("ROMHC_NO_TILE_PAIRS") != nullptr;
+  f->sw_no_tile_stream = getenv("ROMHC_NO_TILE_STREAM") != nullptr;
   f->sw_ext_flat = getenv("ROMHC_EXT_FLAT") ? (atoi(getenv("ROMHC_EXT_FLAT")) != 0 ? 1 : 0) : -1;
   ROMHC_PHASE("end");
   if (getenv("ROMHC_VERBOSE")) {

@@ -261,6 +261,7 @@ struct rom_fem {
    // k_extend128: system group fastest in the workgroup order (tables out of cache, not HBM)
   int sw_ext_flat = -1;
   bool sw_no_tile_pairs = false;  // ROMHC_NO_TILE_PAIRS: tile Cholesky with one system per workgroup
+  bool sw_no_tile_stream = false; // ROMHC_NO_TILE_STREAM: tile assembly in registers (s_tile_load) instead of the stream into LDS
   DenseGroup* d_dgroups = nullptr;
   int* d_dweight = nullptr;    // per (dense group, source position): block of the weight, -1 cross point, -2 none
   int* d_ditem_group = nullptr;

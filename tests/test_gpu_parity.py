@@ -1197,7 +1197,7 @@ def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
 
 
 @pytest.mark.parametrize("env", ["ROMHC_NO_COMPRESS", "ROMHC_NO_PREELIM", "ROMHC_NO_FUSED", "ROMHC_NO_LOWRANK_EXT",
-                                 "ROMHC_NO_EXT128", "ROMHC_NO_EXT_LR", "ROMHC_NO_TILE_PAIRS"])
+                                 "ROMHC_NO_EXT128", "ROMHC_NO_EXT_LR", "ROMHC_NO_TILE_PAIRS", "ROMHC_NO_TILE_STREAM"])
 def test_algorithm_switches_agree(api, env, monkeypatch):
     """Every exact reduction of the solver can be switched off (A/B checks): the snapshots must not move beyond
     rounding, and each variant must itself meet the parity bound against the oracle."""
@@ -1219,6 +1219,8 @@ def test_algorithm_switches_agree(api, env, monkeypatch):
         monkeypatch.delenv(env, raising=False)
         g = ro.Geometry(blocks, N)
         assert relh10(g, alt, ref).max() < 1e-11, (env, blocks, N)
+        if env in ("ROMHC_NO_TILE_PAIRS", "ROMHC_NO_TILE_STREAM"):  # (same sums in the same order)
+            assert np.array_equal(alt, ref), (env, blocks, N)
         if N <= 40:
             assert relh10(g, alt[:4], ro.generate_solutions(g, a[:4].reshape((4,) + blocks))).max() < SNAP_TOL
 
