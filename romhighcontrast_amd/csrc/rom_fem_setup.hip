@@ -24,7 +24,7 @@ FemDev make_dev(const rom_fem* f) {
   d.xb0 = f->xb0; d.pool = f->d_pool; d.alist = f->d_alist; d.aoff = f->d_aoff; d.tile_stream = f->sw_no_tile_stream ? 0 : 1; d.pairs = f->d_pairs; d.npairs = f->npairs; d.pool_acc = f->d_pool_acc; d.wmeta = f->d_wmeta; d.s1_items = f->d_s1_items; d.s1_citems = f->d_s1_citems; for (int i = 0; i < 5; ++i) d.wp0[i] = f->wp0[i]; d.s1_t0 = d.s1_nterm = d.s1_ndr = 0; if (f->fused1 && !f->desc.empty()) { d.s1_t0 = f->desc[0].t0; d.s1_nterm = f->desc[0].t1 - f->desc[0].t0; d.s1_ndr = f->desc[0].ndr; } d.terms = f->d_terms; d.Bt = f->d_Bt; d.P = f->d_P; d.vec = f->d_vec;
   d.rhs = f->d_rhs; d.pre = f->d_pre; d.exp = f->d_exp; d.xred = f->d_xred; d.scb = f->d_scb; d.spos0 = f->spos0; d.nsc = f->nsc;
   d.sblk0 = f->spos0 + f->n_all_edges; d.groups = f->d_groups; d.cm = f->d_cm; d.item_group = f->d_item_group;
-  d.item_k = f->d_item_k; d.ncoef = f->ncoef; d.dgroups = f->d_dgroups; d.dweight = f->d_dweight;
+  d.item_k = f->d_item_k; d.item_cf = f->d_item_cf; d.ctask = f->d_ctask; d.nctask = f->nctask; d.ncf = f->ncf; d.ncoef = f->ncoef; d.dgroups = f->d_dgroups; d.dweight = f->d_dweight;
   d.ditem_group = f->d_ditem_group; d.ditem_k = f->d_ditem_k; d.dmat = f->d_dmat; d.ndg = f->ndg; d.ndi = f->ndi; d.T = f->T; d.nslots = f->nslots;
   d.kblk = f->nrb * f->ncb; d.dim = f->dim;
   d.G = f->d_G; d.Gs = f->d_Gs; d.A0 = f->d_A0; d.Qp = f->d_Qp; d.kmax = f->d_kmax; d.epos = f->d_epos; d.yhat = f->d_yhat; d.W = f->d_W;
@@ -286,7 +286,7 @@ extern "C" int rom_fem_destroy(rom_fem* f) {
   void* ptrs[] = {f->d_A0, f->d_G, f->d_Gs, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
                   f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
                   f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred, f->d_groups, f->d_cm,
-                  f->d_item_group, f->d_item_k, f->d_pairs, f->d_alist, f->d_aoff, f->d_pool_acc, f->d_wmeta, f->d_s1_items, f->d_s1_citems, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
+                  f->d_item_group, f->d_item_k, f->d_item_cf, f->d_ctask, f->d_pairs, f->d_alist, f->d_aoff, f->d_pool_acc, f->d_wmeta, f->d_s1_items, f->d_s1_citems, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
                   f->d_ditem_k, f->d_dmat, f->d_scb};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -1109,6 +1109,30 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   for (size_t g = 0; g < groups.size(); ++g)
     for (int k = 0; k < groups[g].w; ++k) { item_group.push_back(int(g)); item_k.push_back(k); }
   f->ncoef = int(item_group.size());
+  // k_coef spreads the dot products of the closed-form blocks over its workgroup: tasks (group, entry k, term t) ordered by
+  // (group, term, k) -- neighbouring threads read neighbouring entries of a matrix row -- as flat records (rom_fem_dev.h)
+  std::vector<int> item_cf(item_group.size(), -1), ctask;
+  {
+    std::vector<int> first_cf(groups.size(), -1);
+    int ncf = 0;
+    for (size_t it = 0; it < item_group.size(); ++it) {
+      const CoefGroup& cg = groups[item_group[it]];
+      if (cg.kind == 1 && item_k[it] < cg.r) {
+        if (first_cf[item_group[it]] < 0) first_cf[item_group[it]] = ncf;
+        item_cf[it] = ncf++;
+      }
+    }
+    for (size_t g = 0; g < groups.size(); ++g)
+      if (groups[g].kind == 1)
+        for (int t = 0; t < groups[g].nterm; ++t)
+          for (int k = 0; k < groups[g].r; ++k) {
+            const CoefTerm& ct = groups[g].t[t];
+            const int rec[8] = {ct.moff + k, ct.src, ct.len, groups[g].r, ct.voff >= 0 ? ct.voff + k : -1, ct.u0, ct.u1, (first_cf[g] + k) * 8 + t};
+            ctask.insert(ctask.end(), rec, rec + 8);
+          }
+    f->ncf = ncf;
+    f->nctask = int(ctask.size() / 8);
+  }
   {
     // single-tile path: the coefficient blocks of the closed-form edges as one dense product (k_solve1)
     std::vector<DenseGroup> dgroups;
@@ -1358,6 +1382,8 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   ROM_TRY(upload(ctx->stream, &f->d_cm, cm));
   ROM_TRY(upload(ctx->stream, &f->d_item_group, item_group));
   ROM_TRY(upload(ctx->stream, &f->d_item_k, item_k));
+  ROM_TRY(upload(ctx->stream, &f->d_item_cf, item_cf));
+  ROM_TRY(upload(ctx->stream, &f->d_ctask, ctask));
   ROM_TRY(upload(ctx->stream, &f->d_xred, xred));
   {
     std::vector<int> scb;  // (b0, b1) per scalar: an edge's two blocks, or (block, -1)

@@ -143,7 +143,13 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
     }
     {
       ROM_PROF(ctx, "coef", 0, 8.0 * Mc * f->ncoef);
-      k_coef<<<Mc, 256, lds_back, st>>>(d, am);  // (LDS: the nGa reduced unknowns, as in k_backsolve)
+      const size_t lds_coef = lds_back + size_t(f->ncf) * 64;  // the nGa reduced unknowns + 8 dot products per closed-form entry
+      ROM_CHECK(lds_coef <= 156 * 1024, "rom_solve_batch: the coefficient blocks of this geometry do not fit the LDS (%zu bytes)", lds_coef);
+      if (lds_coef > 48 * 1024 && !f->lds_optin_coef) {  // (the attribute belongs to the kernel as loaded on this device)
+        ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_coef), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        f->lds_optin_coef = true;
+      }
+      k_coef<<<Mc, 1024, lds_coef, st>>>(d, am);
     }
   }
   if (!(stages & 2)) {

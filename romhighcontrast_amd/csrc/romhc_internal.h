@@ -252,6 +252,10 @@ struct rom_fem {
   int* d_item_group = nullptr;
   int* d_item_k = nullptr;
   int ncoef = 0;               // entries of all coefficient blocks
+  int* d_item_cf = nullptr;    // k_coef: closed-form index of an entry, tasks {group, k, term, slot} of its dot products (rom_fem_dev.h)
+  int* d_ctask = nullptr;
+  int nctask = 0, ncf = 0;
+  bool lds_optin_coef = false;  // k_coef was given more than the default dynamic LDS on this device
   bool fused1 = false;         // the reduced matrix is one tile: whole solve in k_solve1
   // A/B switches of the kernel sequencing, read from the environment ONCE per FE space (rom_fem_create): ROMHC_NO_FUSED,
   // ROMHC_EXT_FLAT (-1: automatic), ROMHC_NO_EXT128, ROMHC_NO_FOLD_EXPAND
