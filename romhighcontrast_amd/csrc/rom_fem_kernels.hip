@@ -220,31 +220,45 @@ __device__ inline void tile_from_acc(double* Cb, const Acc& acc, const STile& st
 // with v_readlane.  Every entry adds up the same products in the same order as s_tile_load: same bits.
 // Called by all 256 threads; ends with a barrier (the tiles are complete and visible).
 constexpr int TILE_RING = 8;
+// what the stream needs before its first piece -- the wave's first 64 list entries and the weights of the terms (lane t: terms t
+// and 64 + t) -- is fetched AHEAD of the k-loop (s_tile_stream_begin): two dependent memory round trips less behind it
 template <int NS>
-__device__ inline void s_tile_to_lds(double* const (&T)[NS], int slot, const TileDesc& d, const FemDev& f, const double* __restrict__ am0, int nsys) {
+struct TileStream {
+  int e0, ne;
+  int2 mine;
+  double c0[NS], c1[NS];
+};
+template <int NS>
+__device__ inline void s_tile_stream_begin(TileStream<NS>& ts, int slot, const TileDesc& d, const FemDev& f, const double* __restrict__ am0, int nsys) {
+  const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6), l = threadIdx.x & 63;
+  ts.e0 = f.aoff[slot * 4 + w];
+  ts.ne = f.aoff[slot * 4 + w + 1] - ts.e0;  // this wave's pieces (a multiple of TILE_RING: padded with no-ops)
+  ts.mine = (reinterpret_cast<const int2*>(f.alist) + ts.e0)[l];  // lane i: piece i of the first group of 64 (the list carries 128 no-ops behind its end)
+  const int nt = d.t1 - d.t0;
+  const GenTerm g0 = f.terms[d.t0 + min(l, nt - 1)], g1 = f.terms[d.t0 + min(64 + l, nt - 1)];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const double* am = am0 + size_t(q < nsys ? q : 0) * f.kblk;
+    ts.c0[q] = l < nt ? term_coef(g0, am) : 0.0;
+    ts.c1[q] = 64 + l < nt ? term_coef(g1, am) : 0.0;
+  }
+}
+template <int NS>
+__device__ inline void s_tile_to_lds(double* const (&T)[NS], const TileStream<NS>& ts, const TileDesc& d, const FemDev& f) {
   const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6), l = threadIdx.x & 63;
   const int band = 16 * w, rsub = l >> 3, csub = 2 * (l & 7);  // piece x = 4 pr + cs: rows band + 8 pr + rsub, columns 16 cs + csub, + 1
-  const int e0 = f.aoff[slot * 4 + w], ne = f.aoff[slot * 4 + w + 1] - e0;  // this wave's pieces (a multiple of TILE_RING: padded with no-ops)
-  const int2* ent = reinterpret_cast<const int2*>(f.alist) + e0;
+  const int ne = ts.ne;
+  const int2* ent = reinterpret_cast<const int2*>(f.alist) + ts.e0;
   const double2* pool2 = reinterpret_cast<const double2*>(f.pool) + rsub * 32 + (l & 7);  // (a piece: 8 rows x 16 columns = eight whole cache lines)
   double2 v[TILE_RING];
-  int2 mine = ent[l];  // lane i: piece i of the current group of 64 (the list carries 128 no-ops behind its end)
+  int2 mine = ts.mine;
   auto issue = [&](int2 e_lane, int i, double2& dst) { dst = pool2[__builtin_amdgcn_readlane(e_lane.x, i) >> 1]; };
 #pragma unroll
   for (int u = 0; u < TILE_RING; ++u) issue(mine, u, v[u]);
-  // weights of the terms, lane t: terms t and 64 + t
-  const int nt = d.t1 - d.t0;
   double c0[NS], c1[NS];
-  {
-    const GenTerm g0 = f.terms[d.t0 + min(l, nt - 1)], g1 = f.terms[d.t0 + min(64 + l, nt - 1)];
 #pragma unroll
-    for (int q = 0; q < NS; ++q) {
-      const double* am = am0 + size_t(q < nsys ? q : 0) * f.kblk;
-      c0[q] = l < nt ? term_coef(g0, am) : 0.0;
-      c1[q] = 64 + l < nt ? term_coef(g1, am) : 0.0;
-    }
-  }
-  // rows that no term touches stay zero
+  for (int q = 0; q < NS; ++q) { c0[q] = ts.c0[q]; c1[q] = ts.c1[q]; }
+  // positions that no term touches stay zero
 #pragma unroll
   for (int q = 0; q < NS; ++q)
     for (int i = threadIdx.x; i < 64 * LDC / 2; i += 256) reinterpret_cast<double2*>(T[q])[i] = double2{0.0, 0.0};
@@ -596,6 +610,8 @@ __device__ inline void diag_update_body(const FemDev& f, const double* __restric
   if (f.tile_stream && d.t1 - d.t0 <= 128) {
     // the k-loops first (their DMA slots alias the first tile), then ONE pass over the tables assembles S for all NS systems
     // straight into their LDS tiles, minus the accumulators, out
+    TileStream<NS> ts;
+    s_tile_stream_begin<NS>(ts, slot, d, f, am0, nsys);
     Acc acc[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
@@ -608,7 +624,7 @@ __device__ inline void diag_update_body(const FemDev& f, const double* __restric
     double* T[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) T[q] = lds + q * TILE_DOUBLES;
-    s_tile_to_lds<NS>(T, slot, d, f, am0, nsys);
+    s_tile_to_lds<NS>(T, ts, d, f);
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       if (q >= nsys) break;
@@ -1356,13 +1372,15 @@ __device__ inline void panel_body(const FemDev& f, const double* __restrict__ am
     double* Lm = f.L + size_t(m) * f.nslots * 4096;
     if (q > 0) __syncthreads();  // (the rhs update of the previous system reads the tile and yj)
     if (t < 64) yj[t] = f.y[size_t(m) * f.nGp + j * 64 + t];
+    TileStream<1> ts;
+    if (stream) s_tile_stream_begin<1>(ts, slot, d, f, am0 + size_t(q) * f.kblk, 1);
     Acc acc;
     acc_zero(acc);
     accumulate_klist_dma(f, slot, Lm, [](int) { return true; }, acc, reinterpret_cast<char*>(lds), wp);
     if (stream) {
       __syncthreads();  // (the k-loop's slots)
       double* T[1] = {Cb};
-      s_tile_to_lds<1>(T, slot, d, f, am0 + size_t(q) * f.kblk, 1);
+      s_tile_to_lds<1>(T, ts, d, f);
       tile_minus_acc(Cb, acc, wp);
     } else {
       tile_from_acc(Cb, acc, st[q], wp);
