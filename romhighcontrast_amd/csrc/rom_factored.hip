@@ -239,6 +239,21 @@ __global__ __launch_bounds__(1024) void kf_new_direction(int j, int it, int k1, 
   }
 }
 
+// out[i * nb + b] = <A_i, B_b> for a handful of rows (na x nb products of length n), one wave each: the general GEMM spends
+// 56 us on such a launch (split-K bookkeeping for a 50 x 9 result), this one a few
+__global__ __launch_bounds__(256) void kf_small_dots(int na, int nb, int n, const double* __restrict__ A, const double* __restrict__ B,
+                                                     double* __restrict__ out) {
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pair >= na * nb) return;
+  const double* a = A + size_t(pair / nb) * n;
+  const double* b = B + size_t(pair % nb) * n;
+  double s = 0.0;
+  for (int c = lane; c < n; c += 64) s += a[c] * b[c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) out[pair] = s;
+}
+
 // One pass over the residuals: p_m = <R_m, q>, R_m -= p_m q, err2[m] = |R_m|^2 (a sum of squares: exact to rounding).
 __global__ __launch_bounds__(256) void kf_pass(int k1, double* __restrict__ R, const double* __restrict__ q,
                                                double* __restrict__ pj, double* __restrict__ err2) {
@@ -503,7 +518,8 @@ extern "C" int rom_greedy_factored(rom_fem* f, rom_buf* Yc, int64_t c_row0, int 
       const double* wj = W.p() + size_t(j) * Kc;
       kf_sb_apply<<<dim3(unsigned((Kc + 255) / 256), unsigned(k)), 256, 0, ctx->stream>>>(Kc, mp->Sb, wj, T);      // T[b] = S_b w_j
       ROM_HIP(hipGetLastError());
-      ROM_TRY(rom_launch_gemm_nt(ctx, j + 1, k, Kc, 1.0, W, Kc, T, Kc, 0.0, col, k, "gemm_nt"));                      // col[i, b] = w_i . S_b w_j
+      kf_small_dots<<<unsigned(((j + 1) * k + 3) / 4), 256, 0, ctx->stream>>>(j + 1, k, Kc, W, T, col);                // col[i, b] = w_i . S_b w_j
+      ROM_HIP(hipGetLastError());
       kb_grow_ahat<<<unsigned(((j + 1) * k + 255) / 256), 256, 0, ctx->stream>>>(Ahat, k, nb, j, col, d_dead, it - 1);
       ROM_HIP(hipGetLastError());
       ROM_TRY(rom_launch_rowdot(ctx, wj, 1, Kc, mp->bt, bhat.p() + j));                                               // w_j . B^T B_total
