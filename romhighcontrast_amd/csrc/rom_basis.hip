@@ -51,7 +51,7 @@ __global__ void kb_fill_random(double* p, size_t n, unsigned long long seed, int
   }
 }
 
-static int fill_random(rom_ctx* ctx, double* p, size_t n, unsigned long long seed, bool gaussian) {
+int romb_fill_random(rom_ctx* ctx, double* p, size_t n, unsigned long long seed, bool gaussian) {
   if (n == 0) return ROM_OK;
   kb_fill_random<<<unsigned(std::min<size_t>((n + 255) / 256, 4096)), 256, 0, ctx->stream>>>(p, n, seed, gaussian ? 1 : 0);
   ROM_HIP(hipGetLastError());
@@ -98,8 +98,6 @@ static int transpose(rom_ctx* ctx, double* dst, long long ldd, const double* src
 //   SE_WHITEN  row i = q_i^T / sqrt(lam_i) for lam_i > rel_tol * lam_0, zero rows otherwise
 //              (T X has orthonormal rows spanning the numerical row space of X when A = X X^T)
 //   SE_LOWDIN  sum_i q_i q_i^T / sqrt(lam_i) over the same i: the symmetric inverse square root (nearest orthonormal rows)
-enum { SE_EIG = 0, SE_WHITEN = 1, SE_LOWDIN = 2 };
-constexpr int SE_LDS_MAX = 96, SE_MAX = 1024;
 
 // threads of the eigen-solver's workgroup: a template parameter (small matrices are latency bound per round: fewer waves,
 // cheaper barriers)
@@ -113,15 +111,17 @@ __device__ inline double se_rsqrt(double x) {
   return y;
 }
 
-template <int SE_TPB>
+// GWS: matrix and eigenvector rows in the global workspace (n > SE_LDS_MAX); else in LDS -- a compile-time choice, so that the
+// LDS form addresses them with ds_read / ds_write (a pointer that may be either is a FLAT access: several times the latency)
+template <int SE_TPB, bool GWS>
 __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __restrict__ A, int lda, double* __restrict__ lam,
                                                        double* __restrict__ T, int ldt, int mode, double rel_tol, int gram_like,
                                                        double* __restrict__ gws, double* __restrict__ ns_ws) {
   extern __shared__ __align__(16) double sm[];
   const int t = threadIdx.x, ld = n | 1, ne = n + (n & 1), half = ne / 2;
-  double* As = gws ? gws : sm;
+  double* As = GWS ? gws : sm;
   double* Vt = As + size_t(n) * ld;
-  double* vec = gws ? sm : Vt + size_t(n) * ld;  // [cs half | sn half | ev n | nu2 n | red 8 | (int) pp half, qq half, perm n, flag]
+  double* vec = GWS ? sm : Vt + size_t(n) * ld;  // [cs half | sn half | ev n | nu2 n | red 8 | (int) pp half, qq half, perm n, flag]
   double* cs = vec;
   double* sn = vec + half;
   double* ev = vec + 2 * half;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __re
     if (r == c) dmax = fmax(dmax, fabs(v));
   }
   dmax = block_max(dmax);
-  if (mode != SE_EIG && dmax > 0.0 && !gws) {
+  if (mode != SE_EIG && dmax > 0.0 && !GWS) {
     // Rows that are orthogonal up to a moderate defect -- G = g (I + E), g = mean diagonal, ||E|| < 1/2: rotated Ritz
     // vectors of a subspace iteration, lifted modes, a Gaussian start block -- need no eigen-decomposition: the inverse
     // square root comes from the coupled Newton-Schulz iteration
@@ -246,6 +246,22 @@ __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __re
   // A direction that rank deficiency has cancelled to nothing keeps its nu, so the rounding residue that couples it to
   // the rest is recognised as such and the sweeps end; without it they never do (each rotation re-creates the residue).
   // gram_like == 0 (a general symmetric matrix such as Y G Y^T: all entries carry eps ||A||): nu_i^2 = max |a_ii|.
+  // single-wave form (SE_TPB == 64, n <= 32: at most 256 blocks and 512 eigenvector items per round): the items of a lane
+  int bk[4] = {0, 0, 0, 0}, bl[4] = {0, 0, 0, 0}, vk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vj[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (SE_TPB == 64) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = u * 64 + t;
+      bk[u] = idx / half;
+      bl[u] = idx - bk[u] * half;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = u * 64 + t;
+      vk[u] = idx / n;
+      vj[u] = idx - vk[u] * n;
+    }
+  }
   const double tol = double(n > 8 ? n : 8) * 1.1e-16, tol2 = tol * tol, floor_abs = fmax(1e-300, 1e-40 * dmax);
   for (int i = t; i < n; i += SE_TPB) nu2[i] = gram_like ? fabs(As[i * ld + i]) : dmax;
   __syncthreads();
@@ -292,7 +308,8 @@ __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __re
           const int idx = base + u * SE_TPB + t;
           a00[u] = a01[u] = a10[u] = a11[u] = -1;
           if (idx < half * half) {
-            const int k = idx / half, l = idx - k * half;
+            // (one wave, n <= 32: the item -> (k, l) map is the same in every round and was divided out once)
+            const int k = SE_TPB == 64 ? bk[u] : idx / half, l = SE_TPB == 64 ? bl[u] : idx - k * half;
             const double sk = sn[k], sl = sn[l];
             if (sk != 0.0 || sl != 0.0) {  // (s, not c, is the test: c rounds to 1 for tiny angles)
               const int pk = pp[k], qk = qq[k], pl = pp[l], ql = qq[l];
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __re
         }
       }
       // eigenvector rows: Vt <- J^T Vt
-      for (int base = 0; base < half * n; base += 4 * SE_TPB) {
+      auto vt_items = [&](int base, int slot) {
         double op[4], oq[4];
         int ap[4], aq[4];
 #pragma unroll
@@ -327,7 +344,8 @@ __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __re
           const int idx = base + u * SE_TPB + t;
           ap[u] = -1;
           if (idx < half * n) {
-            const int k = idx / n, j = idx - k * n;
+            const int k = SE_TPB == 64 ? vk[slot * 4 + u] : idx / n;
+            const int j = SE_TPB == 64 ? vj[slot * 4 + u] : idx - k * n;
             const double s = sn[k];
             if (s != 0.0) {  // (also every pair with the dummy index)
               const int p = pp[k], q = qq[k];
@@ -346,6 +364,12 @@ __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __re
             Vt[ap[u]] = op[u];
             Vt[aq[u]] = oq[u];
           }
+      };
+      if (SE_TPB == 64) {
+        vt_items(0, 0);
+        if (256 < half * n) vt_items(256, 1);
+      } else {
+        for (int base = 0; base < half * n; base += 4 * SE_TPB) vt_items(base, 0);
       }
       __syncthreads();
     }
@@ -385,6 +409,183 @@ __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __re
       }
       T[size_t(r) * ldt + c] = v;
     }
+  }
+}
+
+// The same cyclic Jacobi for n <= 32, eigenvectors only (SE_EIG), as ONE wave with a branch-free round: the round-robin
+// pairs of a round are at most 16, so the 2 x 2 blocks (<= 256) and the eigenvector items (<= 512) of a round are 4 and 8
+// per lane with an item -> (pair, pair / column) map that never changes (divided out once); every item loads its rotation
+// (c, s) and its index pair unconditionally -- (1, 0) is an exact identity, so pairs that do not rotate need no branch --
+// all loads of a phase are issued before its first store, and nothing in the round is a workgroup barrier.  A round is
+// three LDS round trips + the angle arithmetic instead of a dozen dependent ones: the eigenproblems of the POD's
+// Rayleigh-Ritz steps (b = 20 ... 32, graded, 5 ... 10 sweeps) are latency chains of a few hundred rounds each.
+// Same rotation criterion, same sweep order, same results as kb_small_eig.
+template <int NT>
+__global__ __launch_bounds__(NT) void kb_jacobi32(int n, const double* __restrict__ A, int lda, double* __restrict__ lam,
+                                                  double* __restrict__ T, int ldt, int gram_like) {
+  constexpr int LD = 33;
+  __shared__ double As[32 * LD], Vt[32 * LD];
+  __shared__ double2 csv[16];
+  __shared__ int2 pq[16];
+  __shared__ double nu2[32], ev[32];
+  __shared__ int perm[32];
+  __shared__ int s_any;
+  constexpr int BI = 256 / NT, VI = 512 / NT;   // 2 x 2 blocks / eigenvector items of a lane
+  const int t = threadIdx.x, ne = n + (n & 1), half = ne / 2;
+  double dmax = 0.0;
+  for (int idx = t; idx < n * n; idx += NT) {
+    const int r = idx / n, c = idx - r * n;
+    const double v = 0.5 * (A[size_t(r) * lda + c] + A[size_t(c) * lda + r]);
+    As[r * LD + c] = v;
+    Vt[r * LD + c] = r == c ? 1.0 : 0.0;
+    if (r == c) dmax = fmax(dmax, fabs(v));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+  if (NT > 64) {
+    if ((t & 63) == 0) ev[t >> 6] = dmax;
+    __syncthreads();
+    dmax = ev[0];
+    for (int w = 1; w < NT / 64; ++w) dmax = fmax(dmax, ev[w]);
+  }
+  __syncthreads();
+  if (t < n) nu2[t] = gram_like ? fabs(As[t * LD + t]) : dmax;
+  // items of this lane (fixed for the whole call)
+  int bk[BI], bl[BI], vk[VI], vj[VI];
+  bool bon[BI], von[VI];
+#pragma unroll
+  for (int u = 0; u < BI; ++u) {
+    const int idx = u * NT + t;
+    bon[u] = idx < half * half;
+    bk[u] = bon[u] ? idx / half : 0;
+    bl[u] = bon[u] ? idx - bk[u] * half : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < VI; ++u) {
+    const int idx = u * NT + t;
+    von[u] = idx < half * n;
+    vk[u] = von[u] ? idx / n : 0;
+    vj[u] = von[u] ? idx - vk[u] * n : 0;
+  }
+  const double tol = double(n > 8 ? n : 8) * 1.1e-16, tol2 = tol * tol, floor_abs = fmax(1e-300, 1e-40 * dmax);
+  __syncthreads();
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    bool rotated = false;
+    for (int r = 0; r < ne - 1; ++r) {
+      if (t < half) {
+        int p = ne - 1, q = r;
+        if (t != 0) {
+          p = r + t;
+          if (p >= ne - 1) p -= ne - 1;
+          q = r - t;
+          if (q < 0) q += ne - 1;
+        }
+        if (p > q) { const int x = p; p = q; q = x; }
+        double c = 1.0, s = 0.0;
+        if (q < n) {
+          const double app = As[p * LD + p], aqq = As[q * LD + q], apq = As[p * LD + q];
+          const double np2 = nu2[p], nq2 = nu2[q], apq2 = apq * apq;
+          if (apq2 > tol2 * fabs(app * aqq) && fabs(apq) > floor_abs && apq2 > tol2 * np2 * nq2) {
+            const double a = aqq - app, bb = 2.0 * apq;
+            const double tt = (a >= 0 ? bb : -bb) / (fabs(a) + sqrt(a * a + bb * bb));
+            c = se_rsqrt(1.0 + tt * tt);
+            s = tt * c;
+            nu2[p] = c * c * np2 + s * s * nq2;
+            nu2[q] = s * s * np2 + c * c * nq2;
+            rotated = true;
+          }
+        } else {
+          q = -1;
+        }
+        csv[t] = make_double2(c, s);
+        pq[t] = make_int2(p, q);
+      }
+      __syncthreads();
+      // A <- J^T A J as disjoint 2 x 2 blocks (k, l): rows (p_k, q_k) x columns (p_l, q_l) become R_k B R_l^T
+      {
+        double o00[BI], o01[BI], o10[BI], o11[BI];
+        int a00[BI], a01[BI], a10[BI], a11[BI];
+        bool w01[BI], w10[BI], w11[BI];
+#pragma unroll
+        for (int u = 0; u < BI; ++u) {
+          const double2 rk = csv[bk[u]], rl = csv[bl[u]];
+          const int2 ik = pq[bk[u]], il = pq[bl[u]];
+          const bool vk_ = ik.y >= 0, vl_ = il.y >= 0;
+          const int pk = ik.x, qk = vk_ ? ik.y : ik.x, pl = il.x, ql = vl_ ? il.y : il.x;
+          a00[u] = pk * LD + pl;
+          a01[u] = pk * LD + ql;
+          a10[u] = qk * LD + pl;
+          a11[u] = qk * LD + ql;
+          const double b00 = As[a00[u]], b01 = vl_ ? As[a01[u]] : 0.0;
+          const double b10 = vk_ ? As[a10[u]] : 0.0, b11 = (vk_ && vl_) ? As[a11[u]] : 0.0;
+          const double ck = rk.x, sk = rk.y, cl = rl.x, sl = rl.y;
+          const double r00 = ck * b00 - sk * b10, r01 = ck * b01 - sk * b11;
+          const double r10 = sk * b00 + ck * b10, r11 = sk * b01 + ck * b11;
+          o00[u] = cl * r00 - sl * r01;
+          o01[u] = sl * r00 + cl * r01;
+          o10[u] = cl * r10 - sl * r11;
+          o11[u] = sl * r10 + cl * r11;
+          w01[u] = bon[u] && vl_;
+          w10[u] = bon[u] && vk_;
+          w11[u] = bon[u] && vk_ && vl_;
+        }
+        // eigenvector rows: Vt <- J^T Vt
+        double op[VI], oq[VI];
+        int ap[VI], aq[VI];
+        bool wq[VI];
+#pragma unroll
+        for (int u = 0; u < VI; ++u) {
+          const double2 rk = csv[vk[u]];
+          const int2 ik = pq[vk[u]];
+          const bool vq = ik.y >= 0;
+          ap[u] = ik.x * LD + vj[u];
+          aq[u] = (vq ? ik.y : ik.x) * LD + vj[u];
+          const double vp = Vt[ap[u]], vqv = Vt[aq[u]];
+          op[u] = rk.x * vp - rk.y * vqv;
+          oq[u] = rk.y * vp + rk.x * vqv;
+          wq[u] = von[u] && vq;
+        }
+#pragma unroll
+        for (int u = 0; u < BI; ++u) {
+          if (bon[u]) As[a00[u]] = o00[u];
+          if (w01[u]) As[a01[u]] = o01[u];
+          if (w10[u]) As[a10[u]] = o10[u];
+          if (w11[u]) As[a11[u]] = o11[u];
+        }
+#pragma unroll
+        for (int u = 0; u < VI; ++u) {
+          if (von[u]) Vt[ap[u]] = op[u];   // (a pair with the dummy index: (c, s) = (1, 0), the row keeps its values)
+          if (wq[u]) Vt[aq[u]] = oq[u];
+        }
+      }
+      __syncthreads();
+    }
+    if (NT == 64) {
+      if (!__any(rotated)) break;
+    } else {
+      if (t < 64) {
+        const int any = __any(rotated);
+        if (t == 0) s_any = any;
+      }
+      __syncthreads();
+      const int any = s_any;
+      __syncthreads();
+      if (!any) break;
+    }
+  }
+  if (t < n) ev[t] = As[t * LD + t];
+  __syncthreads();
+  if (t < n) {
+    int rank = 0;
+    const double v = ev[t];
+    for (int j = 0; j < n; ++j) rank += (ev[j] > v || (ev[j] == v && j < t)) ? 1 : 0;
+    perm[rank] = t;
+  }
+  __syncthreads();
+  if (t < n) lam[t] = ev[perm[t]];
+  for (int idx = t; idx < n * n; idx += NT) {
+    const int r = idx / n, c = idx - r * n;
+    T[size_t(r) * ldt + c] = Vt[perm[r] * LD + c];
   }
 }
 
@@ -489,7 +690,7 @@ __global__ __launch_bounds__(256) void kb_pivchol_whiten(int n, const double* __
   for (int i = t; i < n; i += 256) lam[i] = i < r ? As[i * ld + i] * As[i * ld + i] : 0.0;
 }
 
-static int pivchol_whiten(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, double rel_tol) {
+int romb_pivchol_whiten(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, double rel_tol) {
   if (n <= 0) return ROM_OK;
   const int ld = n | 1;
   const size_t lds = 2 * size_t(n) * ld * sizeof(double) + 4 * sizeof(double) + (4 + size_t(n)) * sizeof(int) + 16;
@@ -506,8 +707,8 @@ static int pivchol_whiten(rom_ctx* ctx, int n, const double* A, int lda, double*
   return ROM_OK;
 }
 
-static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, int mode, double rel_tol,
-                     bool gram_like = true) {
+int romb_small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, int mode, double rel_tol,
+                     bool gram_like) {
   if (n <= 0) return ROM_OK;
   ROM_CHECK(n <= SE_MAX, "small symmetric eigenproblem: n = %d beyond %d", n, SE_MAX);
   const int ld = n | 1, half = (n + (n & 1)) / 2;
@@ -523,7 +724,7 @@ static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam,
   }
   if (lds > 64 * 1024 && !ctx->lds_optin_small_eig) {
     ROM_HIP(hipSetDevice(ctx->device));
-    ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb_small_eig<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb_small_eig<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ctx->lds_optin_small_eig = true;
   }
   {
@@ -531,9 +732,11 @@ static int small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam,
     char nm[48];
     detail ? snprintf(nm, sizeof nm, "small_eig_n%d_mode%d_%s", n, mode, gram_like ? "gram" : "sym") : snprintf(nm, sizeof nm, "small_eig");
     ROM_PROF(ctx, nm, 30.0 * n * n * n, 16.0 * n * n);
-    // (512 threads whatever n: a round is a chain of LDS round trips, and more waves hide more of them -- n = 24 takes
-    // 0.34 ms with 512 threads, 0.46 ms with 128)
-    kb_small_eig<512><<<1, 512, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws, ns_ws);
+    // n <= 32: ONE wave -- no barrier between the phases of a round and the item map divided out once: 5x the rounds per
+    // microsecond of the 512-thread form on the same rotations (same results)
+    if (n <= 32 && mode == SE_EIG) kb_jacobi32<256><<<1, 256, 0, ctx->stream>>>(n, A, lda, lam, T, ldt, gram_like ? 1 : 0);
+    else if (!gws) kb_small_eig<512, false><<<1, 512, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws, ns_ws);
+    else kb_small_eig<512, true><<<1, 512, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws, ns_ws);
   }
   ROM_HIP(hipGetLastError());
   return ROM_OK;
@@ -550,8 +753,8 @@ extern "C" int rom_small_eig_host(rom_ctx* ctx, int n, const double* A_host, int
   ROM_TRY(lam.get(ctx, n));
   ROM_TRY(T.get(ctx, size_t(n) * n));
   ROM_HIP(hipMemcpyAsync(A.p(), A_host, size_t(n) * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if (mode == 3) ROM_TRY(pivchol_whiten(ctx, n, A, n, lam, T, n, rel_tol));
-  else ROM_TRY(small_eig(ctx, n, A, n, lam, T, n, mode, rel_tol, gram_like != 0));
+  if (mode == 3) ROM_TRY(romb_pivchol_whiten(ctx, n, A, n, lam, T, n, rel_tol));
+  else ROM_TRY(romb_small_eig(ctx, n, A, n, lam, T, n, mode, rel_tol, gram_like != 0));
   ROM_TRY(download(ctx, lam, lam_host, n));
   return download(ctx, T, T_host, size_t(n) * n);
 }
@@ -563,7 +766,7 @@ extern "C" int rom_small_eig_host(rom_ctx* ctx, int n, const double* A_host, int
 // zero rows) or SE_LOWDIN (rows stay individually close to what they were).  `rounds` repetitions (the second one
 // removes what the squared condition number of the first Gram matrix left).  Y is a scratch block of the same size; the
 // result ends in X.
-static int gram_transform(rom_ctx* ctx, double* X, double* Y, int b, int64_t dim, int mode, double rel_tol, int rounds) {
+int romb_gram_transform(rom_ctx* ctx, double* X, double* Y, int b, int64_t dim, int mode, double rel_tol, int rounds) {
   if (b <= 0) return ROM_OK;
   Tmp G, lam, T;
   ROM_TRY(G.get(ctx, size_t(b) * b));
@@ -571,8 +774,8 @@ static int gram_transform(rom_ctx* ctx, double* X, double* Y, int b, int64_t dim
   ROM_TRY(T.get(ctx, size_t(b) * b));
   for (int r = 0; r < rounds; ++r) {
     ROM_TRY(rom_launch_gram(ctx, b, dim, X, dim, G, b));
-    if (mode == SE_WHITEN && b <= SE_LDS_MAX) ROM_TRY(pivchol_whiten(ctx, b, G, b, lam, T, b, r == 0 ? rel_tol : 1e-8));
-    else ROM_TRY(small_eig(ctx, b, G, b, lam, T, b, mode, r == 0 ? rel_tol : 1e-8));
+    if (mode == SE_WHITEN && b <= SE_LDS_MAX) ROM_TRY(romb_pivchol_whiten(ctx, b, G, b, lam, T, b, r == 0 ? rel_tol : 1e-8));
+    else ROM_TRY(romb_small_eig(ctx, b, G, b, lam, T, b, mode, r == 0 ? rel_tol : 1e-8));
     ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, b, 1.0, T, b, X, dim, 0.0, Y, dim));
     ROM_HIP(hipMemcpyAsync(X, Y, size_t(b) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   }
@@ -581,7 +784,7 @@ static int gram_transform(rom_ctx* ctx, double* X, double* Y, int b, int64_t dim
 
 // rows V[found : found + take] <- orthonormal and orthogonal to the orthonormal rows V[0 : found]: block Gram-Schmidt
 // against the old rows (twice), symmetric orthonormalisation among the new ones
-static int orthonormalize_against(rom_ctx* ctx, double* V, int found, int take, int64_t dim) {
+int romb_orthonormalize_against(rom_ctx* ctx, double* V, int found, int take, int64_t dim) {
   if (take <= 0) return ROM_OK;
   double* Vn = V + size_t(found) * dim;
   if (found > 0) {
@@ -596,7 +799,7 @@ static int orthonormalize_against(rom_ctx* ctx, double* V, int found, int take, 
   ROM_TRY(Y.get(ctx, size_t(take) * dim));
   // (the new rows are orthonormal to ~1e-6 at worst -- lifted Gram modes -- and the symmetric orthonormalisation is second
   // order in that defect: one round)
-  return gram_transform(ctx, Vn, Y, take, dim, SE_LOWDIN, 1e-30, 1);
+  return romb_gram_transform(ctx, Vn, Y, take, dim, SE_LOWDIN, 1e-30, 1);
 }
 
 // kb_cgs_finish: v <- v / ||v||_2 (norm squared given on the device), zero row if the norm underflows
@@ -642,7 +845,7 @@ extern "C" int rom_symmetric_orthonormalize(rom_ctx* ctx, rom_buf* V, int64_t v_
   if (n == 0) return ROM_OK;
   Tmp Y;
   ROM_TRY(Y.get(ctx, size_t(n) * dim));
-  return gram_transform(ctx, V->p + v_row0 * dim, Y, n, dim, SE_LOWDIN, 1e-30, 2);
+  return romb_gram_transform(ctx, V->p + v_row0 * dim, Y, n, dim, SE_LOWDIN, 1e-30, 2);
 }
 
 // rows V[found : found + rest] <- pseudo-random directions (seeded: deterministic) made orthonormal and orthogonal to the
@@ -655,8 +858,8 @@ extern "C" int rom_complete_orthonormal(rom_ctx* ctx, rom_buf* V, int64_t v_row0
   ROM_CHECK(int64_t(found) + rest <= dim && rest <= SE_MAX, "rom_complete_orthonormal: more rows than the space has dimensions");
   if (rest == 0) return ROM_OK;
   double* v = V->p + v_row0 * dim;
-  ROM_TRY(fill_random(ctx, v + size_t(found) * dim, size_t(rest) * dim, 0xc0de0000ull + unsigned(found), false));
-  return orthonormalize_against(ctx, v, found, rest, dim);
+  ROM_TRY(romb_fill_random(ctx, v + size_t(found) * dim, size_t(rest) * dim, 0xc0de0000ull + unsigned(found), false));
+  return romb_orthonormalize_against(ctx, v, found, rest, dim);
 }
 
 // =====================================================================================================================
@@ -1118,352 +1321,4 @@ extern "C" int rom_greedy(rom_fem* f, rom_buf* U, int64_t u_row0, int M, rom_buf
     max_err_out[i] = host[n + i];
   }
   return read_status(ctx, "rom_greedy");
-}
-
-// =====================================================================================================================
-// POD (the PCA fit of ReducedBasisPCA.build, src/lib/ReducedBasis.py:189-200)
-// =====================================================================================================================
-__global__ void kb_next_block(double* __restrict__ Zs, const double* __restrict__ Zr, const double* __restrict__ Yr,
-                              const double* __restrict__ theta, long long M) {
-  // rows: the rotated power step G y_i / theta_i for the resolvable pairs, the Ritz vector itself at the noise floor
-  const double th = theta[blockIdx.y], t0 = fabs(theta[0]);
-  const bool ok = th > 1e-13 * t0;
-  const double a = ok ? 1.0 / th : 0.0;
-  const long long o = blockIdx.y * M;
-  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < M; j += (long long)gridDim.x * blockDim.x)
-    Zs[o + j] = ok ? a * Zr[o + j] : Yr[o + j];
-}
-
-// out[i] = 1 / x[i] (0 where x[i] is not positive)
-__global__ void kb_inv(const double* __restrict__ x, double* __restrict__ out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = x[i] > 0.0 ? 1.0 / x[i] : 0.0;
-}
-
-// out[i] = lam[i] > 0 ? 1 / sqrt(lam[i]) : 0
-__global__ void kb_inv_sqrt(const double* __restrict__ lam, double* __restrict__ out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = lam[i] > 0.0 ? 1.0 / sqrt(lam[i]) : 0.0;
-}
-
-namespace {
-
-constexpr double GRAM_ACCEPT = 1e-10;    // eigenvalues of a Gram matrix are taken down to this fraction of its largest one
-// singular values of a sketch are taken down to this fraction of its largest one: the power step of the range finder
-// weighs a direction with sigma^3, so what lies four orders below the top of a pass is still resolved to ~1e-16 / 1e-12
-// of itself, what lies six orders below is not (measured: angle 1.4e-3 instead of 7e-6 for a mode at 1e-11 sigma_1)
-constexpr double SKETCH_ACCEPT = 1e-4;
-constexpr double NOISE_FLOOR = 1e-13;    // modes below this fraction of sigma_1 are fp64 noise of the snapshots
-
-struct PodInfo {
-  int gram_passes = 0, sketch_passes = 0, completed = 0, resolved = 0, eig_iterations = 0;
-  double executed = 0.0;
-};
-
-// Leading nev eigenpairs of the symmetric PSD matrix G (M x M) by subspace iteration with Rayleigh-Ritz; the projected
-// b x b problems are solved on the device.  theta_host: nev values; W: (nev, M) rows = eigenvectors.
-int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std::vector<double>& theta_host, PodInfo& info,
-                   int oversample = 12, double tol = 2e-14, int max_iter = 30, double accept = GRAM_ACCEPT) {
-  const int b0 = std::min(M, nev + oversample);
-  int b = b0;  // rows in play: shrinks once the spectrum shows how many pairs the caller can use (see below)
-  Tmp Y, Z, H, St, lam, Yr, Zr, Res, res, Zs, scr, nrm;
-  ROM_TRY(Y.get(ctx, size_t(b) * M));
-  ROM_TRY(Z.get(ctx, size_t(b) * M));
-  ROM_TRY(H.get(ctx, size_t(b) * b));
-  ROM_TRY(St.get(ctx, size_t(b) * b));
-  ROM_TRY(lam.get(ctx, 2 * size_t(b)));
-  ROM_TRY(Yr.get(ctx, size_t(b) * M));
-  ROM_TRY(Zr.get(ctx, size_t(b) * M));
-  ROM_TRY(Res.get(ctx, size_t(b) * M));
-  ROM_TRY(Zs.get(ctx, size_t(b) * M));
-  ROM_TRY(scr.get(ctx, size_t(b) * M));
-  ROM_TRY(nrm.get(ctx, b));
-  double* d_res = lam.p() + b0;
-  ROM_TRY(fill_random(ctx, Y, size_t(b) * M, 0x5eed0000ull + unsigned(b) * 131u + unsigned(M), true));
-  std::vector<double> th(2 * size_t(b0), 0.0);
-  double best = 1e300;
-  int stall = 0;
-  if (b == M) {
-    ROM_TRY(gram_transform(ctx, Y, scr, b, M, SE_WHITEN, 1e-30, 2));  // (the full space: one exact Ritz step below)
-  } else {
-    // Iteration 0 is a plain power step: Y_1 = orthonormalised rows of (Gaussian block) G.  A Rayleigh-Ritz step on a
-    // random block only rotates noise -- it costs a b x b eigenproblem and an orthonormalisation of the start block and
-    // leaves the same subspace.
-    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, M, 1.0, Y, M, G, M, 0.0, Zs, M, "gemm_nt"));
-    ROM_TRY(rom_launch_l2norm(ctx, Zs, b, M, nrm, true));
-    kb_inv<<<unsigned((b + 255) / 256), 256, 0, ctx->stream>>>(nrm, nrm, b);
-    ROM_HIP(hipGetLastError());
-    ROM_TRY(rom_launch_rows_scale(ctx, Zs, b, M, nrm));
-    ROM_TRY(gram_transform(ctx, Zs, scr, b, M, SE_WHITEN, 1e-30, 2));
-    ROM_HIP(hipMemcpyAsync(Y.p(), Zs.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  }
-  for (int it = 0; it < max_iter; ++it) {
-    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, M, 1.0, Y, M, G, M, 0.0, Z, M, "gemm_nt"));   // Z = Y G (G symmetric)
-    ROM_TRY(rom_launch_gemm_nt(ctx, b, b, M, 1.0, Z, M, Y, M, 0.0, H, b, "gemm_nt"));   // H = Y G Y^T
-    ROM_TRY(small_eig(ctx, b, H, b, lam, St, b, SE_EIG, 0.0, false));                   // rows of St: Ritz rotations
-    ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Y, M, 0.0, Yr, M));            // Ritz vectors
-    info.eig_iterations = it + 1;
-    if (b == M) {  // full space: exact after one Ritz step
-      ROM_TRY(download(ctx, lam, th.data(), b));
-      break;
-    }
-    ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Z, M, 0.0, Zr, M));            // G applied to them
-    kb_rows_axpy<<<dim3(unsigned(std::min((M + 255) / 256, 64)), b), 256, 0, ctx->stream>>>(Res, Zr, Yr, lam, -1.0, M);
-    ROM_HIP(hipGetLastError());
-    const int ncheck = std::min(nev, b);
-    ROM_TRY(rom_launch_l2norm(ctx, Res, ncheck, M, d_res, true));
-    ROM_TRY(download(ctx, lam, th.data(), size_t(b0) + ncheck));
-    for (int i = b; i < b0; ++i) th[i] = 0.0;  // (pairs dropped from the block)
-    const double t0 = std::max(std::fabs(th[0]), 1e-300);
-    double worst = 0.0;
-    for (int i = 0; i < ncheck; ++i)
-      if (th[i] > accept * std::fabs(th[0])) worst = std::max(worst, th[b0 + i] / t0);
-    if (worst < 0.7 * best) { best = worst; stall = 0; } else { ++stall; }
-    if (worst <= tol || stall >= 3 || it == max_iter - 1) break;
-    // The caller only takes pairs with theta_i > accept * theta_0.  Once a Rayleigh-Ritz step on an orthonormal block
-    // has shown how many there can be (two orders of magnitude of slack on the threshold), the block is cut down to
-    // those + the oversampling: the rows are Ritz vectors in descending order, so the cut keeps the leading ones.
-    // (A snapshot block with 16 usable pairs out of 50 requested then iterates with 28 rows instead of 62.)
-    {
-      int count = 0;
-      while (count < b && th[count] > 1e-2 * accept * std::fabs(th[0])) ++count;
-      b = std::min(b, std::min(nev, count) + oversample);
-    }
-    kb_next_block<<<dim3(unsigned(std::min((M + 255) / 256, 64)), b), 256, 0, ctx->stream>>>(Zs, Zr, Yr, lam, M);
-    ROM_HIP(hipGetLastError());
-    ROM_TRY(gram_transform(ctx, Zs, scr, b, M, SE_WHITEN, 1e-30, 1));  // (rows are rotated Ritz vectors: nearly orthonormal)
-    ROM_HIP(hipMemcpyAsync(Y.p(), Zs.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  }
-  theta_host.assign(th.begin(), th.begin() + nev);
-  for (int i = b; i < nev; ++i) theta_host[i] = 0.0;
-  const int ncopy = std::min(nev, b);
-  ROM_HIP(hipMemcpyAsync(W, Yr.p(), size_t(ncopy) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  if (ncopy < nev) ROM_HIP(hipMemsetAsync(W + size_t(ncopy) * M, 0, size_t(nev - ncopy) * M * sizeof(double), ctx->stream));
-  return ROM_OK;
-}
-
-// Right singular vectors / singular values of a tall factor given TRANSPOSED, Tt (b x M, ld M): Rayleigh-Ritz rounds on
-// the b x b Gram matrix Tt Tt^T.  The first round rotates the rows towards the singular directions; from then on the
-// Gram matrix is graded and nearly diagonal, where Jacobi resolves the small eigenvalues to high relative accuracy --
-// nothing is lost to the squaring that a single eigen-decomposition of an ungraded Gram matrix would lose.
-// Rt (b x b): accumulated rotation (rows = right singular vectors in the coordinates Tt came in); sig2: b values.
-int tall_svd_rotation(rom_ctx* ctx, double* Tt, int b, int M, double* Rt, double* sig2, int rounds = 3) {
-  Tmp H, St, T2, R2;
-  ROM_TRY(H.get(ctx, size_t(b) * b));
-  ROM_TRY(St.get(ctx, size_t(b) * b));
-  ROM_TRY(T2.get(ctx, size_t(b) * M));
-  ROM_TRY(R2.get(ctx, size_t(b) * b));
-  for (int r = 0; r < rounds; ++r) {
-    ROM_TRY(rom_launch_gemm_nt(ctx, b, b, M, 1.0, Tt, M, Tt, M, 0.0, H, b, "gemm_nt"));
-    ROM_TRY(small_eig(ctx, b, H, b, sig2, St, b, SE_EIG, 0.0));
-    ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Tt, M, 0.0, T2, M));
-    ROM_HIP(hipMemcpyAsync(Tt, T2.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    if (r == 0) {
-      ROM_HIP(hipMemcpyAsync(Rt, St.p(), size_t(b) * b * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    } else {
-      ROM_TRY(rom_launch_gemm_nn(ctx, b, b, b, 1.0, St, b, Rt, b, 0.0, R2, b));
-      ROM_HIP(hipMemcpyAsync(Rt, R2.p(), size_t(b) * b * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    }
-  }
-  return ROM_OK;
-}
-
-// Leading k right singular vectors / singular values of the (M, dim) block X by a randomised range finder with one power
-// iteration: thin GEMMs (2 b M dim flops each) instead of the 2 M^2 dim of a Gram matrix.  Used for the DEFLATED
-// remainder of a snapshot block.  Vs: (b, dim) block, its first k rows are the modes; ss_host: b singular values.
-// The block is DEFLATED IMPLICITLY: X_d = X - Bt^T V with the `found` modes accepted so far (V: found x dim, orthonormal
-// rows; Bt: found x M, row j = X v_j).  Every product with X_d is the product with X followed by a rank-`found`
-// correction (two small GEMMs) -- X itself is never rewritten, which saves a read + write of the whole block per
-// accepted batch of modes.  The rounding error is what the explicit subtraction leaves in X_d as well: eps x sigma_1.
-int sketched_modes(rom_ctx* ctx, const double* X, int M, int64_t dim, const double* V, const double* Bt, int found, int k,
-                   int seed, double* Vs, std::vector<double>& ss_host, int& b_out, PodInfo& info, int oversample = 8,
-                   int power = 1) {
-  const int b = int(std::min<int64_t>(std::min<int64_t>(M, dim), k + oversample));
-  b_out = b;
-  Tmp Om, Y, scr, Tt, Rt, s2, Cc;
-  ROM_TRY(Cc.get(ctx, size_t(b) * std::max(found, 1)));
-  // out (b x ncols, ld ncols... ) -= ((lhs (b x kk) rhs_t^T (found x kk)) ) other: the two correction shapes below
-  auto correct_rows = [&](double* out /* b x dim */, const double* left /* b x M */) -> int {   // out -= (left Bt^T) V
-    if (found == 0) return ROM_OK;
-    ROM_TRY(rom_launch_gemm_nt(ctx, b, found, M, 1.0, left, M, Bt, M, 0.0, Cc, found, "gemm_nt"));
-    return rom_launch_gemm_nn(ctx, b, dim, found, -1.0, Cc, found, V, dim, 1.0, out, dim);
-  };
-  ROM_TRY(Om.get(ctx, size_t(b) * M));
-  ROM_TRY(Y.get(ctx, size_t(b) * dim));
-  ROM_TRY(scr.get(ctx, size_t(b) * dim));
-  ROM_TRY(Tt.get(ctx, size_t(b) * M));
-  ROM_TRY(Rt.get(ctx, size_t(b) * b));
-  ROM_TRY(s2.get(ctx, b));
-  ROM_TRY(fill_random(ctx, Om, size_t(b) * M, 0xabcd0000ull + unsigned(seed) * 7919u + unsigned(b), true));
-  ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Om, M, X, dim, 0.0, Y, dim));                 // Y = Omega X_d
-  ROM_TRY(correct_rows(Y, Om));
-  info.executed += 2.0 * b * M * double(dim);
-  for (int it = 0; it <= power; ++it) {
-    // Q (rank may drop: zero rows).  Before the power step one round is enough: the rows only have to span the sketch
-    // and be aligned with its principal directions -- their residual non-orthogonality (eps x the condition number of
-    // the sketch's Gram matrix) does not change what the power step spans; the basis that is USED is whitened twice
-    ROM_TRY(gram_transform(ctx, Y, scr, b, dim, SE_WHITEN, 1e-26, it == power ? 2 : 1));
-    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, dim, 1.0, Y, dim, X, dim, 0.0, Tt, M, "gemm_nt"));      // Tt = Q X_d^T  (b, M)
-    if (found) {                                                                                  // ... - (Q V^T) Bt
-      ROM_TRY(rom_launch_gemm_nt(ctx, b, found, dim, 1.0, Y, dim, V, dim, 0.0, Cc, found, "gemm_nt"));
-      ROM_TRY(rom_launch_gemm_nn(ctx, b, M, found, -1.0, Cc, found, Bt, M, 1.0, Tt, M));
-    }
-    info.executed += 2.0 * b * M * double(dim) + 4.0 * b * b * double(dim);
-    if (it == power) break;
-    ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Tt, M, X, dim, 0.0, scr, dim));               // Q X_d^T X_d
-    ROM_TRY(correct_rows(scr, Tt));
-    ROM_HIP(hipMemcpyAsync(Y.p(), scr.p(), size_t(b) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    info.executed += 2.0 * b * M * double(dim);
-  }
-  // X ~ T Q: the right singular vectors of the small factor rotate Q into the modes
-  ROM_TRY(tall_svd_rotation(ctx, Tt, b, M, Rt, s2));
-  ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, b, 1.0, Rt, b, Y, dim, 0.0, Vs, dim));                  // modes = R^T Q
-  info.executed += 2.0 * b * b * double(dim);
-  ss_host.resize(b);
-  ROM_TRY(download(ctx, s2, ss_host.data(), b));
-  for (double& v : ss_host) v = std::sqrt(std::max(v, 0.0));
-  return ROM_OK;
-}
-
-}  // namespace
-
-// Leading n right singular vectors / singular values of the (M, dim) block X (overwritten when it is centred).
-// center != 0: subtract the column means first (sklearn PCA.fit).  V: (n, dim) rows = modes, sign convention of
-// sklearn's svd_flip(u_based_decision=False); sigma_host: n singular values (0 for completed modes);
-// info_host (8 doubles, may be null): resolved modes, completed modes, Gram passes, sketch passes, executed flops,
-// useful flops, subspace iterations, stop reason (0 filled, 1 floor reached, 2 budget).
-// rel_floor: modes with sigma <= rel_floor * sigma_1 are not looked for (<= 0 or below the fp64 noise floor of the snapshots,
-// 1e-13: that floor -- what a full LAPACK SVD of the block resolves)
-extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t dim, int n, int center, double rel_floor,
-                          rom_buf* Vb, int64_t v_row0, double* sigma_host, double* info_host) {
-  ROM_CHECK(ctx && Xb && Vb && (sigma_host || n == 0), "rom_pod: null argument");
-  const double floor_rel = rel_floor > NOISE_FLOOR ? rel_floor : NOISE_FLOOR;
-  ROM_CHECK(M >= 1 && dim >= 1 && n >= 0 && x_row0 >= 0 && v_row0 >= 0, "rom_pod: bad sizes");
-  ROM_CHECK(n <= std::min<int64_t>(M, dim), "rom_pod: %d modes requested from a %d x %lld block", n, M, (long long)dim);
-  ROM_CHECK(n + 12 <= SE_MAX, "rom_pod: at most %d modes", SE_MAX - 12);
-  ROM_CHECK(size_t(x_row0 + M) * dim <= Xb->n && size_t(v_row0 + n) * dim <= Vb->n, "rom_pod: buffers too small");
-  double* X = Xb->p + x_row0 * dim;
-  double* V = Vb->p + v_row0 * dim;
-  PodInfo info;
-  if (center) {
-    Tmp mean;
-    ROM_TRY(mean.get(ctx, dim));
-    ROM_TRY(rom_launch_center_rows(ctx, X, M, dim, mean));
-  }
-  for (int i = 0; i < n; ++i) sigma_host[i] = 0.0;
-  int found = 0;
-  double sigma_1 = 0.0;
-  Tmp Bt;  // coefficients of the accepted modes, (n, M): row j = X v_j
-  ROM_TRY(Bt.get(ctx, size_t(std::max(n, 1)) * M));
-  auto deflate = [&](int lo, int take) -> int {
-    // coefficients of the modes V[lo : lo + take] into Bt (row j = X v_j; the modes are orthogonal to the earlier ones, so
-    // X and the deflated block give the same coefficients).  X is not touched: the deflation is implicit (sketched_modes)
-    ROM_TRY(rom_launch_gemm_nt(ctx, take, M, dim, 1.0, V + size_t(lo) * dim, dim, X, dim, 0.0, Bt.p() + size_t(lo) * M, M, "gemm_nt"));
-    info.executed += 2.0 * take * M * double(dim);
-    return ROM_OK;
-  };
-  // the sketch passes run until the request is filled or the spectrum has reached the floor; the budget below only guards
-  // against a pass that makes no progress (every pass accepts at least one mode or ends the loop)
-  const int passes = n + 2;
-  bool at_floor_stop = false;
-  if (n > 0) {
-    Tmp G, W, fac;
-    ROM_TRY(G.get(ctx, size_t(M) * M));
-    ROM_TRY(W.get(ctx, size_t(n) * M));
-    ROM_TRY(fac.get(ctx, n));
-    ROM_TRY(rom_launch_gram(ctx, M, dim, X, dim, G, M));
-    info.gram_passes = 1;
-    info.executed += double(M) * (M + 1) * double(dim);
-    std::vector<double> lam;
-    ROM_TRY(top_eigenpairs(ctx, G, M, n, W, lam, info));
-    G.release();
-    for (double& v : lam) v = std::max(v, 0.0);
-    sigma_1 = lam.empty() ? 0.0 : std::sqrt(lam[0]);
-    int take = 0;
-    while (take < n && take < int(lam.size()) && lam[take] > GRAM_ACCEPT * lam[0] && lam[take] > 0) ++take;
-    if (take) {
-      std::vector<double> inv(take);
-      for (int i = 0; i < take; ++i) inv[i] = 1.0 / std::sqrt(lam[i]);
-      ROM_HIP(hipMemcpyAsync(fac.p(), inv.data(), size_t(take) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-      ROM_HIP(hipStreamSynchronize(ctx->stream));
-      ROM_TRY(rom_launch_rows_scale(ctx, W, take, M, fac));
-      ROM_TRY(rom_launch_gemm_nn(ctx, take, dim, M, 1.0, W, M, X, dim, 0.0, V, dim));   // V = S^-1 W^T Xc
-      info.executed += 2.0 * take * M * double(dim);
-      ROM_TRY(orthonormalize_against(ctx, V, 0, take, dim));
-      ROM_TRY(deflate(0, take));
-      found = take;
-    }
-  }
-  for (int p = 1; p < passes; ++p) {
-    if (found >= n || found == 0) break;
-    Tmp Vs;
-    std::vector<double> ss;
-    int b = 0;
-    // a pass accepts modes over four orders of magnitude -- a dozen of them in a spectrum that decays like the snapshot
-    // blocks' do -- so it asks for at most 16 (+ 8 of oversampling): the thin products scale with b, the small dense
-    // problems with b^3; a spectrum that decays more slowly takes more passes
-    // (a request with hundreds of modes left asks for more per pass: 16 per pass would be n / 16 passes over the block)
-    const int want = std::min(n - found, std::max(16, (n - found) / 4));
-    const int bmax = int(std::min<int64_t>(std::min<int64_t>(M, dim), want + 8));
-    ROM_TRY(Vs.get(ctx, size_t(bmax) * dim));
-    ROM_TRY(sketched_modes(ctx, X, M, dim, V, Bt, found, want, p, Vs, ss, b, info));
-    info.sketch_passes += 1;
-    int take = 0;
-    while (take < std::min(b, want) && ss[take] > SKETCH_ACCEPT * ss[0] && ss[take] > floor_rel * sigma_1) ++take;
-    if (take == 0) {
-      at_floor_stop = b == 0 || ss[0] <= floor_rel * sigma_1;
-      break;
-    }
-    ROM_HIP(hipMemcpyAsync(V + size_t(found) * dim, Vs.p(), size_t(take) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    ROM_TRY(orthonormalize_against(ctx, V, found, take, dim));
-    const bool at_floor = take < b && ss[take] <= floor_rel * sigma_1;
-    ROM_TRY(deflate(found, take));
-    found += take;
-    if (at_floor) {  // the spectrum has reached the floor: nothing left to find
-      at_floor_stop = true;
-      break;
-    }
-  }
-  if (found) {
-    // Rayleigh-Ritz on the collected subspace: X ~ B V  ->  the SVD of B orders / rotates the modes
-    Tmp Rt, s2, Vr;
-    ROM_TRY(Rt.get(ctx, size_t(found) * found));
-    ROM_TRY(s2.get(ctx, found));
-    ROM_TRY(Vr.get(ctx, size_t(found) * dim));
-    ROM_TRY(tall_svd_rotation(ctx, Bt, found, M, Rt, s2));
-    ROM_TRY(rom_launch_gemm_nn(ctx, found, dim, found, 1.0, Rt, found, V, dim, 0.0, Vr, dim));
-    ROM_HIP(hipMemcpyAsync(V, Vr.p(), size_t(found) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    info.executed += 2.0 * found * found * double(dim);
-    std::vector<double> s(found);
-    ROM_TRY(download(ctx, s2, s.data(), found));
-    for (int i = 0; i < found; ++i) sigma_host[i] = std::sqrt(std::max(s[i], 0.0));
-  }
-  if (found < n) {
-    // complete the basis: random directions orthonormalised against the modes; they carry no variance (LAPACK and
-    // scikit-learn return SOME orthonormal directions there too).  Seeded by the count of resolved modes: deterministic.
-    const int rest = n - found;
-    ROM_TRY(rom_complete_orthonormal(ctx, Vb, v_row0, found, rest, dim));
-    info.completed = rest;
-  }
-  info.resolved = found;
-  if (n > 0) ROM_TRY(rom_launch_rows_sign_flip(ctx, V, n, dim));  // svd_flip(u_based_decision=False)
-  ROM_HIP(hipStreamSynchronize(ctx->stream));
-  if (info_host) {
-    info_host[0] = info.resolved;
-    info_host[1] = info.completed;
-    info_host[2] = info.gram_passes;
-    info_host[3] = info.sketch_passes;
-    info_host[4] = info.executed;
-    info_host[5] = double(M) * (M + 1) * double(dim) + 2.0 * n * M * double(dim);
-    info_host[6] = info.eig_iterations;
-    // why the call stopped short of n modes: 0 request filled, 1 the spectrum reached the floor (the completed modes are
-    // not determined by the data), 2 no accepted mode in a pass / pass budget (modes above the floor may be missing)
-    info_host[7] = found >= n ? 0.0 : (at_floor_stop || sigma_1 == 0.0 ? 1.0 : 2.0);
-  }
-  return ROM_OK;
-}
-
-extern "C" int rom_pod(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t dim, int n, int center, rom_buf* Vb,
-                       int64_t v_row0, double* sigma_host, double* info_host) {
-  return rom_pod_ex(ctx, Xb, x_row0, M, dim, n, center, 0.0, Vb, v_row0, sigma_host, info_host);
 }

@@ -52,3 +52,15 @@ __global__ void kb_grow_ahat(double* __restrict__ Ahat, int k, int ld, int j, co
                              const int* __restrict__ degenerate, int it);
 __global__ void kb_galerkin_gap(int M, int n, const double* __restrict__ P, const double* __restrict__ c, double* __restrict__ extra2);
 __global__ void kb_ints_to_doubles(const int* __restrict__ src, double* __restrict__ dst, int n);
+
+// ---- small dense problems and orthonormalisation helpers of rom_basis.hip, shared with rom_pod.hip ------------------
+enum { SE_EIG = 0, SE_WHITEN = 1, SE_LOWDIN = 2 };
+constexpr int SE_LDS_MAX = 96, SE_MAX = 1024;
+__global__ void kb_rows_axpy(double* __restrict__ out, const double* __restrict__ x, const double* __restrict__ y,
+                             const double* __restrict__ f, double s, long long dim);
+int romb_fill_random(rom_ctx* ctx, double* p, size_t n, unsigned long long seed, bool gaussian);
+int romb_small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, int mode, double rel_tol,
+                   bool gram_like = true);
+int romb_pivchol_whiten(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, double rel_tol);
+int romb_gram_transform(rom_ctx* ctx, double* X, double* Y, int b, int64_t dim, int mode, double rel_tol, int rounds);
+int romb_orthonormalize_against(rom_ctx* ctx, double* V, int found, int take, int64_t dim);

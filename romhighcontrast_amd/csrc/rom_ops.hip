@@ -1360,37 +1360,70 @@ extern "C" int rom_rows_scale(rom_ctx* ctx, rom_buf* X, int64_t row0, int rows, 
 }
 
 // sklearn's svd_flip(u_based_decision=False) (PCA call at src/lib/ReducedBasis.py:196): every row is multiplied by
-// the sign of its entry of largest magnitude (first one on ties, like np.argmax).  One workgroup per row.
-__global__ __launch_bounds__(256) void k_rows_sign_flip(double* __restrict__ X, long long dim) {
-  __shared__ double bv[256];
-  __shared__ long long bi[256];
-  double* row = X + blockIdx.x * dim;
+// the sign of its entry of largest magnitude (first one on ties, like np.argmax).  Two launches over (segment, row): the
+// per-segment maxima (value, first position), then every segment reduces the SIGN_SEGS candidates of its row in segment
+// order and flips its part -- a row is spread over the chip instead of being one workgroup's 254-iteration chain.
+constexpr int SIGN_SEGS = 16;
+__global__ __launch_bounds__(256) void k_rows_sign_partial(const double* __restrict__ X, long long dim, double* __restrict__ pv,
+                                                           long long* __restrict__ pi) {
+  __shared__ double bv[4];
+  __shared__ long long bi[4];
+  const double* row = X + blockIdx.y * dim;
+  const long long per = (dim + SIGN_SEGS - 1) / SIGN_SEGS, j0 = blockIdx.x * per, j1 = min(dim, j0 + per);
   double best = -1.0;
-  long long at = 0;
-  for (long long j = threadIdx.x; j < dim; j += blockDim.x) {
+  long long at = j0;
+  for (long long j = j0 + threadIdx.x; j < j1; j += 256) {
     const double v = fabs(row[j]);
     if (v > best) { best = v; at = j; }  // ascending j per thread: keeps the first maximum
   }
-  bv[threadIdx.x] = best;
-  bi[threadIdx.x] = at;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (int(threadIdx.x) < s) {
-      const double o = bv[threadIdx.x + s];
-      const long long oi = bi[threadIdx.x + s];
-      if (o > bv[threadIdx.x] || (o == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = o; bi[threadIdx.x] = oi; }
-    }
-    __syncthreads();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ob = __shfl_down(best, o, 64);
+    const long long oa = __shfl_down(at, o, 64);
+    if (ob > best || (ob == best && oa < at)) { best = ob; at = oa; }
   }
-  const bool neg = row[bi[0]] < 0.0;
-  __syncthreads();  // everybody has read the pivot before anybody flips it
-  if (neg)
-    for (long long j = threadIdx.x; j < dim; j += blockDim.x) row[j] = -row[j];
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = at; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < at)) { best = bv[w]; at = bi[w]; }
+    pv[blockIdx.y * SIGN_SEGS + blockIdx.x] = best;
+    pi[blockIdx.y * SIGN_SEGS + blockIdx.x] = at;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rows_sign_apply(double* __restrict__ X, long long dim, const double* __restrict__ pv,
+                                                         const long long* __restrict__ pi, const double* __restrict__ pivot_vals) {
+  double* row = X + blockIdx.y * dim;
+  double best = -1.0;
+  int seg = 0;
+  for (int q = 0; q < SIGN_SEGS; ++q) {  // segments ascend with j: '>' keeps the first maximum
+    const double v = pv[blockIdx.y * SIGN_SEGS + q];
+    if (v > best) { best = v; seg = q; }
+  }
+  if (!(pivot_vals[blockIdx.y * SIGN_SEGS + seg] < 0.0)) return;
+  const long long per = (dim + SIGN_SEGS - 1) / SIGN_SEGS, j0 = blockIdx.x * per, j1 = min(dim, j0 + per);
+  for (long long j = j0 + threadIdx.x; j < j1; j += 256) row[j] = -row[j];
+}
+
+// signed value at each segment's candidate position (read before any segment flips)
+__global__ void k_rows_sign_pivots(const double* __restrict__ X, long long dim, const long long* __restrict__ pi,
+                                   double* __restrict__ pivot_vals, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) pivot_vals[i] = X[(i / SIGN_SEGS) * dim + pi[i]];
 }
 
 int rom_launch_rows_sign_flip(rom_ctx* ctx, double* X, int rows, int64_t dim) {
   if (rows <= 0) return ROM_OK;
-  k_rows_sign_flip<<<rows, 256, 0, ctx->stream>>>(X, dim);
+  double* ws = nullptr;
+  ROM_TRY(rom_ctx_scratch(ctx, size_t(3) * rows * SIGN_SEGS, &ws));
+  double* pv = ws;
+  long long* pi = reinterpret_cast<long long*>(ws + size_t(rows) * SIGN_SEGS);
+  double* piv = ws + size_t(2) * rows * SIGN_SEGS;
+  const dim3 grid(SIGN_SEGS, unsigned(rows));
+  k_rows_sign_partial<<<grid, 256, 0, ctx->stream>>>(X, dim, pv, pi);
+  k_rows_sign_pivots<<<unsigned((rows * SIGN_SEGS + 255) / 256), 256, 0, ctx->stream>>>(X, dim, pi, piv, rows * SIGN_SEGS);
+  k_rows_sign_apply<<<grid, 256, 0, ctx->stream>>>(X, dim, pv, pi, piv);
   ROM_HIP(hipGetLastError());
   return ROM_OK;
 }
