@@ -15,6 +15,7 @@
 #include "rom_ops.h"
 
 #include "rom_basis_int.h"
+#include "rom_small_dense.h"
 
 // =====================================================================================================================
 // small elementwise / indexing kernels
@@ -101,15 +102,6 @@ static int transpose(rom_ctx* ctx, double* dst, long long ldd, const double* src
 
 // threads of the eigen-solver's workgroup: a template parameter (small matrices are latency bound per round: fewer waves,
 // cheaper barriers)
-
-// 1 / sqrt(x) to full precision from the hardware estimate (two Newton steps): the cosine of a rotation must satisfy
-// c^2 (1 + t^2) = 1 to rounding, or the accumulated eigenvector rows drift from orthonormality
-__device__ inline double se_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  y = y * (1.5 - 0.5 * x * y * y);
-  return y;
-}
 
 // GWS: matrix and eigenvector rows in the global workspace (n > SE_LDS_MAX); else in LDS -- a compile-time choice, so that the
 // LDS form addresses them with ds_read / ds_write (a pointer that may be either is a FLAT access: several times the latency)
@@ -412,180 +404,32 @@ __global__ __launch_bounds__(SE_TPB) void kb_small_eig(int n, const double* __re
   }
 }
 
-// The same cyclic Jacobi for n <= 32, eigenvectors only (SE_EIG), as ONE wave with a branch-free round: the round-robin
-// pairs of a round are at most 16, so the 2 x 2 blocks (<= 256) and the eigenvector items (<= 512) of a round are 4 and 8
-// per lane with an item -> (pair, pair / column) map that never changes (divided out once); every item loads its rotation
-// (c, s) and its index pair unconditionally -- (1, 0) is an exact identity, so pairs that do not rotate need no branch --
-// all loads of a phase are issued before its first store, and nothing in the round is a workgroup barrier.  A round is
-// three LDS round trips + the angle arithmetic instead of a dozen dependent ones: the eigenproblems of the POD's
-// Rayleigh-Ritz steps (b = 20 ... 32, graded, 5 ... 10 sweeps) are latency chains of a few hundred rounds each.
-// Same rotation criterion, same sweep order, same results as kb_small_eig.
-template <int NT>
-__global__ __launch_bounds__(NT) void kb_jacobi32(int n, const double* __restrict__ A, int lda, double* __restrict__ lam,
-                                                  double* __restrict__ T, int ldt, int gram_like) {
-  constexpr int LD = 33;
-  __shared__ double As[32 * LD], Vt[32 * LD];
-  __shared__ double2 csv[16];
-  __shared__ int2 pq[16];
-  __shared__ double nu2[32], ev[32];
-  __shared__ int perm[32];
-  __shared__ int s_any;
-  constexpr int BI = 256 / NT, VI = 512 / NT;   // 2 x 2 blocks / eigenvector items of a lane
-  const int t = threadIdx.x, ne = n + (n & 1), half = ne / 2;
+// Eigen-decomposition (SE_EIG) of a symmetric matrix of order n <= 32: jacobi32_run (rom_small_dense.h), 256 threads.
+// The eigenproblems of the POD's Rayleigh-Ritz steps (b = 20 ... 32, graded, 5 ... 10 sweeps) are latency chains of a few
+// hundred rounds each; same rotation criterion, same sweep order, same results as kb_small_eig.
+__global__ __launch_bounds__(256) void kb_jacobi32(int n, const double* __restrict__ A, int lda, double* __restrict__ lam,
+                                                   double* __restrict__ T, int ldt, int gram_like) {
+  __shared__ Jacobi32Lds L;
+  __shared__ double red[4];
+  const int t = threadIdx.x;
   double dmax = 0.0;
-  for (int idx = t; idx < n * n; idx += NT) {
+  for (int idx = t; idx < n * n; idx += 256) {
     const int r = idx / n, c = idx - r * n;
     const double v = 0.5 * (A[size_t(r) * lda + c] + A[size_t(c) * lda + r]);
-    As[r * LD + c] = v;
-    Vt[r * LD + c] = r == c ? 1.0 : 0.0;
+    L.As[r * J32_LD + c] = v;
+    L.Vt[r * J32_LD + c] = r == c ? 1.0 : 0.0;
     if (r == c) dmax = fmax(dmax, fabs(v));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
-  if (NT > 64) {
-    if ((t & 63) == 0) ev[t >> 6] = dmax;
-    __syncthreads();
-    dmax = ev[0];
-    for (int w = 1; w < NT / 64; ++w) dmax = fmax(dmax, ev[w]);
-  }
+  if ((t & 63) == 0) red[t >> 6] = dmax;
   __syncthreads();
-  if (t < n) nu2[t] = gram_like ? fabs(As[t * LD + t]) : dmax;
-  // items of this lane (fixed for the whole call)
-  int bk[BI], bl[BI], vk[VI], vj[VI];
-  bool bon[BI], von[VI];
-#pragma unroll
-  for (int u = 0; u < BI; ++u) {
-    const int idx = u * NT + t;
-    bon[u] = idx < half * half;
-    bk[u] = bon[u] ? idx / half : 0;
-    bl[u] = bon[u] ? idx - bk[u] * half : 0;
-  }
-#pragma unroll
-  for (int u = 0; u < VI; ++u) {
-    const int idx = u * NT + t;
-    von[u] = idx < half * n;
-    vk[u] = von[u] ? idx / n : 0;
-    vj[u] = von[u] ? idx - vk[u] * n : 0;
-  }
-  const double tol = double(n > 8 ? n : 8) * 1.1e-16, tol2 = tol * tol, floor_abs = fmax(1e-300, 1e-40 * dmax);
-  __syncthreads();
-  for (int sweep = 0; sweep < 40; ++sweep) {
-    bool rotated = false;
-    for (int r = 0; r < ne - 1; ++r) {
-      if (t < half) {
-        int p = ne - 1, q = r;
-        if (t != 0) {
-          p = r + t;
-          if (p >= ne - 1) p -= ne - 1;
-          q = r - t;
-          if (q < 0) q += ne - 1;
-        }
-        if (p > q) { const int x = p; p = q; q = x; }
-        double c = 1.0, s = 0.0;
-        if (q < n) {
-          const double app = As[p * LD + p], aqq = As[q * LD + q], apq = As[p * LD + q];
-          const double np2 = nu2[p], nq2 = nu2[q], apq2 = apq * apq;
-          if (apq2 > tol2 * fabs(app * aqq) && fabs(apq) > floor_abs && apq2 > tol2 * np2 * nq2) {
-            const double a = aqq - app, bb = 2.0 * apq;
-            const double tt = (a >= 0 ? bb : -bb) / (fabs(a) + sqrt(a * a + bb * bb));
-            c = se_rsqrt(1.0 + tt * tt);
-            s = tt * c;
-            nu2[p] = c * c * np2 + s * s * nq2;
-            nu2[q] = s * s * np2 + c * c * nq2;
-            rotated = true;
-          }
-        } else {
-          q = -1;
-        }
-        csv[t] = make_double2(c, s);
-        pq[t] = make_int2(p, q);
-      }
-      __syncthreads();
-      // A <- J^T A J as disjoint 2 x 2 blocks (k, l): rows (p_k, q_k) x columns (p_l, q_l) become R_k B R_l^T
-      {
-        double o00[BI], o01[BI], o10[BI], o11[BI];
-        int a00[BI], a01[BI], a10[BI], a11[BI];
-        bool w01[BI], w10[BI], w11[BI];
-#pragma unroll
-        for (int u = 0; u < BI; ++u) {
-          const double2 rk = csv[bk[u]], rl = csv[bl[u]];
-          const int2 ik = pq[bk[u]], il = pq[bl[u]];
-          const bool vk_ = ik.y >= 0, vl_ = il.y >= 0;
-          const int pk = ik.x, qk = vk_ ? ik.y : ik.x, pl = il.x, ql = vl_ ? il.y : il.x;
-          a00[u] = pk * LD + pl;
-          a01[u] = pk * LD + ql;
-          a10[u] = qk * LD + pl;
-          a11[u] = qk * LD + ql;
-          const double b00 = As[a00[u]], b01 = vl_ ? As[a01[u]] : 0.0;
-          const double b10 = vk_ ? As[a10[u]] : 0.0, b11 = (vk_ && vl_) ? As[a11[u]] : 0.0;
-          const double ck = rk.x, sk = rk.y, cl = rl.x, sl = rl.y;
-          const double r00 = ck * b00 - sk * b10, r01 = ck * b01 - sk * b11;
-          const double r10 = sk * b00 + ck * b10, r11 = sk * b01 + ck * b11;
-          o00[u] = cl * r00 - sl * r01;
-          o01[u] = sl * r00 + cl * r01;
-          o10[u] = cl * r10 - sl * r11;
-          o11[u] = sl * r10 + cl * r11;
-          w01[u] = bon[u] && vl_;
-          w10[u] = bon[u] && vk_;
-          w11[u] = bon[u] && vk_ && vl_;
-        }
-        // eigenvector rows: Vt <- J^T Vt
-        double op[VI], oq[VI];
-        int ap[VI], aq[VI];
-        bool wq[VI];
-#pragma unroll
-        for (int u = 0; u < VI; ++u) {
-          const double2 rk = csv[vk[u]];
-          const int2 ik = pq[vk[u]];
-          const bool vq = ik.y >= 0;
-          ap[u] = ik.x * LD + vj[u];
-          aq[u] = (vq ? ik.y : ik.x) * LD + vj[u];
-          const double vp = Vt[ap[u]], vqv = Vt[aq[u]];
-          op[u] = rk.x * vp - rk.y * vqv;
-          oq[u] = rk.y * vp + rk.x * vqv;
-          wq[u] = von[u] && vq;
-        }
-#pragma unroll
-        for (int u = 0; u < BI; ++u) {
-          if (bon[u]) As[a00[u]] = o00[u];
-          if (w01[u]) As[a01[u]] = o01[u];
-          if (w10[u]) As[a10[u]] = o10[u];
-          if (w11[u]) As[a11[u]] = o11[u];
-        }
-#pragma unroll
-        for (int u = 0; u < VI; ++u) {
-          if (von[u]) Vt[ap[u]] = op[u];   // (a pair with the dummy index: (c, s) = (1, 0), the row keeps its values)
-          if (wq[u]) Vt[aq[u]] = oq[u];
-        }
-      }
-      __syncthreads();
-    }
-    if (NT == 64) {
-      if (!__any(rotated)) break;
-    } else {
-      if (t < 64) {
-        const int any = __any(rotated);
-        if (t == 0) s_any = any;
-      }
-      __syncthreads();
-      const int any = s_any;
-      __syncthreads();
-      if (!any) break;
-    }
-  }
-  if (t < n) ev[t] = As[t * LD + t];
-  __syncthreads();
-  if (t < n) {
-    int rank = 0;
-    const double v = ev[t];
-    for (int j = 0; j < n; ++j) rank += (ev[j] > v || (ev[j] == v && j < t)) ? 1 : 0;
-    perm[rank] = t;
-  }
-  __syncthreads();
-  if (t < n) lam[t] = ev[perm[t]];
-  for (int idx = t; idx < n * n; idx += NT) {
+  dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  jacobi32_run<256>(n, L, gram_like, dmax);
+  if (t < n) lam[t] = L.ev[L.perm[t]];
+  for (int idx = t; idx < n * n; idx += 256) {
     const int r = idx / n, c = idx - r * n;
-    T[size_t(r) * ldt + c] = Vt[perm[r] * LD + c];
+    T[size_t(r) * ldt + c] = L.Vt[L.perm[r] * J32_LD + c];
   }
 }
 
@@ -734,7 +578,7 @@ int romb_small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, d
     ROM_PROF(ctx, nm, 30.0 * n * n * n, 16.0 * n * n);
     // n <= 32: ONE wave -- no barrier between the phases of a round and the item map divided out once: 5x the rounds per
     // microsecond of the 512-thread form on the same rotations (same results)
-    if (n <= 32 && mode == SE_EIG) kb_jacobi32<256><<<1, 256, 0, ctx->stream>>>(n, A, lda, lam, T, ldt, gram_like ? 1 : 0);
+    if (n <= 32 && mode == SE_EIG) kb_jacobi32<<<1, 256, 0, ctx->stream>>>(n, A, lda, lam, T, ldt, gram_like ? 1 : 0);
     else if (!gws) kb_small_eig<512, false><<<1, 512, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws, ns_ws);
     else kb_small_eig<512, true><<<1, 512, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws, ns_ws);
   }

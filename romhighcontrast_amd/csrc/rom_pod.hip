@@ -8,9 +8,11 @@
 #include <cstring>
 #include <vector>
 
+#include "rom_mma.h"
 #include "rom_ops.h"
 
 #include "rom_basis_int.h"
+#include "rom_small_dense.h"
 
 // =====================================================================================================================
 // POD (the PCA fit of ReducedBasisPCA.build, src/lib/ReducedBasis.py:189-200)
@@ -54,7 +56,6 @@ __global__ __launch_bounds__(1024) void kp_pivchol_lowrank(int M, const double* 
                                                            double* __restrict__ out) {
   __shared__ double red_v[16];
   __shared__ int red_i[16];
-  __shared__ double lp[128];
   __shared__ double s_best;
   __shared__ int s_piv;
   const int t = threadIdx.x;
@@ -92,12 +93,11 @@ __global__ __launch_bounds__(1024) void kp_pivchol_lowrank(int M, const double* 
     if (!(piv > tol * first) || !(piv > 0.0)) { by_tol = 1; break; }
     // (slow decay: after k steps the pivots have fallen by piv / first; at that rate tol is more than rcap steps away)
     if ((k & 15) == 0 && k >= 16 && log(piv / first) * double(rcap) > log(tol) * double(k)) break;
-    if (t < k && t < 128) lp[t] = Lt[size_t(t) * M + p];
-    __syncthreads();
     const double s = 1.0 / sqrt(piv);
     for (int i = t; i < M; i += 1024) {
       double c = G[size_t(p) * ldg + i];
-      for (int j = 0; j < k; ++j) c -= Lt[size_t(j) * M + i] * lp[j];
+      // (the pivot's own entries Lt[j][p] are wave-uniform loads issued with the column's: one latency, no LDS stage)
+      for (int j = 0; j < k; ++j) c -= Lt[size_t(j) * M + i] * Lt[size_t(j) * M + p];
       c = (i == p) ? sqrt(piv) : c * s;
       Lt[size_t(k) * M + i] = c;
       dwork[i] = (i == p) ? -1e300 : dwork[i] - c * c;
@@ -134,6 +134,218 @@ __global__ void kp_scale_eigvec_rows(double* __restrict__ W, long long M, const 
   for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < M; j += (long long)gridDim.x * blockDim.x) row[j] *= a;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused small kernels of the sketch passes.  A pass is four thin products over the snapshot block plus ~70 small dense
+// operations on b <= 32 rows; launched one by one (Gram product, split-K reduction, mirror, factorisation, apply, copy
+// back ...) they cost more than the products.  Two kernels replace most of them:
+//   kp_combine_rows  OUT = T1 Y + alpha2 T2 V2 for row blocks of any length, in place when OUT == Y (applies a transform,
+//                    subtracts a projection, lifts modes: no scratch block, no copy back)
+//   kp_tall_svd      the Rayleigh-Ritz rounds on a b x M factor (Gram, Jacobi, rotation, accumulated rotation), one
+//                    workgroup from the first round to the last
+// ---------------------------------------------------------------------------------------------------------------------
+// OUT (bo x ncols) = T1 (bo x b1) Y (b1 x ncols) + alpha2 T2 (bo x b2) V2 (b2 x ncols).  T1 == nullptr: the identity
+// (bo == b1).  OUT may be Y: a thread owns a column and reads all of its inputs before it writes.  Coefficients are staged
+// through LDS in chunks of KC input rows, [k][BO] so that the BO coefficients of an input row are one broadcast run.
+template <int BO>
+__global__ __launch_bounds__(256) void kp_combine_rows(int bo, int b1, int b2, const double* __restrict__ T1, int ldt1,
+                                                       const double* __restrict__ T2, int ldt2, double alpha2,
+                                                       const double* Y, long long ldy, const double* __restrict__ V2, long long ldv,
+                                                       double* OUT, long long ldo, long long ncols) {
+  constexpr int KC = 32;
+  __shared__ double Tc[KC * BO];
+  const long long j = blockIdx.x * 256LL + threadIdx.x;
+  const bool on = j < ncols;
+  double acc[BO];
+#pragma unroll
+  for (int i = 0; i < BO; ++i) acc[i] = 0.0;
+  if (!T1) {
+#pragma unroll
+    for (int i = 0; i < BO; ++i)
+      if (i < bo && on) acc[i] = Y[i * ldy + j];
+  }
+  const int ktot = (T1 ? b1 : 0) + b2;
+  for (int k0 = 0; k0 < ktot; k0 += KC) {
+    const int kc = min(KC, ktot - k0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < KC * BO; idx += 256) {
+      const int k = idx / BO, i = idx - k * BO, kg = k0 + k;
+      double v = 0.0;
+      if (k < kc && i < bo) {
+        if (T1 && kg < b1) v = T1[i * ldt1 + kg];
+        else v = alpha2 * T2[i * ldt2 + (kg - (T1 ? b1 : 0))];
+      }
+      Tc[idx] = v;
+    }
+    __syncthreads();
+    if (on) {
+      // all input rows of the chunk in flight before the first product (a column's inputs are one latency, not kc of them)
+      double x[KC];
+#pragma unroll
+      for (int u = 0; u < KC; ++u) {
+        const int kg = k0 + u;
+        x[u] = 0.0;
+        if (u < kc) x[u] = (T1 && kg < b1) ? Y[kg * ldy + j] : V2[(kg - (T1 ? b1 : 0)) * ldv + j];
+      }
+#pragma unroll
+      for (int u = 0; u < KC; ++u) {
+        if (u < kc) {
+          const double* tc = Tc + u * BO;
+#pragma unroll
+          for (int i = 0; i < BO; ++i) acc[i] += tc[i] * x[u];
+        }
+      }
+    }
+  }
+  if (on) {
+#pragma unroll
+    for (int i = 0; i < BO; ++i)
+      if (i < bo) OUT[i * ldo + j] = acc[i];
+  }
+}
+
+// Rayleigh-Ritz rounds on a tall factor given TRANSPOSED, Tt (b x M, ld M, b <= 32), one workgroup of 256 threads:
+// per round  H = Tt Tt^T (MFMA, one 16 x 16 output block per wave),  H = S^T diag(sig2) S (jacobi32_run),  Tt <- S Tt,
+// Rt <- S Rt.  The first round rotates the rows towards the singular directions; from then on H is graded and nearly
+// diagonal, where Jacobi resolves the small eigenvalues to high relative accuracy.  Out: Rt (b x b), sig2 (b), Tt rotated.
+__global__ __launch_bounds__(256) void kp_tall_svd(int b, int M, double* __restrict__ Tt, int rounds, double* __restrict__ Rt,
+                                                   double* __restrict__ sig2) {
+  __shared__ Jacobi32Lds L;
+  __shared__ double St[32 * J32_LD], Rs[32 * J32_LD], Rn[32 * J32_LD];
+  __shared__ double Hp[4 * 3 * 256];   // partial H blocks of the four waves
+  __shared__ double red[4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int fr = lane & 15, kq = lane >> 4;
+  for (int idx = t; idx < 32 * J32_LD; idx += 256) {
+    Rs[idx] = 0.0;
+    St[idx] = 0.0;   // (columns behind b stay zero: the rotation below runs over 32)
+  }
+  __syncthreads();
+  if (t < b) Rs[t * J32_LD + t] = 1.0;
+  for (int round = 0; round < rounds; ++round) {
+    // H = Tt Tt^T: wave w takes the columns [w Mq, (w + 1) Mq) of Tt for the three 16 x 16 blocks (0,0), (1,0), (1,1) --
+    // a quarter of the loads per wave of a block-per-wave split, 16 k-steps (32 loads) in flight; partial blocks are
+    // added up over the waves in wave order
+    {
+      const int Mq = ((M + 3) / 4 + 3) / 4 * 4, kb0 = w * Mq, kb1 = min(M, kb0 + Mq);
+      const bool v0 = fr < b, v1 = 16 + fr < b;
+      const double* p0 = Tt + size_t(v0 ? fr : 0) * M + kq;
+      const double* p1 = Tt + size_t(v1 ? 16 + fr : 0) * M + kq;
+      d4_t h00 = d4_t{0.0, 0.0, 0.0, 0.0}, h10 = h00, h11 = h00;
+      for (int k = kb0; k < kb1; k += 64) {
+        double a0[16], a1[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int kk = k + 4 * u + kq;
+          a0[u] = (v0 && kk < kb1) ? p0[k + 4 * u] : 0.0;
+          a1[u] = (v1 && kk < kb1) ? p1[k + 4 * u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          h00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], a0[u], h00, 0, 0, 0);
+          h10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], a0[u], h10, 0, 0, 0);
+          h11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], a1[u], h11, 0, 0, 0);
+        }
+      }
+      double* hp = Hp + w * (3 * 256);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int e = ((lane >> 4) + 4 * g) * 16 + (lane & 15);
+        hp[e] = h00[g];
+        hp[256 + e] = h10[g];
+        hp[512 + e] = h11[g];
+      }
+    }
+    __syncthreads();
+    for (int idx = t; idx < 3 * 256; idx += 256) {
+      const int blk = idx >> 8, e = idx & 255, i = e >> 4, j = e & 15;
+      const double s = ((Hp[idx] + Hp[768 + idx]) + Hp[2 * 768 + idx]) + Hp[3 * 768 + idx];
+      const int r = (blk == 0 ? 0 : 16) + i, c = (blk == 2 ? 16 : 0) + j;
+      if (r < b && c < b) {
+        L.As[r * J32_LD + c] = s;
+        if (blk == 1) L.As[c * J32_LD + r] = s;
+      }
+    }
+    __syncthreads();
+    double dmax = 0.0;
+    for (int idx = t; idx < b * b; idx += 256) {
+      const int r = idx / b, c = idx - r * b;
+      L.Vt[r * J32_LD + c] = r == c ? 1.0 : 0.0;
+      if (r == c) dmax = fmax(dmax, fabs(L.As[r * J32_LD + r]));
+    }
+    // (symmetrise: the two triangles come from different waves with the same products in the same order -- equal bits)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+    if (lane == 0) red[w] = dmax;
+    __syncthreads();
+    dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    jacobi32_run<256>(b, L, 1, dmax);
+    for (int idx = t; idx < b * b; idx += 256) {
+      const int r = idx / b, c = idx - r * b;
+      St[r * J32_LD + c] = L.Vt[L.perm[r] * J32_LD + c];
+    }
+    __syncthreads();
+    // Rt <- S Rt
+    for (int idx = t; idx < b * b; idx += 256) {
+      const int r = idx / b, c = idx - r * b;
+      double s = 0.0;
+      for (int k = 0; k < b; ++k) s += St[r * J32_LD + k] * Rs[k * J32_LD + c];
+      Rn[r * J32_LD + c] = s;
+    }
+    // Tt <- S Tt on the matrix cores: a wave owns 16-column blocks of Tt (all b rows of them: read before written), the
+    // A operand (S, from LDS) is the same for every block and stays in registers, two blocks in flight
+    {
+      double sa[2][8];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) sa[rb][ks] = St[(rb * 16 + fr) * J32_LD + 4 * ks + kq];
+      const int ncb = (M + 15) / 16;
+      for (int cb = w; cb < ncb; cb += 8) {
+        double xb[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = (cb + 4 * h) * 16 + fr;
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            const int k = 4 * ks + kq;
+            xb[h][ks] = (k < b && j < M) ? Tt[size_t(k) * M + j] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          d4_t o0 = d4_t{0.0, 0.0, 0.0, 0.0}, o1 = o0;
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[0][ks], xb[h][ks], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[1][ks], xb[h][ks], o1, 0, 0, 0);
+          }
+          const int j = (cb + 4 * h) * 16 + (lane & 15);
+          if (j < M) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int r = (lane >> 4) + 4 * g;
+              if (r < b) Tt[size_t(r) * M + j] = o0[g];
+              if (16 + r < b) Tt[size_t(16 + r) * M + j] = o1[g];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = t; idx < b * b; idx += 256) {
+      const int r = idx / b, c = idx - r * b;
+      Rs[r * J32_LD + c] = Rn[r * J32_LD + c];
+    }
+    __syncthreads();
+  }
+  for (int idx = t; idx < b * b; idx += 256) {
+    const int r = idx / b, c = idx - r * b;
+    Rt[r * b + c] = Rs[r * J32_LD + c];
+  }
+  if (t < b) sig2[t] = L.ev[L.perm[t]];
+}
+
 namespace {
 
 constexpr double GRAM_ACCEPT = 1e-10;    // eigenvalues of a Gram matrix are taken down to this fraction of its largest one
@@ -157,8 +369,8 @@ constexpr double LOWRANK_RESIDUAL = 2e-14;  // accepted ||G - L L^T|| (bounded b
 // against the eigenpairs of G itself is that of a perturbation of norm <= trace(remaining diagonal), which the kernel
 // reports; the caller falls back to the subspace iteration when that bound is above LOWRANK_RESIDUAL x theta_0 or the
 // factor did not end within LOWRANK_CAP steps (a slowly decaying spectrum).  done = 1 on success.
-int lowrank_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std::vector<double>& theta_host, PodInfo& info,
-                       int& done) {
+int lowrank_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std::vector<double>& theta_host, double* theta_dev,
+                       PodInfo& info, int& done) {
   done = 0;
   const int rcap = std::min(M, LOWRANK_CAP);
   if (M <= rcap) return ROM_OK;  // (the full space: one exact Ritz step of the general path)
@@ -190,6 +402,8 @@ int lowrank_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W,
   ROM_HIP(hipGetLastError());
   ROM_HIP(hipMemcpyAsync(W, Wr.p(), size_t(ncopy) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   if (ncopy < nev) ROM_HIP(hipMemsetAsync(W + size_t(ncopy) * M, 0, size_t(nev - ncopy) * M * sizeof(double), ctx->stream));
+  ROM_HIP(hipMemsetAsync(theta_dev, 0, size_t(nev) * sizeof(double), ctx->stream));
+  ROM_HIP(hipMemcpyAsync(theta_dev, lam.p(), size_t(ncopy) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   theta_host.assign(nev, 0.0);
   for (int i = 0; i < ncopy; ++i) theta_host[i] = std::max(th[i], 0.0);
   info.eig_iterations = 0;
@@ -199,13 +413,13 @@ int lowrank_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W,
 }
 
 // Leading nev eigenpairs of the symmetric PSD matrix G (M x M) by subspace iteration with Rayleigh-Ritz; the projected
-// b x b problems are solved on the device.  theta_host: nev values; W: (nev, M) rows = eigenvectors.
-int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std::vector<double>& theta_host, PodInfo& info,
+// b x b problems are solved on the device.  theta_host / theta_dev: nev values (host / device); W: (nev, M) rows = eigenvectors.
+int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std::vector<double>& theta_host, double* theta_dev,
+                   PodInfo& info,
                    int oversample = 12, double tol = 2e-14, int max_iter = 30, double accept = GRAM_ACCEPT) {
   {
-    static const bool no_lowrank = getenv("ROMHC_POD_NO_LOWRANK") != nullptr;   // dev A/B switch
     int done = 0;
-    if (!no_lowrank) ROM_TRY(lowrank_eigenpairs(ctx, G, M, nev, W, theta_host, info, done));
+    ROM_TRY(lowrank_eigenpairs(ctx, G, M, nev, W, theta_host, theta_dev, info, done));
     if (done) return ROM_OK;
   }
   const int b0 = std::min(M, nev + oversample);
@@ -281,8 +495,63 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
   theta_host.assign(th.begin(), th.begin() + nev);
   for (int i = b; i < nev; ++i) theta_host[i] = 0.0;
   const int ncopy = std::min(nev, b);
+  ROM_HIP(hipMemsetAsync(theta_dev, 0, size_t(nev) * sizeof(double), ctx->stream));
+  ROM_HIP(hipMemcpyAsync(theta_dev, lam.p(), size_t(ncopy) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   ROM_HIP(hipMemcpyAsync(W, Yr.p(), size_t(ncopy) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   if (ncopy < nev) ROM_HIP(hipMemsetAsync(W + size_t(ncopy) * M, 0, size_t(nev - ncopy) * M * sizeof(double), ctx->stream));
+  return ROM_OK;
+}
+
+// ---- launchers of the fused kernels --------------------------------------------------------------------------------
+constexpr int FUSED_ROWS = 32;   // row blocks up to this size take the fused kernels (one Jacobi / Cholesky wave, LDS resident)
+
+// OUT (bo x ncols) = T1 Y + alpha2 T2 V2 (see kp_combine_rows); bo <= 64
+int combine_rows(rom_ctx* ctx, int bo, int b1, const double* T1, int ldt1, int b2, const double* T2, int ldt2, double alpha2,
+                 const double* Y, int64_t ldy, const double* V2, int64_t ldv, double* OUT, int64_t ldo, int64_t ncols) {
+  if (bo <= 0 || ncols <= 0) return ROM_OK;
+  ROM_CHECK(bo <= 64, "combine_rows: %d output rows", bo);
+  const unsigned grid = unsigned((ncols + 255) / 256);
+  ROM_PROF(ctx, "combine_rows", 2.0 * bo * ((T1 ? b1 : 0) + b2) * double(ncols), 8.0 * double(ncols) * (bo + (T1 ? b1 : bo) + b2));
+  if (bo <= 32) kp_combine_rows<32><<<grid, 256, 0, ctx->stream>>>(bo, b1, b2, T1, ldt1, T2, ldt2, alpha2, Y, ldy, V2, ldv, OUT, ldo, ncols);
+  else kp_combine_rows<64><<<grid, 256, 0, ctx->stream>>>(bo, b1, b2, T1, ldt1, T2, ldt2, alpha2, Y, ldy, V2, ldv, OUT, ldo, ncols);
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// rows of X (b x dim) <- orthonormal rows spanning its numerical row space, graded, zero rows behind the rank (the
+// whitening of romb_gram_transform with SE_WHITEN): per round the Gram product + its split-K sum, the pivoted Cholesky,
+// the transform in place (no scratch block, no copy back).  Tm: b x b, lam: b (device scratch of the caller).
+// (Measured and dropped: ONE launch for Gram matrix + factorisation -- the last split-K workgroup to arrive adds up and
+// factorises: 110-160 us against 16 + 5 + 40 for the three launches, the device-scope release of 450 workgroups is a
+// write-back of an XCD's L2 each; the pivoted Cholesky as one wave without barriers: 45-100 us against 30-55 for the
+// 256-thread kernel -- a lone wave pays every LDS round trip in full.)
+int whiten_rows(rom_ctx* ctx, double* X, int b, int64_t dim, double rel_tol, int rounds, double* Tm, double* lam) {
+  if (b <= 0) return ROM_OK;
+  if (b > FUSED_ROWS) {
+    Tmp scr;
+    ROM_TRY(scr.get(ctx, size_t(b) * dim));
+    return romb_gram_transform(ctx, X, scr, b, dim, SE_WHITEN, rel_tol, rounds);
+  }
+  Tmp G;
+  ROM_TRY(G.get(ctx, size_t(b) * b));
+  for (int r = 0; r < rounds; ++r) {
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, b, dim, 1.0, X, dim, X, dim, 0.0, G, b, "gram_small"));
+    ROM_TRY(romb_pivchol_whiten(ctx, b, G, b, lam, Tm, b, r == 0 ? rel_tol : 1e-8));
+    ROM_TRY(combine_rows(ctx, b, b, Tm, b, 0, nullptr, 0, 0.0, X, dim, nullptr, 0, X, dim, dim));
+  }
+  return ROM_OK;
+}
+
+// nearly orthonormal rows X (b x dim) <- (X X^T)^(-1/2) X in place; T_out (b x b, device): the transform that was applied
+int lowdin_rows(rom_ctx* ctx, double* X, int b, int64_t dim, double* G, double* lam, double* T_out) {
+  if (b <= 0) return ROM_OK;
+  ROM_TRY(rom_launch_gram(ctx, b, dim, X, dim, G, b));
+  ROM_TRY(romb_small_eig(ctx, b, G, b, lam, T_out, b, SE_LOWDIN, 1e-30));
+  if (b <= 64) return combine_rows(ctx, b, b, T_out, b, 0, nullptr, 0, 0.0, X, dim, nullptr, 0, X, dim, dim);
+  Tmp Y;
+  ROM_TRY(Y.get(ctx, size_t(b) * dim));
+  ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, b, 1.0, T_out, b, X, dim, 0.0, Y, dim));
+  ROM_HIP(hipMemcpyAsync(X, Y.p(), size_t(b) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return ROM_OK;
 }
 
@@ -292,6 +561,12 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
 // nothing is lost to the squaring that a single eigen-decomposition of an ungraded Gram matrix would lose.
 // Rt (b x b): accumulated rotation (rows = right singular vectors in the coordinates Tt came in); sig2: b values.
 int tall_svd_rotation(rom_ctx* ctx, double* Tt, int b, int M, double* Rt, double* sig2, int rounds = 3) {
+  if (b <= FUSED_ROWS && M <= 4096) {   // one workgroup from the first round to the last
+    ROM_PROF(ctx, "tall_svd", rounds * (4.0 * b * b * M + 30.0 * b * b * b), 8.0 * rounds * 2.0 * b * M);
+    kp_tall_svd<<<1, 256, 0, ctx->stream>>>(b, M, Tt, rounds, Rt, sig2);
+    ROM_HIP(hipGetLastError());
+    return ROM_OK;
+  }
   Tmp H, St, T2, R2;
   ROM_TRY(H.get(ctx, size_t(b) * b));
   ROM_TRY(St.get(ctx, size_t(b) * b));
@@ -312,57 +587,62 @@ int tall_svd_rotation(rom_ctx* ctx, double* Tt, int b, int M, double* Rt, double
   return ROM_OK;
 }
 
-// Leading k right singular vectors / singular values of the (M, dim) block X by a randomised range finder with one power
-// iteration: thin GEMMs (2 b M dim flops each) instead of the 2 M^2 dim of a Gram matrix.  Used for the DEFLATED
-// remainder of a snapshot block.  Vs: (b, dim) block, its first k rows are the modes; ss_host: b singular values.
-// The block is DEFLATED IMPLICITLY: X_d = X - Bt^T V with the `found` modes accepted so far (V: found x dim, orthonormal
+// One sketch pass over the DEFLATED remainder of the (M, dim) block X: a randomised range finder with one power iteration,
+// thin products (2 b M dim flops each) instead of the 2 M^2 dim of a Gram matrix.
+// The block is deflated IMPLICITLY: X_d = X - Bt^T V with the `found` modes accepted so far (V: found x dim, orthonormal
 // rows; Bt: found x M, row j = X v_j).  Every product with X_d is the product with X followed by a rank-`found`
-// correction (two small GEMMs) -- X itself is never rewritten, which saves a read + write of the whole block per
-// accepted batch of modes.  The rounding error is what the explicit subtraction leaves in X_d as well: eps x sigma_1.
-int sketched_modes(rom_ctx* ctx, const double* X, int M, int64_t dim, const double* V, const double* Bt, int found, int k,
-                   int seed, double* Vs, std::vector<double>& ss_host, int& b_out, PodInfo& info, int oversample = 8,
-                   int power = 1) {
-  const int b = int(std::min<int64_t>(std::min<int64_t>(M, dim), k + oversample));
-  b_out = b;
-  Tmp Om, Y, scr, Tt, Rt, s2, Cc;
+// correction -- X itself is never rewritten, which saves a read + write of the whole block per accepted batch of modes.
+// The rounding error is what the explicit subtraction leaves in X_d as well: eps x sigma_1.
+// Out: Q (b x dim): orthonormal rows spanning the sketch; Rt (b x b): rows = right singular vectors of Q X_d^T in Q's
+// coordinates (mode i = row i of Rt Q); Traw (b x M) = Q X^T, the coefficients of the UNDEFLATED block (mode i's
+// coefficient row X v_i = row i of Rt Traw: the caller's next deflation needs no pass over X); ss_host: b singular values.
+int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double* V, const double* Bt, int found, int b, int seed,
+                double* Q, double* Rt, double* Traw, std::vector<double>& ss_host, PodInfo& info, int power = 1) {
+  Tmp Om, Tt, Cc, Tm, lam, s2;
+  ROM_TRY(Om.get(ctx, size_t(b) * M));
+  ROM_TRY(Tt.get(ctx, size_t(b) * M));
   ROM_TRY(Cc.get(ctx, size_t(b) * std::max(found, 1)));
-  // out (b x ncols, ld ncols... ) -= ((lhs (b x kk) rhs_t^T (found x kk)) ) other: the two correction shapes below
-  auto correct_rows = [&](double* out /* b x dim */, const double* left /* b x M */) -> int {   // out -= (left Bt^T) V
+  ROM_TRY(Tm.get(ctx, size_t(b) * b));
+  ROM_TRY(lam.get(ctx, b));
+  ROM_TRY(s2.get(ctx, b));
+  const bool fused = found <= 512;   // (the correction kernel walks the found rows one by one: fine for any POD request)
+  // out (b x dim) -= (left (b x M) Bt^T) V
+  auto correct_rows = [&](double* out, const double* left) -> int {
     if (found == 0) return ROM_OK;
     ROM_TRY(rom_launch_gemm_nt(ctx, b, found, M, 1.0, left, M, Bt, M, 0.0, Cc, found, "gemm_nt"));
+    if (fused && b <= 64) return combine_rows(ctx, b, b, nullptr, 0, found, Cc, found, -1.0, out, dim, V, dim, out, dim, dim);
     return rom_launch_gemm_nn(ctx, b, dim, found, -1.0, Cc, found, V, dim, 1.0, out, dim);
   };
-  ROM_TRY(Om.get(ctx, size_t(b) * M));
-  ROM_TRY(Y.get(ctx, size_t(b) * dim));
-  ROM_TRY(scr.get(ctx, size_t(b) * dim));
-  ROM_TRY(Tt.get(ctx, size_t(b) * M));
-  ROM_TRY(Rt.get(ctx, size_t(b) * b));
-  ROM_TRY(s2.get(ctx, b));
   ROM_TRY(romb_fill_random(ctx, Om, size_t(b) * M, 0xabcd0000ull + unsigned(seed) * 7919u + unsigned(b), true));
-  ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Om, M, X, dim, 0.0, Y, dim));                 // Y = Omega X_d
-  ROM_TRY(correct_rows(Y, Om));
+  ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Om, M, X, dim, 0.0, Q, dim));                 // Q = Omega X_d
+  ROM_TRY(correct_rows(Q, Om));
   info.executed += 2.0 * b * M * double(dim);
+  double* Tdefl = Tt;
   for (int it = 0; it <= power; ++it) {
-    // Q (rank may drop: zero rows).  Before the power step one round is enough: the rows only have to span the sketch
-    // and be aligned with its principal directions -- their residual non-orthogonality (eps x the condition number of
+    // orthonormal rows (rank may drop: zero rows).  Before the power step one round is enough: the rows only have to span the
+    // sketch and be aligned with its principal directions -- their residual non-orthogonality (eps x the condition number of
     // the sketch's Gram matrix) does not change what the power step spans; the basis that is USED is whitened twice
-    ROM_TRY(romb_gram_transform(ctx, Y, scr, b, dim, SE_WHITEN, 1e-26, it == power ? 2 : 1));
-    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, dim, 1.0, Y, dim, X, dim, 0.0, Tt, M, "gemm_nt"));      // Tt = Q X_d^T  (b, M)
-    if (found) {                                                                                  // ... - (Q V^T) Bt
-      ROM_TRY(rom_launch_gemm_nt(ctx, b, found, dim, 1.0, Y, dim, V, dim, 0.0, Cc, found, "gemm_nt"));
-      ROM_TRY(rom_launch_gemm_nn(ctx, b, M, found, -1.0, Cc, found, Bt, M, 1.0, Tt, M));
+    ROM_TRY(whiten_rows(ctx, Q, b, dim, 1e-26, it == power ? 2 : 1, Tm, lam));
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, dim, 1.0, Q, dim, X, dim, 0.0, Traw, M, "gemm_nt"));    // Q X^T  (b, M)
+    if (found) {                                                                                  // Q X_d^T = Q X^T - (Q V^T) Bt
+      ROM_TRY(rom_launch_gemm_nt(ctx, b, found, dim, 1.0, Q, dim, V, dim, 0.0, Cc, found, "gemm_nt"));
+      if (fused && b <= 64) {
+        ROM_TRY(combine_rows(ctx, b, b, nullptr, 0, found, Cc, found, -1.0, Traw, M, Bt, M, Tt, M, M));
+      } else {
+        ROM_HIP(hipMemcpyAsync(Tt.p(), Traw, size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        ROM_TRY(rom_launch_gemm_nn(ctx, b, M, found, -1.0, Cc, found, Bt, M, 1.0, Tt, M));
+      }
+    } else {
+      ROM_HIP(hipMemcpyAsync(Tt.p(), Traw, size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     }
     info.executed += 2.0 * b * M * double(dim) + 4.0 * b * b * double(dim);
     if (it == power) break;
-    ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Tt, M, X, dim, 0.0, scr, dim));               // Q X_d^T X_d
-    ROM_TRY(correct_rows(scr, Tt));
-    ROM_HIP(hipMemcpyAsync(Y.p(), scr.p(), size_t(b) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Tdefl, M, X, dim, 0.0, Q, dim));              // Q X_d^T X_d (Q is rebuilt)
+    ROM_TRY(correct_rows(Q, Tdefl));
     info.executed += 2.0 * b * M * double(dim);
   }
-  // X ~ T Q: the right singular vectors of the small factor rotate Q into the modes
+  // X_d ~ T Q: the right singular vectors of the small factor rotate Q into the modes (Tt is rotated along, not used again)
   ROM_TRY(tall_svd_rotation(ctx, Tt, b, M, Rt, s2));
-  ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, b, 1.0, Rt, b, Y, dim, 0.0, Vs, dim));                  // modes = R^T Q
-  info.executed += 2.0 * b * b * double(dim);
   ss_host.resize(b);
   ROM_TRY(download(ctx, s2, ss_host.data(), b));
   for (double& v : ss_host) v = std::sqrt(std::max(v, 0.0));
@@ -419,38 +699,43 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     info.gram_passes = 1;
     info.executed += double(M) * (M + 1) * double(dim);
     std::vector<double> lam;
-    ROM_TRY(top_eigenpairs(ctx, G, M, n, W, lam, info));
+    ROM_TRY(top_eigenpairs(ctx, G, M, n, W, lam, fac, info));
     G.release();
     for (double& v : lam) v = std::max(v, 0.0);
     sigma_1 = lam.empty() ? 0.0 : std::sqrt(lam[0]);
     int take = 0;
     while (take < n && take < int(lam.size()) && lam[take] > GRAM_ACCEPT * lam[0] && lam[take] > 0) ++take;
     if (take) {
-      std::vector<double> inv(take);
-      for (int i = 0; i < take; ++i) inv[i] = 1.0 / std::sqrt(lam[i]);
-      ROM_HIP(hipMemcpyAsync(fac.p(), inv.data(), size_t(take) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-      ROM_HIP(hipStreamSynchronize(ctx->stream));
-      ROM_TRY(rom_launch_rows_scale(ctx, W, take, M, fac));
+      // rows of W / sigma_i, with the eigenvalues top_eigenpairs left on the device (no upload, no host synchronisation)
+      kp_scale_eigvec_rows<<<dim3(unsigned(std::min((M + 255) / 256, 64)), take), 256, 0, ctx->stream>>>(W, M, fac, 0.0);
+      ROM_HIP(hipGetLastError());
       ROM_TRY(rom_launch_gemm_nn(ctx, take, dim, M, 1.0, W, M, X, dim, 0.0, V, dim));   // V = S^-1 W^T Xc
       info.executed += 2.0 * take * M * double(dim);
-      ROM_TRY(romb_orthonormalize_against(ctx, V, 0, take, dim));
+      {  // (lifted Gram modes are orthonormal to ~1e-6 at worst; the symmetric orthonormalisation is second order in that defect)
+        Tmp Gs, ls, Ts;
+        ROM_TRY(Gs.get(ctx, size_t(take) * take));
+        ROM_TRY(ls.get(ctx, take));
+        ROM_TRY(Ts.get(ctx, size_t(take) * take));
+        ROM_TRY(lowdin_rows(ctx, V, take, dim, Gs, ls, Ts));
+      }
       ROM_TRY(deflate(0, take));
       found = take;
     }
   }
   for (int p = 1; p < passes; ++p) {
     if (found >= n || found == 0) break;
-    Tmp Vs;
     std::vector<double> ss;
-    int b = 0;
     // a pass accepts modes over four orders of magnitude -- a dozen of them in a spectrum that decays like the snapshot
     // blocks' do -- so it asks for at most 16 (+ 8 of oversampling): the thin products scale with b, the small dense
     // problems with b^3; a spectrum that decays more slowly takes more passes
     // (a request with hundreds of modes left asks for more per pass: 16 per pass would be n / 16 passes over the block)
     const int want = std::min(n - found, std::max(16, (n - found) / 4));
-    const int bmax = int(std::min<int64_t>(std::min<int64_t>(M, dim), want + 8));
-    ROM_TRY(Vs.get(ctx, size_t(bmax) * dim));
-    ROM_TRY(sketched_modes(ctx, X, M, dim, V, Bt, found, want, p, Vs, ss, b, info));
+    const int b = int(std::min<int64_t>(std::min<int64_t>(M, dim), want + 8));
+    Tmp Q, Rt, Traw;
+    ROM_TRY(Q.get(ctx, size_t(b) * dim));
+    ROM_TRY(Rt.get(ctx, size_t(b) * b));
+    ROM_TRY(Traw.get(ctx, size_t(b) * M));
+    ROM_TRY(sketch_pass(ctx, X, M, dim, V, Bt, found, b, p, Q, Rt, Traw, ss, info));
     info.sketch_passes += 1;
     int take = 0;
     while (take < std::min(b, want) && ss[take] > SKETCH_ACCEPT * ss[0] && ss[take] > floor_rel * sigma_1) ++take;
@@ -458,10 +743,47 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
       at_floor_stop = b == 0 || ss[0] <= floor_rel * sigma_1;
       break;
     }
-    ROM_HIP(hipMemcpyAsync(V + size_t(found) * dim, Vs.p(), size_t(take) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    ROM_TRY(romb_orthonormalize_against(ctx, V, found, take, dim));
+    double* Vn = V + size_t(found) * dim;
+    double* Bn = Bt.p() + size_t(found) * M;
+    // the accepted modes = the first `take` rows of Rt Q, written where they belong; their coefficient rows X v_i = Rt Traw
+    if (b <= 64 && take <= 64) {
+      ROM_TRY(combine_rows(ctx, take, b, Rt, b, 0, nullptr, 0, 0.0, Q, dim, nullptr, 0, Vn, dim, dim));
+      ROM_TRY(combine_rows(ctx, take, b, Rt, b, 0, nullptr, 0, 0.0, Traw, M, nullptr, 0, Bn, M, M));
+    } else {
+      ROM_TRY(rom_launch_gemm_nn(ctx, take, dim, b, 1.0, Rt, b, Q, dim, 0.0, Vn, dim));
+      ROM_TRY(rom_launch_gemm_nn(ctx, take, M, b, 1.0, Rt, b, Traw, M, 0.0, Bn, M));
+    }
+    info.executed += 2.0 * take * b * double(dim);
+    // orthogonal to the earlier modes (block Gram-Schmidt, twice), orthonormal among themselves (symmetric
+    // orthonormalisation); every step is a small linear map of the new rows and of the old ones, so the coefficient rows
+    // follow by the same maps in M space: X (v - C V_old)^T = X v^T - C Bt_old -- no pass over the block for the deflation
+    {
+      Tmp C, Gs, ls, Ts;
+      ROM_TRY(C.get(ctx, size_t(take) * found));
+      ROM_TRY(Gs.get(ctx, size_t(take) * take));
+      ROM_TRY(ls.get(ctx, take));
+      ROM_TRY(Ts.get(ctx, size_t(take) * take));
+      for (int r = 0; r < 2; ++r) {
+        ROM_TRY(rom_launch_gemm_nt(ctx, take, found, dim, 1.0, Vn, dim, V, dim, 0.0, C, found, "gemm_nt"));
+        if (take <= 64) {
+          ROM_TRY(combine_rows(ctx, take, take, nullptr, 0, found, C, found, -1.0, Vn, dim, V, dim, Vn, dim, dim));
+          ROM_TRY(combine_rows(ctx, take, take, nullptr, 0, found, C, found, -1.0, Bn, M, Bt, M, Bn, M, M));
+        } else {
+          ROM_TRY(rom_launch_gemm_nn(ctx, take, dim, found, -1.0, C, found, V, dim, 1.0, Vn, dim));
+          ROM_TRY(rom_launch_gemm_nn(ctx, take, M, found, -1.0, C, found, Bt, M, 1.0, Bn, M));
+        }
+      }
+      ROM_TRY(lowdin_rows(ctx, Vn, take, dim, Gs, ls, Ts));
+      if (take <= 64) {
+        ROM_TRY(combine_rows(ctx, take, take, Ts, take, 0, nullptr, 0, 0.0, Bn, M, nullptr, 0, Bn, M, M));
+      } else {
+        Tmp B2;
+        ROM_TRY(B2.get(ctx, size_t(take) * M));
+        ROM_TRY(rom_launch_gemm_nn(ctx, take, M, take, 1.0, Ts, take, Bn, M, 0.0, B2, M));
+        ROM_HIP(hipMemcpyAsync(Bn, B2.p(), size_t(take) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      }
+    }
     const bool at_floor = take < b && ss[take] <= floor_rel * sigma_1;
-    ROM_TRY(deflate(found, take));
     found += take;
     if (at_floor) {  // the spectrum has reached the floor: nothing left to find
       at_floor_stop = true;
@@ -473,10 +795,14 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     Tmp Rt, s2, Vr;
     ROM_TRY(Rt.get(ctx, size_t(found) * found));
     ROM_TRY(s2.get(ctx, found));
-    ROM_TRY(Vr.get(ctx, size_t(found) * dim));
     ROM_TRY(tall_svd_rotation(ctx, Bt, found, M, Rt, s2));
-    ROM_TRY(rom_launch_gemm_nn(ctx, found, dim, found, 1.0, Rt, found, V, dim, 0.0, Vr, dim));
-    ROM_HIP(hipMemcpyAsync(V, Vr.p(), size_t(found) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (found <= 64) {
+      ROM_TRY(combine_rows(ctx, found, found, Rt, found, 0, nullptr, 0, 0.0, V, dim, nullptr, 0, V, dim, dim));   // in place
+    } else {
+      ROM_TRY(Vr.get(ctx, size_t(found) * dim));
+      ROM_TRY(rom_launch_gemm_nn(ctx, found, dim, found, 1.0, Rt, found, V, dim, 0.0, Vr, dim));
+      ROM_HIP(hipMemcpyAsync(V, Vr.p(), size_t(found) * dim * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     info.executed += 2.0 * found * found * double(dim);
     std::vector<double> s(found);
     ROM_TRY(download(ctx, s2, s.data(), found));
