@@ -754,10 +754,13 @@ __global__ __launch_bounds__(256) void k_gemm_nn_thin(long long m, long long n, 
 // ============================================================================================
 // NN GEMM: C[m,n] = alpha * sum_k A[m,k] B[k,n] + beta C   (k small: the lift  c . basis)
 // ============================================================================================
+// grid.z > 1: split-K -- slice z takes the K range [z kper, (z + 1) kper) and writes its raw partial tile to `part`
+// ([z][m][n], ld n) for the deterministic reduction kernel (a short, wide product with a long K: a handful of tiles)
 __global__ __launch_bounds__(256) void k_gemm_nn(long long m, long long n, long long K, double alpha,
                                                  const double* __restrict__ A, long long lda,
                                                  const double* __restrict__ B, long long ldb, double beta,
-                                                 double* __restrict__ C, long long ldc) {
+                                                 double* __restrict__ C, long long ldc, long long kper,
+                                                 double* __restrict__ part) {
   __shared__ __align__(16) double stage[2 * STAGE_DOUBLES];
   double* sA = stage;
   double* sB = stage + STAGE_DOUBLES;
@@ -771,7 +774,9 @@ __global__ __launch_bounds__(256) void k_gemm_nn(long long m, long long n, long 
   const int bc = t & 63, bk0 = t >> 6;
   Acc acc;
   acc_zero(acc);
-  for (long long k0 = 0; k0 < K; k0 += BK) {
+  const long long kbeg = part ? blockIdx.z * kper : 0;
+  if (part) K = min(K, kbeg + kper);
+  for (long long k0 = kbeg; k0 < K; k0 += BK) {
     double va[4], vb[4];
     load4_row<false>(Ar, k0 + sseg, K, va);
 #pragma unroll
@@ -796,8 +801,12 @@ __global__ __launch_bounds__(256) void k_gemm_nn(long long m, long long n, long 
       for (int j = 0; j < 2; ++j) {
         long long c = c0 + acc_col(wp, j);
         if (c >= n) continue;
-        double* p = C + r * ldc + c;
         double v = acc.c[i][j][g];
+        if (part) {
+          part[(blockIdx.z * m + r) * n + c] = v;
+          continue;
+        }
+        double* p = C + r * ldc + c;
         *p = beta == 0.0 ? alpha * v : alpha * v + beta * *p;
       }
     }
@@ -824,13 +833,31 @@ int rom_launch_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alp
     return ROM_OK;
   }
   dim3 grid(unsigned((n + 63) / 64), unsigned((m + 63) / 64));
+  // a handful of output tiles under a long K (the sketches of a FACTORED block: 24 x 272 x 1024): split-K, 64 rows of B each
+  const long long tiles = (long long)grid.x * grid.y;
+  long long splits = 1, kper = k;
+  if (tiles <= 32 && k >= 256) {
+    splits = std::min<long long>((256 + tiles - 1) / tiles, k / 64);
+    kper = ((k + splits - 1) / splits + BK - 1) / BK * BK;
+    splits = (k + kper - 1) / kper;
+  }
+  double* part = nullptr;
+  if (splits > 1) {
+    ROM_TRY(rom_ctx_scratch(ctx, size_t(splits) * m * n, &part));
+    grid.z = unsigned(splits);
+  }
   {
     char nm[64];
     detail ? snprintf(nm, sizeof nm, "gemm_nn_%lldx%lldx%lld", (long long)m, (long long)n, (long long)k) : snprintf(nm, sizeof nm, "gemm_nn");
     ROM_PROF(ctx, nm, 2.0 * m * n * k, 8.0 * (double(m) * k + double(n) * k + double(m) * n));
-    k_gemm_nn<<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+    k_gemm_nn<<<grid, 256, 0, ctx->stream>>>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, kper, part);
   }
   ROM_HIP(hipGetLastError());
+  if (splits > 1) {
+    ROM_PROF(ctx, "splitk_reduce", double(splits) * m * n, 8.0 * double(splits + 1) * m * n);
+    k_splitk_reduce<<<unsigned((m * n + 255) / 256), 256, 0, ctx->stream>>>(m, n, int(splits), alpha, part, beta, C, ldc, 0);
+    ROM_HIP(hipGetLastError());
+  }
   return ROM_OK;
 }
 
