@@ -388,8 +388,8 @@ def main():
         else:
             ctx.solve_status()  # waits for the compute stream; raises if any system was not positive definite
 
-    for _ in range(args.warmup):
-        step()
+    for _ in range(max(args.warmup, 1) if comm and not args.replicate else args.warmup):
+        step()   # (the exchange pre-flight below compares gathered buffers: at least one group must have been sent)
     drain()
     exchange_note = None
     if comm and not args.replicate:
@@ -512,9 +512,9 @@ def main():
     # PMC-measured memory-side traffic of the dominant kernel, if a summary of separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command is committed
     cfg_sizes = {"c2": ((2, 2), 128, 1024), "c4": ((3, 3), 171, 1024), "c5": ((4, 4), 256, 4096)}
-    pmc_files = {"c2": ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"),
-                 "c4": ("r04_pmc_traffic_c4.json", "r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json"),
-                 "c5": ("r04_pmc_traffic_c5.json", "r03_pmc_traffic_c5.json", "r02_pmc_traffic_c5.json")}
+    pmc_files = {"c2": ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"),
+                 "c4": ("r05_pmc_traffic_c4.json", "r04_pmc_traffic_c4.json", "r03_pmc_traffic_c4.json", "r02_pmc_traffic_c4.json"),
+                 "c5": ("r05_pmc_traffic_c5.json", "r04_pmc_traffic_c5.json", "r03_pmc_traffic_c5.json", "r02_pmc_traffic_c5.json")}
     for pmc_name in pmc_files.get(args.config, ()):
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc_path) and (blocks, N, M) == cfg_sizes[args.config]:
@@ -522,9 +522,18 @@ def main():
             pmc = next((v for k, v in allk.items() if dom.startswith("extend") and k.startswith("k_extend")), None) \
                 if dom.startswith("extend") else allk.get("k_" + dom)
             if pmc:
-                roofline["traffic"] = pmc["traffic_bytes_per_launch"]
+                # a number from a COMMITTED profile, not from this run: say which build it was taken on (hash of the kernel
+                # sources, tools/pmc_summary.py) and withhold it when that is not the build running now
+                taken_on, now = json.load(open(pmc_path)).get("csrc_sha16"), csrc_sha16()
+                roofline["traffic_source"] = {"file": f"profiles/{pmc_name}", "csrc_sha16_of_profile": taken_on, "csrc_sha16_of_this_build": now,
+                                              "same_build": taken_on == now}
+                if taken_on == now:
+                    roofline["traffic"] = pmc["traffic_bytes_per_launch"]
+                else:
+                    roofline["traffic_of_other_build"] = pmc["traffic_bytes_per_launch"]
                 roofline["traffic_note"] = (f"bytes per launch from profiles/{pmc_name}: rocprofv3 --pmc FETCH_SIZE (x2, "
-                                            "gfx950) + WRITE_SIZE, separate passes; includes Infinity-Cache hits")
+                                            "gfx950) + WRITE_SIZE, separate passes of this same command; includes Infinity-Cache "
+                                            "hits; `traffic` is null when the profile was taken on other kernel sources")
                 break
     ms_all = [w / args.steps * 1e3 for w in walls]
     out = {
@@ -636,6 +645,17 @@ def main():
 # =====================================================================================================================
 # secondary legs (one GPU, after the timed sweep)
 # =====================================================================================================================
+def csrc_sha16():
+    """Hash of the kernel sources (csrc/*.hip, *.h, include/romhc.h): identifies the build a committed profile was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "romhighcontrast_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "romhc.h")]):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _timed(ctx, f, reps=2):
     best, res = 1e30, None
     for _ in range(reps):
@@ -697,7 +717,12 @@ def extras_pod_c2(out, args, ctx, sm, fem, a_dev, U_loc, M, dim, blocks):
     for _ in range(4):  # (the first run pays one-off kernel loads; best of the rest)
         (_, sig), dt2 = run_rows(X, U_loc, M)
         dt = min(dt, dt2)
-    out["pod"] = pod_record(M, dt, sig, dict(getattr(pod_modes, "last_info", {}),
+    ctx.profile_reset()
+    ctx.profile(True)
+    run_rows(X, U_loc, M)
+    ctx.profile(False)
+    launches = int(sum(v["launches"] for v in ctx.profile_report().values()))
+    out["pod"] = pod_record(M, dt, sig, dict(getattr(pod_modes, "last_info", {}), kernel_launches_profiled=launches,
                             note="gflops = USEFUL flops (symmetric half of ONE Gram matrix + lift of r modes, no eigh term) over "
                                  "the wall time of pod_modes incl. the download of the r modes; executed flops in `executed_*`"))
     if fem.expansion_is_linear:
@@ -778,6 +803,14 @@ def extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim, factored_to
         fs = factored.FactoredSnapshots(sm, Yf, M)
         _, t_e = _timed(ctx, lambda: fs.map.build(3), reps=1)
         rec["energy_map_once_s"] = round(t_e, 3)  # rom_fem_energy_map: H^1_0 geometry + Galerkin forms, once per FE space
+        # the reference-shaped call on a block fresh from the sweep: build(n, sm, sm.generate_solutions_device(a), a, h1) -- the
+        # block carries its interface vectors, the H^1_0 greedy takes them (the Galerkin one stays on rows: lib/ReducedBasis.py)
+        Ud_api = sm.generate_solutions_device(a_loc)
+        for tag, mode in (("h10", RB.GREEDY_FOR_H10), ("galerkin", RB.GREEDY_FOR_GALERKIN)):
+            rb, t = _timed(ctx, lambda: RB.ReducedBasisGreedy(mode).build(n, sm, Ud_api, a_loc, h1), reps=2)
+            rec[f"api_{tag}"] = {"seconds": round(t, 4), "route": "interface vectors" if (Ud_api.factored is not None and mode == RB.GREEDY_FOR_H10) else "rows",
+                                 "picks_equal_to_rows": int(sum(p == q for p, q in zip(rb.picks, picks[tag])))}
+        del Ud_api
         for tag, mode in (("h10", RB.GREEDY_FOR_H10), ("galerkin", RB.GREEDY_FOR_GALERKIN)):
             rb, t = _timed(ctx, lambda: RB.ReducedBasisGreedy(mode).build(n, sm, fs, a_loc, h1), reps=2)
             rec[f"factored_{tag}"] = {"seconds": round(t, 4),
@@ -789,8 +822,9 @@ def extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim, factored_to
 def other_config_leg(ctx, dev, config):
     """Compact run of another single-GPU workload (C4 / C5) for the default line: sweep rate (median of 3 regions behind a
     pre-roll), per-kernel HIP events of one pass, dominant kernel against its roofline, and the workload's basis stage
-    (C4: greedy n = 50 in both modes on rows; C5: 50-mode POD of the rows).  `python bench.py --config c4|c5` has the
-    full legs (factored forms, CPU baselines, API rates)."""
+    (C4: greedy n = 50 in both modes on rows, on the factored block and through the plain build() call on a block fresh from
+    the sweep; C5: 50-mode POD of the rows and of the interface vectors).  `python bench.py --config c4|c5` adds the CPU
+    baselines and API rates."""
     from romhighcontrast_amd.lib.SolutionsManagers import SolutionsManagerFEM
     cfg = CONFIGS[config]
     blocks, N, M = cfg["blocks"], cfg["N"], cfg["M"]
@@ -844,11 +878,13 @@ def other_config_leg(ctx, dev, config):
                    "sub-batches), `kernels` is one extra pass on ONE stream with every launch bracketed by HIP events"}
     sub = {}
     if config == "c4":
-        extras_greedy_c4(sub, ctx, sm, fem, a_loc, a_dev, U, M, dim, factored_too=False)
+        extras_greedy_c4(sub, ctx, sm, fem, a_loc, a_dev, U, M, dim, factored_too=True)
         rec["greedy"] = sub["greedy"]
     else:
-        extras_pod_c5(sub, ctx, sm, fem, a_dev, U, M, dim, factored_too=False)
+        extras_pod_c5(sub, ctx, sm, fem, a_dev, U, M, dim, factored_too=True)
         rec["pod"] = sub["pod"]
+        if "pod_factored" in sub:
+            rec["pod_factored"] = sub["pod_factored"]
         rec["pod"]["frac_of_matrix_peak"] = round(rec["pod"]["gflops"] * 1e-3 / FP64_MATRIX_PEAK_TFLOPS, 4)
     del U, a_dev, sm, fem
     return rec

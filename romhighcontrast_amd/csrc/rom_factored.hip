@@ -599,6 +599,7 @@ extern "C" int rom_pod_factored(rom_fem* f, rom_buf* Yc, int64_t c_row0, int M, 
   if (nz < n) {  // more modes requested than the snapshot manifold has dimensions: completed like rom_pod completes
     ROM_TRY(rom_complete_orthonormal(ctx, V, v_row0, nz, n - nz, dim));
     info[1] += n - nz;
+    if (info[7] == 0.0) info[7] = 1.0;   // (not "filled": the completed modes lie beyond the rank of the snapshot manifold)
   }
   ROM_TRY(rom_launch_rows_sign_flip(ctx, V->p + v_row0 * dim, n, dim));  // svd_flip(u_based_decision=False)
   ROM_HIP(hipStreamSynchronize(ctx->stream));

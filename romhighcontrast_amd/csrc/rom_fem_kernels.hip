@@ -235,7 +235,8 @@ __device__ inline void s_tile_stream_begin(TileStream<NS>& ts, int slot, const T
   ts.ne = f.aoff[slot * 4 + w + 1] - ts.e0;  // this wave's pieces (a multiple of TILE_RING: padded with no-ops)
   ts.mine = (reinterpret_cast<const int2*>(f.alist) + ts.e0)[l];  // lane i: piece i of the first group of 64 (the list carries 128 no-ops behind its end)
   const int nt = d.t1 - d.t0;
-  const GenTerm g0 = f.terms[d.t0 + min(l, nt - 1)], g1 = f.terms[d.t0 + min(64 + l, nt - 1)];
+  // (a fill-only tile has no direct terms: nt = 0 -- the index stays inside the list and the coefficients are zero)
+  const GenTerm g0 = f.terms[d.t0 + max(min(l, nt - 1), 0)], g1 = f.terms[d.t0 + max(min(64 + l, nt - 1), 0)];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     const double* am = am0 + size_t(q < nsys ? q : 0) * f.kblk;

@@ -17,6 +17,13 @@
 #include "rom_fem_dev.h"
 #include "rom_hostla.h"
 
+// forcing switches of the A/B build (see the end of rom_fem_create); the product build reads none of them
+#ifdef ROMHC_AB
+static const char* ab_env(const char* name) { return getenv(name); }
+#else
+static const char* ab_env(const char*) { return nullptr; }
+#endif
+
 FemDev make_dev(const rom_fem* f) {
   FemDev d;
   d.nrb = f->nrb; d.ncb = f->ncb; d.N = f->N; d.n1 = f->n1; d.n1p = f->n1p; d.nr = f->nr; d.nc = f->nc;
@@ -1323,7 +1330,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
         if (es.mode == 2) { ++nlr; nch += es.nch; }
         else if (es.mode != 0) ++nother;
       }
-      if (nlr > 0 && nother == 0 && !getenv("ROMHC_NO_EXT_LR")) {
+      if (nlr > 0 && nother == 0 && !ab_env("ROMHC_NO_EXT_LR")) {
         lr_blocks.push_back(b);
         f->lr_nch = std::max(f->lr_nch, nch);
       } else {
@@ -1416,13 +1423,18 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   f->sw_no_fused = getenv("ROMHC_NO_FUSED") != nullptr;
   // k_extend128's workgroup order: system group fastest once the extension tables outgrow what the caches keep next to
   // the store stream (measured: C5, 4 x 4 / N = 256, tables 100+ MB: fetch 21.7 -> 10.6 GB per launch of 2048 systems, kernel -2...-6 %;
-  // C4, 3 x 3 / N = 171: no gain; C2, 16 MB of tables: 5 % slower) -- ROMHC_X128_SYS_FAST = 0 / 1 / 2 overrides
-  f->sw_x128_sys_fast = getenv("ROMHC_X128_SYS_FAST") ? atoi(getenv("ROMHC_X128_SYS_FAST")) : -1;
+  // C4, 3 x 3 / N = 171: no gain; C2, 16 MB of tables: 5 % slower) -- ROMHC_X128_SYS_FAST = 0 / 1 / 2 overrides in the A/B build
   f->sw_no_ext128 = getenv("ROMHC_NO_EXT128") != nullptr;
-  f->sw_no_fold = getenv("ROMHC_NO_FOLD_EXPAND") != nullptr;
-  f->sw_no_tile_pairs = getenv("ROMHC_NO_TILE_PAIRS") != nullptr;
-  f->sw_no_tile_stream = getenv("ROMHC_NO_TILE_STREAM") != nullptr;
-  f->sw_ext_flat = getenv("ROMHC_EXT_FLAT") ? (atoi(getenv("ROMHC_EXT_FLAT")) != 0 ? 1 : 0) : -1;
+#ifdef ROMHC_AB
+  // The A/B build (libromhc_ab.so, `make ab`; only tests/ab_variants.py loads it) can FORCE choices that the product makes by
+  // geometry -- tilings, workgroup orders, one system per workgroup, tiles assembled in registers -- to check that the forms
+  // the product uses on different geometries give the same bits on one.  The product build does not read these.
+  f->sw_x128_sys_fast = ab_env("ROMHC_X128_SYS_FAST") ? atoi(ab_env("ROMHC_X128_SYS_FAST")) : -1;
+  f->sw_no_fold = ab_env("ROMHC_NO_FOLD_EXPAND") != nullptr;
+  f->sw_no_tile_pairs = ab_env("ROMHC_NO_TILE_PAIRS") != nullptr;
+  f->sw_no_tile_stream = ab_env("ROMHC_NO_TILE_STREAM") != nullptr;
+  f->sw_ext_flat = ab_env("ROMHC_EXT_FLAT") ? (atoi(ab_env("ROMHC_EXT_FLAT")) != 0 ? 1 : 0) : -1;
+#endif
   ROMHC_PHASE("end");
   if (getenv("ROMHC_VERBOSE")) {
     fprintf(stderr, "romhc: %dx%d blocks N=%d: %d edges (%d closed-form, %d of them compressed), reduced size %d -> %d tiles, "

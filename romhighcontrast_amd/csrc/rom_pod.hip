@@ -704,7 +704,9 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     for (double& v : lam) v = std::max(v, 0.0);
     sigma_1 = lam.empty() ? 0.0 : std::sqrt(lam[0]);
     int take = 0;
-    while (take < n && take < int(lam.size()) && lam[take] > GRAM_ACCEPT * lam[0] && lam[take] > 0) ++take;
+    // (the caller's floor applies here as well as in the sketch passes: modes below rel_floor x sigma_1 are not looked for)
+    while (take < n && take < int(lam.size()) && lam[take] > GRAM_ACCEPT * lam[0] && lam[take] > 0 &&
+           lam[take] > floor_rel * floor_rel * lam[0]) ++take;
     if (take) {
       // rows of W / sigma_i, with the eigenvalues top_eigenpairs left on the device (no upload, no host synchronisation)
       kp_scale_eigvec_rows<<<dim3(unsigned(std::min((M + 255) / 256, 64)), take), 256, 0, ctx->stream>>>(W, M, fac, 0.0);

@@ -143,6 +143,9 @@ def pod_modes_factored(fs: FactoredSnapshots, n: int, center=True):
     V = ctx.alloc(max(n * dim, 1))
     sig, info = em.fem.pod_factored(fs.Yc, M, n, V, center=center)
     pod_modes_factored.last_info = info
+    if info["completed_modes"]:
+        from .lib.ReducedBasis import warn_completed_modes
+        warn_completed_modes(info, n, 0.0)
     if n == 0:
         return np.zeros((0, dim)), sig
     return V.download(n * dim, shape=(n, dim)), sig

@@ -160,6 +160,17 @@ class ReducedBasisGreedy(BaseReducedBasis):
         a2train = np.asarray(a2train)
         U = _as_device(ctx, solutions2train, dim)  # training set stays in HBM for the whole build
         M = U.rows
+        fs = getattr(U, "factored", None)
+        if fs is not None and fs.M == M and self.greedy_for == GREEDY_FOR_H10:
+            # A block that sm.generate_solutions_device has just produced carries its interface vectors: the H^1_0 greedy
+            # runs on them (rom_greedy_factored: M x ~300 numbers per pass instead of M x dim; same picks, curves within
+            # 1e-12 of the row path's and 3e-13 of the reference arithmetic's on the same rows: tests/test_gpu_parity.py, C4).  The Galerkin mode
+            # stays on the rows: against the 80-bit truth of the reduced systems (tests/referee.py) its factored form is
+            # 1.2e-9 off at contrast 1e8 where the row form is 1.9e-10 and the reference's own arithmetic 6.5e-10.
+            self.picks, self.max_errors = greedy_factored(fs, a2train, n, False, solutions2train_h1norm)
+            basis = ctx.alloc(max(len(self.picks) * dim, 1)).gather_rows_from(U.buf, np.asarray(self.picks), dim)
+            super().set(basis=DeviceArray(basis, len(self.picks), dim).numpy(), a=[a2train[i] for i in self.picks])
+            return self
         # One C call (rom_greedy): the reference re-orthonormalises the contrast-sorted picks from scratch in every
         # iteration (:135-136) and recomputes the approximations of all snapshots (:122/:124); both depend on the SPAN of
         # the basis only, which the library carries as an A_1-orthonormal basis with the projection residuals updated in
@@ -214,6 +225,23 @@ class ReducedBasisRandom(BaseReducedBasis):
 _pod_warned = set()
 
 
+def warn_completed_modes(info, n, rel_floor):
+    """One warning per process and message when a POD call completed modes the data do not determine (pod_modes and
+    pod_modes_factored alike), with the reason the C call reported."""
+    floor = max(rel_floor, 1e-13)
+    if info["stop_reason"] == "budget":
+        msg = (f"POD: {info['completed_modes']} of the {n} requested modes were NOT found although the spectrum had not "
+               f"reached the floor ({floor:g} sigma_1): a sketch pass accepted nothing; completed with orthonormal "
+               "directions of zero singular value")
+    else:
+        msg = (f"POD: {info['completed_modes']} of the {n} requested modes lie below the floor of the snapshot block (sigma < "
+               f"{floor:g} sigma_1" + ("" if rel_floor > 1e-13 else ": fp64 noise of the data") + "); completed with "
+               "orthonormal directions of zero singular value")
+    if msg not in _pod_warned:  # (once per process and message: a bench calls this a dozen times on the same block)
+        _pod_warned.add(msg)
+        warning(msg)
+
+
 def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, rel_floor=0.0, download=True):
     """Leading ``n`` right singular vectors / singular values of the (M, dim) snapshot block: one C call (rom_pod).
 
@@ -232,22 +260,12 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, rel_floor=
     M, dim = X.rows, X.dim
     n = min(n, M, dim)
     V = ctx.alloc(max(n * dim, 1))
+    X.factored = None  # (the rows are about to be centred in place: they stop being the image of their interface vectors)
     sig, info = ctx.pod(X.buf, M, dim, n, V, center=center, rel_floor=rel_floor)
     pod_modes.last_info = info
     pod_modes.resolved = info["resolved_modes"]
     if info["completed_modes"]:
-        floor = max(rel_floor, 1e-13)
-        if info["stop_reason"] == "budget":
-            msg = (f"POD: {info['completed_modes']} of the {n} requested modes were NOT found although the spectrum had not "
-                   f"reached the floor ({floor:g} sigma_1): a sketch pass accepted nothing; completed with orthonormal "
-                   "directions of zero singular value")
-        else:
-            msg = (f"POD: {info['completed_modes']} of the {n} requested modes lie below the floor of the snapshot block (sigma < "
-                   f"{floor:g} sigma_1" + ("" if rel_floor > 1e-13 else ": fp64 noise of the data") + "); completed with "
-                   "orthonormal directions of zero singular value")
-        if msg not in _pod_warned:  # (once per process and message: a bench calls this a dozen times on the same block)
-            _pod_warned.add(msg)
-            warning(msg)
+        warn_completed_modes(info, n, rel_floor)
     if n == 0:
         return (np.zeros((0, dim)) if download else DeviceArray(V, 0, dim)), sig
     return (V.download(n * dim, shape=(n, dim)) if download else DeviceArray(V, n, dim)), sig
@@ -282,6 +300,10 @@ class ReducedBasisPCA(BaseReducedBasis):
             # (get_starting_basis, :153-164, does it on host rows), the pool is gathered into the private copy that rom_pod
             # overwrites, and only the basis rows ever cross PCIe
             Ud, a2 = solutions2train, np.asarray(a2train)
+            if getattr(Ud, "factored", None) is not None and Ud.factored.M == Ud.rows:
+                # fresh from sm.generate_solutions_device: the block's interface vectors are at hand -- the PCA of the rows IS
+                # the PCA of their energy coordinates (rom_pod_factored: same modes, a matrix dim / ~300 times narrower)
+                return self.build(n, sm, Ud.factored, a2, solutions2train_h1norm, **kwargs)
             ctx, dim = sm._ctx, Ud.dim
             has_inf = (a2 == INFINIT_A).reshape(len(a2), -1).sum(axis=1) > 0
             pool_idx = np.flatnonzero(~has_inf)

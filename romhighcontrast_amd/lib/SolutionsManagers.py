@@ -26,10 +26,16 @@ _DENSE_LIMIT_BYTES = 2 << 30  # largest A_preassembled we are willing to materia
 
 
 class DeviceArray:
-    """(rows, dim) fp64 matrix resident in HBM.  ``.numpy()`` downloads it."""
+    """(rows, dim) fp64 matrix resident in HBM.  ``.numpy()`` downloads it.
 
-    def __init__(self, buf: _ffi.Buffer, rows: int, dim: int):
+    ``factored``: when the rows are snapshots that ``generate_solutions_device`` has just produced, the same block in
+    factored form (``romhighcontrast_amd.factored.FactoredSnapshots``: the interface vectors the rows are a fixed linear
+    image of).  The basis builders take it when they find it -- the H^1_0 greedy and the PCA run on M x ~300 numbers
+    instead of M x dim -- so whoever rewrites the rows in place (``pod_modes`` centres its input) must drop it."""
+
+    def __init__(self, buf: _ffi.Buffer, rows: int, dim: int, factored=None):
         self.buf, self.rows, self.dim = buf, int(rows), int(dim)
+        self.factored = factored
 
     @property
     def shape(self):
@@ -133,15 +139,29 @@ class SolutionsManager:
         k = int(np.prod(self.blocks_geometry))
         return np.ascontiguousarray(a.reshape(-1, k))
 
-    def generate_solutions_device(self, a2try) -> DeviceArray:
-        """The sweep with the (M, dim) result left in HBM."""
+    def generate_solutions_device(self, a2try, keep_interface_vectors=True) -> DeviceArray:
+        """The sweep with the (M, dim) result left in HBM.  Where the expansion of the FE space is a linear map of the
+        interface vectors (every geometry that compresses its edges: N >~ 16), the sweep runs as its two stages --
+        parameters -> interface vectors -> rows, bit-identical rows (tests: test_two_stage_sweep_is_bit_identical) -- and the
+        block remembers its interface vectors (``DeviceArray.factored``, M x 784 doubles at 2x2 / N = 128 beside M x 65 025),
+        which is what lets ``ReducedBasisGreedy.build`` / ``ReducedBasisPCA.build`` on this block run on them."""
         _check_method(self.method)
         a = self._a_batch(a2try)
         M = a.shape[0]
         U = self._ctx.alloc(max(M * self.vspace_dim, 1))
+        fs = None
         if M:
-            self._fem.solve_batch(self._ctx.upload(a), M, U)
-        return DeviceArray(U, M, self.vspace_dim)
+            a_dev = self._ctx.upload(a)
+            if keep_interface_vectors and self._fem.expansion_is_linear:
+                from ..factored import FactoredSnapshots
+                Y = self._ctx.alloc(M * self._fem.reduced_stride)
+                self._fem.solve_reduced(a_dev, M, Y)
+                self._fem.expand(a_dev, M, Y, U)
+                self._ctx.solve_status()
+                fs = FactoredSnapshots(self, Y, M)
+            else:
+                self._fem.solve_batch(a_dev, M, U)
+        return DeviceArray(U, M, self.vspace_dim, factored=fs)
 
     def generate_solutions(self, a2try):
         """``generate_solutions`` (:64-68): (M, dim) ndarray, row m = A(a_m)^-1 B_total."""

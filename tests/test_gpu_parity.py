@@ -13,6 +13,8 @@ Tolerances (relative H^1_0 norm of the difference unless stated):
     bound = FLOATING_FACTOR x the worse of the reference's two solvers on the same row; every other row keeps 1e-11;
   * reduced-basis relative errors: |err_gpu - err_ref| <= 1e-10 (BASELINE.json target).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -477,12 +479,26 @@ def test_pca_class_from_a_device_block_stays_on_the_device(api):
     inf_rows = [5, 4000, 8191]
     for k, r in enumerate(inf_rows):
         a[r].flat[k] = RB.INFINIT_A
-    Ud = sm.generate_solutions_device(a)
+    Uf = sm.generate_solutions_device(a)                     # fresh from the sweep: carries its interface vectors
+    assert Uf.factored is not None and Uf.factored.M == M
+    Ud = SM.DeviceArray(Uf.buf, M, dim)                      # the same rows as a plain device block: the row route
     before = _ffi.D2H_BYTES[0]
     rb = RB.ReducedBasisPCA(add_inf_solutions=True).build(n, sm, Ud, a)
     moved = _ffi.D2H_BYTES[0] - before
     assert moved <= (n + len(inf_rows) + 2) * dim * 8, f"{moved} bytes left the device; the block is {M * dim * 8}"
     assert rb.basis.shape == (n, dim) and np.array_equal(np.asarray(rb.a[:3]), a[inf_rows])
+    # the block that remembers its interface vectors takes the factored route (rom_pod_factored): same peel-off, same modes
+    before = _ffi.D2H_BYTES[0]
+    rbf = RB.ReducedBasisPCA(add_inf_solutions=True).build(n, sm, Uf, a)
+    moved = _ffi.D2H_BYTES[0] - before
+    assert moved <= (n + len(inf_rows) + 2) * dim * 8, f"{moved} bytes left the device (factored route)"
+    assert np.array_equal(rbf.basis[:3], rb.basis[:3]) and np.array_equal(np.asarray(rbf.a[:3]), a[inf_rows])
+    big = rb.singular_values_ > 1e-6 * rb.singular_values_[0]
+    observed("PCA class on a fresh device block (factored route) vs the row route: singular values > 1e-6 sigma_1 (relative)",
+             np.abs(rbf.singular_values_[big] / rb.singular_values_[big] - 1), 1e-7)
+    kb = min(int(big.sum()), n - 3)
+    observed("PCA class on a fresh device block (factored route) vs the row route: |<mode, mode>| - 1 for those modes",
+             np.abs(np.abs(np.sum(rbf.basis[3:3 + kb] * rb.basis[3:3 + kb], axis=1)) - 1), 1e-6)
     # the same from the building blocks
     pool_idx = np.setdiff1d(np.arange(M), inf_rows)
     X = ctx.alloc(len(pool_idx) * dim).gather_rows_from(Ud.buf, pool_idx, dim)
@@ -1207,39 +1223,23 @@ def test_gram_128_tiles_vs_numpy(api, M, D):
     assert (np.abs(g - ref) / scale).max() < 1e-13
 
 
-@pytest.mark.parametrize("blocks,N,M", [((2, 2), 128, 130), ((3, 3), 24, 140), ((2, 3), 40, 200), ((2, 2), 90, 128),
-                                        ((1, 2), 9, 129), ((3, 2), 171, 128), ((5, 4), 33, 128), ((2, 2), 65, 257),
-                                        ((2, 2), 66, 128), ((1, 2), 128, 384), ((2, 2), 128, 1024)])
-def test_extension_tilings_agree(api, blocks, N, M, monkeypatch):
-    """The extension into the blocks has three tilings (128 vertices of one mesh row, 128 consecutive vertices of the
-    block, 64 vertices of one mesh row): same products in the same order, so the snapshots must be identical.
-    (5 x 4 blocks: more than the 16 block descriptors one launch of the 128-tile kernel carries; N = 65 / 66: mesh rows of
-    64 / 65 vertices; M = 130, 257: a last system group of two systems / one system.)"""
-    from romhighcontrast_amd import _ffi
-    ctx = _ffi.get_context()
-    a = 10.0 ** np.random.default_rng(N).uniform(0, 3, size=(M, blocks[0] * blocks[1]))
-    ab = ctx.upload(a)
-    out = {}
-    for name, env in (("row", {"ROMHC_EXT_FLAT": "0"}), ("flat", {"ROMHC_EXT_FLAT": "1"}), ("t64", {"ROMHC_NO_EXT128": "1"}),
-                      ("sysfast", {"ROMHC_X128_SYS_FAST": "1"}), ("xcd", {"ROMHC_X128_SYS_FAST": "2"}), ("default", {})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        fem = _ffi.Fem(ctx, blocks[0], blocks[1], N)  # (the switches are read once per FE space)
-        U = ctx.alloc(M * fem.dim)
-        U.fill(float("nan"))
-        fem.solve_batch(ab, M, U)
-        out[name] = U.download(shape=(M, fem.dim))
-        for k in env:
-            monkeypatch.delenv(k)
-    for name in ("flat", "t64", "sysfast", "xcd", "default"):  # (sysfast / xcd: the two other workgroup orders of k_extend128)
-        assert np.array_equal(out[name], out["row"]), name
-    g = ro.Geometry(blocks, N)
-    if N <= 40:
-        assert relh10(g, out["default"][:3], ro.generate_solutions(g, a[:3].reshape((3,) + blocks))).max() < SNAP_TOL
+def test_ab_build_variants_agree():
+    """The product picks extension tilings, workgroup orders, systems per workgroup and the tile-assembly form by geometry;
+    libromhc_ab.so (the same objects with rom_fem_setup.hip compiled -DROMHC_AB) can FORCE each of them, and
+    tests/ab_variants.py asserts on eleven geometries that every forced form gives the rows of the default, bit for bit
+    (in a subprocess: a process loads one library; the product build reads none of those switches)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_ab = os.path.join(root, "romhighcontrast_amd", "csrc", "libromhc_ab.so")
+    assert os.path.exists(lib_ab), "libromhc_ab.so missing: `make -C romhighcontrast_amd/csrc` builds it beside libromhc.so"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "ab_variants.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and out.rstrip().endswith("OK"), out[-4000:]
 
 
-@pytest.mark.parametrize("env", ["ROMHC_NO_COMPRESS", "ROMHC_NO_PREELIM", "ROMHC_NO_FUSED", "ROMHC_NO_LOWRANK_EXT",
-                                 "ROMHC_NO_EXT128", "ROMHC_NO_EXT_LR", "ROMHC_NO_TILE_PAIRS", "ROMHC_NO_TILE_STREAM"])
+@pytest.mark.parametrize("env", ["ROMHC_NO_COMPRESS", "ROMHC_NO_PREELIM", "ROMHC_NO_FUSED", "ROMHC_NO_LOWRANK_EXT", "ROMHC_NO_EXT128"])
 def test_algorithm_switches_agree(api, env, monkeypatch):
     """Every exact reduction of the solver can be switched off (A/B checks): the snapshots must not move beyond
     rounding, and each variant must itself meet the parity bound against the oracle."""
@@ -1261,8 +1261,6 @@ def test_algorithm_switches_agree(api, env, monkeypatch):
         monkeypatch.delenv(env, raising=False)
         g = ro.Geometry(blocks, N)
         assert relh10(g, alt, ref).max() < 1e-11, (env, blocks, N)
-        if env in ("ROMHC_NO_TILE_PAIRS", "ROMHC_NO_TILE_STREAM"):  # (same sums in the same order)
-            assert np.array_equal(alt, ref), (env, blocks, N)
         if N <= 40:
             assert relh10(g, alt[:4], ro.generate_solutions(g, a[:4].reshape((4,) + blocks))).max() < SNAP_TOL
 
@@ -1424,6 +1422,29 @@ def test_rccl_single_rank_allgather(api):
             fem.expand(a_dev, M, Yfull, rows)
             ctx.solve_status()
             assert np.array_equal(rows.download(shape=(M, fem.dim)), ref), (slot, part)
+        # the same on a MULTI-TILE geometry (the general tile-Cholesky path: 3 x 3 blocks, reduced matrix of several 64 x 64
+        # tiles), M = 70 rows (not a multiple of anything): factored gather + the grouped step loop, groups of 3 over 7 steps
+        sm3 = SM.SolutionsManagerFEM((3, 3), 64)
+        fem3, M3 = sm3._fem, 70
+        assert fem3.n_tiles > 1 and fem3.expansion_is_linear
+        a3 = 10.0 ** np.random.default_rng(11).uniform(0, 4, size=(M3, 3, 3))
+        ref3 = sm3.generate_solutions_device(a3, keep_interface_vectors=False).numpy()
+        fs3 = sweep.RcclSweep(sm3, 0, 1).generate_factored(a3)
+        assert fs3.M == M3 and np.array_equal(fs3.rows().numpy(), ref3)
+        a3_dev = ctx.upload(np.ascontiguousarray(a3).reshape(M3, -1))
+        be3 = sweep.GpuStepBackend(ctx, fem3, a3_dev, M3, 1, every=3)
+        assert be3.cstride < be3.stride
+        for step in range(7):
+            k3 = sweep.run_step(be3, step, 3)
+        sweep.drain(be3, 7, 3)
+        assert np.array_equal(be3.U_loc.download(shape=(M3, fem3.dim)), ref3)
+        for slot in (0, 1):
+            for part in range(be3.parts[slot]):
+                Yfull = be3.gathered_vectors(slot, 0, part, 0, M3)
+                rows = ctx.alloc(M3 * fem3.dim)
+                fem3.expand(a3_dev, M3, Yfull, rows)
+                ctx.solve_status()
+                assert np.array_equal(rows.download(shape=(M3, fem3.dim)), ref3), (slot, part)
     finally:
         ctx.comm_destroy()
 

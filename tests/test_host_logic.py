@@ -511,7 +511,14 @@ def test_environment_switches_are_documented():
         read |= set(re.findall(r'environ(?:\.get)?[\[(]\s*"(ROMHC_[A-Z0-9_]+)"', open(os.path.join(root, rel)).read()))
     doc = set(re.findall(r"ROMHC_[A-Z0-9_]+", open(os.path.join(root, "INTEGRATION.md")).read()))
     dev_only = {"ROMHC_EXT_LDS_PAD"}                      # timeline builds (-DROMHC_STAMPS): tools/README.md
+    # (the forcing switches of the A/B build go through ab_env(...), not getenv("..."): the product library reads none of them)
+    assert not re.findall(r'getenv\("ROMHC_(?:NO_EXT_LR|NO_FOLD_EXPAND|EXT_FLAT|X128_SYS_FAST|NO_TILE_PAIRS|NO_TILE_STREAM)"\)',
+                          "".join(open(os.path.join(csrc, fn)).read() for fn in os.listdir(csrc) if fn.endswith((".hip", ".h"))))
     launcher = {"ROMHC_LAUNCH_ID", "ROMHC_FORCE_DEVICE"}  # set / read by bench.py's launcher, not by the library
+    ab_build = set(re.findall(r'ab_env\("(ROMHC_[A-Z0-9_]+)"\)', open(os.path.join(csrc, "rom_fem_setup.hip")).read())) | {"ROMHC_AB"}
+    assert ab_build == {"ROMHC_AB", "ROMHC_NO_EXT_LR", "ROMHC_NO_FOLD_EXPAND", "ROMHC_EXT_FLAT", "ROMHC_X128_SYS_FAST", "ROMHC_NO_TILE_PAIRS",
+                        "ROMHC_NO_TILE_STREAM"}, ab_build   # (named in INTEGRATION.md as retired: read by libromhc_ab.so only)
+    launcher |= ab_build
     assert read - dev_only <= doc, sorted(read - dev_only - doc)
     assert doc - launcher <= read, sorted(doc - launcher - read)
 

@@ -8,7 +8,11 @@ usage: python tools/pmc_summary.py <fetch counter_collection.csv> <write counter
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha16  # noqa: E402  (hash of the kernel sources: bench.py withholds `traffic` taken on another build)
 
 
 def agg(path):
@@ -27,7 +31,7 @@ for k in f:
     wa = sum(w.get(k, [0.0])) / max(1, len(w.get(k, [0.0]))) * 1024.0
     out[k] = {"launches_sampled": len(f[k]), "fetch_bytes_raw": fa, "fetch_bytes_x2": 2 * fa, "write_bytes": wa,
               "traffic_bytes_per_launch": 2 * fa + wa}
-json.dump({"unit": "bytes per launch (average over the sampled launches)",
+json.dump({"unit": "bytes per launch (average over the sampled launches)", "csrc_sha16": csrc_sha16(),
            "correction": "FETCH_SIZE x 2 (gfx950, 16-B-per-lane reads); WRITE_SIZE as reported; MALL hits included",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
