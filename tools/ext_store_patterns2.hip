@@ -42,6 +42,50 @@ __global__ __launch_bounds__(512) void k_b0(double* U, int M) {
     }
 }
 
+
+// Round 5 ("a workgroup that owns two adjacent mesh rows of a block").  The per-instruction pattern of
+// k_extend128 (B0) unchanged; what changes is WHICH stores leave one CU together:
+//   B2r  one 1024-thread workgroup = two ADJACENT MESH ROWS (iv, iv + 1) of one block, waves 0-7 / 8-15 (the literal reading:
+//        in the reference layout those are two separate 1016-B runs 2040 B apart, not one 2032-B run)
+//   B2q  one 1024-thread workgroup = the same mesh row of the two blocks q = 0, 1 side by side: the two halves of ONE snapshot-row
+//        line run (127 | interface vertex | 127), the reading under which the partial lines between the halves meet in one L2
+//   B2t  a 64-system x 256-vertex tile (rows iv, iv + 1 of one block), eight waves of 32 systems x 64 vertices
+__global__ __launch_bounds__(1024) void k_b2(double* U, int M, int mode) {
+  const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 7, half = threadIdx.x >> 9, wr = w >> 2, wc = w & 3;
+  int p, q, iv;
+  if (mode == 0) { const int b = blockIdx.z; p = b / 2; q = b % 2; iv = 2 * blockIdx.x + half; }   // B2r
+  else { p = blockIdx.z; q = half; iv = blockIdx.x; }                                              // B2q
+  if (iv >= n1) return;
+  const int fr = lane & 15, kq = lane >> 4, odd = lane & 1;
+  const int t = wc * 32 + (odd ? 16 : 0) + fr - odd;
+  for (int i = 0; i < 4; ++i)
+    for (int g = 0; g < 4; ++g) {
+      const int m = blockIdx.y * 128 + wr * 64 + i * 16 + kq + 4 * g;
+      if (m >= M) continue;
+      double* dst = U + m * LD + (long long)(p * N + iv) * NC + (q * N + t);
+      if (t + 1 < n1) st16u(dst, 3.0, 4.0);
+      else if (t < n1) dst[0] = 3.0;
+    }
+}
+__global__ __launch_bounds__(512) void k_b2t(double* U, int M) {
+  const int b = blockIdx.z, p = b / 2, q = b % 2;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w >> 2, wc = w & 3;   // 2 x 4 wave tiles of 32 systems x 64 vertices
+  const int fr = lane & 15, kq = lane >> 4, odd = lane & 1;
+  for (int j = 0; j < 2; ++j) {
+    const int tv = wc * 64 + j * 32 + (odd ? 16 : 0) + fr - odd;   // 0 .. 255: vertex of the two-row tile
+    const int iv = 2 * blockIdx.x + tv / 128, t = tv % 128;
+    if (iv >= n1) continue;
+    for (int i = 0; i < 2; ++i)
+      for (int g = 0; g < 4; ++g) {
+        const int m = blockIdx.y * 64 + wr * 32 + i * 16 + kq + 4 * g;
+        if (m >= M) continue;
+        double* dst = U + m * LD + (long long)(p * N + iv) * NC + (q * N + t);
+        if (t + 1 < n1) st16u(dst, 3.0, 4.0);
+        else if (t < n1) dst[0] = 3.0;
+      }
+  }
+}
+
 // decode a workgroup id: ord 0 = grid (row, sysgroup, block) as launched; ord 1 = sysgroup fastest (one per XCD at 8
 // groups), then block column q, then row, then block row p
 __device__ inline void decode(int ord, int nsg, int& iv, int& sg, int& p, int& q) {
@@ -175,6 +219,9 @@ int main(int argc, char** argv) {
   }
   for (int rep = 0; rep < reps; ++rep) {
     TIME("k_extend128's pattern: 4 systems x 256 B per instruction, 8-byte alignment", "B0", (k_b0<<<dim3(n1, M / 128, 4), 512>>>(U, M)));
+    TIME("B0's instructions, 1024-thread workgroup = two adjacent mesh rows of one block", "B2r", (k_b2<<<dim3((n1 + 1) / 2, M / 128, 4), 1024>>>(U, M, 0)));
+    TIME("B0's instructions, 1024-thread workgroup = one mesh row of both blocks q = 0, 1", "B2q", (k_b2<<<dim3(n1, M / 128, 2), 1024>>>(U, M, 1)));
+    TIME("64 systems x 256 vertices (two mesh rows) per 512-thread workgroup", "B2t", (k_b2t<<<dim3((n1 + 1) / 2, M / 64, 4), 512>>>(U, M)));
     TIME("one system's 1016-B run per instruction, 8-byte alignment", "P1", (k_run<false><<<dim3(n1, M / 128, 4), 512>>>(U, M, 0, 8)));
     TIME("one system's run per instruction, 16-byte aligned lanes", "P2", (k_run<true><<<dim3(n1, M / 128, 4), 512>>>(U, M, 0, 8)));
     TIME("P1 + order: system group = id % 8, row neighbours adjacent", "P1o", (k_run<false><<<n1 * 8 * 4, 512>>>(U, M, 1, 8)));
