@@ -1665,11 +1665,6 @@ __global__ __launch_bounds__(256) void k_extend(FemDev f, const double* __restri
 // reads conflict free.  Rows that do not exist (systems >= Mc, vertices behind the end of the mesh row / the block) are
 // clamped to the last one that does: their products are not stored.
 constexpr int X128_SLOT = 4 * 128 * 64;  // bytes
-#ifndef X128_STAGED
-#define X128_STAGED 0
-#endif
-constexpr int X128_STAGE_ROW = 1024 + 64;  // bytes between the staged rows of two systems (X128_STAGED)
-static_assert(64 * X128_STAGE_ROW >= 2 * X128_SLOT, "the staging area holds the chunk slots");
 
 // FLAT: the 128 vertices of a tile are consecutive in the block's row-major vertex numbering instead of lying in
 // one mesh row -- no padding when n1 is not close to a multiple of 128 (n1 = 170: 226 tiles per block instead of
@@ -1678,11 +1673,7 @@ template <bool FLAT>
 __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, const double* __restrict__ a, int Mc,
                                                       double* __restrict__ U, long long row0, int with_expand,
                                                       int sys_fast) {
-#if X128_STAGED
-  __shared__ __align__(16) char lds_bytes[64 * X128_STAGE_ROW];  // two chunk slots (65,536 B), reused as 64 staged system rows
-#else
   __shared__ __align__(16) char lds_bytes[2 * X128_SLOT];  // two chunk slots = 65,536 B: two workgroups per CU
-#endif
   __shared__ double scs[128];                               // h^2 / a_b of the workgroup's systems
   double* const lds = reinterpret_cast<double*>(lds_bytes);
   const int n1 = f.n1, N = f.N;
@@ -1907,81 +1898,6 @@ __global__ __launch_bounds__(512, 2) void k_extend128(FemDev f, X128Args xa, con
   __builtin_amdgcn_s_setprio(ROMHC_EPI_PRIO);
   if (threadIdx.x < 128) scs[threadIdx.x] = my_sc;
   __syncthreads();
-#if X128_STAGED
-  // Staged epilogue: ONE STORE INSTRUCTION = ONE SYSTEM'S WHOLE RUN of the tile (128 vertices, 1016 B of a mesh row) instead of
-  // 4 systems x 256 B.  The MFMA result layout gives a wave 64 systems x 32 vertices; the tile goes through LDS (the chunk
-  // slots are free now) half a tile at a time -- the four waves of system half `ph` write their pieces as [system][vertex],
-  // then all eight waves store eight systems each, lane = vertex pair.  A store-only replica of that pattern writes
-  // 3.3 TB/s into the reference layout against 2.9 for the direct one (tools/ext_store_patterns2.hip, P1 vs B0).
-  {
-    const bool odd = lane & 1;
-    const int t = 2 * lane;  // the lane's first vertex, tile-local
-    long long off0, off1;
-    bool ok0, ok1;
-    if (FLAT) {
-      const int v = vt0 + t, i0 = v / n1, j0 = v - i0 * n1;
-      off0 = (long long)(p * N + i0) * f.nc + q * N + j0;
-      off1 = j0 + 1 < n1 ? off0 + 1 : (long long)(p * N + i0 + 1) * f.nc + q * N;
-      ok0 = v < nvert;
-      ok1 = v + 1 < nvert;
-    } else {
-      const int jcol = jv0 + t;  // 1-based
-      off0 = (long long)(p * N + iv - 1) * f.nc + q * N - 1 + jcol;
-      off1 = off0 + 1;
-      ok0 = jcol <= n1;
-      ok1 = jcol + 1 <= n1;
-    }
-    const bool straddle = FLAT && off1 != off0 + 1;
-    const unsigned long long k16 = __builtin_amdgcn_ballot_w64(ok1 && !straddle), k8 = __builtin_amdgcn_ballot_w64(ok0 && (!ok1 || straddle)),
-                             k8b = __builtin_amdgcn_ballot_w64(ok1 && straddle);
-    const long long d1 = (off1 - off0) * 8;
-    char* sp = reinterpret_cast<char*>(U) + size_t(row0 + m0 + 8 * w) * size_t(f.dim) * 8 + off0 * 8;   // the wave's first system of phase 0
-    const long long rowb = (long long)f.dim * 8;
-#pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-      if (wr == ph) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int sl = i * 16 + kq + 4 * g;
-            const double sc = scs[ph * 64 + sl];
-#pragma unroll
-            for (int hp = 0; hp < NJ / 2; ++hp) {
-              const double x0 = acc[i][2 * hp][g] + sc * w_own[2 * hp], x1 = acc[i][2 * hp + 1][g] + sc * w_own[2 * hp + 1];
-              const double got = lane_swap1(odd ? x0 : x1);
-              const int tt = wc * (16 * NJ) + (2 * hp + (odd ? 1 : 0)) * 16 + fr - (odd ? 1 : 0);
-              *reinterpret_cast<double2*>(lds_bytes + sl * X128_STAGE_ROW + tt * 8) = double2{odd ? got : x0, odd ? x1 : got};
-            }
-          }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-      for (int sx = 0; sx < 8; ++sx) {
-        const int sl = 8 * w + sx;
-        const double2 v2 = *reinterpret_cast<const double2*>(lds_bytes + sl * X128_STAGE_ROW + lane * 16);
-        const double2_u pr = double2_u{v2.x, v2.y};
-        const unsigned long long in = (m0 + ph * 64 + sl < Mc) ? ~0ull : 0ull;
-        const unsigned long long m16 = x128_uniform(k16 & in), m8 = x128_uniform(k8 & in), m8b = x128_uniform(k8b & in);
-        char* dst = sp + (long long)(ph * 64 + sx) * rowb;
-        unsigned long long sv;
-        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx4 %2, %3, off" X128_STORE_POLICY "\n\ts_mov_b64 exec, %0"
-                     : "=&s"(sv)
-                     : "s"(m16), "v"(dst), "v"(pr));
-        if (m8 != 0)
-          asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx2 %2, %3, off" X128_STORE_POLICY "\n\ts_mov_b64 exec, %0"
-                       : "=&s"(sv)
-                       : "s"(m8), "v"(dst), "v"(pr.x));
-        if (FLAT && m8b != 0)
-          asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx2 %2, %3, off" X128_STORE_POLICY "\n\ts_mov_b64 exec, %0"
-                       : "=&s"(sv)
-                       : "s"(m8b), "v"(dst + d1), "v"(pr.y));
-      }
-      if (ph == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the staged rows are read before they are rewritten
-    }
-  }
-  return;
-#endif
   // epilogue: add the particular solution, swap between lane pairs so that every lane owns two adjacent vertices of
   // one 16-vertex block, 16-byte stores.  The stores of a wave walk down its 64 systems four rows at a time (rows
   // 16 i + 4 g + kq, i and g ascending): the lane's pointer advances by a constant, what a lane stores
