@@ -126,6 +126,39 @@ __global__ __launch_bounds__(1024) void kp_pivchol_lowrank(int M, const double* 
   }
 }
 
+// Eigen-decomposition of the leading n x n block of A (nmax x nmax, nmax <= 32) with n read FROM THE DEVICE (n_dev[0], the
+// rank a kernel in front of this one has just found): the host need not know n to launch it.  lam (nmax) and T (nmax x nmax)
+// are zero behind n.
+__global__ __launch_bounds__(256) void kp_jacobi32_devn(int nmax, const double* __restrict__ n_dev, const double* __restrict__ A,
+                                                        double* __restrict__ lam, double* __restrict__ T) {
+  __shared__ Jacobi32Lds L;
+  __shared__ double red[4];
+  const int t = threadIdx.x, n = max(0, min(nmax, int(n_dev[0])));
+  for (int idx = t; idx < nmax * nmax; idx += 256) T[idx] = 0.0;
+  if (t < nmax) lam[t] = 0.0;
+  if (n == 0) return;
+  double dmax = 0.0;
+  for (int idx = t; idx < n * n; idx += 256) {
+    const int r = idx / n, c = idx - r * n;
+    const double v = 0.5 * (A[size_t(r) * nmax + c] + A[size_t(c) * nmax + r]);
+    L.As[r * J32_LD + c] = v;
+    L.Vt[r * J32_LD + c] = r == c ? 1.0 : 0.0;
+    if (r == c) dmax = fmax(dmax, fabs(v));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+  if ((t & 63) == 0) red[t >> 6] = dmax;
+  __syncthreads();
+  dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  jacobi32_run<256>(n, L, 1, dmax);
+  __syncthreads();   // (the zero fill of T above is complete for everybody)
+  if (t < n) lam[t] = L.ev[L.perm[t]];
+  for (int idx = t; idx < n * n; idx += 256) {
+    const int r = idx / n, c = idx - r * n;
+    T[size_t(r) * nmax + c] = L.Vt[L.perm[r] * J32_LD + c];
+  }
+}
+
 // rows of W (r x M) scaled by 1 / sqrt(lam_i) where lam_i > floor_rel * lam_0, zeroed elsewhere
 __global__ void kp_scale_eigvec_rows(double* __restrict__ W, long long M, const double* __restrict__ lam, double floor_rel) {
   const double l = lam[blockIdx.y], l0 = lam[0];
@@ -279,7 +312,7 @@ __global__ __launch_bounds__(256) void kp_tall_svd(int b, int M, double* __restr
     if (lane == 0) red[w] = dmax;
     __syncthreads();
     dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-    jacobi32_run<256>(b, L, 1, dmax);
+    const bool rotated = jacobi32_run<256>(b, L, 1, dmax);
     for (int idx = t; idx < b * b; idx += 256) {
       const int r = idx / b, c = idx - r * b;
       St[r * J32_LD + c] = L.Vt[L.perm[r] * J32_LD + c];
@@ -338,6 +371,9 @@ __global__ __launch_bounds__(256) void kp_tall_svd(int b, int M, double* __restr
       Rs[r * J32_LD + c] = Rn[r * J32_LD + c];
     }
     __syncthreads();
+    // H was diagonal by Jacobi's own criterion (S = a sorting permutation, applied above): the rows ARE the singular
+    // directions to working accuracy, and a further round would compute the same H and rotate nothing
+    if (!rotated) break;
   }
   for (int idx = t; idx < b * b; idx += 256) {
     const int r = idx / b, c = idx - r * b;
@@ -375,9 +411,56 @@ int lowrank_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W,
   const int rcap = std::min(M, LOWRANK_CAP);
   if (M <= rcap) return ROM_OK;  // (the full space: one exact Ritz step of the general path)
   Tmp Lt, dw, out, H, St, lam, Wr;
-  ROM_TRY(Lt.get(ctx, size_t(rcap) * M));
   ROM_TRY(dw.get(ctx, M));
   ROM_TRY(out.get(ctx, 4));
+  {
+    // First a factor of at most 32 steps with everything behind it enqueued BEFORE the host knows the rank (the small
+    // eigenproblem reads it from the device): ONE host synchronisation for the whole Gram stage when the block's Gram
+    // matrix has numerical rank <= 32 -- a sweep over a handful of parameters -- instead of two round trips.
+    constexpr int R32 = 32;
+    ROM_TRY(Lt.get(ctx, size_t(R32) * M));
+    ROM_TRY(H.get(ctx, size_t(R32) * R32));
+    ROM_TRY(St.get(ctx, size_t(R32) * R32));
+    ROM_TRY(lam.get(ctx, R32));
+    ROM_TRY(Wr.get(ctx, size_t(R32) * M));
+    ROM_HIP(hipMemsetAsync(Lt.p(), 0, size_t(R32) * M * sizeof(double), ctx->stream));
+    {
+      ROM_PROF(ctx, "pivchol_lowrank", double(R32) * R32 * M, 8.0 * R32 * M);
+      kp_pivchol_lowrank<<<1, 1024, 0, ctx->stream>>>(M, G, M, R32, LOWRANK_TOL, Lt, dw, out);
+    }
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(rom_launch_gemm_nt(ctx, R32, R32, M, 1.0, Lt, M, Lt, M, 0.0, H, R32, "gemm_nt"));
+    {
+      ROM_PROF(ctx, "small_eig", 30.0 * R32 * R32 * R32, 16.0 * R32 * R32);
+      kp_jacobi32_devn<<<1, 256, 0, ctx->stream>>>(R32, out, H, lam, St);
+    }
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(rom_launch_gemm_nn(ctx, R32, M, R32, 1.0, St, R32, Lt, M, 0.0, Wr, M));
+    kp_scale_eigvec_rows<<<dim3(unsigned(std::min((M + 255) / 256, 64)), R32), 256, 0, ctx->stream>>>(Wr, M, lam, 0.0);
+    ROM_HIP(hipGetLastError());
+    double o[4 + R32];
+    ROM_HIP(hipMemcpyAsync(o, out.p(), 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ROM_HIP(hipMemcpyAsync(o + 4, lam.p(), R32 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ROM_HIP(hipStreamSynchronize(ctx->stream));
+    const int r = int(o[0]);
+    if (r < 1) return ROM_OK;
+    if (o[3] != 0.0 && o[4] > 0.0 && o[1] <= LOWRANK_RESIDUAL * o[4]) {
+      const int ncopy = std::min(nev, r);
+      ROM_HIP(hipMemcpyAsync(W, Wr.p(), size_t(ncopy) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      if (ncopy < nev) ROM_HIP(hipMemsetAsync(W + size_t(ncopy) * M, 0, size_t(nev - ncopy) * M * sizeof(double), ctx->stream));
+      ROM_HIP(hipMemsetAsync(theta_dev, 0, size_t(nev) * sizeof(double), ctx->stream));
+      ROM_HIP(hipMemcpyAsync(theta_dev, lam.p(), size_t(ncopy) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      theta_host.assign(nev, 0.0);
+      for (int i = 0; i < ncopy; ++i) theta_host[i] = std::max(o[4 + i], 0.0);
+      info.eig_iterations = 0;
+      info.lowrank = r;
+      done = 1;
+      return ROM_OK;
+    }
+    if (o[3] != 0.0) return ROM_OK;   // (ended by tolerance but the residual bound failed: the general path)
+  }
+  // (rank above 32: the factor again up to LOWRANK_CAP steps, sizes known to the host before the small problems are launched)
+  ROM_TRY(Lt.get(ctx, size_t(rcap) * M));
   {
     ROM_PROF(ctx, "pivchol_lowrank", double(rcap) * rcap * M, 8.0 * rcap * M);
     kp_pivchol_lowrank<<<1, 1024, 0, ctx->stream>>>(M, G, M, rcap, LOWRANK_TOL, Lt, dw, out);

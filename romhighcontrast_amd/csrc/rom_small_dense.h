@@ -33,8 +33,9 @@ struct Jacobi32Lds {
 // (Demmel-Veselic) -- AND |a_pq| > tol nu_p nu_q, the rounding noise of the entry (gram_like: nu_i^2 = |a_ii| at the
 // start, rotated along; else max |a_ii|).  On return: eigenvalues on the diagonal of L.As, descending order in L.perm
 // (L.ev[L.perm[i]] is the i-th largest), every thread past a barrier.  dmax = max |a_ii| (the caller has it from the load).
+// Returns (uniformly) whether any rotation was applied: false = the matrix was diagonal by the criterion on entry.
 template <int NT>
-__device__ inline void jacobi32_run(int n, Jacobi32Lds& L, int gram_like, double dmax) {
+__device__ inline bool jacobi32_run(int n, Jacobi32Lds& L, int gram_like, double dmax) {
   constexpr int LD = J32_LD;
   constexpr int BI = 256 / NT, VI = 512 / NT;   // 2 x 2 blocks / eigenvector items of a lane
   double* As = L.As;
@@ -59,6 +60,7 @@ __device__ inline void jacobi32_run(int n, Jacobi32Lds& L, int gram_like, double
   }
   const double tol = double(n > 8 ? n : 8) * 1.1e-16, tol2 = tol * tol, floor_abs = fmax(1e-300, 1e-40 * dmax);
   __syncthreads();
+  bool ever = false;
   for (int sweep = 0; sweep < 40; ++sweep) {
     bool rotated = false;
     for (int r = 0; r < ne - 1; ++r) {
@@ -153,6 +155,7 @@ __device__ inline void jacobi32_run(int n, Jacobi32Lds& L, int gram_like, double
     }
     if (NT == 64) {
       if (!__any(rotated)) break;
+      ever = true;
     } else {
       if (t < 64) {
         const int any = __any(rotated);
@@ -162,6 +165,7 @@ __device__ inline void jacobi32_run(int n, Jacobi32Lds& L, int gram_like, double
       const int any = L.any;
       __syncthreads();
       if (!any) break;
+      ever = true;
     }
   }
   if (t < n) L.ev[t] = As[t * LD + t];
@@ -173,4 +177,5 @@ __device__ inline void jacobi32_run(int n, Jacobi32Lds& L, int gram_like, double
     L.perm[rank] = t;
   }
   __syncthreads();
+  return ever;
 }
