@@ -35,89 +35,166 @@ struct rom_factored_map {
   double* LT2 = nullptr;    // (k2, Kc): row c = column c of the Cholesky factor, over ORIGINAL coordinate indices
   int* piv2 = nullptr;      // (k2): pivot order
   double* d2 = nullptr;     // (Kc): equilibration
+  double* Li2 = nullptr;    // (k2, k2): inverse of the pivot rows' triangle L1 (L1[r][c] = LT2[c][piv2[r]]): x L1 = v is x = v Li2
 };
 
 void rom_factored_map_free(void* p) {
   auto* m = static_cast<rom_factored_map*>(p);
   if (!m) return;
-  for (void* q : {(void*)m->ET1, (void*)m->Sb, (void*)m->bt, (void*)m->ET2, (void*)m->LT2, (void*)m->piv2, (void*)m->d2})
+  for (void* q : {(void*)m->ET1, (void*)m->Sb, (void*)m->bt, (void*)m->ET2, (void*)m->LT2, (void*)m->piv2, (void*)m->d2, (void*)m->Li2})
     if (q) hipFree(q);
   delete m;
 }
 
 namespace {
 
-constexpr int PC_MAX = 3072;      // coordinates the one-workgroup factorisation takes (its LDS: 63 KB)
 constexpr double PC_TOL = 1e-14;  // pivots of the equilibrated matrix below this are rounding of the tables
+constexpr int PC_PANEL = 32;      // pivots per panel of the blocked factorisation
 
-// Diagonally pivoted Cholesky of the equilibrated matrix D^-1 S D^-1 (d_i = sqrt(S_ii)), left-looking, ONE workgroup:
-// step j picks the largest remaining diagonal entry (first index on ties), forms column j from row `piv` of S and the j
-// earlier columns (a thread owns rows tid, tid + 1024, ...: coalesced reads of LT, the pivot row broadcast from LDS) and
-// downdates the diagonal.  LT[c * n + i] = L[i][c] over ORIGINAL indices i (rows pivoted before step c hold 0): no row is
-// ever swapped.  Stops when the pivot falls to `tol`: rank_out[0] columns.
-__global__ __launch_bounds__(1024) void kf_pivchol(int n, const double* __restrict__ S, double tol, double* __restrict__ LT,
-                                                   int* __restrict__ piv, double* __restrict__ dscale, int* __restrict__ rank_out) {
-  __shared__ double diag[PC_MAX];
-  __shared__ double rowp[PC_MAX];
-  __shared__ unsigned char used[PC_MAX];
-  __shared__ double rv[1024];
-  __shared__ int ri[1024];
-  __shared__ int s_p;
-  __shared__ double s_ljj;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < n; i += 1024) {
-    const double sii = S[size_t(i) * n + i];
-    const bool ok = sii > 0.0;
-    dscale[i] = ok ? sqrt(sii) : 1.0;
-    diag[i] = ok ? 1.0 : 0.0;
+// A = D^-1 S D^-1 (d_i = sqrt(S_ii); a non-positive diagonal entry: d_i = 1 and the coordinate is never pivoted), diag = its
+// diagonal (1 or 0), nobody used yet
+__global__ void kf_equilibrate(int n, const double* __restrict__ S, double* __restrict__ A, double* __restrict__ d,
+                               double* __restrict__ diag, int* __restrict__ used, int* __restrict__ state) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx == 0) { state[0] = 0; state[1] = 0; }
+  if (idx >= (long long)n * n) return;
+  const int i = int(idx / n), j = int(idx - (long long)i * n);
+  const double sii = S[size_t(i) * n + i], sjj = S[size_t(j) * n + j];
+  const double di = sii > 0.0 ? sqrt(sii) : 1.0, dj = sjj > 0.0 ? sqrt(sjj) : 1.0;
+  A[idx] = S[idx] / (di * dj);
+  if (i == j) {
+    d[i] = di;
+    diag[i] = sii > 0.0 ? 1.0 : 0.0;
     used[i] = 0;
   }
-  __syncthreads();
-  int j = 0;
-  for (; j < n; ++j) {
+}
+
+// Diagonally pivoted Cholesky of the equilibrated matrix, BLOCKED (round 5; round 4 ran all steps in one workgroup, every
+// column against all earlier ones: 44 ms for 769 pivots of 928 coordinates, and its LDS arrays capped the map at 3072
+// coordinates).  One panel = PC_PANEL pivots in ONE workgroup on the matrix A that already carries the downdates of all
+// earlier panels: step j picks the largest remaining diagonal entry (first index on ties), forms column j from row `piv` of A
+// and the columns of THIS panel, downdates the diagonal.  Between panels A -= P^T P (the panel's rows of LT) is one MFMA
+// product on the whole chip.  LT[c * n + i] = L[i][c] over ORIGINAL indices i (rows pivoted before step c hold 0): no row is
+// ever swapped.  state[0] = columns so far, state[1] = 1 once the pivot has fallen to `tol` (later panels return at once).
+__global__ __launch_bounds__(1024) void kf_pivchol_panel(int n, const double* __restrict__ A, double tol, double* __restrict__ LT,
+                                                         int* __restrict__ piv, double* __restrict__ diag, int* __restrict__ used,
+                                                         int* __restrict__ state, int j0) {
+  __shared__ double rv[16];
+  __shared__ int ri[16];
+  __shared__ double lp[PC_PANEL];
+  __shared__ int s_p;
+  __shared__ double s_best;
+  const int tid = threadIdx.x;
+  if (state[1]) return;
+  int j = j0;
+  const int jend = min(n, j0 + PC_PANEL);
+  bool done = false;
+  for (; j < jend; ++j) {
     double best = -1.0;
-    int at = 0;
+    int at = 0x7fffffff;
     for (int i = tid; i < n; i += 1024)
       if (!used[i] && diag[i] > best) { best = diag[i]; at = i; }
-    rv[tid] = best;
-    ri[tid] = at;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-      if (tid < s) {
-        const double o = rv[tid + s];
-        const int oi = ri[tid + s];
-        if (o > rv[tid] || (o == rv[tid] && oi < ri[tid])) { rv[tid] = o; ri[tid] = oi; }
-      }
-      __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_down(best, o, 64);
+      const int oa = __shfl_down(at, o, 64);
+      if (ob > best || (ob == best && oa < at)) { best = ob; at = oa; }
     }
-    if (!(rv[0] > tol)) break;  // (uniform: everybody reads the same value)
+    if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = at; }
+    __syncthreads();
     if (tid == 0) {
-      s_p = ri[0];
-      s_ljj = sqrt(rv[0]);
-      piv[j] = ri[0];
+      double bb = rv[0];
+      int ba = ri[0];
+      for (int w = 1; w < 16; ++w)
+        if (rv[w] > bb || (rv[w] == bb && ri[w] < ba)) { bb = rv[w]; ba = ri[w]; }
+      s_best = bb;
+      s_p = ba;
     }
     __syncthreads();
+    const double pv = s_best;
     const int p = s_p;
-    const double ljj = s_ljj, dp = dscale[p];
-    for (int k = tid; k < j; k += 1024) rowp[k] = LT[size_t(k) * n + p];
+    if (!(pv > tol)) { done = true; break; }  // (uniform)
+    const double ljj = sqrt(pv);
+    if (tid < j - j0) lp[tid] = LT[size_t(j0 + tid) * n + p];
     __syncthreads();
+    const int kk = j - j0;
     for (int i = tid; i < n; i += 1024) {
       double l = 0.0;
       if (i == p) {
         l = ljj;
       } else if (!used[i]) {
-        double v = S[size_t(p) * n + i] / (dscale[i] * dp);
-        for (int k = 0; k < j; ++k) v -= LT[size_t(k) * n + i] * rowp[k];
+        double v = A[size_t(p) * n + i];
+        for (int k = 0; k < kk; ++k) v -= LT[size_t(j0 + k) * n + i] * lp[k];
         l = v / ljj;
         diag[i] = fmax(diag[i] - l * l, 0.0);
       }
       LT[size_t(j) * n + i] = l;
     }
-    __syncthreads();
-    if (tid == 0) used[p] = 1;
+    if (tid == 0) {
+      piv[j] = p;
+      used[p] = 1;
+    }
     __syncthreads();
   }
-  if (tid == 0) rank_out[0] = j;
+  if (tid == 0) {
+    state[0] = j;
+    if (done || j >= n) state[1] = 1;
+  }
+}
+
+// Pt (n x PC_PANEL) = the transpose of the panel's rows of LT (zero columns behind the rows the panel wrote)
+__global__ void kf_panel_transpose(int n, const double* __restrict__ LT, int j0, const int* __restrict__ state, double* __restrict__ Pt,
+                                   double* __restrict__ Pz) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= (long long)n * PC_PANEL) return;
+  const int i = int(idx / PC_PANEL), k = int(idx - (long long)i * PC_PANEL);
+  const double v = j0 + k < state[0] ? LT[size_t(j0 + k) * n + i] : 0.0;   // (rows behind the rank hold stale numbers: zero)
+  Pt[idx] = v;
+  Pz[size_t(k) * n + i] = v;
+}
+
+// OUT[k][i * w + j] = IN[k][(r0 + i) * ld + c0 + j]: the part of K FE vectors on a rectangle of the mesh
+__global__ void kf_gather_rect(const double* __restrict__ IN, long long dim, int ld, int r0, int c0, int h, int w,
+                               double* __restrict__ OUT) {
+  const long long hw = (long long)h * w;
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= hw) return;
+  const int i = int(idx / w), j = int(idx - (long long)i * w);
+  OUT[blockIdx.y * hw + idx] = IN[blockIdx.y * dim + (long long)(r0 + i) * ld + c0 + j];
+}
+
+__global__ void kf_add_inplace(double* __restrict__ acc, const double* __restrict__ x, long long n) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx < n) acc[idx] += x[idx];
+}
+
+// L1[r][c] = LT[c * n + piv[r]] (c <= r; 0 above the diagonal): the k x k triangle of the pivot rows, dense and row-major
+__global__ void kf_gather_triangle(int k, int n, const double* __restrict__ LT, const int* __restrict__ piv, double* __restrict__ L1) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= (long long)k * k) return;
+  const int r = int(idx / k), c = int(idx - (long long)r * k);
+  L1[idx] = c <= r ? LT[size_t(c) * n + piv[r]] : 0.0;
+}
+
+// X = L1^-1 (k x k lower triangular, row-major): ONE WAVE per column j walks down it by forward substitution, the row's dot
+// product spread over the lanes; the column lives in LDS until it is written out.  (A thread per column -- 769 columns of
+// 300k dependent multiply-adds each -- took 55 ms at C4.)
+__global__ __launch_bounds__(256) void kf_tri_inverse(int k, const double* __restrict__ L1, double* __restrict__ X) {
+  extern __shared__ double xcol[];   // blockDim.x / 64 columns of k doubles
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * int(blockDim.x >> 6) + w;
+  if (j >= k) return;
+  double* x = xcol + size_t(w) * k;
+  for (int i = j; i < k; ++i) {
+    const double* row = L1 + size_t(i) * k;
+    double s = 0.0;
+    for (int q = j + lane; q < i; q += 64) s += row[q] * x[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const double xi = ((i == j ? 1.0 : 0.0) - s) / row[i];
+    if (lane == 0) x[i] = xi;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // (lgkmcnt(0): the store to LDS is in before the next row reads it; one wave, no barrier)
+  }
+  for (int i = lane; i < k; i += 64) X[size_t(i) * k + j] = i >= j ? x[i] : 0.0;
 }
 
 // ET[c][i] = d[i] * LT[c][i]
@@ -131,32 +208,13 @@ __global__ void kf_set_identity(double* __restrict__ A, int n) {
   if (i < n) A[size_t(i) * n + i] = 1.0;
 }
 
-// The way back from the factor's coordinates: row m of V (k numbers) -> the coordinate vector w with w E = v supported
-// on the pivot coordinates, w[piv[r]] = x[r] / d[piv[r]], x L1 = v (L1 = the k x k triangle of the pivot rows; back
-// substitution from the last column).  One workgroup per row; W (rows x n) is zero-filled by the caller.
-__global__ __launch_bounds__(256) void kf_solve_triangle(int k, int n, const double* __restrict__ LT, const int* __restrict__ piv,
-                                                         const double* __restrict__ d, const double* __restrict__ V,
-                                                         double* __restrict__ W) {
-  extern __shared__ double xs[];  // k doubles + k ints + 256 doubles
-  int* pv = reinterpret_cast<int*>(xs + k);
-  double* red = reinterpret_cast<double*>(pv + k + (k & 1));
-  const int m = blockIdx.x, tid = threadIdx.x;
-  for (int r = tid; r < k; r += 256) pv[r] = piv[r];
-  __syncthreads();
-  for (int r = k - 1; r >= 0; --r) {
-    const double* col = LT + size_t(r) * n;  // L[.][r]
-    double s = 0.0;
-    for (int q = r + 1 + tid; q < k; q += 256) s += xs[q] * col[pv[q]];
-    red[tid] = s;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-      if (tid < st) red[tid] += red[tid + st];
-      __syncthreads();
-    }
-    if (tid == 0) xs[r] = (V[size_t(m) * k + r] - red[0]) / col[pv[r]];
-    __syncthreads();
-  }
-  for (int r = tid; r < k; r += 256) W[size_t(m) * n + pv[r]] = xs[r] / d[pv[r]];
+// The way back from the factor's coordinates: x L1 = v (L1 = the k x k triangle of the pivot rows) gives the coordinate
+// vector w with w E = v supported on the pivot coordinates, w[piv[r]] = x[r] / d[piv[r]].  W (rows x n) is zero-filled by
+// the caller; x = v L1^-1 is a product with the inverse kept in the map.
+__global__ void kf_scatter_pivots(int k, int n, const int* __restrict__ piv, const double* __restrict__ d, const double* __restrict__ X,
+                                  double* __restrict__ W) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  if (r < k) W[size_t(m) * n + piv[r]] = X[size_t(m) * k + r] / d[piv[r]];
 }
 
 // iteration 0 of the greedy: with the snapshots' own norms as normalisation the reference gets exactly 1.0 for every
@@ -306,15 +364,41 @@ __global__ __launch_bounds__(256) void kf_sb_apply(int Kc, const double* __restr
   if (i < Kc) T[size_t(b) * Kc + i] = acc;
 }
 
-// equilibrated pivoted Cholesky of the n x n matrix S: LT (n x n scratch), piv, d on the device; returns the rank
+// equilibrated pivoted Cholesky of the n x n matrix S (blocked, see kf_pivchol_panel): LT (n x n scratch), piv, d on the
+// device; returns the rank.  No limit on n beyond memory.
 int pivoted_factor(rom_ctx* ctx, int n, const double* S, double* LT, int* piv, double* d, int* rank_host) {
-  ROM_CHECK(n <= PC_MAX, "factored map: %d coordinates, at most %d", n, PC_MAX);
-  Tmp rk;
-  ROM_TRY(rk.get(ctx, 1));
-  kf_pivchol<<<1, 1024, 0, ctx->stream>>>(n, S, PC_TOL, LT, piv, d, reinterpret_cast<int*>(rk.p()));
+  Tmp A, diag, used, st, Pt, Pz;
+  ROM_TRY(A.get(ctx, size_t(n) * n));
+  ROM_TRY(diag.get(ctx, n));
+  ROM_TRY(used.get(ctx, n));
+  ROM_TRY(st.get(ctx, 2));
+  ROM_TRY(Pt.get(ctx, size_t(n) * PC_PANEL));
+  ROM_TRY(Pz.get(ctx, size_t(n) * PC_PANEL));
+  int* d_used = reinterpret_cast<int*>(used.p());
+  int* d_state = reinterpret_cast<int*>(st.p());
+  kf_equilibrate<<<unsigned((size_t(n) * n + 255) / 256), 256, 0, ctx->stream>>>(n, S, A, d, diag, d_used, d_state);
   ROM_HIP(hipGetLastError());
-  ROM_HIP(hipMemcpyAsync(rank_host, rk.p(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  int state[2] = {0, 0};
+  int panel = 0;
+  for (int j0 = 0; j0 < n; j0 += PC_PANEL, ++panel) {
+    {
+      ROM_PROF(ctx, "pivchol_panel", 2.0 * n * PC_PANEL * PC_PANEL, 8.0 * n * PC_PANEL);
+      kf_pivchol_panel<<<1, 1024, 0, ctx->stream>>>(n, A, PC_TOL, LT, piv, diag, d_used, d_state, j0);
+    }
+    ROM_HIP(hipGetLastError());
+    if (j0 + PC_PANEL >= n) break;
+    if (panel % 8 == 7) {  // (every eighth panel the host looks whether the pivots have reached the tolerance)
+      ROM_HIP(hipMemcpyAsync(state, d_state, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      ROM_HIP(hipStreamSynchronize(ctx->stream));
+      if (state[1]) break;
+    }
+    kf_panel_transpose<<<unsigned((size_t(n) * PC_PANEL + 255) / 256), 256, 0, ctx->stream>>>(n, LT, j0, d_state, Pt, Pz);
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(rom_launch_gemm_nn(ctx, n, n, PC_PANEL, -1.0, Pt, PC_PANEL, Pz, n, 1.0, A, n));   // A -= P^T P
+  }
+  ROM_HIP(hipMemcpyAsync(state, d_state, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   ROM_HIP(hipStreamSynchronize(ctx->stream));
+  *rank_host = state[0];
   return ROM_OK;
 }
 
@@ -346,6 +430,23 @@ int basis_rows(rom_fem* f, int Kc, double* Bt) {
   return rom_solve_status(ctx);
 }
 
+// What a part of the map owns on the device while it is being built: freed on any early return, handed to the map only
+// when the whole part (ranks included) is complete -- a failure halfway leaves the map as it was.
+struct DevOwner {
+  std::vector<void*> ptrs;
+  ~DevOwner() {
+    for (void* p : ptrs)
+      if (p) hipFree(p);
+  }
+  template <class T>
+  int alloc(T** p, size_t n) {
+    ROM_TRY(dev_alloc(p, n));
+    ptrs.push_back(*p);
+    return ROM_OK;
+  }
+  void release() { ptrs.clear(); }
+};
+
 int ensure_map(rom_fem* f, int parts) {
   int lin = 0;
   ROM_TRY(rom_fem_expansion_is_linear(f, &lin));
@@ -357,7 +458,7 @@ int ensure_map(rom_fem* f, int parts) {
   auto* mp = static_cast<rom_factored_map*>(f->fmap);
   const int Kc = f->nGp - (f->xb0 - f->nGa);
   mp->Kc = Kc;
-  const int kblk = f->nrb * f->ncb;
+  const int kblk = f->nrb * f->ncb, N = f->N;
   const bool need1 = (parts & 1) && !mp->ET1, need2 = (parts & 2) && !mp->have_galerkin, need4 = (parts & 4) && !mp->ET2;
   if (!need1 && !need2 && !need4) return ROM_OK;
   const int64_t dim = f->dim;
@@ -369,56 +470,113 @@ int ensure_map(rom_fem* f, int parts) {
   ROM_TRY(pv.get(ctx, Kc));
   ROM_TRY(dd.get(ctx, Kc));
   if (need1 || need2) ROM_TRY(ABt.get(ctx, size_t(Kc) * dim));
-  if (need1) {
-    ROM_TRY(rom_launch_stencil_apply(f, nullptr, Bt, Kc, ABt));                                          // rows: A_1 B e_i
-    ROM_TRY(rom_launch_gemm_nt_ex(ctx, Kc, Kc, dim, 1.0, Bt, dim, ABt, dim, 0.0, Sm, Kc, "gemm_nt", 1));  // S1 = B^T A_1 B (symmetric: lower tiles + mirror)
-    int rank = 0;
-    ROM_TRY(pivoted_factor(ctx, Kc, Sm, LT, reinterpret_cast<int*>(pv.p()), dd, &rank));
-    ROM_CHECK(rank >= 1, "factored map: the H^1_0 form of the expansion has rank 0");
-    ROM_TRY(dev_alloc(&mp->ET1, size_t(rank) * Kc));
-    kf_scale_cols<<<unsigned((size_t(rank) * Kc + 255) / 256), 256, 0, ctx->stream>>>(rank, Kc, LT, dd, mp->ET1);
-    ROM_HIP(hipGetLastError());
-    mp->k1 = rank;
-  }
+  bool have_s1 = false;   // Sm holds S1 = B^T A_1 B
   if (need2) {
-    ROM_TRY(dev_alloc(&mp->Sb, size_t(kblk) * Kc * Kc));
-    ROM_TRY(dev_alloc(&mp->bt, size_t(Kc)));
-    Tmp coef, Btot;
+    // The block forms S_b = B^T A_b B.  A_b B e_i lives on the closure of block b -- (N + 1)^2 of the dim vertices -- so the
+    // product runs over THAT rectangle of both operands (gathered into compact rows): nine products of a ninth of the
+    // length at 3 x 3 instead of nine of the full length (round 4: 60 of the map's 127 ms).  S1 = sum_b S_b (A_1 = sum_b A_b).
+    DevOwner own;
+    double *Sb = nullptr, *bt = nullptr;
+    ROM_TRY(own.alloc(&Sb, size_t(kblk) * Kc * Kc));
+    ROM_TRY(own.alloc(&bt, size_t(Kc)));
+    Tmp coef, Btot, Bc, Zc;
     ROM_TRY(coef.get(ctx, size_t(kblk) * kblk));
     ROM_TRY(Btot.get(ctx, dim));
+    const size_t rect = size_t(N + 1) * (N + 1);
+    ROM_TRY(Bc.get(ctx, size_t(Kc) * rect));
+    ROM_TRY(Zc.get(ctx, size_t(Kc) * rect));
     std::vector<double> eye(size_t(kblk) * kblk, 0.0);
     for (int b = 0; b < kblk; ++b) eye[size_t(b) * kblk + b] = 1.0;
     ROM_HIP(hipMemcpyAsync(coef.p(), eye.data(), eye.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     ROM_HIP(hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < kblk; ++b) {
-      ROM_TRY(rom_launch_stencil_apply(f, coef.p() + size_t(b) * kblk, Bt, Kc, ABt));                    // rows: A_b B e_i
-      ROM_TRY(rom_launch_gemm_nt_ex(ctx, Kc, Kc, dim, 1.0, Bt, dim, ABt, dim, 0.0, mp->Sb + size_t(b) * Kc * Kc, Kc, "gemm_nt", 1));
+      const int p = b / f->ncb, q = b % f->ncb;
+      // inner vertices (0-based rows r, columns c) touched by the cells of block (p, q): r in [p N - 1, (p + 1) N - 1] clipped
+      const int r0 = std::max(0, p * N - 1), r1 = std::min(f->nr - 1, (p + 1) * N - 1);
+      const int c0 = std::max(0, q * N - 1), c1 = std::min(f->nc - 1, (q + 1) * N - 1);
+      const int h = r1 - r0 + 1, w = c1 - c0 + 1;
+      ROM_TRY(rom_launch_stencil_apply_band(f, coef.p() + size_t(b) * kblk, Bt, Kc, ABt, r0, r1));       // rows: A_b B e_i on the block's band
+      const dim3 gg(unsigned((size_t(h) * w + 255) / 256), unsigned(Kc));
+      kf_gather_rect<<<gg, 256, 0, ctx->stream>>>(Bt, dim, f->nc, r0, c0, h, w, Bc);
+      kf_gather_rect<<<gg, 256, 0, ctx->stream>>>(ABt, dim, f->nc, r0, c0, h, w, Zc);
+      ROM_HIP(hipGetLastError());
+      ROM_TRY(rom_launch_gemm_nt_ex(ctx, Kc, Kc, int64_t(h) * w, 1.0, Bc, int64_t(h) * w, Zc, int64_t(h) * w, 0.0, Sb + size_t(b) * Kc * Kc, Kc,
+                                    "gemm_nt", 1));
+      if (need1) {
+        if (b == 0) ROM_HIP(hipMemcpyAsync(Sm.p(), Sb, size_t(Kc) * Kc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        else kf_add_inplace<<<unsigned((size_t(Kc) * Kc + 255) / 256), 256, 0, ctx->stream>>>(Sm, Sb + size_t(b) * Kc * Kc, (long long)Kc * Kc);
+        ROM_HIP(hipGetLastError());
+      }
     }
     {
-      std::vector<double> bt(size_t(dim), 1.0 / (double(f->N) * f->N));  // B_total (:177-185: every inner entry h^2)
-      ROM_HIP(hipMemcpyAsync(Btot.p(), bt.data(), bt.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      std::vector<double> bt_h(size_t(dim), 1.0 / (double(f->N) * f->N));  // B_total (:177-185: every inner entry h^2)
+      ROM_HIP(hipMemcpyAsync(Btot.p(), bt_h.data(), bt_h.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
       ROM_HIP(hipStreamSynchronize(ctx->stream));
     }
-    ROM_TRY(rom_launch_rowdot(ctx, Bt, Kc, dim, Btot, mp->bt));
+    ROM_TRY(rom_launch_rowdot(ctx, Bt, Kc, dim, Btot, bt));
+    ROM_HIP(hipStreamSynchronize(ctx->stream));
+    mp->Sb = Sb;
+    mp->bt = bt;
     mp->have_galerkin = true;
+    own.release();
+    have_s1 = need1;
+  }
+  if (need1) {
+    if (!have_s1) {
+      ROM_TRY(rom_launch_stencil_apply(f, nullptr, Bt, Kc, ABt));                                          // rows: A_1 B e_i
+      ROM_TRY(rom_launch_gemm_nt_ex(ctx, Kc, Kc, dim, 1.0, Bt, dim, ABt, dim, 0.0, Sm, Kc, "gemm_nt", 1));  // S1 = B^T A_1 B (symmetric: lower tiles + mirror)
+    }
+    int rank = 0;
+    ROM_TRY(pivoted_factor(ctx, Kc, Sm, LT, reinterpret_cast<int*>(pv.p()), dd, &rank));
+    ROM_CHECK(rank >= 1, "factored map: the H^1_0 form of the expansion has rank 0");
+    DevOwner own;
+    double* ET1 = nullptr;
+    ROM_TRY(own.alloc(&ET1, size_t(rank) * Kc));
+    kf_scale_cols<<<unsigned((size_t(rank) * Kc + 255) / 256), 256, 0, ctx->stream>>>(rank, Kc, LT, dd, ET1);
+    ROM_HIP(hipGetLastError());
+    ROM_HIP(hipStreamSynchronize(ctx->stream));
+    mp->ET1 = ET1;
+    mp->k1 = rank;
+    own.release();
   }
   if (need4) {
     ROM_TRY(rom_launch_gram(ctx, Kc, dim, Bt, dim, Sm, Kc));                                             // S = B^T B
     int rank = 0;
     ROM_TRY(pivoted_factor(ctx, Kc, Sm, LT, reinterpret_cast<int*>(pv.p()), dd, &rank));
     ROM_CHECK(rank >= 1, "factored map: the expansion has rank 0");
-    ROM_TRY(dev_alloc(&mp->ET2, size_t(rank) * Kc));
-    ROM_TRY(dev_alloc(&mp->LT2, size_t(rank) * Kc));
-    ROM_TRY(dev_alloc(&mp->piv2, size_t(rank)));
-    ROM_TRY(dev_alloc(&mp->d2, size_t(Kc)));
-    kf_scale_cols<<<unsigned((size_t(rank) * Kc + 255) / 256), 256, 0, ctx->stream>>>(rank, Kc, LT, dd, mp->ET2);
+    DevOwner own;
+    double *ET2 = nullptr, *LT2 = nullptr, *d2 = nullptr, *Li2 = nullptr;
+    int* piv2 = nullptr;
+    ROM_TRY(own.alloc(&ET2, size_t(rank) * Kc));
+    ROM_TRY(own.alloc(&LT2, size_t(rank) * Kc));
+    ROM_TRY(own.alloc(&piv2, size_t(rank)));
+    ROM_TRY(own.alloc(&d2, size_t(Kc)));
+    ROM_TRY(own.alloc(&Li2, size_t(rank) * rank));
+    kf_scale_cols<<<unsigned((size_t(rank) * Kc + 255) / 256), 256, 0, ctx->stream>>>(rank, Kc, LT, dd, ET2);
     ROM_HIP(hipGetLastError());
-    ROM_HIP(hipMemcpyAsync(mp->LT2, LT.p(), size_t(rank) * Kc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    ROM_HIP(hipMemcpyAsync(mp->piv2, pv.p(), size_t(rank) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-    ROM_HIP(hipMemcpyAsync(mp->d2, dd.p(), size_t(Kc) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ROM_HIP(hipMemcpyAsync(LT2, LT.p(), size_t(rank) * Kc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ROM_HIP(hipMemcpyAsync(piv2, pv.p(), size_t(rank) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    ROM_HIP(hipMemcpyAsync(d2, dd.p(), size_t(Kc) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    // the way back from the factor's coordinates needs L1^-1 (L1 = the pivot rows' triangle): once here, a product per call
+    {
+      Tmp L1;
+      ROM_TRY(L1.get(ctx, size_t(rank) * rank));
+      kf_gather_triangle<<<unsigned((size_t(rank) * rank + 255) / 256), 256, 0, ctx->stream>>>(rank, Kc, LT2, piv2, L1);
+      const int cpw = rank <= 1920 ? 4 : rank <= 3840 ? 2 : 1;   // columns (waves) per workgroup: their LDS stays below 64 KB
+      ROM_CHECK(size_t(cpw) * rank * sizeof(double) <= 62 * 1024, "factored map: rank %d beyond what the inverse kernel's LDS columns hold", rank);
+      kf_tri_inverse<<<unsigned((rank + cpw - 1) / cpw), 64 * cpw, size_t(cpw) * rank * sizeof(double), ctx->stream>>>(rank, L1, Li2);
+      ROM_HIP(hipGetLastError());
+      ROM_HIP(hipStreamSynchronize(ctx->stream));   // (L1 is a temporary)
+    }
+    ROM_HIP(hipStreamSynchronize(ctx->stream));
+    mp->ET2 = ET2;
+    mp->LT2 = LT2;
+    mp->piv2 = piv2;
+    mp->d2 = d2;
+    mp->Li2 = Li2;
     mp->k2 = rank;
+    own.release();
   }
-  ROM_HIP(hipStreamSynchronize(ctx->stream));
   return ROM_OK;
 }
 
@@ -579,9 +737,11 @@ extern "C" int rom_pod_factored(rom_fem* f, rom_buf* Yc, int64_t c_row0, int M, 
   ROM_TRY(Wc.get(ctx, size_t(nz) * Kc));
   ROM_HIP(hipMemsetAsync(Wc.p(), 0, size_t(nz) * Kc * sizeof(double), ctx->stream));
   {
-    const size_t lds = size_t(k2) * 8 + size_t(k2 + (k2 & 1)) * 4 + 256 * 8;
-    ROM_CHECK(lds <= 64 * 1024, "rom_pod_factored: map of rank %d too large for the substitution kernel", k2);
-    kf_solve_triangle<<<nz, 256, lds, ctx->stream>>>(k2, Kc, mp->LT2, mp->piv2, mp->d2, Vz, Wc);
+    // x L1 = v  =>  x = v L1^-1 (the inverse is part of the map); w[piv[r]] = x[r] / d[piv[r]]
+    Tmp Xs;
+    ROM_TRY(Xs.get(ctx, size_t(nz) * k2));
+    ROM_TRY(rom_launch_gemm_nn(ctx, nz, k2, k2, 1.0, Vz, k2, mp->Li2, k2, 0.0, Xs, k2));
+    kf_scatter_pivots<<<dim3(unsigned((k2 + 255) / 256), unsigned(nz)), 256, 0, ctx->stream>>>(k2, Kc, mp->piv2, mp->d2, Xs, Wc);
     ROM_HIP(hipGetLastError());
   }
   ROM_TRY(Yfull.get(ctx, size_t(nz) * f->nGp));

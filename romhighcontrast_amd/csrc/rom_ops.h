@@ -16,6 +16,8 @@ int rom_launch_gemm_nn(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double alp
 int rom_launch_gram(rom_ctx* ctx, int64_t m, int64_t k, const double* A, int64_t lda, double* C, int64_t ldc);
 // Y[k,:] = A(coef) X[k,:]; d_coef: kblk block coefficients ON THE DEVICE, or null for the unit operator A_1
 int rom_launch_stencil_apply(rom_fem* f, const double* d_coef, const double* X, int K, double* Y);
+// the same on the interior mesh rows [row_lo, row_hi] only (Y is not written outside the slabs that cover them)
+int rom_launch_stencil_apply_band(rom_fem* f, const double* d_coef, const double* X, int K, double* Y, int row_lo, int row_hi);
 // Y[b, :] = A_b x for all kblk blocks in one launch (d_onehot: kblk x kblk identity on the device)
 int rom_launch_stencil_apply_blocks(rom_fem* f, const double* d_onehot, const double* x, double* Y);
 // d_out[k] = ||U_k - V_k||_{H10} (V may be null); squared norms if !take_sqrt.  Same kernels, same bits as rom_h10norm.

@@ -887,7 +887,7 @@ constexpr int SA_UNROLL = 8;   // loads in flight per thread
 template <bool UNIT>
 __global__ __launch_bounds__(256) void k_stencil_apply_cols(StencilGeom g, const double* __restrict__ a_one, int coef_stride,
                                                             const double* __restrict__ X, long long x_stride,
-                                                            double* __restrict__ Y) {
+                                                            double* __restrict__ Y, int slab0) {
   // vector z of the launch: input row X + z x_stride (0: the same row for every z), coefficients a_one + z coef_stride
   __shared__ double am[64];
   if (!UNIT)
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256) void k_stencil_apply_cols(StencilGeom g, const
   const double* x = X + blockIdx.z * x_stride;
   double* y = Y + blockIdx.z * g.dim;
   const int c = blockIdx.x * 256 + threadIdx.x;  // 0-based interior column
-  const int r0 = blockIdx.y * SA_ROWS, r1 = min(g.nr, r0 + SA_ROWS);
+  const int r0 = (slab0 + blockIdx.y) * SA_ROWS, r1 = min(g.nr, r0 + SA_ROWS);   // (slab0: a launch over a band of mesh rows)
   const bool in = c < g.nc;
   const int lane = threadIdx.x & 63;
   const int N = g.N;
@@ -1057,8 +1057,25 @@ int rom_launch_stencil_apply(rom_fem* f, const double* d_coef, const double* X, 
   {
     ROM_PROF(ctx, "stencil_apply", 14.0 * g.dim * K, 16.0 * g.dim * K);
     const dim3 grid((g.nc + 255) / 256, (g.nr + SA_ROWS - 1) / SA_ROWS, K);
-    if (!d_coef) k_stencil_apply_cols<true><<<grid, 256, 0, ctx->stream>>>(g, nullptr, 0, X, g.dim, Y);
-    else k_stencil_apply_cols<false><<<grid, 256, 0, ctx->stream>>>(g, d_coef, 0, X, g.dim, Y);
+    if (!d_coef) k_stencil_apply_cols<true><<<grid, 256, 0, ctx->stream>>>(g, nullptr, 0, X, g.dim, Y, 0);
+    else k_stencil_apply_cols<false><<<grid, 256, 0, ctx->stream>>>(g, d_coef, 0, X, g.dim, Y, 0);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
+// The same on the mesh rows [row_lo, row_hi] only (0-based interior rows; whole slabs of SA_ROWS that cover them): entries of Y
+// outside the band are NOT written.  For operators that vanish outside a band -- the one-hot block operators A_b.
+int rom_launch_stencil_apply_band(rom_fem* f, const double* d_coef, const double* X, int K, double* Y, int row_lo, int row_hi) {
+  if (K <= 0) return ROM_OK;
+  rom_ctx* ctx = f->ctx;
+  StencilGeom g = rom_make_geom(f->nrb, f->ncb, f->N);
+  ROM_CHECK(K <= 65535 && d_coef && row_lo >= 0 && row_hi >= row_lo && row_hi < g.nr, "stencil apply on a band: bad arguments");
+  const int s0 = row_lo / SA_ROWS, s1 = row_hi / SA_ROWS;
+  {
+    ROM_PROF(ctx, "stencil_apply", 14.0 * double(s1 - s0 + 1) * SA_ROWS * g.nc * K, 16.0 * double(s1 - s0 + 1) * SA_ROWS * g.nc * K);
+    const dim3 grid((g.nc + 255) / 256, unsigned(s1 - s0 + 1), K);
+    k_stencil_apply_cols<false><<<grid, 256, 0, ctx->stream>>>(g, d_coef, 0, X, g.dim, Y, s0);
   }
   ROM_HIP(hipGetLastError());
   return ROM_OK;
@@ -1072,7 +1089,7 @@ int rom_launch_stencil_apply_blocks(rom_fem* f, const double* d_onehot, const do
   {
     ROM_PROF(ctx, "stencil_apply_blocks", 14.0 * g.dim * g.kblk, 16.0 * g.dim * g.kblk);
     const dim3 grid((g.nc + 255) / 256, (g.nr + SA_ROWS - 1) / SA_ROWS, g.kblk);
-    k_stencil_apply_cols<false><<<grid, 256, 0, ctx->stream>>>(g, d_onehot, g.kblk, x, 0, Y);
+    k_stencil_apply_cols<false><<<grid, 256, 0, ctx->stream>>>(g, d_onehot, g.kblk, x, 0, Y, 0);
   }
   ROM_HIP(hipGetLastError());
   return ROM_OK;
