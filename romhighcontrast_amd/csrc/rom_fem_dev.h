@@ -46,6 +46,7 @@ struct FemDev {
   const int* item_cf;   // k_coef: index of an entry among the closed-form entries (its dot products: 8 slots from 8 * item_cf), -1 for the others
   const int* ctask;     // k_coef: a flat record of 8 ints per dot product of the closed-form blocks: {matrix offset of the entry's column, source, length, row stride | vector entry or -1, u0, u1, slot}
   int nctask, ncf;
+  double* gdots;        // k_coef: the tasks' dot products in global memory ([system][ncf * 8]) where they outgrow the LDS; else null
   int ncoef;
   const double* G;     // extension tables of the compressed edges: per table (n1*n1) x (rank+1 padded)
   const double* Gs;    // segment-major copies: [8-wide K segment][row][8], rows ordered so that the vertices of a mesh

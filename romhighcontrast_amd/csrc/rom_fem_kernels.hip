@@ -507,7 +507,7 @@ __global__ __launch_bounds__(1024) void k_coef(FemDev f, const double* __restric
   const double* am = a + size_t(m) * f.kblk;
   double* y = f.y + size_t(m) * f.nGp;
   extern __shared__ double ys[];  // the nGa reduced unknowns of the system (what the coefficient blocks are built from) | the tasks' dot products
-  double* dots = ys + f.nGa;
+  double* dots = f.gdots ? f.gdots + size_t(m) * f.ncf * 8 : ys + f.nGa;   // (global only where ncf * 64 bytes outgrow the LDS)
   for (int v = threadIdx.x; v < f.nGa; v += blockDim.x) ys[v] = y[v];
   __syncthreads();
   for (int x = threadIdx.x; x < f.ncross; x += blockDim.x) y[f.xb0 + x] = ys[f.xred[x]];

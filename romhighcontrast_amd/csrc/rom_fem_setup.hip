@@ -38,7 +38,7 @@ FemDev make_dev(const rom_fem* f) {
   d.g = f->d_g; d.desc = f->d_desc;
   d.kptr = f->d_kptr; d.kpair = f->d_kpair; d.colptr = f->d_colptr; d.colrow = f->d_colrow;
   d.colti = f->d_colti; d.sides = f->d_sides; d.lr_blocks = f->d_lr_blocks; d.n_lr = f->n_lr_blocks; d.gen_blocks = f->d_gen_blocks; d.vmap = f->d_vmap; d.scat = f->d_scat; d.nscat = f->nscat; d.L = f->d_L; d.invL = f->d_invL;
-  d.y = f->d_y; d.status = f->ctx->d_status;
+  d.y = f->d_y; d.status = f->ctx->d_status; d.gdots = f->d_dots;
   return d;
 }
 
@@ -290,7 +290,7 @@ void put_table(std::vector<double>& pool, size_t idx, int n1p, const Mat& A, boo
 extern "C" int rom_fem_destroy(rom_fem* f) {
   if (!f) return ROM_OK;
   hipStreamSynchronize(f->ctx->stream);
-  void* ptrs[] = {f->d_A0, f->d_G, f->d_Gs, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
+  void* ptrs[] = {f->d_A0, f->d_G, f->d_Gs, f->d_Qp, f->d_kmax, f->d_epos, f->d_yhat, f->d_dots, f->d_W, f->d_g, f->d_desc, f->d_terms, f->d_pool,
                   f->d_kptr, f->d_kpair, f->d_colptr, f->d_colrow, f->d_colti, f->d_sides, f->d_vmap, f->d_L,
                   f->d_invL, f->d_y, f->d_Bt, f->d_P, f->d_vec, f->d_rhs, f->d_pre, f->d_exp, f->d_xred, f->d_groups, f->d_cm,
                   f->d_item_group, f->d_item_k, f->d_item_cf, f->d_ctask, f->d_pairs, f->d_alist, f->d_aoff, f->d_pool_acc, f->d_wmeta, f->d_s1_items, f->d_s1_citems, f->d_lr_blocks, f->d_gen_blocks, f->d_scat, f->d_dgroups, f->d_dweight, f->d_ditem_group,
@@ -1431,6 +1431,7 @@ extern "C" int rom_fem_create(rom_ctx* ctx, int nrb, int ncb, int N, rom_fem** o
   // the product uses on different geometries give the same bits on one.  The product build does not read these.
   f->sw_x128_sys_fast = ab_env("ROMHC_X128_SYS_FAST") ? atoi(ab_env("ROMHC_X128_SYS_FAST")) : -1;
   f->sw_no_fold = ab_env("ROMHC_NO_FOLD_EXPAND") != nullptr;
+  f->sw_coef_global = ab_env("ROMHC_COEF_GLOBAL") != nullptr;
   f->sw_no_tile_pairs = ab_env("ROMHC_NO_TILE_PAIRS") != nullptr;
   f->sw_no_tile_stream = ab_env("ROMHC_NO_TILE_STREAM") != nullptr;
   f->sw_ext_flat = ab_env("ROMHC_EXT_FLAT") ? (atoi(ab_env("ROMHC_EXT_FLAT")) != 0 ? 1 : 0) : -1;

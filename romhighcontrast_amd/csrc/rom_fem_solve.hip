@@ -68,7 +68,8 @@ static int ensure_workspace(rom_fem* f, int Mc) {
   if (f->d_invL) hipFree(f->d_invL);
   if (f->d_y) hipFree(f->d_y);
   if (f->d_yhat) hipFree(f->d_yhat);
-  f->d_L = f->d_invL = f->d_y = f->d_yhat = nullptr;
+  if (f->d_dots) hipFree(f->d_dots);
+  f->d_L = f->d_invL = f->d_y = f->d_yhat = f->d_dots = nullptr;
   f->ws_M = 0;
   const size_t nL = std::max<size_t>(size_t(Mc) * f->nslots * 4096, 1) * sizeof(double);
   const size_t nI = std::max<size_t>(size_t(Mc) * f->T * 4096, 1) * sizeof(double);
@@ -77,6 +78,8 @@ static int ensure_workspace(rom_fem* f, int Mc) {
   ROM_HIP(hipMalloc(&f->d_invL, nI));
   ROM_HIP(hipMalloc(&f->d_y, nY));
   ROM_HIP(hipMalloc(&f->d_yhat, nY));
+  // (k_coef keeps its dot products in LDS up to 156 KB; a geometry with more closed-form entries than that gets them in HBM)
+  if (f->ncf > 0 && (f->sw_coef_global || size_t(std::max(f->nGa, 1)) * 8 + size_t(f->ncf) * 64 > 156 * 1024)) ROM_HIP(hipMalloc(&f->d_dots, size_t(Mc) * f->ncf * 8 * sizeof(double)));
   // Zeroed once: padding slots of d_y are read (against zero table entries) before anything writes them, and a
   // fresh hipMalloc block may hold another process's NaN bits.  The fill goes on the context's compute stream:
   // that stream and the sub-batch streams forked from it are hipStreamNonBlocking, so a null-stream hipMemset
@@ -143,8 +146,8 @@ static int enqueue_solve(rom_fem* f, const FemDev& d, const double* am, int Mc, 
     }
     {
       ROM_PROF(ctx, "coef", 0, 8.0 * Mc * f->ncoef);
-      const size_t lds_coef = lds_back + size_t(f->ncf) * 64;  // the nGa reduced unknowns + 8 dot products per closed-form entry
-      ROM_CHECK(lds_coef <= 156 * 1024, "rom_solve_batch: the coefficient blocks of this geometry do not fit the LDS (%zu bytes)", lds_coef);
+      // the nGa reduced unknowns + 8 dot products per closed-form entry (those in HBM where they outgrow the LDS: d.gdots)
+      const size_t lds_coef = d.gdots ? lds_back : lds_back + size_t(f->ncf) * 64;
       if (lds_coef > 48 * 1024 && !f->lds_optin_coef) {  // (the attribute belongs to the kernel as loaded on this device)
         ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_coef), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         f->lds_optin_coef = true;
@@ -279,6 +282,7 @@ static int solve_batch_impl(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t r
       if (Y) d.y = Y->p + size_t(y_row0 + m0 + off) * f->nGp;
       else d.y += size_t(off) * f->nGp;
       d.yhat += size_t(off) * f->nGp;
+      if (d.gdots) d.gdots += size_t(off) * f->ncf * 8;
       ROM_TRY(enqueue_solve(f, d, a->p + size_t(m0 + off) * kblk, Mc, U ? U->p : nullptr, (long long)(row0 + m0 + off), st,
                             lds_back, stages));
     }

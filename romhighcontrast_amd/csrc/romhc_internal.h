@@ -219,6 +219,7 @@ struct rom_fem {
   int n_edges = 0;
   double ext_flops = 0;
   double* d_yhat = nullptr;  // [ws_M][nGp]
+  double* d_dots = nullptr;  // [ws_M][ncf * 8]: k_coef's dot products, only where they do not fit the LDS (large geometries)
   double* d_W = nullptr;     // n1*n1 : L^{-1} 1
   double* d_g = nullptr;     // nGa : parameter independent part of the reduced rhs
   TileDesc* d_desc = nullptr;
@@ -264,6 +265,7 @@ struct rom_fem {
   size_t gs_bytes = 0;         // bytes of the segment-major extension tables (k_extend128's B operand)
    // k_extend128: system group fastest in the workgroup order (tables out of cache, not HBM)
   int sw_ext_flat = -1;
+  bool sw_coef_global = false;    // (A/B build) k_coef's dot products in HBM although they fit the LDS
   bool sw_no_tile_pairs = false;  // ROMHC_NO_TILE_PAIRS: tile Cholesky with one system per workgroup
   bool sw_no_tile_stream = false; // ROMHC_NO_TILE_STREAM: tile assembly in registers (s_tile_load) instead of the stream into LDS
   DenseGroup* d_dgroups = nullptr;

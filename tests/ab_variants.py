@@ -61,8 +61,9 @@ def tilings(ctx):
 def forced_forms(ctx):
     """One system per workgroup in the diagonal update, tiles assembled in registers, the general extension kernel for blocks
     whose sides are all compressed: forms the product uses on OTHER geometries (more than 2048 systems, tiles of more than
-    128 terms, blocks with a side in sine modes), forced here."""
-    for env in ("ROMHC_NO_EXT_LR", "ROMHC_NO_TILE_PAIRS", "ROMHC_NO_TILE_STREAM"):
+    128 terms, blocks with a side in sine modes; ROMHC_COEF_GLOBAL: k_coef's dot products in HBM, the form of geometries whose
+    closed-form entries outgrow 156 KB of LDS), forced here."""
+    for env in ("ROMHC_NO_EXT_LR", "ROMHC_NO_TILE_PAIRS", "ROMHC_NO_TILE_STREAM", "ROMHC_COEF_GLOBAL"):
         for blocks, N, M in (((2, 2), 128, 130), ((3, 3), 24, 40), ((2, 3), 40, 20), ((3, 3), 64, 70)):
             a = 10.0 ** np.random.default_rng(N).uniform(0, 3, size=(M, blocks[0] * blocks[1]))
             ab = ctx.upload(a)

@@ -517,7 +517,7 @@ def test_environment_switches_are_documented():
     launcher = {"ROMHC_LAUNCH_ID", "ROMHC_FORCE_DEVICE"}  # set / read by bench.py's launcher, not by the library
     ab_build = set(re.findall(r'ab_env\("(ROMHC_[A-Z0-9_]+)"\)', open(os.path.join(csrc, "rom_fem_setup.hip")).read())) | {"ROMHC_AB"}
     assert ab_build == {"ROMHC_AB", "ROMHC_NO_EXT_LR", "ROMHC_NO_FOLD_EXPAND", "ROMHC_EXT_FLAT", "ROMHC_X128_SYS_FAST", "ROMHC_NO_TILE_PAIRS",
-                        "ROMHC_NO_TILE_STREAM"}, ab_build   # (named in INTEGRATION.md as retired: read by libromhc_ab.so only)
+                        "ROMHC_NO_TILE_STREAM", "ROMHC_COEF_GLOBAL"}, ab_build   # (named in INTEGRATION.md as retired: read by libromhc_ab.so only)
     launcher |= ab_build
     assert read - dev_only <= doc, sorted(read - dev_only - doc)
     assert doc - launcher <= read, sorted(doc - launcher - read)
