@@ -670,6 +670,50 @@ int tall_svd_rotation(rom_ctx* ctx, double* Tt, int b, int M, double* Rt, double
   return ROM_OK;
 }
 
+// The first product of a sketch pass, Q = Omega X (b x dim), does not depend on what the passes before it found -- only its
+// rank-`found` correction does -- so it is started on a SECOND STREAM while the small dense problems in front of the pass
+// (one-workgroup factorisations, Jacobi, a host read-back) leave the chip idle.  Same seeds, same kernels, same bits as
+// the product enqueued in line; a guess of b that turns out wrong is discarded.
+struct SketchAhead {
+  rom_ctx* ctx = nullptr;
+  Tmp Om, Q;
+  int b = 0, seed = 0;
+  bool pending = false;
+  ~SketchAhead() {   // (an error return with the product still in flight: its buffers go back to the allocator only when it is done)
+    if (pending && ctx && ctx->aux[0]) hipStreamSynchronize(ctx->aux[0]);
+  }
+};
+
+int sketch_ahead_start(rom_ctx* ctx, SketchAhead& sa, const double* X, int M, int64_t dim, int b, int seed) {
+  if (ctx->profile || !ctx->aux[0]) return ROM_OK;   // (per-kernel profiling keeps everything on one stream)
+  sa.ctx = ctx;
+  ROM_TRY(sa.Om.get(ctx, size_t(b) * M));
+  ROM_TRY(sa.Q.get(ctx, size_t(b) * dim));
+  ROM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+  ROM_HIP(hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+  hipStream_t main_stream = ctx->stream;
+  ctx->stream = ctx->aux[0];
+  int st = romb_fill_random(ctx, sa.Om, size_t(b) * M, 0xabcd0000ull + unsigned(seed) * 7919u + unsigned(b), true);
+  if (st == ROM_OK) st = rom_launch_gemm_nn(ctx, b, dim, M, 1.0, sa.Om, M, X, dim, 0.0, sa.Q, dim);
+  ctx->stream = main_stream;
+  ROM_TRY(st);
+  ROM_HIP(hipEventRecord(ctx->ev_join[0], ctx->aux[0]));
+  sa.b = b;
+  sa.seed = seed;
+  sa.pending = true;
+  return ROM_OK;
+}
+
+// the main stream waits for the product in flight (always, so that nothing is left running); true if it is the one asked for
+int sketch_ahead_take(rom_ctx* ctx, SketchAhead& sa, int b, int seed, bool& hit) {
+  hit = false;
+  if (!sa.pending) return ROM_OK;
+  ROM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[0], 0));
+  sa.pending = false;
+  hit = sa.b == b && sa.seed == seed;
+  return ROM_OK;
+}
+
 // One sketch pass over the DEFLATED remainder of the (M, dim) block X: a randomised range finder with one power iteration,
 // thin products (2 b M dim flops each) instead of the 2 M^2 dim of a Gram matrix.
 // The block is deflated IMPLICITLY: X_d = X - Bt^T V with the `found` modes accepted so far (V: found x dim, orthonormal
@@ -679,10 +723,13 @@ int tall_svd_rotation(rom_ctx* ctx, double* Tt, int b, int M, double* Rt, double
 // Out: Q (b x dim): orthonormal rows spanning the sketch; Rt (b x b): rows = right singular vectors of Q X_d^T in Q's
 // coordinates (mode i = row i of Rt Q); Traw (b x M) = Q X^T, the coefficients of the UNDEFLATED block (mode i's
 // coefficient row X v_i = row i of Rt Traw: the caller's next deflation needs no pass over X); ss_host: b singular values.
+template <class Hook>
 int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double* V, const double* Bt, int found, int b, int seed,
-                double* Q, double* Rt, double* Traw, std::vector<double>& ss_host, PodInfo& info, int power = 1) {
-  Tmp Om, Tt, Cc, Tm, lam, s2;
-  ROM_TRY(Om.get(ctx, size_t(b) * M));
+                double* Q, const double* Om_ready, double* Rt, double* Traw, std::vector<double>& ss_host, PodInfo& info,
+                Hook before_rotation, int power = 1) {
+  Tmp Om_own, Tt, Cc, Tm, lam, s2;
+  if (!Om_ready) ROM_TRY(Om_own.get(ctx, size_t(b) * M));
+  const double* Om = Om_ready ? Om_ready : Om_own.p();
   ROM_TRY(Tt.get(ctx, size_t(b) * M));
   ROM_TRY(Cc.get(ctx, size_t(b) * std::max(found, 1)));
   ROM_TRY(Tm.get(ctx, size_t(b) * b));
@@ -696,8 +743,10 @@ int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double*
     if (fused && b <= 64) return combine_rows(ctx, b, b, nullptr, 0, found, Cc, found, -1.0, out, dim, V, dim, out, dim, dim);
     return rom_launch_gemm_nn(ctx, b, dim, found, -1.0, Cc, found, V, dim, 1.0, out, dim);
   };
-  ROM_TRY(romb_fill_random(ctx, Om, size_t(b) * M, 0xabcd0000ull + unsigned(seed) * 7919u + unsigned(b), true));
-  ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Om, M, X, dim, 0.0, Q, dim));                 // Q = Omega X_d
+  if (!Om_ready) {   // (else Q = Omega X is there already: started ahead on the second stream)
+    ROM_TRY(romb_fill_random(ctx, Om_own, size_t(b) * M, 0xabcd0000ull + unsigned(seed) * 7919u + unsigned(b), true));
+    ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Om, M, X, dim, 0.0, Q, dim));               // Q = Omega X_d
+  }
   ROM_TRY(correct_rows(Q, Om));
   info.executed += 2.0 * b * M * double(dim);
   double* Tdefl = Tt;
@@ -724,6 +773,7 @@ int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double*
     ROM_TRY(correct_rows(Q, Tdefl));
     info.executed += 2.0 * b * M * double(dim);
   }
+  ROM_TRY(before_rotation());   // (the last pass over the block is enqueued: what may run beside the small problems starts here)
   // X_d ~ T Q: the right singular vectors of the small factor rotate Q into the modes (Tt is rotated along, not used again)
   ROM_TRY(tall_svd_rotation(ctx, Tt, b, M, Rt, s2));
   ss_host.resize(b);
@@ -769,6 +819,7 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     info.executed += 2.0 * take * M * double(dim);
     return ROM_OK;
   };
+  SketchAhead ahead;
   // the sketch passes run until the request is filled or the spectrum has reached the floor; the budget below only guards
   // against a pass that makes no progress (every pass accepts at least one mode or ends the loop)
   const int passes = n + 2;
@@ -779,6 +830,12 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     ROM_TRY(W.get(ctx, size_t(n) * M));
     ROM_TRY(fac.get(ctx, n));
     ROM_TRY(rom_launch_gram(ctx, M, dim, X, dim, G, M));
+    // (blocks of 64 MB ... 2 GB: below, the product is shorter than the stream hand-over; above, the small problems are a
+    // small part of the call and a wrong guess costs a whole pass.  The first pass's product starts now, with the b a request of
+    // this size most likely asks for)
+    const bool worth_ahead = size_t(M) * dim * sizeof(double) <= (size_t(2) << 30) && size_t(M) * dim * sizeof(double) >= (size_t(64) << 20);
+    if (n >= 17 && worth_ahead)
+      ROM_TRY(sketch_ahead_start(ctx, ahead, X, M, dim, int(std::min<int64_t>(std::min<int64_t>(M, dim), 24)), 1));
     info.gram_passes = 1;
     info.executed += double(M) * (M + 1) * double(dim);
     std::vector<double> lam;
@@ -816,11 +873,27 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     // (a request with hundreds of modes left asks for more per pass: 16 per pass would be n / 16 passes over the block)
     const int want = std::min(n - found, std::max(16, (n - found) / 4));
     const int b = int(std::min<int64_t>(std::min<int64_t>(M, dim), want + 8));
-    Tmp Q, Rt, Traw;
-    ROM_TRY(Q.get(ctx, size_t(b) * dim));
+    Tmp Q, Om, Rt, Traw;
+    bool hit = false;
+    ROM_TRY(sketch_ahead_take(ctx, ahead, b, p, hit));
+    if (hit) {   // Q = Omega X of this pass is already there
+      std::swap(Q.b, ahead.Q.b);
+      std::swap(Om.b, ahead.Om.b);
+    } else {
+      ROM_TRY(Q.get(ctx, size_t(b) * dim));
+    }
     ROM_TRY(Rt.get(ctx, size_t(b) * b));
     ROM_TRY(Traw.get(ctx, size_t(b) * M));
-    ROM_TRY(sketch_pass(ctx, X, M, dim, V, Bt, found, b, p, Q, Rt, Traw, ss, info));
+    // the next pass's product beside this pass's Rayleigh-Ritz rounds, when its b is certain whatever this pass accepts:
+    // 16 <= modes still wanted afterwards <= 64  =>  16 + 8 rows
+    const int left_min = n - found - want, left_max = n - found - 1;
+    auto start_next = [&]() -> int {
+      if (left_min >= 16 && left_max <= 64 && size_t(M) * dim * sizeof(double) <= (size_t(2) << 30) &&
+          size_t(M) * dim * sizeof(double) >= (size_t(64) << 20))
+        return sketch_ahead_start(ctx, ahead, X, M, dim, int(std::min<int64_t>(std::min<int64_t>(M, dim), 24)), p + 1);
+      return ROM_OK;
+    };
+    ROM_TRY(sketch_pass(ctx, X, M, dim, V, Bt, found, b, p, Q, hit ? Om.p() : nullptr, Rt, Traw, ss, info, start_next));
     info.sketch_passes += 1;
     int take = 0;
     while (take < std::min(b, want) && ss[take] > SKETCH_ACCEPT * ss[0] && ss[take] > floor_rel * sigma_1) ++take;
@@ -874,6 +947,10 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
       at_floor_stop = true;
       break;
     }
+  }
+  {
+    bool unused = false;
+    ROM_TRY(sketch_ahead_take(ctx, ahead, -1, -1, unused));   // (a product started for a pass that did not happen)
   }
   if (found) {
     // Rayleigh-Ritz on the collected subspace: X ~ B V  ->  the SVD of B orders / rotates the modes
