@@ -576,8 +576,8 @@ def main():
                       "canonical_banded_equiv_gbs": round(value * work["bytes_banded"] * 1e-9, 1)},
         "roofline": roofline, "kernels": kernels,
         "kernels_note": "per-kernel HIP-event times of one extra pass of the same K steps with the sweep on ONE stream "
-                        "(rom_profile_enable); the timed regions behind `value` run C4 / C5 as two concurrent sub-batches "
-                        "(ROMHC_STREAMS; C2 is one batch either way), so `ms_per_step` can be below the sum of `kernels`",
+                        "(rom_profile_enable): the stream the timed regions behind `value` use as well since round 5 (ROMHC_STREAMS=2..4 "
+                        "splits a sweep into concurrent sub-batches; no longer the default)",
     }
 
     if world == 1 and not args.no_extras:
@@ -874,8 +874,8 @@ def other_config_leg(ctx, dev, config):
            "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / FP64_MATRIX_PEAK_TFLOPS, 4), "avg_launch_ms": round(d["total_ms"] / d["launches"], 5)},
            "kernels": kernels,
-           "note": "compact leg of the default run: the timed regions run the sweep as the library does by default (two concurrent "
-                   "sub-batches), `kernels` is one extra pass on ONE stream with every launch bracketed by HIP events"}
+           "note": "compact leg of the default run: the timed regions run the sweep as the library does by default (one stream), "
+                   "`kernels` is one extra pass with every launch bracketed by HIP events"}
     sub = {}
     if config == "c4":
         extras_greedy_c4(sub, ctx, sm, fem, a_loc, a_dev, U, M, dim, factored_too=True)

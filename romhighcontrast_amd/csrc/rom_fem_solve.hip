@@ -261,7 +261,10 @@ static int solve_batch_impl(rom_fem* f, rom_buf* a, int M, rom_buf* U, int64_t r
   // Sub-batches run on separate HIP streams: the wave-per-system diagonal kernels are latency bound
   // (one wave per SIMD), the MFMA kernels of another sub-batch fill the chip meanwhile.
   // (under per-kernel profiling the sweep stays on one stream: an event bracket then times its kernel alone)
-  const int want = ctx->profile ? 1 : ctx->n_streams > 0 ? ctx->n_streams : (f->fused1 && !f->sw_no_fused ? 1 : 2);
+  // (default: ONE stream.  Rounds 1-3 ran the tile Cholesky as two concurrent sub-batches, +1.4 % at C4 / +2.8 % at C5 then; with
+  // round 4's kernels -- four workgroups per CU in the update and panel kernels -- one stream is 0.5-1 % FASTER at both
+  // (profiles/r05_tile_cholesky_probes.txt).  ROMHC_STREAMS=2..4 still splits the sweep.)
+  const int want = ctx->profile ? 1 : ctx->n_streams > 0 ? ctx->n_streams : 1;
   const int nsub = std::max(1, std::min(want, (M + 255) / 256));
   if (nsub > 1) {  // (no marker packet in the compute queue when the sweep stays on one stream: it costs a kernel-to-kernel bubble)
     ROM_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));

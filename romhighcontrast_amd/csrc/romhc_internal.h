@@ -55,9 +55,8 @@ struct rom_ctx {
   hipStream_t stream = nullptr;
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // sub-batch streams of rom_solve_batch
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-  // A sweep is split into n_streams concurrent sub-batches on separate streams.  0 = by geometry: 2 where the reduced
-  // solve is the tile Cholesky (its one-wave-per-system diagonal kernels are latency bound: C4 +1.4 %, C5 +2.8 %), 1 for the
-  // single-tile solve (C2: -1 % with 2).  ROMHC_STREAMS=1..4 overrides.
+  // A sweep can be split into n_streams concurrent sub-batches on separate streams (ROMHC_STREAMS=1..4).  0 = the default:
+  // one stream (round 5: no gain left from two at C4 / C5, -1 % at C2).
   int n_streams = 0;
   hipStream_t prof_stream = nullptr;  // stream the next ROM_PROF bracket records on (null: `stream`)
   size_t ws_limit = size_t(24) << 30;

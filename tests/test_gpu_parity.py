@@ -1292,14 +1292,14 @@ def test_edge_compression_tolerance(api, monkeypatch):
 
 
 def test_sub_batch_streams_agree(api, monkeypatch):
-    """A sweep over a geometry whose reduced solve is the tile Cholesky runs as two concurrent sub-batches on
-    separate HIP streams (disjoint workspaces and rows): same rows as one batch on one stream (ROMHC_STREAMS=1, read
-    when the context is created), and as four sub-batches."""
+    """A sweep over a geometry whose reduced solve is the tile Cholesky can run as concurrent sub-batches on separate HIP
+    streams (ROMHC_STREAMS = 2 .. 4, read when the context is created; disjoint workspaces and rows): same rows as the default
+    -- one batch on one stream since round 5 -- with two and with four sub-batches."""
     from romhighcontrast_amd import _ffi
     blocks, N, M = (3, 3), 24, 700
     a = 10.0 ** np.random.default_rng(5).uniform(0, 3, size=(M, 9))
     out = {}
-    for name, streams in (("default", None), ("one", "1"), ("four", "4")):
+    for name, streams in (("default", None), ("one", "2"), ("four", "4")):
         if streams is None:
             monkeypatch.delenv("ROMHC_STREAMS", raising=False)
             ctx = _ffi.get_context()
