@@ -646,13 +646,14 @@ def main():
 # secondary legs (one GPU, after the timed sweep)
 # =====================================================================================================================
 def csrc_sha16():
-    """Hash of the kernel sources (csrc/*.hip, *.h, include/romhc.h): identifies the build a committed profile was taken on."""
-    import glob
+    """Hash of the sources of the SWEEP kernels (the files that decide what k_extend128 / k_solve1 / the tile Cholesky do and how
+    they are launched): identifies the build a committed traffic profile was taken on."""
     import hashlib
     h = hashlib.sha256()
-    for p in sorted(glob.glob(os.path.join(ROOT, "romhighcontrast_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "romhc.h")]):
-        h.update(os.path.basename(p).encode())
-        h.update(open(p, "rb").read())
+    csrc = os.path.join(ROOT, "romhighcontrast_amd", "csrc")
+    for name in ("rom_fem_kernels.hip", "rom_fem_solve.hip", "rom_fem_setup.hip", "rom_fem_dev.h", "rom_mma.h", "romhc_internal.h"):
+        h.update(name.encode())
+        h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
 
 
