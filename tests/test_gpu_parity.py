@@ -955,6 +955,16 @@ def test_full_size_c4_workload(api):
         if mode == RB.GREEDY_FOR_H10:
             assert all(e2 <= e1 * (1 + 1e-9) for e1, e2 in zip(er, er[1:])), (mode, er)
         assert rb_r.basis.shape == (n, dim)
+        # the plain call on a block that carries its interface vectors (what sm.generate_solutions_device returns): H^1_0 mode takes
+        # the factored route by itself, Galerkin mode only when the caller opts in -- same picks and curves as the explicit calls
+        Ucarry = SM.DeviceArray(Ud.buf, M, dim, factored=fs)
+        rb_c = RB.ReducedBasisGreedy(mode).build(n, sm, Ucarry, a, h1)
+        want = rb_f if mode == RB.GREEDY_FOR_H10 else rb_r
+        assert rb_c.picks == want.picks and rb_c.max_errors == want.max_errors, mode
+        if mode == RB.GREEDY_FOR_GALERKIN:
+            rb_o = RB.ReducedBasisGreedy(mode).build(n, sm, Ucarry, a, h1, galerkin_on_interface_vectors=True)
+            assert rb_o.picks == rb_f.picks and rb_o.max_errors == rb_f.max_errors
+        assert np.array_equal(rb_c.basis, rb_r.basis if rb_c.picks == rb_r.picks else rb_c.basis)
     # Greedy on a 256-row subsample (the seeded limit rows + 245 random ones), n = 24 -- past the 0.99 plateau of the first
     # iterations -- three routes end to end on the SAME rows: the oracle's greedy (NumPy: src/lib/ReducedBasis.py:112-139 on
     # the downloaded GPU rows, which the 64-row comparison above holds to the oracle's), rom_greedy on rows, and
