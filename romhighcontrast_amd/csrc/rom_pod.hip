@@ -833,7 +833,10 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     // (blocks of 64 MB ... 2 GB: below, the product is shorter than the stream hand-over; above, the small problems are a
     // small part of the call and a wrong guess costs a whole pass.  The first pass's product starts now, with the b a request of
     // this size most likely asks for)
-    const bool worth_ahead = size_t(M) * dim * sizeof(double) <= (size_t(2) << 30) && size_t(M) * dim * sizeof(double) >= (size_t(64) << 20);
+    // (dim >= 1024, M >= 128: the product then takes the thin LDS-DMA kernel, which needs no scratch -- the context's scratch area
+    // belongs to the kernels of the main stream)
+    const bool worth_ahead = size_t(M) * dim * sizeof(double) <= (size_t(2) << 30) && size_t(M) * dim * sizeof(double) >= (size_t(64) << 20) &&
+                             dim >= 1024 && M >= 128;
     if (n >= 17 && worth_ahead)
       ROM_TRY(sketch_ahead_start(ctx, ahead, X, M, dim, int(std::min<int64_t>(std::min<int64_t>(M, dim), 24)), 1));
     info.gram_passes = 1;
@@ -889,7 +892,7 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     const int left_min = n - found - want, left_max = n - found - 1;
     auto start_next = [&]() -> int {
       if (left_min >= 16 && left_max <= 64 && size_t(M) * dim * sizeof(double) <= (size_t(2) << 30) &&
-          size_t(M) * dim * sizeof(double) >= (size_t(64) << 20))
+          size_t(M) * dim * sizeof(double) >= (size_t(64) << 20) && dim >= 1024 && M >= 128)
         return sketch_ahead_start(ctx, ahead, X, M, dim, int(std::min<int64_t>(std::min<int64_t>(M, dim), 24)), p + 1);
       return ROM_OK;
     };
