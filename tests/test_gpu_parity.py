@@ -797,7 +797,7 @@ def test_full_size_c3_workload(api):
     modes_r, sig_r = RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), r)
     info = dict(RB.pod_modes.last_info)
     del X
-    assert info["gram_passes"] == 1 and info["resolved_modes"] >= 25
+    assert info["sketch_passes"] <= 3 and info["resolved_modes"] >= 25
     big = sig_r > 1e-6 * sig_r[0]
     assert big.sum() >= 12
     observed("C3 POD: singular values > 1e-6 sigma_1, rows vs factored (relative)", np.abs(sig_f[big] - sig_r[big]) / sig_r[big], 1e-7)
