@@ -534,8 +534,100 @@ __global__ __launch_bounds__(256) void kb_pivchol_whiten(int n, const double* __
   for (int i = t; i < n; i += 256) lam[i] = i < r ? As[i * ld + i] * As[i * ld + i] : 0.0;
 }
 
+
+// The same factorisation for n <= 32 (the row blocks of the POD's sketch passes, six calls per pass): ONE barrier per step.
+// No row / column is moved -- a bit mask of the indices still in play replaces the symmetric swap, the factor's column k is
+// stored by ORIGINAL row index (Lc[i][k]) -- every wave finds the pivot for itself (an LDS atomic max over keys that
+// carry the index: no shuffle chain, no barrier), the trailing update and the factor's
+// column are one phase (the update reads row / column pv only, which it does not write), and L^-1 is one forward substitution
+// per lane on REGISTERS (fully unrolled; the generic kernel's column-per-thread loop reads back what it has just stored to
+// LDS, 500 dependent round trips for the first column).  Same pivots (largest remaining diagonal entry, first on ties), same
+// stopping rule, same outputs as kb_pivchol_whiten up to the rounding of x / sqrt(d) against x * (1 / sqrt(d)).
+__global__ __launch_bounds__(256) void kb_pivchol_whiten32(int n, const double* __restrict__ A, int lda, double* __restrict__ lam,
+                                                           double* __restrict__ T, int ldt, double rel_tol) {
+  constexpr int LD = 33;
+  __shared__ double As[32 * LD], Lc[32 * LD], dpiv[32];
+  __shared__ unsigned long long smax[4];
+  __shared__ int perm[32];
+  const int t = threadIdx.x;
+  for (int idx = t; idx < 32 * 32; idx += 256) {
+    const int r = idx >> 5, c = idx & 31;
+    As[r * LD + c] = (r < n && c < n) ? 0.5 * (A[size_t(r) * lda + c] + A[size_t(c) * lda + r]) : 0.0;
+    Lc[r * LD + c] = 0.0;
+  }
+  __syncthreads();
+  unsigned active = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+  double first = 0.0;
+  int rank = n;
+  const int w = t >> 6, lane = t & 63;
+  const int j = t & 31, i0 = t >> 5;   // the four entries of a thread: (i0 + 8 u, j) -- the same for every step (nothing moves)
+  const unsigned mj = 1u << j;
+  for (int k = 0; k < n; ++k) {
+    // pivot = largest remaining diagonal entry: one LDS atomic max per lane on a key = the entry's bits with the low five
+    // replaced by 31 - index (positive doubles order like their bit patterns; entries that agree to 2^-47 count as ties and
+    // the lower index wins, like the first-on-ties rule of the generic kernel).  Each wave does this for itself.
+    if (lane == 0) smax[w] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32 && ((active >> lane) & 1u)) {
+      const double d = As[lane * LD + lane];
+      if (d > 0.0) atomicMax(&smax[w], (static_cast<unsigned long long>(__double_as_longlong(d)) & ~31ull) | unsigned(31 - lane));
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long best = *const_cast<volatile unsigned long long*>(&smax[w]);
+    const int pv = best ? 31 - int(best & 31ull) : -1;
+    const double dk = pv >= 0 ? As[pv * LD + pv] : 0.0;
+    if (k == 0) first = dk;
+    if (!(pv >= 0 && dk > rel_tol * first && dk > 0.0)) { rank = k; break; }   // (uniform: every thread sees the same values)
+    const double lkk = sqrt(dk), rs = 1.0 / lkk;
+    active &= ~(1u << pv);
+    const double lj = As[j * LD + pv] * rs;
+    if (active & mj) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 8 * u;
+        if ((active >> i) & 1u) As[i * LD + j] -= (As[i * LD + pv] * rs) * lj;
+      }
+    }
+    if (t < 32) Lc[t * LD + k] = t == pv ? lkk : ((active & mj) ? lj : 0.0);
+    if (t == 0) { perm[k] = pv; dpiv[k] = lkk; }
+    __syncthreads();
+  }
+  if (t == 0) {   // the indices that never became a pivot complete the permutation (their columns of T are zero)
+    int at = rank;
+    for (int j = 0; j < n; ++j)
+      if ((active >> j) & 1u) perm[at++] = j;
+  }
+  __syncthreads();
+  if (t < 32) {
+    // column t of L^-1 in pivot order: x_i = (delta_it - sum_{q < i} L[i][q] x_q) / L[i][i]  (x_q = 0 for q < t by itself)
+    double x[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int pi = i < n ? perm[i] : 0;
+      double s = i == t ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < i; ++q) s -= Lc[pi * LD + q] * x[q];
+      x[i] = (i < rank && t < rank) ? s / dpiv[i] : 0.0;
+    }
+    // T[i, perm[t]] = Li[i, t]
+    if (t < n) {
+      const int col = perm[t];
+#pragma unroll
+      for (int i = 0; i < 32; ++i)
+        if (i < n) T[size_t(i) * ldt + col] = x[i];
+      lam[t] = t < rank ? dpiv[t] * dpiv[t] : 0.0;
+    }
+  }
+}
+
 int romb_pivchol_whiten(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, double rel_tol) {
   if (n <= 0) return ROM_OK;
+  if (n <= 32) {
+    ROM_PROF(ctx, "pivchol_whiten", 1.0 * n * n * n, 16.0 * n * n);
+    kb_pivchol_whiten32<<<1, 256, 0, ctx->stream>>>(n, A, lda, lam, T, ldt, rel_tol);
+    ROM_HIP(hipGetLastError());
+    return ROM_OK;
+  }
   const int ld = n | 1;
   const size_t lds = 2 * size_t(n) * ld * sizeof(double) + 4 * sizeof(double) + (4 + size_t(n)) * sizeof(int) + 16;
   if (lds > 64 * 1024 && !ctx->lds_optin_pivchol) {

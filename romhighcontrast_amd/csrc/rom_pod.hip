@@ -415,10 +415,14 @@ int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double*
   info.executed += 2.0 * b * M * double(dim);
   double* Tdefl = Tt;
   for (int it = 0; it <= power; ++it) {
-    // orthonormal rows (rank may drop: zero rows).  Before the power step one round is enough: the rows only have to span the
-    // sketch and be aligned with its principal directions -- their residual non-orthogonality (eps x the condition number of
-    // the sketch's Gram matrix) does not change what the power step spans; the basis that is USED is whitened twice
-    ROM_TRY(whiten_rows(ctx, Q, b, dim, 1e-26, it == power ? 2 : 1, Tm, lam));
+    // orthonormal rows (rank may drop: zero rows), one round of Cholesky whitening each time.  Before the power step the
+    // rows only have to span the sketch and be aligned with its principal directions.  After it they are T' X_d with
+    // orthonormal T': graded and nearly orthogonal, the case in which a pivoted Cholesky factor of their Gram matrix is
+    // accurate relative to each row (its error follows the condition number of the SCALED matrix), so one round leaves
+    // them orthonormal to ~1e-15 (measured: the same singular values, angles and orthonormality as two rounds on the C2
+    // block and on spectra of 1 and 3 modes per decade over 13 orders -- tools/dev/pod_synth.py); the accepted modes are
+    // orthonormalised again by the caller
+    ROM_TRY(whiten_rows(ctx, Q, b, dim, 1e-26, 1, Tm, lam));
     ROM_TRY(rom_launch_gemm_nt(ctx, b, M, dim, 1.0, Q, dim, X, dim, 0.0, Traw, M, "gemm_nt"));    // Q X^T  (b, M)
     if (found) {                                                                                  // Q X_d^T = Q X^T - (Q V^T) Bt
       ROM_TRY(rom_launch_gemm_nt(ctx, b, found, dim, 1.0, Q, dim, V, dim, 0.0, Cc, found, "gemm_nt"));
@@ -443,7 +447,9 @@ int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double*
   }
   ROM_TRY(before_rotation());   // (the last pass over the block is enqueued: what may run beside the small problems starts here)
   // X_d ~ T Q: the right singular vectors of the small factor rotate Q into the modes (Tt is rotated along, not used again)
-  ROM_TRY(tall_svd_rotation(ctx, Tt, b, M, Rt, s2));
+  // (one round: the pass only has to separate its leading directions from the rest and to rank them for the accept rule --
+  // the Rayleigh-Ritz step over ALL collected modes at the end of rom_pod_ex iterates to convergence)
+  ROM_TRY(tall_svd_rotation(ctx, Tt, b, M, Rt, s2, 1));
   ss_host.resize(b);
   ROM_TRY(download(ctx, s2, ss_host.data(), b));
   for (double& v : ss_host) v = std::sqrt(std::max(v, 0.0));

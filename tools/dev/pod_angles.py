@@ -24,6 +24,7 @@ for rep in range(3):
     ctx.synchronize()
     t = time.perf_counter() - t0
 print("wall ms", t * 1e3, RB.pod_modes.last_info)
+print("orthonormality defect", np.abs(comps @ comps.T - np.eye(n)).max())
 for i in range(n):
     # angle of mode i to the LAPACK subspace of the modes with sigma within a factor 3 (close values rotate freely)
     grp = (sv[:n] < 3 * sv[i]) & (sv[:n] > sv[i] / 3)

@@ -24,7 +24,7 @@ full = np.concatenate([s, 1e-15 * rng.uniform(0.3, 1, M - n)])
 Xh = (Q1 * full) @ Q2.T
 X = ctx.upload(Xh)
 comps, sig = RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), n, center=False)
-print(RB.pod_modes.last_info)
+print(RB.pod_modes.last_info, "orthonormality defect", np.abs(comps @ comps.T - np.eye(n)).max())
 for i in range(n):
     c = comps[i]
     ang = np.linalg.norm(c - (c @ Q2[:, i]) * Q2[:, i])
