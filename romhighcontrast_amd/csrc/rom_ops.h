@@ -33,4 +33,5 @@ int rom_launch_reduced_solve(rom_ctx* ctx, int n, int ldA, int kb, int M, const 
 // X[row, :] *= fac[row] with the factors on the device
 int rom_launch_rows_scale(rom_ctx* ctx, double* X, int rows, int64_t dim, const double* d_fac);
 int rom_launch_center_rows(rom_ctx* ctx, double* X, int M, int64_t dim, double* d_mean);
+int rom_launch_subtract_row(rom_ctx* ctx, double* X, int M, int64_t dim, const double* d_row);
 int rom_launch_rows_sign_flip(rom_ctx* ctx, double* X, int rows, int64_t dim);

@@ -1357,6 +1357,26 @@ __global__ void k_center_apply(double* __restrict__ X, int M, long long dim, con
   for (int m = m0; m < m1; ++m) X[m * dim + j] -= s;
 }
 
+// X[m, :] -= row[:] for every m (the second half of the centring when the column means are already known)
+__global__ void k_subtract_row(double* __restrict__ X, int M, long long dim, const double* __restrict__ row) {
+  const long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (j >= dim) return;
+  const double s = row[j];
+  const int per = (M + CENTER_SLABS - 1) / CENTER_SLABS;
+  const int m0 = blockIdx.y * per, m1 = min(M, m0 + per);
+  for (int m = m0; m < m1; ++m) X[m * dim + j] -= s;
+}
+
+int rom_launch_subtract_row(rom_ctx* ctx, double* X, int M, int64_t dim, const double* d_row) {
+  const dim3 grid(unsigned((dim + 255) / 256), CENTER_SLABS);
+  {
+    ROM_PROF(ctx, "center_rows", 1.0 * M * dim, 16.0 * M * dim);
+    k_subtract_row<<<grid, 256, 0, ctx->stream>>>(X, M, dim, d_row);
+  }
+  ROM_HIP(hipGetLastError());
+  return ROM_OK;
+}
+
 int rom_launch_center_rows(rom_ctx* ctx, double* X, int M, int64_t dim, double* d_mean) {
   double* part = nullptr;
   ROM_TRY(rom_ctx_scratch(ctx, size_t(CENTER_SLABS) * dim, &part));

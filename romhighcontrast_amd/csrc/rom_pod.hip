@@ -231,6 +231,28 @@ __global__ __launch_bounds__(256) void kp_tall_svd(int b, int M, double* __restr
   if (t < b) sig2[t] = L.ev[L.perm[t]];
 }
 
+// Sketch rows for a block that is still to be centred: rows 0 .. b - 2 of Om (b x M) lose their own mean -- a row with zero
+// sum gives the same product with the block as with its centred rows, Om' X = Om' (X - 1 mu^T), and nothing of the sketch
+// is lost: the columns of the centred block are orthogonal to the vector of ones -- and row b - 1 becomes 1 / M, so that the
+// last row of Om X IS the column mean mu: the first product of the first pass replaces the pass over X that the means cost.
+__global__ __launch_bounds__(256) void kp_zero_sum_rows(double* __restrict__ Om, int M, int b) {
+  __shared__ double red[4];
+  double* row = Om + size_t(blockIdx.x) * M;
+  const int t = threadIdx.x;
+  if (int(blockIdx.x) == b - 1) {
+    for (int m = t; m < M; m += 256) row[m] = 1.0 / double(M);
+    return;
+  }
+  double s = 0.0;
+  for (int m = t; m < M; m += 256) s += row[m];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((t & 63) == 0) red[t >> 6] = s;
+  __syncthreads();
+  const double mean = (((red[0] + red[1]) + red[2]) + red[3]) / double(M);
+  for (int m = t; m < M; m += 256) row[m] -= mean;
+}
+
 namespace {
 
 // How far below its largest singular value a sketch pass accepts modes.  A pass orthonormalises its rows through their
@@ -477,7 +499,9 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
   double* X = Xb->p + x_row0 * dim;
   double* V = Vb->p + v_row0 * dim;
   PodInfo info;
-  if (center) {
+  // centring: the column means come out of the first pass's first product (kp_zero_sum_rows) when there is a pass
+  const bool mean_from_sketch = center && n > 0 && std::min<int64_t>(M, dim) >= 2;
+  if (center && !mean_from_sketch) {
     Tmp mean;
     ROM_TRY(mean.get(ctx, dim));
     ROM_TRY(rom_launch_center_rows(ctx, X, M, dim, mean));
@@ -504,7 +528,7 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     // (a request with hundreds of modes left asks for more per pass: 24 per pass would be n / 24 passes over the block)
     const int left = n - found;
     const int want = std::min(left, std::max(PASS_MODES, left / 4));
-    const int b = int(std::min<int64_t>(std::min<int64_t>(M, dim), want + 8));
+    int b = int(std::min<int64_t>(std::min<int64_t>(M, dim), want + 8));
     Tmp Q, Om, Rt, Traw;
     bool hit = false;
     ROM_TRY(sketch_ahead_take(ctx, ahead, b, p, hit));
@@ -513,6 +537,20 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
       std::swap(Om.b, ahead.Om.b);
     } else {
       ROM_TRY(Q.get(ctx, size_t(b) * dim));
+    }
+    if (p == 1 && mean_from_sketch) {
+      // the first product on the block as it came, with zero-sum sketch rows and a row of 1 / M: its last row is the column
+      // mean, which is then subtracted from the block (the one pass over X that the centring still costs); the pass goes on
+      // with the b - 1 sketch rows.  (The product sees the uncentred values: its rounding is eps x THEIR size -- a sketch
+      // only has to span the range, and every later product of the pass works on the centred block)
+      ROM_TRY(Om.get(ctx, size_t(b) * M));
+      ROM_TRY(romb_fill_random(ctx, Om, size_t(b) * M, 0xabcd0000ull + unsigned(p) * 7919u, true));
+      kp_zero_sum_rows<<<b, 256, 0, ctx->stream>>>(Om, M, b);
+      ROM_HIP(hipGetLastError());
+      ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Om, M, X, dim, 0.0, Q, dim));
+      ROM_TRY(rom_launch_subtract_row(ctx, X, M, dim, Q.p() + size_t(b - 1) * dim));
+      hit = true;
+      b -= 1;
     }
     ROM_TRY(Rt.get(ctx, size_t(b) * b));
     ROM_TRY(Traw.get(ctx, size_t(b) * M));
@@ -607,7 +645,21 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     // complete the basis: random directions orthonormalised against the modes; they carry no variance (LAPACK and
     // scikit-learn return SOME orthonormal directions there too).  Seeded by the count of resolved modes: deterministic.
     const int rest = n - found;
-    ROM_TRY(rom_complete_orthonormal(ctx, Vb, v_row0, found, rest, dim));
+    if (rest <= FUSED_ROWS && found <= 512) {   // (the fused row kernels; same seed as rom_complete_orthonormal)
+      double* Vn = V + size_t(found) * dim;
+      Tmp C, Tm, lam;
+      ROM_TRY(C.get(ctx, size_t(rest) * std::max(found, 1)));
+      ROM_TRY(Tm.get(ctx, size_t(rest) * rest));
+      ROM_TRY(lam.get(ctx, rest));
+      ROM_TRY(romb_fill_random(ctx, Vn, size_t(rest) * dim, 0xc0de0000ull + unsigned(found), false));
+      for (int r = 0; r < 2 && found > 0; ++r) {
+        ROM_TRY(rom_launch_gemm_nt(ctx, rest, found, dim, 1.0, Vn, dim, V, dim, 0.0, C, found, "gemm_nt"));
+        ROM_TRY(combine_rows(ctx, rest, rest, nullptr, 0, found, C, found, -1.0, Vn, dim, V, dim, Vn, dim, dim));
+      }
+      ROM_TRY(whiten_rows(ctx, Vn, rest, dim, 1e-26, 1, Tm, lam));
+    } else {
+      ROM_TRY(rom_complete_orthonormal(ctx, Vb, v_row0, found, rest, dim));
+    }
     info.completed = rest;
   }
   info.resolved = found;

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 M=1024 REPS=3 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 $R/tools/pod_time.py > $O/kt.out 2> $O/kt.err
 find $O/kt -name "*kernel_trace.csv" | tail -1 | xargs -I{} cp {} $O/pod_rows_trace.csv
 rm -rf $O/kt
-python3 $R/tools/dev/kernel_timeline.py $O/pod_rows_trace.csv k_center_partial > $O/pod_rows_timeline.txt
+python3 $R/tools/dev/kernel_timeline.py $O/pod_rows_trace.csv kp_zero_sum_rows > $O/pod_rows_timeline.txt
 if [ "$1" = "fact" ]; then
   cd $R
   timeout -k 10 300 python3 tools/pod_factored_prof.py > $O/pod_factored_time.txt 2>&1
