@@ -15,160 +15,149 @@ __device__ inline double se_rsqrt(double x) {
 
 constexpr int J32_LD = 33;   // row stride of the LDS matrices (odd: column walks are conflict free)
 struct Jacobi32Lds {
-  double As[32 * J32_LD], Vt[32 * J32_LD];
-  double2 csv[16];
-  int2 pq[16];
-  double nu2[32], ev[32];
+  double As[32 * J32_LD], Vt[32 * J32_LD];   // the matrix in / the eigenvector rows out (buffer 0 of the rounds)
+  double A1[32 * J32_LD], V1[32 * J32_LD];   // buffer 1
+  double nu2[2][32], ev[32];
   int perm[32];
   int any;
 };
 
+// One Jacobi rotation from the 2 x 2 pivot block (a_pp, a_pq; a_pq, a_qq) and the noise levels of its rows: applied when
+// |a_pq| > tol sqrt(|a_pp a_qq|) -- the relative criterion under which graded matrices keep their small eigenvalues
+// (Demmel-Veselic) -- AND |a_pq| > tol nu_p nu_q, the rounding noise of the entry.  (c, s) = (1, 0) otherwise: an exact
+// identity, so callers apply it without a branch.  No division and no square root: with a = a_qq - a_pp, b = 2 a_pq
+// (scaled by a power of two so that a^2 + b^2 neither overflows nor underflows), r = 1 / sqrt(a^2 + b^2):
+//   cos 2phi = |a| r,  c = cos phi = sqrt((1 + cos 2phi) / 2),  s = sin phi = sign(a) b r / (2 c)
+// -- the angle of the classical formula t = sign(a) b / (|a| + sqrt(a^2 + b^2)), |phi| <= pi / 4, with s from b itself (no
+// cancellation for small angles) and c^2 + s^2 = 1 to rounding.  A pure function of its arguments: every thread that
+// evaluates the rotation of a pair gets the same bits.
+__device__ inline bool jacobi_rotation(double app, double aqq, double apq, double np2, double nq2, double tol2, double floor_abs,
+                                       double& c, double& s, double& np2o, double& nq2o) {
+  c = 1.0;
+  s = 0.0;
+  np2o = np2;
+  nq2o = nq2;
+  const double apq2 = apq * apq;
+  if (!(apq2 > tol2 * fabs(app * aqq) && fabs(apq) > floor_abs && apq2 > tol2 * np2 * nq2)) return false;
+  double a = aqq - app, b = 2.0 * apq;
+  int e;
+  (void)frexp(fmax(fabs(a), fabs(b)), &e);
+  a = ldexp(a, -e);
+  b = ldexp(b, -e);
+  const double r = se_rsqrt(a * a + b * b);
+  const double c2 = 0.5 + 0.5 * (fabs(a) * r);
+  const double rc = se_rsqrt(c2);
+  c = c2 * rc;
+  s = (a >= 0.0 ? b : -b) * r * (0.5 * rc);
+  np2o = c * c * np2 + s * s * nq2;
+  nq2o = s * s * np2 + c * c * nq2;
+  return true;
+}
+
 // Cyclic Jacobi for a symmetric matrix of order n <= 32 that sits in L.As (both triangles; L.Vt receives the eigenvector
-// rows), NT threads (64: one wave, no barrier instruction at all; 256: the items of a round are one 2 x 2 block and two
-// eigenvector entries per lane).  A branch-free round: the round-robin pairs of a round are at most 16, so its 2 x 2
-// blocks (<= 256) and eigenvector items (<= 512) are dealt to the lanes by a map that never changes (divided out once);
-// every item loads its rotation (c, s) and its index pair unconditionally -- (1, 0) is an exact identity, so pairs that
-// do not rotate need no branch -- and all loads of a phase are issued before its first store.  A rotation is applied
-// when |a_pq| > tol sqrt(|a_pp a_qq|) -- the relative criterion under which graded matrices keep their small eigenvalues
-// (Demmel-Veselic) -- AND |a_pq| > tol nu_p nu_q, the rounding noise of the entry (gram_like: nu_i^2 = |a_ii| at the
-// start, rotated along; else max |a_ii|).  On return: eigenvalues on the diagonal of L.As, descending order in L.perm
-// (L.ev[L.perm[i]] is the i-th largest), every thread past a barrier.  dmax = max |a_ii| (the caller has it from the load).
-// Returns (uniformly) whether any rotation was applied: false = the matrix was diagonal by the criterion on entry.
+// rows), 256 threads, ONE barrier per round.  The round-robin pairs of a round are at most 16; thread (k, l) owns the
+// 2 x 2 block rows (p_k, q_k) x columns (p_l, q_l) of the matrix and the entries of the eigenvector rows (p_k, q_k) in
+// columns 2 l, 2 l + 1.  It computes the rotations of its two pairs ITSELF from the pivot blocks (jacobi_rotation: the
+// same bits in every thread) -- no lane computes rotations for the others, so there is no second phase behind a barrier and
+// no dependent LDS round trip: all loads of a round are issued at once, from the buffer the previous round wrote, and the
+// results go to the other buffer (every entry is written every round: the pairs cover all indices; orders below 32 / odd
+// orders are padded with zero rows and columns, which never rotate).  gram_like: nu_i^2 = |a_ii| at the start (the
+// rounding noise of a Gram matrix of explicit rows), rotated along; else max |a_ii|.  On return: eigenvalues on the
+// diagonal of L.As, eigenvector rows in L.Vt, descending order in L.perm (L.ev[L.perm[i]] is the i-th largest), every
+// thread past a barrier.  dmax = max |a_ii| (the caller has it from the load).  Returns (uniformly) whether any rotation
+// was applied: false = the matrix was diagonal by the criterion on entry.
 template <int NT>
 __device__ inline bool jacobi32_run(int n, Jacobi32Lds& L, int gram_like, double dmax) {
+  static_assert(NT == 256, "jacobi32_run: 256 threads");
   constexpr int LD = J32_LD;
-  constexpr int BI = 256 / NT, VI = 512 / NT;   // 2 x 2 blocks / eigenvector items of a lane
-  double* As = L.As;
-  double* Vt = L.Vt;
-  const int t = threadIdx.x, ne = n + (n & 1), half = ne / 2;
-  if (t < n) L.nu2[t] = gram_like ? fabs(As[t * LD + t]) : dmax;
-  int bk[BI], bl[BI], vk[VI], vj[VI];
-  bool bon[BI], von[VI];
-#pragma unroll
-  for (int u = 0; u < BI; ++u) {
-    const int idx = u * NT + t;
-    bon[u] = idx < half * half;
-    bk[u] = bon[u] ? idx / half : 0;
-    bl[u] = bon[u] ? idx - bk[u] * half : 0;
+  const int t = threadIdx.x, ne = n + (n & 1), half = ne / 2, nm1 = ne - 1;
+  for (int idx = t; idx < 32 * 32; idx += 256) {
+    const int r = idx >> 5, c = idx & 31;
+    if (r >= n || c >= n) {
+      L.As[r * LD + c] = 0.0;
+      L.Vt[r * LD + c] = r == c ? 1.0 : 0.0;
+    }
   }
-#pragma unroll
-  for (int u = 0; u < VI; ++u) {
-    const int idx = u * NT + t;
-    von[u] = idx < half * n;
-    vk[u] = von[u] ? idx / n : 0;
-    vj[u] = von[u] ? idx - vk[u] * n : 0;
-  }
+  if (t < 32) L.nu2[0][t] = t < n ? (gram_like ? fabs(L.As[t * LD + t]) : dmax) : 0.0;
+  const bool on = t < half * half;
+  const int bk = on ? t / half : 0, bl = on ? t - bk * half : 0;
   const double tol = double(n > 8 ? n : 8) * 1.1e-16, tol2 = tol * tol, floor_abs = fmax(1e-300, 1e-40 * dmax);
   __syncthreads();
+  int cur = 0;
   bool ever = false;
   for (int sweep = 0; sweep < 40; ++sweep) {
     bool rotated = false;
-    for (int r = 0; r < ne - 1; ++r) {
-      if (t < half) {
-        int p = ne - 1, q = r;
-        if (t != 0) {
-          p = r + t;
-          if (p >= ne - 1) p -= ne - 1;
-          q = r - t;
-          if (q < 0) q += ne - 1;
+    for (int r = 0; r < nm1; ++r) {
+      const double* A = cur ? L.A1 : L.As;
+      const double* V = cur ? L.V1 : L.Vt;
+      double* An = cur ? L.As : L.A1;
+      double* Vn = cur ? L.Vt : L.V1;
+      if (on) {
+        // the pairs of this round (round robin: index ne - 1 stays, the others move around it)
+        int pk = r, qk = nm1, pl = r, ql = nm1;
+        if (bk) {
+          pk = r + bk;
+          if (pk >= nm1) pk -= nm1;
+          qk = r - bk;
+          if (qk < 0) qk += nm1;
+          if (pk > qk) { const int x = pk; pk = qk; qk = x; }
         }
-        if (p > q) { const int x = p; p = q; q = x; }
-        double c = 1.0, s = 0.0;
-        if (q < n) {
-          const double app = As[p * LD + p], aqq = As[q * LD + q], apq = As[p * LD + q];
-          const double np2 = L.nu2[p], nq2 = L.nu2[q], apq2 = apq * apq;
-          if (apq2 > tol2 * fabs(app * aqq) && fabs(apq) > floor_abs && apq2 > tol2 * np2 * nq2) {
-            // t = tan(phi) = sign(a) b / (|a| + sqrt(a^2 + b^2)), a = a_qq - a_pp, b = 2 a_pq; c = 1 / sqrt(1 + t^2), s = t c
-            const double a = aqq - app, bb = 2.0 * apq;
-            const double tt = (a >= 0 ? bb : -bb) / (fabs(a) + sqrt(a * a + bb * bb));
-            c = se_rsqrt(1.0 + tt * tt);
-            s = tt * c;
-            L.nu2[p] = c * c * np2 + s * s * nq2;
-            L.nu2[q] = s * s * np2 + c * c * nq2;
-            rotated = true;
-          }
-        } else {
-          q = -1;   // p is paired with the dummy index of an odd n: no rotation
+        if (bl) {
+          pl = r + bl;
+          if (pl >= nm1) pl -= nm1;
+          ql = r - bl;
+          if (ql < 0) ql += nm1;
+          if (pl > ql) { const int x = pl; pl = ql; ql = x; }
         }
-        L.csv[t] = make_double2(c, s);
-        L.pq[t] = make_int2(p, q);
-      }
-      __syncthreads();
-      {
-        // A <- J^T A J as disjoint 2 x 2 blocks (k, l): rows (p_k, q_k) x columns (p_l, q_l) become R_k B R_l^T
-        double o00[BI], o01[BI], o10[BI], o11[BI];
-        int a00[BI], a01[BI], a10[BI], a11[BI];
-        bool w01[BI], w10[BI], w11[BI];
-#pragma unroll
-        for (int u = 0; u < BI; ++u) {
-          const double2 rk = L.csv[bk[u]], rl = L.csv[bl[u]];
-          const int2 ik = L.pq[bk[u]], il = L.pq[bl[u]];
-          const bool vk_ = ik.y >= 0, vl_ = il.y >= 0;
-          const int pk = ik.x, qk = vk_ ? ik.y : ik.x, pl = il.x, ql = vl_ ? il.y : il.x;
-          a00[u] = pk * LD + pl;
-          a01[u] = pk * LD + ql;
-          a10[u] = qk * LD + pl;
-          a11[u] = qk * LD + ql;
-          const double b00 = As[a00[u]], b01 = vl_ ? As[a01[u]] : 0.0;
-          const double b10 = vk_ ? As[a10[u]] : 0.0, b11 = (vk_ && vl_) ? As[a11[u]] : 0.0;
-          const double ck = rk.x, sk = rk.y, cl = rl.x, sl = rl.y;
-          const double r00 = ck * b00 - sk * b10, r01 = ck * b01 - sk * b11;
-          const double r10 = sk * b00 + ck * b10, r11 = sk * b01 + ck * b11;
-          o00[u] = cl * r00 - sl * r01;
-          o01[u] = sl * r00 + cl * r01;
-          o10[u] = cl * r10 - sl * r11;
-          o11[u] = sl * r10 + cl * r11;
-          w01[u] = bon[u] && vl_;
-          w10[u] = bon[u] && vk_;
-          w11[u] = bon[u] && vk_ && vl_;
-        }
+        const double kpp = A[pk * LD + pk], kqq = A[qk * LD + qk], kpq = A[pk * LD + qk];
+        const double lpp = A[pl * LD + pl], lqq = A[ql * LD + ql], lpq = A[pl * LD + ql];
+        const double nkp = L.nu2[cur][pk], nkq = L.nu2[cur][qk], nlp = L.nu2[cur][pl], nlq = L.nu2[cur][ql];
+        const double b00 = A[pk * LD + pl], b01 = A[pk * LD + ql], b10 = A[qk * LD + pl], b11 = A[qk * LD + ql];
+        const int j0 = 2 * bl;
+        const double vp0 = V[pk * LD + j0], vp1 = V[pk * LD + j0 + 1], vq0 = V[qk * LD + j0], vq1 = V[qk * LD + j0 + 1];
+        double ck, sk, cl, sl, nkpo, nkqo, nlpo, nlqo;
+        const bool rk = jacobi_rotation(kpp, kqq, kpq, nkp, nkq, tol2, floor_abs, ck, sk, nkpo, nkqo);
+        (void)jacobi_rotation(lpp, lqq, lpq, nlp, nlq, tol2, floor_abs, cl, sl, nlpo, nlqo);
+        rotated = rotated || rk;
+        // A <- J^T A J on the block: R_k B R_l^T
+        const double r00 = ck * b00 - sk * b10, r01 = ck * b01 - sk * b11;
+        const double r10 = sk * b00 + ck * b10, r11 = sk * b01 + ck * b11;
+        An[pk * LD + pl] = cl * r00 - sl * r01;
+        An[pk * LD + ql] = sl * r00 + cl * r01;
+        An[qk * LD + pl] = cl * r10 - sl * r11;
+        An[qk * LD + ql] = sl * r10 + cl * r11;
         // eigenvector rows: Vt <- J^T Vt
-        double op[VI], oq[VI];
-        int ap[VI], aq[VI];
-        bool wq[VI];
-#pragma unroll
-        for (int u = 0; u < VI; ++u) {
-          const double2 rk = L.csv[vk[u]];
-          const int2 ik = L.pq[vk[u]];
-          const bool vq = ik.y >= 0;
-          ap[u] = ik.x * LD + vj[u];
-          aq[u] = (vq ? ik.y : ik.x) * LD + vj[u];
-          const double vp = Vt[ap[u]], vqv = Vt[aq[u]];
-          op[u] = rk.x * vp - rk.y * vqv;
-          oq[u] = rk.y * vp + rk.x * vqv;
-          wq[u] = von[u] && vq;
-        }
-#pragma unroll
-        for (int u = 0; u < BI; ++u) {
-          if (bon[u]) As[a00[u]] = o00[u];
-          if (w01[u]) As[a01[u]] = o01[u];
-          if (w10[u]) As[a10[u]] = o10[u];
-          if (w11[u]) As[a11[u]] = o11[u];
-        }
-#pragma unroll
-        for (int u = 0; u < VI; ++u) {
-          if (von[u]) Vt[ap[u]] = op[u];   // (a pair with the dummy index: (c, s) = (1, 0), the row keeps its values)
-          if (wq[u]) Vt[aq[u]] = oq[u];
+        Vn[pk * LD + j0] = ck * vp0 - sk * vq0;
+        Vn[pk * LD + j0 + 1] = ck * vp1 - sk * vq1;
+        Vn[qk * LD + j0] = sk * vp0 + ck * vq0;
+        Vn[qk * LD + j0 + 1] = sk * vp1 + ck * vq1;
+        if (bl == 0) {
+          L.nu2[cur ^ 1][pk] = nkpo;
+          L.nu2[cur ^ 1][qk] = nkqo;
         }
       }
+      cur ^= 1;
       __syncthreads();
     }
-    if (NT == 64) {
-      if (!__any(rotated)) break;
-      ever = true;
-    } else {
-      if (t < 64) {
-        const int any = __any(rotated);
-        if (t == 0) L.any = any;
-      }
-      __syncthreads();
-      const int any = L.any;
-      __syncthreads();
-      if (!any) break;
-      ever = true;
+    if (t < 64) {
+      const int any = __any(rotated);
+      if (t == 0) L.any = any;
     }
+    __syncthreads();
+    const int any = L.any;
+    __syncthreads();
+    if (!any) break;
+    ever = true;
   }
-  if (t < n) L.ev[t] = As[t * LD + t];
+  if (cur) {   // an odd number of rounds: the results sit in buffer 1
+    for (int idx = t; idx < 32 * 32; idx += 256) {
+      const int r = idx >> 5, c = idx & 31;
+      L.As[r * LD + c] = L.A1[r * LD + c];
+      L.Vt[r * LD + c] = L.V1[r * LD + c];
+    }
+    __syncthreads();
+  }
+  if (t < n) L.ev[t] = L.As[t * LD + t];
   __syncthreads();
   if (t < n) {
     int rank = 0;
