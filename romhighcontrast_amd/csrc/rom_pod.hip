@@ -17,6 +17,161 @@
 // =====================================================================================================================
 // POD (the PCA fit of ReducedBasisPCA.build, src/lib/ReducedBasis.py:189-200)
 // =====================================================================================================================
+// =====================================================================================================================
+// The Gram route (slowly decaying spectra): Gram matrix on MFMA, leading eigenpairs by a pivoted-Cholesky low-rank factor or
+// by subspace iteration IN M SPACE -- an iteration costs 2 M^2 b flops there instead of two passes over the block
+// =====================================================================================================================
+__global__ void kb_next_block(double* __restrict__ Zs, const double* __restrict__ Zr, const double* __restrict__ Yr,
+                              const double* __restrict__ theta, long long M) {
+  // rows: the rotated power step G y_i / theta_i for the resolvable pairs, the Ritz vector itself at the noise floor
+  const double th = theta[blockIdx.y], t0 = fabs(theta[0]);
+  const bool ok = th > 1e-13 * t0;
+  const double a = ok ? 1.0 / th : 0.0;
+  const long long o = blockIdx.y * M;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < M; j += (long long)gridDim.x * blockDim.x)
+    Zs[o + j] = ok ? a * Zr[o + j] : Yr[o + j];
+}
+
+// out[i] = 1 / x[i] (0 where x[i] is not positive)
+__global__ void kb_inv(const double* __restrict__ x, double* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[i] > 0.0 ? 1.0 / x[i] : 0.0;
+}
+
+// out[i] = lam[i] > 0 ? 1 / sqrt(lam[i]) : 0
+__global__ void kb_inv_sqrt(const double* __restrict__ lam, double* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = lam[i] > 0.0 ? 1.0 / sqrt(lam[i]) : 0.0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Low-rank factor of a symmetric PSD matrix by diagonally pivoted Cholesky, ONE workgroup of 1024 threads:
+//   G (M x M) ~ Lt^T Lt,  Lt (rcap x M; row k = column k of the factor), stopped at the first pivot <= tol x the first one
+// (rank r) or at r = rcap.  A snapshot Gram matrix whose spectrum falls below the fp64 resolution of its entries within a few
+// dozen directions -- the block of a low-dimensional parameter sweep -- is REPRODUCED by that factor to rounding: the
+// trace of what is left of the diagonal bounds ||G - Lt^T Lt||_2, and the eigenpairs of G follow from the r x r problem
+// Lt Lt^T with no subspace iteration.  Every step is one row of G (contiguous) and the rows of Lt so far (L2 resident).
+// `slow` (checked every 16 steps): the decay so far extrapolates to more than rcap steps -- give up early.
+// out[0] = r, out[1] = trace of the remaining diagonal (>= 0), out[2] = first pivot, out[3] = 1 if stopped by tol.
+// dwork: M doubles (remaining diagonal).
+__global__ __launch_bounds__(1024) void kp_pivchol_lowrank(int M, const double* __restrict__ G, long long ldg, int rcap, double tol,
+                                                           double* __restrict__ Lt, double* __restrict__ dwork,
+                                                           double* __restrict__ out) {
+  __shared__ double red_v[16];
+  __shared__ int red_i[16];
+  __shared__ double s_best;
+  __shared__ int s_piv;
+  const int t = threadIdx.x;
+  for (int i = t; i < M; i += 1024) dwork[i] = G[size_t(i) * ldg + i];
+  __syncthreads();
+  double first = 0.0;
+  int r = 0, by_tol = 0;
+  for (int k = 0; k < rcap; ++k) {
+    double best = -1e300;
+    int at = 0x7fffffff;
+    for (int i = t; i < M; i += 1024) {
+      const double v = dwork[i];
+      if (v > best) { best = v; at = i; }   // ascending i per thread: first maximum
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_down(best, o, 64);
+      const int oa = __shfl_down(at, o, 64);
+      if (ob > best || (ob == best && oa < at)) { best = ob; at = oa; }
+    }
+    if ((t & 63) == 0) { red_v[t >> 6] = best; red_i[t >> 6] = at; }
+    __syncthreads();
+    if (t == 0) {
+      double bb = red_v[0];
+      int ba = red_i[0];
+      for (int w = 1; w < 16; ++w)
+        if (red_v[w] > bb || (red_v[w] == bb && red_i[w] < ba)) { bb = red_v[w]; ba = red_i[w]; }
+      s_best = bb;
+      s_piv = ba;
+    }
+    __syncthreads();
+    const double piv = s_best;
+    const int p = s_piv;
+    if (k == 0) first = piv;
+    if (!(piv > tol * first) || !(piv > 0.0)) { by_tol = 1; break; }
+    // (slow decay: after k steps the pivots have fallen by piv / first; at that rate tol is more than rcap steps away)
+    if ((k & 15) == 0 && k >= 16 && log(piv / first) * double(rcap) > log(tol) * double(k)) break;
+    const double s = 1.0 / sqrt(piv);
+    for (int i = t; i < M; i += 1024) {
+      double c = G[size_t(p) * ldg + i];
+      // (the pivot's own entries Lt[j][p] are wave-uniform loads issued with the column's: one latency, no LDS stage)
+      for (int j = 0; j < k; ++j) c -= Lt[size_t(j) * M + i] * Lt[size_t(j) * M + p];
+      c = (i == p) ? sqrt(piv) : c * s;
+      Lt[size_t(k) * M + i] = c;
+      dwork[i] = (i == p) ? -1e300 : dwork[i] - c * c;
+    }
+    r = k + 1;
+    __syncthreads();
+  }
+  // what is left of the diagonal (pivots excluded; rounding may leave entries slightly negative)
+  double tr = 0.0;
+  for (int i = t; i < M; i += 1024) {
+    const double v = dwork[i];
+    if (v > 0.0) tr += v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tr += __shfl_down(tr, o, 64);
+  __syncthreads();
+  if ((t & 63) == 0) red_v[t >> 6] = tr;
+  __syncthreads();
+  if (t == 0) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += red_v[w];
+    out[0] = double(r);
+    out[1] = s;
+    out[2] = first;
+    out[3] = double(by_tol);
+  }
+}
+
+// Eigen-decomposition of the leading n x n block of A (nmax x nmax, nmax <= 32) with n read FROM THE DEVICE (n_dev[0], the
+// rank a kernel in front of this one has just found): the host need not know n to launch it.  lam (nmax) and T (nmax x nmax)
+// are zero behind n.
+__global__ __launch_bounds__(256) void kp_jacobi32_devn(int nmax, const double* __restrict__ n_dev, const double* __restrict__ A,
+                                                        double* __restrict__ lam, double* __restrict__ T) {
+  __shared__ Jacobi32Lds L;
+  __shared__ double red[4];
+  const int t = threadIdx.x, n = max(0, min(nmax, int(n_dev[0])));
+  for (int idx = t; idx < nmax * nmax; idx += 256) T[idx] = 0.0;
+  if (t < nmax) lam[t] = 0.0;
+  if (n == 0) return;
+  double dmax = 0.0;
+  for (int idx = t; idx < n * n; idx += 256) {
+    const int r = idx / n, c = idx - r * n;
+    const double v = 0.5 * (A[size_t(r) * nmax + c] + A[size_t(c) * nmax + r]);
+    L.As[r * J32_LD + c] = v;
+    L.Vt[r * J32_LD + c] = r == c ? 1.0 : 0.0;
+    if (r == c) dmax = fmax(dmax, fabs(v));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+  if ((t & 63) == 0) red[t >> 6] = dmax;
+  __syncthreads();
+  dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  jacobi32_run<256>(n, L, 1, dmax);
+  __syncthreads();   // (the zero fill of T above is complete for everybody)
+  if (t < n) lam[t] = L.ev[L.perm[t]];
+  for (int idx = t; idx < n * n; idx += 256) {
+    const int r = idx / n, c = idx - r * n;
+    T[size_t(r) * nmax + c] = L.Vt[L.perm[r] * J32_LD + c];
+  }
+}
+
+// rows of W (r x M) scaled by 1 / sqrt(lam_i) where lam_i > floor_rel * lam_0, zeroed elsewhere
+__global__ void kp_scale_eigvec_rows(double* __restrict__ W, long long M, const double* __restrict__ lam, double floor_rel) {
+  const double l = lam[blockIdx.y], l0 = lam[0];
+  const double a = (l > floor_rel * l0 && l > 0.0) ? 1.0 / sqrt(l) : 0.0;
+  double* row = W + blockIdx.y * M;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < M; j += (long long)gridDim.x * blockDim.x) row[j] *= a;
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Fused small kernels of the sketch passes.  A pass is four thin products over the snapshot block plus ~70 small dense
 // operations on b <= 32 rows; launched one by one (Gram product, split-K reduction, mirror, factorisation, apply, copy
@@ -267,9 +422,200 @@ constexpr double NOISE_FLOOR = 1e-13;    // modes below this fraction of sigma_1
 constexpr int PASS_MODES = 24;           // modes asked of one sketch pass (+ 8 rows of oversampling = 32: the one-workgroup small kernels)
 
 struct PodInfo {
-  int sketch_passes = 0, completed = 0, resolved = 0;
+  int gram_passes = 0, sketch_passes = 0, completed = 0, resolved = 0, eig_iterations = 0, lowrank = 0;
   double executed = 0.0;
 };
+
+constexpr double GRAM_ACCEPT = 1e-10;    // eigenvalues of a Gram matrix are taken down to this fraction of its largest one
+constexpr int LOWRANK_CAP = 96;          // most steps of the pivoted Cholesky that replaces the subspace iteration
+constexpr double LOWRANK_TOL = 1e-14;    // its stopping pivot, relative to the first one
+constexpr double LOWRANK_RESIDUAL = 2e-14;  // accepted ||G - L L^T|| (bounded by the trace of the remaining diagonal) / lambda_1
+
+// The leading eigenpairs of a numerically low-rank PSD matrix without iteration: G ~ Lt^T Lt by pivoted Cholesky (rank r,
+// one launch), the r x r problem Lt Lt^T = Q diag(theta) Q^T, eigenvectors w_i = Lt^T q_i / sqrt(theta_i).  The error
+// against the eigenpairs of G itself is that of a perturbation of norm <= trace(remaining diagonal), which the kernel
+// reports; the caller falls back to the subspace iteration when that bound is above LOWRANK_RESIDUAL x theta_0 or the
+// factor did not end within LOWRANK_CAP steps (a slowly decaying spectrum).  done = 1 on success.
+int lowrank_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std::vector<double>& theta_host, double* theta_dev,
+                       PodInfo& info, int& done) {
+  done = 0;
+  const int rcap = std::min(M, LOWRANK_CAP);
+  if (M <= rcap) return ROM_OK;  // (the full space: one exact Ritz step of the general path)
+  Tmp Lt, dw, out, H, St, lam, Wr;
+  ROM_TRY(dw.get(ctx, M));
+  ROM_TRY(out.get(ctx, 4));
+  {
+    // First a factor of at most 32 steps with everything behind it enqueued BEFORE the host knows the rank (the small
+    // eigenproblem reads it from the device): ONE host synchronisation for the whole Gram stage when the block's Gram
+    // matrix has numerical rank <= 32 -- a sweep over a handful of parameters -- instead of two round trips.
+    constexpr int R32 = 32;
+    ROM_TRY(Lt.get(ctx, size_t(R32) * M));
+    ROM_TRY(H.get(ctx, size_t(R32) * R32));
+    ROM_TRY(St.get(ctx, size_t(R32) * R32));
+    ROM_TRY(lam.get(ctx, R32));
+    ROM_TRY(Wr.get(ctx, size_t(R32) * M));
+    ROM_HIP(hipMemsetAsync(Lt.p(), 0, size_t(R32) * M * sizeof(double), ctx->stream));
+    {
+      ROM_PROF(ctx, "pivchol_lowrank", double(R32) * R32 * M, 8.0 * R32 * M);
+      kp_pivchol_lowrank<<<1, 1024, 0, ctx->stream>>>(M, G, M, R32, LOWRANK_TOL, Lt, dw, out);
+    }
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(rom_launch_gemm_nt(ctx, R32, R32, M, 1.0, Lt, M, Lt, M, 0.0, H, R32, "gemm_nt"));
+    {
+      ROM_PROF(ctx, "small_eig", 30.0 * R32 * R32 * R32, 16.0 * R32 * R32);
+      kp_jacobi32_devn<<<1, 256, 0, ctx->stream>>>(R32, out, H, lam, St);
+    }
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(rom_launch_gemm_nn(ctx, R32, M, R32, 1.0, St, R32, Lt, M, 0.0, Wr, M));
+    kp_scale_eigvec_rows<<<dim3(unsigned(std::min((M + 255) / 256, 64)), R32), 256, 0, ctx->stream>>>(Wr, M, lam, 0.0);
+    ROM_HIP(hipGetLastError());
+    double o[4 + R32];
+    ROM_HIP(hipMemcpyAsync(o, out.p(), 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ROM_HIP(hipMemcpyAsync(o + 4, lam.p(), R32 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ROM_HIP(hipStreamSynchronize(ctx->stream));
+    const int r = int(o[0]);
+    if (r < 1) return ROM_OK;
+    if (o[3] != 0.0 && o[4] > 0.0 && o[1] <= LOWRANK_RESIDUAL * o[4]) {
+      const int ncopy = std::min(nev, r);
+      ROM_HIP(hipMemcpyAsync(W, Wr.p(), size_t(ncopy) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      if (ncopy < nev) ROM_HIP(hipMemsetAsync(W + size_t(ncopy) * M, 0, size_t(nev - ncopy) * M * sizeof(double), ctx->stream));
+      ROM_HIP(hipMemsetAsync(theta_dev, 0, size_t(nev) * sizeof(double), ctx->stream));
+      ROM_HIP(hipMemcpyAsync(theta_dev, lam.p(), size_t(ncopy) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      theta_host.assign(nev, 0.0);
+      for (int i = 0; i < ncopy; ++i) theta_host[i] = std::max(o[4 + i], 0.0);
+      info.eig_iterations = 0;
+      info.lowrank = r;
+      done = 1;
+      return ROM_OK;
+    }
+    if (o[3] != 0.0) return ROM_OK;   // (ended by tolerance but the residual bound failed: the general path)
+  }
+  // (rank above 32: the factor again up to LOWRANK_CAP steps, sizes known to the host before the small problems are launched)
+  ROM_TRY(Lt.get(ctx, size_t(rcap) * M));
+  {
+    ROM_PROF(ctx, "pivchol_lowrank", double(rcap) * rcap * M, 8.0 * rcap * M);
+    kp_pivchol_lowrank<<<1, 1024, 0, ctx->stream>>>(M, G, M, rcap, LOWRANK_TOL, Lt, dw, out);
+  }
+  ROM_HIP(hipGetLastError());
+  double o[4];
+  ROM_TRY(download(ctx, out, o, 4));
+  const int r = int(o[0]);
+  if (r < 1 || o[3] == 0.0) return ROM_OK;   // nothing there, or not low rank within the cap
+  ROM_TRY(H.get(ctx, size_t(r) * r));
+  ROM_TRY(St.get(ctx, size_t(r) * r));
+  ROM_TRY(lam.get(ctx, r));
+  ROM_TRY(Wr.get(ctx, size_t(r) * M));
+  ROM_TRY(rom_launch_gemm_nt(ctx, r, r, M, 1.0, Lt, M, Lt, M, 0.0, H, r, "gemm_nt"));
+  ROM_TRY(romb_small_eig(ctx, r, H, r, lam, St, r, SE_EIG, 0.0, true));   // (graded: the factor's rows fall off like the pivots)
+  std::vector<double> th(r);
+  ROM_TRY(download(ctx, lam, th.data(), r));
+  if (!(th[0] > 0.0) || o[1] > LOWRANK_RESIDUAL * th[0]) return ROM_OK;
+  ROM_TRY(rom_launch_gemm_nn(ctx, r, M, r, 1.0, St, r, Lt, M, 0.0, Wr, M));
+  const int ncopy = std::min(nev, r);
+  kp_scale_eigvec_rows<<<dim3(unsigned(std::min((M + 255) / 256, 64)), ncopy), 256, 0, ctx->stream>>>(Wr, M, lam, 0.0);
+  ROM_HIP(hipGetLastError());
+  ROM_HIP(hipMemcpyAsync(W, Wr.p(), size_t(ncopy) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  if (ncopy < nev) ROM_HIP(hipMemsetAsync(W + size_t(ncopy) * M, 0, size_t(nev - ncopy) * M * sizeof(double), ctx->stream));
+  ROM_HIP(hipMemsetAsync(theta_dev, 0, size_t(nev) * sizeof(double), ctx->stream));
+  ROM_HIP(hipMemcpyAsync(theta_dev, lam.p(), size_t(ncopy) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  theta_host.assign(nev, 0.0);
+  for (int i = 0; i < ncopy; ++i) theta_host[i] = std::max(th[i], 0.0);
+  info.eig_iterations = 0;
+  info.lowrank = r;
+  done = 1;
+  return ROM_OK;
+}
+
+// Leading nev eigenpairs of the symmetric PSD matrix G (M x M) by subspace iteration with Rayleigh-Ritz; the projected
+// b x b problems are solved on the device.  theta_host / theta_dev: nev values (host / device); W: (nev, M) rows = eigenvectors.
+int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std::vector<double>& theta_host, double* theta_dev,
+                   PodInfo& info,
+                   int oversample = 12, double tol = 2e-14, int max_iter = 30, double accept = GRAM_ACCEPT) {
+  {
+    int done = 0;
+    ROM_TRY(lowrank_eigenpairs(ctx, G, M, nev, W, theta_host, theta_dev, info, done));
+    if (done) return ROM_OK;
+  }
+  const int b0 = std::min(M, nev + oversample);
+  int b = b0;  // rows in play: shrinks once the spectrum shows how many pairs the caller can use (see below)
+  Tmp Y, Z, H, St, lam, Yr, Zr, Res, res, Zs, scr, nrm;
+  ROM_TRY(Y.get(ctx, size_t(b) * M));
+  ROM_TRY(Z.get(ctx, size_t(b) * M));
+  ROM_TRY(H.get(ctx, size_t(b) * b));
+  ROM_TRY(St.get(ctx, size_t(b) * b));
+  ROM_TRY(lam.get(ctx, 2 * size_t(b)));
+  ROM_TRY(Yr.get(ctx, size_t(b) * M));
+  ROM_TRY(Zr.get(ctx, size_t(b) * M));
+  ROM_TRY(Res.get(ctx, size_t(b) * M));
+  ROM_TRY(Zs.get(ctx, size_t(b) * M));
+  ROM_TRY(scr.get(ctx, size_t(b) * M));
+  ROM_TRY(nrm.get(ctx, b));
+  double* d_res = lam.p() + b0;
+  ROM_TRY(romb_fill_random(ctx, Y, size_t(b) * M, 0x5eed0000ull + unsigned(b) * 131u + unsigned(M), true));
+  std::vector<double> th(2 * size_t(b0), 0.0);
+  double best = 1e300;
+  int stall = 0;
+  if (b == M) {
+    ROM_TRY(romb_gram_transform(ctx, Y, scr, b, M, SE_WHITEN, 1e-30, 2));  // (the full space: one exact Ritz step below)
+  } else {
+    // Iteration 0 is a plain power step: Y_1 = orthonormalised rows of (Gaussian block) G.  A Rayleigh-Ritz step on a
+    // random block only rotates noise -- it costs a b x b eigenproblem and an orthonormalisation of the start block and
+    // leaves the same subspace.
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, M, 1.0, Y, M, G, M, 0.0, Zs, M, "gemm_nt"));
+    ROM_TRY(rom_launch_l2norm(ctx, Zs, b, M, nrm, true));
+    kb_inv<<<unsigned((b + 255) / 256), 256, 0, ctx->stream>>>(nrm, nrm, b);
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(rom_launch_rows_scale(ctx, Zs, b, M, nrm));
+    ROM_TRY(romb_gram_transform(ctx, Zs, scr, b, M, SE_WHITEN, 1e-30, 2));
+    ROM_HIP(hipMemcpyAsync(Y.p(), Zs.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  for (int it = 0; it < max_iter; ++it) {
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, M, 1.0, Y, M, G, M, 0.0, Z, M, "gemm_nt"));   // Z = Y G (G symmetric)
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, b, M, 1.0, Z, M, Y, M, 0.0, H, b, "gemm_nt"));   // H = Y G Y^T
+    ROM_TRY(romb_small_eig(ctx, b, H, b, lam, St, b, SE_EIG, 0.0, false));                   // rows of St: Ritz rotations
+    ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Y, M, 0.0, Yr, M));            // Ritz vectors
+    info.eig_iterations = it + 1;
+    if (b == M) {  // full space: exact after one Ritz step
+      ROM_TRY(download(ctx, lam, th.data(), b));
+      break;
+    }
+    ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Z, M, 0.0, Zr, M));            // G applied to them
+    kb_rows_axpy<<<dim3(unsigned(std::min((M + 255) / 256, 64)), b), 256, 0, ctx->stream>>>(Res, Zr, Yr, lam, -1.0, M);
+    ROM_HIP(hipGetLastError());
+    const int ncheck = std::min(nev, b);
+    ROM_TRY(rom_launch_l2norm(ctx, Res, ncheck, M, d_res, true));
+    ROM_TRY(download(ctx, lam, th.data(), size_t(b0) + ncheck));
+    for (int i = b; i < b0; ++i) th[i] = 0.0;  // (pairs dropped from the block)
+    const double t0 = std::max(std::fabs(th[0]), 1e-300);
+    double worst = 0.0;
+    for (int i = 0; i < ncheck; ++i)
+      if (th[i] > accept * std::fabs(th[0])) worst = std::max(worst, th[b0 + i] / t0);
+    if (worst < 0.7 * best) { best = worst; stall = 0; } else { ++stall; }
+    if (worst <= tol || stall >= 3 || it == max_iter - 1) break;
+    // The caller only takes pairs with theta_i > accept * theta_0.  Once a Rayleigh-Ritz step on an orthonormal block
+    // has shown how many there can be (two orders of magnitude of slack on the threshold), the block is cut down to
+    // those + the oversampling: the rows are Ritz vectors in descending order, so the cut keeps the leading ones.
+    // (A snapshot block with 16 usable pairs out of 50 requested then iterates with 28 rows instead of 62.)
+    {
+      int count = 0;
+      while (count < b && th[count] > 1e-2 * accept * std::fabs(th[0])) ++count;
+      b = std::min(b, std::min(nev, count) + oversample);
+    }
+    kb_next_block<<<dim3(unsigned(std::min((M + 255) / 256, 64)), b), 256, 0, ctx->stream>>>(Zs, Zr, Yr, lam, M);
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(romb_gram_transform(ctx, Zs, scr, b, M, SE_WHITEN, 1e-30, 1));  // (rows are rotated Ritz vectors: nearly orthonormal)
+    ROM_HIP(hipMemcpyAsync(Y.p(), Zs.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  theta_host.assign(th.begin(), th.begin() + nev);
+  for (int i = b; i < nev; ++i) theta_host[i] = 0.0;
+  const int ncopy = std::min(nev, b);
+  ROM_HIP(hipMemsetAsync(theta_dev, 0, size_t(nev) * sizeof(double), ctx->stream));
+  ROM_HIP(hipMemcpyAsync(theta_dev, lam.p(), size_t(ncopy) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  ROM_HIP(hipMemcpyAsync(W, Yr.p(), size_t(ncopy) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  if (ncopy < nev) ROM_HIP(hipMemsetAsync(W + size_t(ncopy) * M, 0, size_t(nev - ncopy) * M * sizeof(double), ctx->stream));
+  return ROM_OK;
+}
+
 
 // ---- launchers of the fused kernels --------------------------------------------------------------------------------
 constexpr int FUSED_ROWS = 32;   // row blocks up to this size take the fused kernels (one Jacobi / Cholesky wave, LDS resident)
@@ -511,6 +857,68 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
   double sigma_1 = 0.0;
   Tmp Bt;  // coefficients of the accepted modes, (n, M): row j = X v_j
   ROM_TRY(Bt.get(ctx, size_t(std::max(n, 1)) * M));
+  auto deflate = [&](int lo, int take) -> int {
+    // coefficients of the modes V[lo : lo + take] into Bt (row j = X v_j; the modes are orthogonal to the earlier ones, so
+    // X and the deflated block give the same coefficients).  X is not touched: the deflation is implicit (sketch_pass)
+    ROM_TRY(rom_launch_gemm_nt(ctx, take, M, dim, 1.0, V + size_t(lo) * dim, dim, X, dim, 0.0, Bt.p() + size_t(lo) * M, M, "gemm_nt"));
+    info.executed += 2.0 * take * M * double(dim);
+    return ROM_OK;
+  };
+  // The Gram route, for a spectrum that decays too slowly for the sketch passes (see the loop below): the leading modes
+  // from the M x M Gram matrix of the (centred) block -- eigenpairs to convergence in M space, modes down to 1e-5 sigma_1
+  // (GRAM_ACCEPT) lifted, orthonormalised, deflated; the passes below go on from there.
+  auto gram_route = [&]() -> int {
+    Tmp G, W, fac;
+    ROM_TRY(G.get(ctx, size_t(M) * M));
+    ROM_TRY(W.get(ctx, size_t(n) * M));
+    ROM_TRY(fac.get(ctx, n));
+    ROM_TRY(rom_launch_gram(ctx, M, dim, X, dim, G, M));
+    info.gram_passes = 1;
+    info.executed += double(M) * (M + 1) * double(dim);
+    std::vector<double> lam;
+    ROM_TRY(top_eigenpairs(ctx, G, M, n, W, lam, fac, info));
+    G.release();
+    for (double& v : lam) v = std::max(v, 0.0);
+    sigma_1 = lam.empty() ? 0.0 : std::sqrt(lam[0]);
+    int take = 0;
+    // (the caller's floor applies here as well as in the sketch passes: modes below rel_floor x sigma_1 are not looked for)
+    while (take < n && take < int(lam.size()) && lam[take] > GRAM_ACCEPT * lam[0] && lam[take] > 0 &&
+           lam[take] > floor_rel * floor_rel * lam[0]) ++take;
+    found = 0;
+    if (take) {
+      // rows of W / sigma_i, with the eigenvalues top_eigenpairs left on the device (no upload, no host synchronisation)
+      kp_scale_eigvec_rows<<<dim3(unsigned(std::min((M + 255) / 256, 64)), take), 256, 0, ctx->stream>>>(W, M, fac, 0.0);
+      ROM_HIP(hipGetLastError());
+      ROM_TRY(rom_launch_gemm_nn(ctx, take, dim, M, 1.0, W, M, X, dim, 0.0, V, dim));   // V = S^-1 W^T Xc
+      info.executed += 2.0 * take * M * double(dim);
+      {  // (lifted Gram modes are orthonormal to ~1e-6 at worst; the symmetric orthonormalisation is second order in that defect)
+        Tmp Gs, ls, Ts;
+        ROM_TRY(Gs.get(ctx, size_t(take) * take));
+        ROM_TRY(ls.get(ctx, take));
+        ROM_TRY(Ts.get(ctx, size_t(take) * take));
+        ROM_TRY(lowdin_rows(ctx, V, take, dim, Gs, ls, Ts));
+      }
+      ROM_TRY(deflate(0, take));
+      found = take;
+    }
+    return ROM_OK;
+  };
+  // How many of the `take` leading modes of a pass have converged.  The range finder with one power step leaves
+  // (sigma_{b+1} / sigma_k)^3 of the directions beyond its b rows in mode k; sigma_{b+1} is not known, the smallest Ritz
+  // value of the sketch stands for it with a factor 10 (a Ritz value underestimates).  Wanted: LAPACK's own bound
+  // eps sigma_1 / sigma_k (x 10), or 1e-10 where that is smaller.  A sketch that spans the whole range is exact.
+  auto converged_prefix = [&](const std::vector<double>& ss, int b, int take) -> int {
+    if (b + found >= std::min<int64_t>(M, dim) - (center ? 1 : 0) || take == 0) return take;
+    const double tail = 10.0 * ss[b - 1];
+    int k = 0;
+    while (k < take) {
+      const double rho = tail / ss[k];
+      if (rho * rho * rho > std::max(1e-10, 10.0 * 1.1e-16 * sigma_1 / ss[k])) break;
+      ++k;
+    }
+    return k;
+  };
+  bool gram_done = false;
   SketchAhead ahead;
   // (blocks from 64 MB: below, the product is shorter than the stream hand-over.  dim >= 1024, M >= 128: the product then
   // takes the thin LDS-DMA kernel, which needs no scratch -- the context's scratch area belongs to the kernels of the main stream)
@@ -528,7 +936,9 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     // (a request with hundreds of modes left asks for more per pass: 24 per pass would be n / 24 passes over the block)
     const int left = n - found;
     const int want = std::min(left, std::max(PASS_MODES, left / 4));
-    int b = int(std::min<int64_t>(std::min<int64_t>(M, dim), want + 8));
+    // (never fewer than 32 rows: the thin products are bound by the read of the block and the small kernels hold 32 rows at
+    // the same cost, and every extra row lowers sigma_{b+1} -- what the accuracy of the accepted modes is measured against)
+    int b = int(std::min<int64_t>(std::min<int64_t>(M, dim), std::max(want + 8, FUSED_ROWS)));
     Tmp Q, Om, Rt, Traw;
     bool hit = false;
     ROM_TRY(sketch_ahead_take(ctx, ahead, b, p, hit));
@@ -571,6 +981,35 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     if (take == 0) {
       at_floor_stop = b == 0 || ss[0] <= floor_rel * sigma_1;
       break;
+    }
+    {
+      // A slowly decaying spectrum: only a prefix of the modes has converged (the rest stays in the deflated block for the
+      // next pass, at the top of its sketch).  When the first pass shows that the passes would cost more than the Gram
+      // route -- whose iterations run in M space, 2 M^2 b flops each instead of two passes over the block -- its result is
+      // dropped and the Gram route takes over; later passes without a converged mode accept what the rules above give.
+      const int good = converged_prefix(ss, b, take);
+      if (getenv("DEV_POD_TRACE")) fprintf(stderr, "pass %d found %d b %d want %d take %d good %d ss0 %.3e ss[take-1] %.3e ss[b-1] %.3e sigma_1 %.3e\n", p, found, b, want, take, good, ss[0], ss[take - 1], ss[b - 1], sigma_1);
+      if (good < take && found == 0 && !gram_done) {
+        const double t_prod = double(M) * double(dim) * 8.0 / 4.5e12 + 30e-6, t_pass = 4.0 * t_prod + 0.5e-3;
+        const double t_gram = double(M) * double(M) * double(dim) / 55e12 + 1.5e-3;
+        const double passes_left = good > 0 ? std::ceil(double(left) / good) : 1e9;
+        if (passes_left * t_pass > t_gram + t_pass) {
+          gram_done = true;
+          ROM_TRY(gram_route());
+          if (found == 0) break;   // (a zero block)
+          continue;
+        }
+      }
+      if (good >= 1) {
+        take = good;
+      } else {
+        // no mode of this pass meets the bound (a slowly decaying spectrum below the reach of the Gram route): best effort --
+        // the modes at least a factor 4 above the bottom of the sketch (their share of the directions beyond the sketch is
+        // ~(1/4)^3), at least one; the rest is left for the next pass, where it sits at the top
+        int k = 0;
+        while (k < take && ss[k] >= 4.0 * ss[b - 1]) ++k;
+        take = std::max(1, k);
+      }
     }
     double* Vn = V + size_t(found) * dim;
     double* Bn = Bt.p() + size_t(found) * M;
@@ -668,11 +1107,11 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
   if (info_host) {
     info_host[0] = info.resolved;
     info_host[1] = info.completed;
-    info_host[2] = 0.0;   // (Gram passes: none since round 5 -- the slot keeps its place in the ABI)
+    info_host[2] = info.gram_passes;
     info_host[3] = info.sketch_passes;
     info_host[4] = info.executed;
     info_host[5] = 8.0 * n * M * double(dim);   // the four thin products of a pass for the n requested modes alone (no oversampling)
-    info_host[6] = 0.0;   // (subspace iterations of the Gram stage: retired with it)
+    info_host[6] = info.eig_iterations;
     // why the call stopped short of n modes: 0 request filled, 1 the spectrum reached the floor (the completed modes are
     // not determined by the data), 2 no accepted mode in a pass / pass budget (modes above the floor may be missing)
     info_host[7] = found >= n ? 0.0 : (at_floor_stop || sigma_1 == 0.0 ? 1.0 : 2.0);

@@ -17,10 +17,12 @@ if os.environ.get("DEEP8"):   # eight orders below the reach of the Gram stage, 
 s = np.concatenate([lead, deep])
 if os.environ.get("FULL13"):   # one mode per 10^(-1/PER) from 1 down to 2e-13
     s = np.concatenate([10.0 ** -np.arange(0, 12.5, 1.0 / per), [2e-13]])
+if os.environ.get("SLOW"):   # one decade per SLOW modes, 50 modes asked
+    s = 10.0 ** (-np.arange(50) / float(os.environ["SLOW"]))
 n = len(s)
 Q1, _ = np.linalg.qr(rng.standard_normal((M, M)))
 Q2, _ = np.linalg.qr(rng.standard_normal((dim, M)))
-full = np.concatenate([s, 1e-15 * rng.uniform(0.3, 1, M - n)])
+full = np.concatenate([s, (s[-1] * 10.0 ** (-np.arange(1, M - n + 1) / float(os.environ['SLOW'])) if os.environ.get('SLOW') else 1e-15 * rng.uniform(0.3, 1, M - n))])
 Xh = (Q1 * full) @ Q2.T
 X = ctx.upload(Xh)
 comps, sig = RB.pod_modes(ctx, SM.DeviceArray(X, M, dim), n, center=False)
