@@ -250,8 +250,9 @@ def gathered_rows_ok(ctx, fem, be, a_all, rank, world, M, dim, k_last) -> bool:
 
 
 def pod_accounting(M, dim, r):
-    """Flops of a POD by the Gram route that are USEFUL work (SURVEY 8d without its 10 M^3 'eigh' term, which the
-    subspace iteration never executes): the symmetric half of ONE Gram matrix + the lift of r modes."""
+    """Flop count of a POD in the Gram formulation (SURVEY 8d without its 10 M^3 'eigh' term): the symmetric half of ONE
+    Gram matrix + the lift of r modes.  Since round 5 rom_pod takes that route only for slowly decaying spectra; otherwise it
+    executes thin products (`executed_flops` in the record) and `gflops` is an EQUIVALENT rate on this count."""
     return float(M) * (M + 1) * dim + 2.0 * r * M * dim
 
 
@@ -724,8 +725,10 @@ def extras_pod_c2(out, args, ctx, sm, fem, a_dev, U_loc, M, dim, blocks):
     ctx.profile(False)
     launches = int(sum(v["launches"] for v in ctx.profile_report().values()))
     out["pod"] = pod_record(M, dt, sig, dict(getattr(pod_modes, "last_info", {}), kernel_launches_profiled=launches,
-                            note="gflops = USEFUL flops (symmetric half of ONE Gram matrix + lift of r modes, no eigh term) over "
-                                 "the wall time of pod_modes incl. the download of the r modes; executed flops in `executed_*`"))
+                            note="gflops = the flop count of the Gram formulation (SURVEY 8d: symmetric half of ONE Gram matrix + lift of r "
+                                 "modes, no eigh term) over the wall time of pod_modes incl. the download of the r modes: an "
+                                 "EQUIVALENT rate -- rom_pod executes `executed_flops` (thin products of the sketch passes; a "
+                                 "Gram matrix only when `gram_passes` = 1)"))
     if fem.expansion_is_linear:
         # the same POD on the block held in factored form (interface vectors; no row is read)
         from romhighcontrast_amd import factored
@@ -891,7 +894,7 @@ def other_config_leg(ctx, dev, config):
         rec["pod"] = sub["pod"]
         if "pod_factored" in sub:
             rec["pod_factored"] = sub["pod_factored"]
-        rec["pod"]["frac_of_matrix_peak"] = round(rec["pod"]["gflops"] * 1e-3 / FP64_MATRIX_PEAK_TFLOPS, 4)
+        rec["pod"]["frac_of_matrix_peak"] = round(rec["pod"].get("executed_flops", 0.0) / rec["pod"]["seconds"] * 1e-12 / FP64_MATRIX_PEAK_TFLOPS, 4)
     del U, a_dev, sm, fem
     return rec
 
@@ -914,7 +917,8 @@ def extras_pod_c5(out, ctx, sm, fem, a_dev, U_loc, M, dim, factored_too=True):
     out["pod"] = {"gflops": round(useful / dt * 1e-9, 1), "seconds": round(dt, 4), "M": M, "dim": dim, "modes": r,
                   "useful_flops": useful, "sigma_1": float(sig[0]), "resolved_modes": int((sig > 0).sum()),
                   **getattr(pod_modes, "last_info", {}),
-                  "note": "gflops = useful flops (symmetric half of ONE Gram + lift, no eigh term) over the wall time of pod_modes"}
+                  "note": "gflops = flop count of the Gram formulation (symmetric half of ONE Gram + lift, no eigh term) over the wall "
+                          "time of pod_modes; executed: `executed_flops` (a Gram matrix when `gram_passes` = 1)"}
     del X
     if fem.expansion_is_linear and factored_too:
         from romhighcontrast_amd import factored

@@ -215,12 +215,15 @@ int rom_greedy(rom_fem* fem, rom_buf* U, int64_t u_row0, int M, rom_buf* a, cons
  * X[x_row0 ...] -- OVERWRITTEN when center != 0 (the column means are subtracted in place) -- into V[v_row0 ...] (n x dim, orthonormal rows,
  * scikit-learn's svd_flip(u_based_decision=False) signs) and their singular values into sigma_host (n).  Randomised
  * range-finder passes over the implicitly deflated block (thin products 2 b M dim, one power step, rows orthonormalised on
- * both sides of it: a pass resolves modes over seven orders of magnitude to LAPACK's own noise bound eps sigma_1 / sigma),
- * Rayleigh-Ritz over the collected modes; modes below 1e-13 sigma_1 do not exist in fp64 data and are completed with
- * orthonormal directions of singular value 0.  info_host (8 doubles or NULL): resolved modes, completed modes, 0 (was: Gram
- * passes), sketch passes, executed flops, 8 n M dim (the four thin products for the n modes alone), 0 (was: subspace
- * iterations), stop reason (0: all n modes resolved; 1: the spectrum reached the floor -- the completed modes are not
- * determined by the data; 2: a pass accepted nothing although the floor was not reached -- modes above it may be missing). */
+ * both sides of it: a pass resolves modes over seven orders of magnitude to LAPACK's own noise bound eps sigma_1 / sigma)
+ * with a convergence rule per pass; when the first pass shows a spectrum that decays too slowly for that (its modes do not
+ * separate from what lies beyond the sketch) the leading modes come from the M x M Gram matrix instead (MFMA, eigenpairs
+ * iterated to convergence in M space) and the passes continue below its reach (1e-5 sigma_1).  Rayleigh-Ritz over the
+ * collected modes; modes below 1e-13 sigma_1 do not exist in fp64 data and are completed with orthonormal directions of
+ * singular value 0.  info_host (8 doubles or NULL): resolved modes, completed modes, Gram passes (0 or 1), sketch passes,
+ * executed flops, 8 n M dim (the four thin products of a pass for the n modes alone), subspace iterations of the Gram
+ * route, stop reason (0: all n modes resolved; 1: the spectrum reached the floor -- the completed modes are not determined
+ * by the data; 2: a pass accepted nothing although the floor was not reached -- modes above it may be missing). */
 int rom_pod(rom_ctx* ctx, rom_buf* X, int64_t x_row0, int M, int64_t dim, int n, int center, rom_buf* V, int64_t v_row0,
             double* sigma_host, double* info_host);
 /* the same with the floor chosen by the caller: modes with sigma <= rel_floor * sigma_1 are not looked for (every sketch

@@ -1,7 +1,8 @@
 // POD of a snapshot block behind the C-ABI (rom_pod / rom_pod_ex): the PCA fit inside ReducedBasisPCA.build
 // (src/lib/ReducedBasis.py:189-200).  Randomised range finder passes over the implicitly deflated block -- thin products
-// 2 b M dim each, never the M^2 dim of a Gram matrix -- with one power step per pass, orthonormalised on both sides of
-// it; Rayleigh-Ritz on the collected subspace; every small dense problem runs on the device.
+// 2 b M dim each -- with one power step per pass, orthonormalised on both sides of it, and a convergence rule per pass;
+// the Gram route (M x M Gram matrix on MFMA, eigenpairs iterated in M space) when the first pass shows a spectrum that
+// decays too slowly for the passes; Rayleigh-Ritz on the collected subspace; every small dense problem runs on the device.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -829,9 +830,9 @@ int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double*
 // Leading n right singular vectors / singular values of the (M, dim) block X (overwritten when it is centred).
 // center != 0: subtract the column means first (sklearn PCA.fit).  V: (n, dim) rows = modes, sign convention of
 // sklearn's svd_flip(u_based_decision=False); sigma_host: n singular values (0 for completed modes);
-// info_host (8 doubles, may be null): resolved modes, completed modes, 0 (Gram passes: none), sketch passes, executed
-// flops, 8 n M dim (the thin products for the requested modes alone), 0 (subspace iterations: none), stop reason (0 filled,
-// 1 floor reached, 2 budget).
+// info_host (8 doubles, may be null): resolved modes, completed modes, Gram passes (0 / 1), sketch passes, executed flops,
+// 8 n M dim (the thin products for the requested modes alone), subspace iterations of the Gram route, stop reason
+// (0 filled, 1 floor reached, 2 budget).
 // rel_floor: modes with sigma <= rel_floor * sigma_1 are not looked for (<= 0 or below the fp64 noise floor of the snapshots,
 // 1e-13: that floor -- what a full LAPACK SVD of the block resolves)
 extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int64_t dim, int n, int center, double rel_floor,
@@ -988,7 +989,6 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
       // route -- whose iterations run in M space, 2 M^2 b flops each instead of two passes over the block -- its result is
       // dropped and the Gram route takes over; later passes without a converged mode accept what the rules above give.
       const int good = converged_prefix(ss, b, take);
-      if (getenv("DEV_POD_TRACE")) fprintf(stderr, "pass %d found %d b %d want %d take %d good %d ss0 %.3e ss[take-1] %.3e ss[b-1] %.3e sigma_1 %.3e\n", p, found, b, want, take, good, ss[0], ss[take - 1], ss[b - 1], sigma_1);
       if (good < take && found == 0 && !gram_done) {
         const double t_prod = double(M) * double(dim) * 8.0 / 4.5e12 + 30e-6, t_pass = 4.0 * t_prod + 0.5e-3;
         const double t_gram = double(M) * double(M) * double(dim) / 55e12 + 1.5e-3;
