@@ -965,10 +965,9 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     }
     ROM_TRY(Rt.get(ctx, size_t(b) * b));
     ROM_TRY(Traw.get(ctx, size_t(b) * M));
-    // the next pass's product beside this pass's Rayleigh-Ritz rounds, when its b is certain whatever this pass accepts:
-    // 16 <= modes still wanted afterwards <= 64  =>  16 + 8 rows
-    // (a next pass is certain -- unless the floor is reached -- when this one cannot fill the request; it asks for at most
-    // PASS_MODES + 8 rows as long as fewer than 4 PASS_MODES modes are left)
+    // the next pass's product beside this pass's Rayleigh-Ritz kernel: a next pass is certain -- unless the floor is reached --
+    // when this one cannot fill the request, and it asks for at most PASS_MODES + 8 rows as long as fewer than 4 PASS_MODES
+    // modes are left (32 rows are computed, the pass uses the leading b of them)
     auto start_next = [&]() -> int {
       if (left - want >= 1 && left - 1 <= 4 * PASS_MODES && worth_ahead)
         return sketch_ahead_start(ctx, ahead, X, M, dim, int(std::min<int64_t>(std::min<int64_t>(M, dim), PASS_MODES + 8)), p + 1);
