@@ -677,7 +677,7 @@ int lowdin_rows(rom_ctx* ctx, double* X, int b, int64_t dim, double* G, double* 
 // nothing is lost to the squaring that a single eigen-decomposition of an ungraded Gram matrix would lose.
 // Rt (b x b): accumulated rotation (rows = right singular vectors in the coordinates Tt came in); sig2: b values.
 int tall_svd_rotation(rom_ctx* ctx, double* Tt, int b, int M, double* Rt, double* sig2, int rounds = 3) {
-  if (b <= FUSED_ROWS && M <= 65536) {   // one workgroup from the first round to the last (b x M doubles: L2 resident)
+  if (b <= FUSED_ROWS && M <= 4096) {   // one workgroup from the first round to the last (beyond: its reads of the b x M factor, ~80 GB/s for ONE workgroup, outweigh the launches saved)
     ROM_PROF(ctx, "tall_svd", rounds * (4.0 * b * b * M + 30.0 * b * b * b), 8.0 * rounds * 2.0 * b * M);
     kp_tall_svd<<<1, 256, 0, ctx->stream>>>(b, M, Tt, rounds, Rt, sig2);
     ROM_HIP(hipGetLastError());
@@ -686,13 +686,17 @@ int tall_svd_rotation(rom_ctx* ctx, double* Tt, int b, int M, double* Rt, double
   Tmp H, St, T2, R2;
   ROM_TRY(H.get(ctx, size_t(b) * b));
   ROM_TRY(St.get(ctx, size_t(b) * b));
-  ROM_TRY(T2.get(ctx, size_t(b) * M));
+  if (b > 64) ROM_TRY(T2.get(ctx, size_t(b) * M));
   ROM_TRY(R2.get(ctx, size_t(b) * b));
   for (int r = 0; r < rounds; ++r) {
     ROM_TRY(rom_launch_gemm_nt(ctx, b, b, M, 1.0, Tt, M, Tt, M, 0.0, H, b, "gemm_nt"));
     ROM_TRY(romb_small_eig(ctx, b, H, b, sig2, St, b, SE_EIG, 0.0));
-    ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Tt, M, 0.0, T2, M));
-    ROM_HIP(hipMemcpyAsync(Tt, T2.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (b <= 64) {
+      ROM_TRY(combine_rows(ctx, b, b, St, b, 0, nullptr, 0, 0.0, Tt, M, nullptr, 0, Tt, M, M));   // Tt <- S Tt in place
+    } else {
+      ROM_TRY(rom_launch_gemm_nn(ctx, b, M, b, 1.0, St, b, Tt, M, 0.0, T2, M));
+      ROM_HIP(hipMemcpyAsync(Tt, T2.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     if (r == 0) {
       ROM_HIP(hipMemcpyAsync(Rt, St.p(), size_t(b) * b * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     } else {
@@ -908,18 +912,19 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
   // (sigma_{b+1} / sigma_k)^3 of the directions beyond its b rows in mode k; sigma_{b+1} is not known, the smallest Ritz
   // value of the sketch stands for it with a factor 10 (a Ritz value underestimates).  Wanted: LAPACK's own bound
   // eps sigma_1 / sigma_k (x 10), or 1e-10 where that is smaller.  A sketch that spans the whole range is exact.
-  auto converged_prefix = [&](const std::vector<double>& ss, int b, int take) -> int {
+  auto converged_prefix = [&](const std::vector<double>& ss, int b, int take, int power) -> int {
     if (b + found >= std::min<int64_t>(M, dim) - (center ? 1 : 0) || take == 0) return take;
     const double tail = 10.0 * ss[b - 1];
     int k = 0;
     while (k < take) {
       const double rho = tail / ss[k];
-      if (rho * rho * rho > std::max(1e-10, 10.0 * 1.1e-16 * sigma_1 / ss[k])) break;
+      if (std::pow(rho, 2 * power + 1) > std::max(1e-10, 10.0 * 1.1e-16 * sigma_1 / ss[k])) break;   // (q power steps: rho^(2 q + 1))
       ++k;
     }
     return k;
   };
   bool gram_done = false;
+  int power = 1;   // power steps per pass: 2 once a pass has shown a spectrum too flat for one (best-effort regime below)
   SketchAhead ahead;
   // (blocks from 64 MB: below, the product is shorter than the stream hand-over.  dim >= 1024, M >= 128: the product then
   // takes the thin LDS-DMA kernel, which needs no scratch -- the context's scratch area belongs to the kernels of the main stream)
@@ -973,7 +978,7 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
         return sketch_ahead_start(ctx, ahead, X, M, dim, int(std::min<int64_t>(std::min<int64_t>(M, dim), PASS_MODES + 8)), p + 1);
       return ROM_OK;
     };
-    ROM_TRY(sketch_pass(ctx, X, M, dim, V, Bt, found, b, p, Q, hit ? Om.p() : nullptr, Rt, Traw, ss, info, start_next));
+    ROM_TRY(sketch_pass(ctx, X, M, dim, V, Bt, found, b, p, Q, hit ? Om.p() : nullptr, Rt, Traw, ss, info, start_next, power));
     info.sketch_passes += 1;
     if (found == 0) sigma_1 = ss.empty() ? 0.0 : ss[0];
     int take = 0;
@@ -987,7 +992,7 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
       // next pass, at the top of its sketch).  When the first pass shows that the passes would cost more than the Gram
       // route -- whose iterations run in M space, 2 M^2 b flops each instead of two passes over the block -- its result is
       // dropped and the Gram route takes over; later passes without a converged mode accept what the rules above give.
-      const int good = converged_prefix(ss, b, take);
+      const int good = converged_prefix(ss, b, take, power);
       if (good < take && found == 0 && !gram_done) {
         const double t_prod = double(M) * double(dim) * 8.0 / 4.5e12 + 30e-6, t_pass = 4.0 * t_prod + 0.5e-3;
         const double t_gram = double(M) * double(M) * double(dim) / 55e12 + 1.5e-3;
@@ -1008,6 +1013,7 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
         int k = 0;
         while (k < take && ss[k] >= 4.0 * ss[b - 1]) ++k;
         take = std::max(1, k);
+        power = 2;   // (and the passes from here on take a second power step: (1/4)^5 instead of (1/4)^3)
       }
     }
     double* Vn = V + size_t(found) * dim;
