@@ -475,6 +475,55 @@ def test_pod_slow_decay_takes_the_gram_route(api):
     observed("  ... orthonormality of the rows", np.abs(comps @ comps.T - np.eye(n)), 1e-13)
 
 
+def test_pod_awkward_blocks(api):
+    """Blocks the sketch passes could stumble over: a mean a million times the variation (the first product of the first
+    pass runs on the uncentred block -- its last row is the mean, rom_pod.hip kp_zero_sum_rows), clusters of ten equal
+    singular values, rank-deficient data with more modes asked than exist, two and three rows, as many modes as rows."""
+    SM, RB = api
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    rng = np.random.default_rng(3)
+    Q1, _ = np.linalg.qr(rng.standard_normal((300, 300)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((4000, 300)))
+
+    def pod(Xh, n, center):
+        comps, sig = RB.pod_modes(ctx, SM.DeviceArray(ctx.upload(Xh), *Xh.shape), n, center=center)
+        return comps, sig, dict(RB.pod_modes.last_info)
+
+    s = 10.0 ** -np.arange(0, 6, 0.5)
+    base = (Q1[:, :len(s)] * s) @ Q2[:, :len(s)].T
+    for scale in (1.0, 1e3, 1e6):
+        Xh = base + scale * rng.standard_normal(4000)[None, :]
+        _, sv, Vt = np.linalg.svd(Xh - Xh.mean(axis=0), full_matrices=False)
+        comps, sig, info = pod(Xh, len(s), True)
+        # what the stored numbers determine: eps x the size of the UNCENTRED block
+        noise = 1.1e-16 * np.linalg.norm(Xh, 2)
+        observed(f"POD, mean {scale:g} x the variation: |sigma - LAPACK's| / (1e-12 sigma + 100 eps ||X||_2)",
+                 np.abs(sig - sv[:len(s)]) / (1e-12 * sv[:len(s)] + 100 * noise), 1.0)
+        k = int((sv[:len(s)] > 1e4 * noise).sum())
+        observed("  ... projector onto the modes above 1e4 eps ||X||_2 vs LAPACK", np.abs(comps[:k].T @ comps[:k] - Vt[:k].T @ Vt[:k]), 1e-9)
+        observed("  ... orthonormality", np.abs(comps @ comps.T - np.eye(len(s))), 1e-13)
+    cl = np.repeat([1.0, 1e-3, 1e-6, 1e-9], 10)
+    comps, sig, info = pod((Q1[:, :40] * cl) @ Q2[:, :40].T, 40, False)
+    observed("POD, four clusters of ten equal singular values: values (relative)", np.abs(sig / cl - 1), 1e-6)
+    for c in range(4):
+        Vc = Q2[:, 10 * c:10 * c + 10]
+        observed(f"  ... projector onto cluster {c} / (eps sigma_1 / sigma + 1e-15)",
+                 np.abs(comps[10 * c:10 * c + 10].T @ comps[10 * c:10 * c + 10] - Vc @ Vc.T) / (1.1e-16 / cl[10 * c] + 1e-15), 1.0)
+    comps, sig, info = pod((Q1[:, :5] * [1, .5, .1, .01, .001]) @ Q2[:, :5].T, 10, False)
+    assert info["resolved_modes"] == 5 and info["completed_modes"] == 5 and info["stop_reason"] == "floor", info
+    observed("POD, rank 5 with 10 modes asked: the five values (relative)", np.abs(sig[:5] / [1, .5, .1, .01, .001] - 1), 1e-12)
+    assert np.all(sig[5:] == 0.0)
+    observed("  ... orthonormality of resolved + completed rows", np.abs(comps @ comps.T - np.eye(10)), 1e-13)
+    for M_, n_, c_ in ((2, 2, True), (3, 3, True), (24, 24, False)):
+        Xh = rng.standard_normal((M_, 500))
+        sv = np.linalg.svd(Xh - Xh.mean(axis=0) if c_ else Xh, compute_uv=False)
+        comps, sig, info = pod(Xh, n_, c_)
+        r = M_ - 1 if c_ else M_
+        observed(f"POD, {M_} rows, {n_} modes{' (centred)' if c_ else ''}: values vs LAPACK (relative)", np.abs(sig[:r] / sv[:r] - 1), 1e-12)
+        observed("  ... orthonormality", np.abs(comps @ comps.T - np.eye(n_)), 1e-13)
+
+
 def test_pod_slowly_decaying_spectrum_many_modes(api):
     """a request of hundreds of modes from a spectrum that decays slowly -- 320 modes over 12 orders of
     magnitude, 195 of them below the reach of the Gram matrix -- must be FILLED by the sketch passes (the round-3 loop gave
