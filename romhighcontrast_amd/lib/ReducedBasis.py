@@ -6,7 +6,7 @@ solutions2train_h1norm, **kwargs)`` contract; citations are reference file:line.
 
 The arithmetic runs on the GPU: Euclidean orthonormalisation is a re-orthogonalised Gram-Schmidt
 (two passes of MFMA GEMMs per vector), the greedy sweep keeps the training set, the approximations
-and the residual norms in HBM, and the PCA is an MFMA Gram matrix + a small eigenproblem.
+and the residual norms in HBM, and the PCA is a few passes of thin MFMA products over the block (rom_pod).
 Orthonormal bases are defined up to the sign of each vector (NumPy's Householder QR at :19 may
 return negative diagonals in R); every consumer in the reference is sign-invariant.
 """
@@ -247,11 +247,12 @@ def warn_completed_modes(info, n, rel_floor):
 def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, rel_floor=0.0, download=True):
     """Leading ``n`` right singular vectors / singular values of the (M, dim) snapshot block: one C call (rom_pod).
 
-    MFMA Gram matrix ``G = Xc Xc^T`` -> leading eigenpairs by subspace iteration (projected problems by a one-workgroup
-    Jacobi on the device) -> lift; the Gram matrix squares the condition number, so only the modes with lambda_k >
-    1e-10 lambda_1 come from it, the rest from the DEFLATED block through a randomised range finder (thin GEMMs), each
-    pass four orders of magnitude further down, until the request is filled or the spectrum has reached the fp64 noise
-    of the snapshots (1e-13 sigma_1); a Rayleigh-Ritz step over the collected modes orders them.  What is still missing
+    Randomised range-finder passes over the implicitly deflated block (four thin GEMMs each, one power step, the rows
+    orthonormalised on both sides of it: a pass resolves modes over seven orders of magnitude to LAPACK's own bound
+    eps sigma_1 / sigma) with a convergence rule per pass; a spectrum that decays too slowly for that -- the first pass
+    says so -- gets its leading modes from the MFMA Gram matrix ``G = Xc Xc^T`` instead (eigenpairs iterated in M space,
+    modes with lambda_k > 1e-10 lambda_1) and the passes go on below; until the request is filled or the spectrum has
+    reached the fp64 noise of the snapshots (1e-13 sigma_1); a Rayleigh-Ritz step over the collected modes orders them.  What is still missing
     then does not exist in the data; like LAPACK / scikit-learn, which return SOME orthonormal directions there, the
     basis is completed with orthonormalised pseudo-random directions (singular value 0, seeded by the number of
     resolved modes: deterministic), so the rows returned are always orthonormal.  Rows follow scikit-learn's
