@@ -203,6 +203,11 @@ __global__ void kf_scale_cols(int k, int n, const double* __restrict__ LT, const
   if (idx < (long long)k * n) ET[idx] = LT[idx] * d[idx % n];
 }
 
+__global__ void kf_fill_const(double* __restrict__ p, long long n, double v) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 __global__ void kf_set_identity(double* __restrict__ A, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) A[size_t(i) * n + i] = 1.0;
@@ -746,23 +751,24 @@ extern "C" int rom_pod_factored(rom_fem* f, rom_buf* Yc, int64_t c_row0, int M, 
   }
   ROM_TRY(Yfull.get(ctx, size_t(nz) * f->nGp));
   ROM_TRY(ones.get(ctx, size_t(nz) * kblk));
-  {
-    std::vector<double> one(size_t(nz) * kblk, 1.0);
-    ROM_HIP(hipMemcpyAsync(ones.p(), one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    ROM_HIP(hipStreamSynchronize(ctx->stream));
-  }
+  kf_fill_const<<<unsigned((size_t(nz) * kblk + 255) / 256), 256, 0, ctx->stream>>>(ones, (long long)nz * kblk, 1.0);
+  ROM_HIP(hipGetLastError());
   ROM_TRY(rom_fem_unpack_reduced_async(f, Wc.b, 0, nz, Yfull.b, 0));
   ROM_TRY(rom_expand_batch_async(f, ones.b, nz, Yfull.b, 0, V, v_row0));
-  ROM_TRY(rom_solve_status(ctx));
-  // the map is orthonormal to the accuracy of its factor (~1e-9 relative to the leading directions): clean up
-  ROM_TRY(rom_symmetric_orthonormalize(ctx, V, v_row0, nz, dim));
+  // the map is orthonormal to the accuracy of its factor (~1e-9 relative to the leading directions): clean up (symmetric
+  // orthonormalisation through the eigen-decomposition of the n x n Gram matrix: exact for any defect, one round)
+  {
+    Tmp Ys;
+    ROM_TRY(Ys.get(ctx, size_t(nz) * dim));
+    ROM_TRY(romb_gram_transform(ctx, V->p + v_row0 * dim, Ys, nz, dim, SE_LOWDIN, 1e-30, 1));
+  }
   if (nz < n) {  // more modes requested than the snapshot manifold has dimensions: completed like rom_pod completes
     ROM_TRY(rom_complete_orthonormal(ctx, V, v_row0, nz, n - nz, dim));
     info[1] += n - nz;
     if (info[7] == 0.0) info[7] = 1.0;   // (not "filled": the completed modes lie beyond the rank of the snapshot manifold)
   }
   ROM_TRY(rom_launch_rows_sign_flip(ctx, V->p + v_row0 * dim, n, dim));  // svd_flip(u_based_decision=False)
-  ROM_HIP(hipStreamSynchronize(ctx->stream));
+  ROM_TRY(rom_solve_status(ctx));   // (synchronises; the status word of the expansion)
   if (info_host) {
     info[4] += 2.0 * M * double(Kc) * k2 + 2.0 * nz * double(Kc) * double(dim);
     memcpy(info_host, info, sizeof(info));
