@@ -125,6 +125,30 @@ __global__ void k_splitk_reduce(long long m, long long n, int splits, double alp
   *p = beta == 0.0 ? alpha * s : alpha * s + beta * *p;
 }
 
+// the same reduction for outputs of a few thousand to tens of thousands of entries with dozens of splits (the b x M
+// coefficient rows of a thin product over a snapshot-long K): 64 consecutive entries x 4 groups of splits per workgroup --
+// every wave reads 512 contiguous bytes per split (the one-wave-per-entry form below reads a 64-byte sector for 8 of its
+// bytes: 21 us for 25 MB of partials), four times the threads of the entry-per-thread form; fixed order: deterministic
+__global__ __launch_bounds__(256) void k_splitk_reduce_quad(long long m, long long n, int splits, double alpha,
+                                                            const double* __restrict__ part, double beta,
+                                                            double* __restrict__ C, long long ldc, int lower_only) {
+  __shared__ double red[4][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long long idx = blockIdx.x * 64LL + e;
+  const bool in = idx < m * n;
+  double s = 0.0;
+  if (in)
+    for (int z = g; z < splits; z += 4) s += part[z * m * n + idx];
+  red[g][e] = s;
+  __syncthreads();
+  if (g != 0 || !in) return;
+  if (lower_only == 1 && (idx % n) / 64 > (idx / n) / 64) return;
+  s = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+  const long long r = idx / n, c = idx % n;
+  double* p = lower_only == 2 ? C + c * ldc + r : C + r * ldc + c;
+  *p = beta == 0.0 ? alpha * s : alpha * s + beta * *p;
+}
+
 // the same reduction with one WAVE per output element (the splits are spread over its lanes): thin outputs with hundreds
 // of splits -- m x 1 dot products over a snapshot-long K -- are latency bound with one thread walking all the partials
 __global__ __launch_bounds__(256) void k_splitk_reduce_wave(long long m, long long n, int splits, double alpha,
@@ -183,7 +207,10 @@ static int launch_gemm_nt_thin(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, do
   ROM_HIP(hipGetLastError());
   {
     ROM_PROF(ctx, "splitk_reduce", double(splits) * m * n, 8.0 * double(splits + 1) * m * n);
-    if (splits >= 16 && m * n <= 65536)
+    if (splits >= 8 && m * n >= 4096 && m * n <= (1 << 20))
+      k_splitk_reduce_quad<<<unsigned((m * n + 63) / 64), 256, 0, ctx->stream>>>(m, n, int(splits), alpha, part, beta, C, ldc,
+                                                                                transposed ? 2 : 0);
+    else if (splits >= 16 && m * n <= 65536)
       k_splitk_reduce_wave<<<unsigned((m * n + 3) / 4), 256, 0, ctx->stream>>>(m, n, int(splits), alpha, part, beta, C, ldc,
                                                                                transposed ? 2 : 0);
     else
@@ -245,7 +272,9 @@ int rom_launch_gemm_nt_ex(rom_ctx* ctx, int64_t m, int64_t n, int64_t k, double 
   ROM_HIP(hipGetLastError());
   if (splits > 1) {
     ROM_PROF(ctx, "splitk_reduce", double(splits) * m * n, 8.0 * double(splits + 1) * m * n);
-    if (splits >= 16 && m * n <= 65536)
+    if (splits >= 8 && m * n >= 4096 && m * n <= (1 << 20))
+      k_splitk_reduce_quad<<<unsigned((m * n + 63) / 64), 256, 0, ctx->stream>>>(m, n, splits, alpha, part, beta, C, ldc, lower_only);
+    else if (splits >= 16 && m * n <= 65536)
       k_splitk_reduce_wave<<<unsigned((m * n + 3) / 4), 256, 0, ctx->stream>>>(m, n, splits, alpha, part, beta, C, ldc, lower_only);
     else
       k_splitk_reduce<<<unsigned((m * n + 255) / 256), 256, 0, ctx->stream>>>(m, n, splits, alpha, part, beta, C, ldc,
