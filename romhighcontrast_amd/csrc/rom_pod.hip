@@ -177,70 +177,90 @@ __global__ void kp_scale_eigvec_rows(double* __restrict__ W, long long M, const 
 // Fused small kernels of the sketch passes.  A pass is four thin products over the snapshot block plus ~70 small dense
 // operations on b <= 32 rows; launched one by one (Gram product, split-K reduction, mirror, factorisation, apply, copy
 // back ...) they cost more than the products.  Two kernels replace most of them:
-//   kp_combine_rows  OUT = T1 Y + alpha2 T2 V2 for row blocks of any length, in place when OUT == Y (applies a transform,
-//                    subtracts a projection, lifts modes: no scratch block, no copy back)
+//   kp_combine_rows_mma  OUT = T1 Y + alpha2 T2 V2 for row blocks of any length, in place when OUT == Y (applies a
+//                    transform, subtracts a projection, lifts modes: no scratch block, no copy back)
 //   kp_tall_svd      the Rayleigh-Ritz rounds on a b x M factor (Gram, Jacobi, rotation, accumulated rotation), one
 //                    workgroup from the first round to the last
 // ---------------------------------------------------------------------------------------------------------------------
 // OUT (bo x ncols) = T1 (bo x b1) Y (b1 x ncols) + alpha2 T2 (bo x b2) V2 (b2 x ncols).  T1 == nullptr: the identity
-// (bo == b1).  OUT may be Y: a thread owns a column and reads all of its inputs before it writes.  Coefficients are staged
-// through LDS in chunks of KC input rows, [k][BO] so that the BO coefficients of an input row are one broadcast run.
-template <int BO>
-__global__ __launch_bounds__(256) void kp_combine_rows(int bo, int b1, int b2, const double* __restrict__ T1, int ldt1,
-                                                       const double* __restrict__ T2, int ldt2, double alpha2,
-                                                       const double* Y, long long ldy, const double* __restrict__ V2, long long ldv,
-                                                       double* OUT, long long ldo, long long ncols) {
-  constexpr int KC = 32;
-  __shared__ double Tc[KC * BO];
-  const long long j = blockIdx.x * 256LL + threadIdx.x;
-  const bool on = j < ncols;
-  double acc[BO];
+// (bo == b1).  OUT may be Y: a wave owns 64 columns -- four 16-column blocks -- and reads every input row of them before it
+// writes one.  On the matrix cores: the coefficients of a 32-row chunk of inputs are the wave's A fragments (from LDS, once
+// per chunk), the inputs its B fragments (lane = (column, k mod 4): 16 columns x 4 input rows per load instruction, all 32
+// loads of a chunk in flight before the first product), 8 NRB MFMAs per column block and chunk; NRB = ceil(bo / 16) row
+// blocks of outputs.  (The first form of this kernel was a thread per column on the vector pipe: bo x b products per column
+// on a wave that is alone on its SIMD and pays ~9 cycles per instruction it issues, a third of them LDS reads of
+// coefficients -- 15-17 us for 32 x 32 x 65 025; this one 12.  A form with the coefficients as scalar operands, read
+// through the scalar cache, took 45: 512 s_loads per chunk.)
+template <int NRB>
+__global__ __launch_bounds__(256) void kp_combine_rows_mma(int bo, int b1, int b2, const double* __restrict__ T1, int ldt1,
+                                                           const double* __restrict__ T2, int ldt2, double alpha2,
+                                                           const double* Y, long long ldy, const double* __restrict__ V2,
+                                                           long long ldv, double* OUT, long long ldo, long long ncols) {
+  constexpr int KC = 32, LDT = KC + 1;
+  __shared__ double Tc[NRB * 16 * LDT];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fr = lane & 15, kq = lane >> 4;
+  const long long c0 = blockIdx.x * 256LL + w * 64;
+  d4_t acc[NRB][4];
 #pragma unroll
-  for (int i = 0; i < BO; ++i) acc[i] = 0.0;
-  if (!T1) {
+  for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-    for (int i = 0; i < BO; ++i)
-      if (i < bo && on) acc[i] = Y[i * ldy + j];
-  }
-  const int ktot = (T1 ? b1 : 0) + b2;
-  for (int k0 = 0; k0 < ktot; k0 += KC) {
-    const int kc = min(KC, ktot - k0);
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < KC * BO; idx += 256) {
-      const int k = idx / BO, i = idx - k * BO, kg = k0 + k;
-      double v = 0.0;
-      if (k < kc && i < bo) {
-        if (T1 && kg < b1) v = T1[i * ldt1 + kg];
-        else v = alpha2 * T2[i * ldt2 + (kg - (T1 ? b1 : 0))];
-      }
-      Tc[idx] = v;
-    }
-    __syncthreads();
-    if (on) {
-      // all input rows of the chunk in flight before the first product (a column's inputs are one latency, not kc of them)
-      double x[KC];
+    for (int cb = 0; cb < 4; ++cb) {
+      acc[rb][cb] = d4_t{0.0, 0.0, 0.0, 0.0};
+      if (!T1) {
+        const long long col = c0 + cb * 16 + fr;
 #pragma unroll
-      for (int u = 0; u < KC; ++u) {
-        const int kg = k0 + u;
-        x[u] = 0.0;
-        if (u < kc) x[u] = (T1 && kg < b1) ? Y[kg * ldy + j] : V2[(kg - (T1 ? b1 : 0)) * ldv + j];
-      }
-#pragma unroll
-      for (int u = 0; u < KC; ++u) {
-        if (u < kc) {
-          const double* tc = Tc + u * BO;
-#pragma unroll
-          for (int i = 0; i < BO; ++i) acc[i] += tc[i] * x[u];
+        for (int g = 0; g < 4; ++g) {
+          const int row = rb * 16 + kq + 4 * g;
+          if (row < bo && col < ncols) acc[rb][cb][g] = Y[row * ldy + col];
         }
       }
     }
-  }
-  if (on) {
+  const int n1 = T1 ? b1 : 0, ktot = n1 + b2;
+  for (int k0 = 0; k0 < ktot; k0 += KC) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NRB * 16 * KC; idx += 256) {
+      const int i = idx / KC, k = idx - i * KC, kg = k0 + k;
+      double v = 0.0;
+      if (i < bo && kg < ktot) v = kg < n1 ? T1[i * ldt1 + kg] : alpha2 * T2[i * ldt2 + (kg - n1)];
+      Tc[i * LDT + k] = v;
+    }
+    __syncthreads();
+    double xb[4][8];
 #pragma unroll
-    for (int i = 0; i < BO; ++i)
-      if (i < bo) OUT[i * ldo + j] = acc[i];
+    for (int cb = 0; cb < 4; ++cb) {
+      const long long col = c0 + cb * 16 + fr;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int kg = k0 + 4 * ks + kq;
+        xb[cb][ks] = 0.0;
+        if (kg < ktot && col < ncols) xb[cb][ks] = kg < n1 ? Y[kg * ldy + col] : V2[(kg - n1) * ldv + col];
+      }
+    }
+    double sa[NRB][8];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) sa[rb][ks] = Tc[(rb * 16 + fr) * LDT + 4 * ks + kq];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[rb][ks], xb[cb][ks], acc[rb][cb], 0, 0, 0);
   }
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const long long col = c0 + cb * 16 + fr;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = rb * 16 + kq + 4 * g;
+        if (row < bo && col < ncols) OUT[row * ldo + col] = acc[rb][cb][g];
+      }
+    }
 }
+
 
 // Rayleigh-Ritz rounds on a tall factor given TRANSPOSED, Tt (b x M, ld M, b <= 32), one workgroup of 256 threads:
 // per round  H = Tt Tt^T (MFMA, one 16 x 16 output block per wave),  H = S^T diag(sig2) S (jacobi32_run),  Tt <- S Tt,
@@ -621,15 +641,20 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
 // ---- launchers of the fused kernels --------------------------------------------------------------------------------
 constexpr int FUSED_ROWS = 32;   // row blocks up to this size take the fused kernels (one Jacobi / Cholesky wave, LDS resident)
 
-// OUT (bo x ncols) = T1 Y + alpha2 T2 V2 (see kp_combine_rows); bo <= 64
+// OUT (bo x ncols) = T1 Y + alpha2 T2 V2 (see kp_combine_rows_mma); bo <= 64
 int combine_rows(rom_ctx* ctx, int bo, int b1, const double* T1, int ldt1, int b2, const double* T2, int ldt2, double alpha2,
                  const double* Y, int64_t ldy, const double* V2, int64_t ldv, double* OUT, int64_t ldo, int64_t ncols) {
   if (bo <= 0 || ncols <= 0) return ROM_OK;
   ROM_CHECK(bo <= 64, "combine_rows: %d output rows", bo);
   const unsigned grid = unsigned((ncols + 255) / 256);
   ROM_PROF(ctx, "combine_rows", 2.0 * bo * ((T1 ? b1 : 0) + b2) * double(ncols), 8.0 * double(ncols) * (bo + (T1 ? b1 : bo) + b2));
-  if (bo <= 32) kp_combine_rows<32><<<grid, 256, 0, ctx->stream>>>(bo, b1, b2, T1, ldt1, T2, ldt2, alpha2, Y, ldy, V2, ldv, OUT, ldo, ncols);
-  else kp_combine_rows<64><<<grid, 256, 0, ctx->stream>>>(bo, b1, b2, T1, ldt1, T2, ldt2, alpha2, Y, ldy, V2, ldv, OUT, ldo, ncols);
+  if (bo <= 16) {
+    kp_combine_rows_mma<1><<<grid, 256, 0, ctx->stream>>>(bo, b1, b2, T1, ldt1, T2, ldt2, alpha2, Y, ldy, V2, ldv, OUT, ldo, ncols);
+  } else if (bo <= 32) {
+    kp_combine_rows_mma<2><<<grid, 256, 0, ctx->stream>>>(bo, b1, b2, T1, ldt1, T2, ldt2, alpha2, Y, ldy, V2, ldv, OUT, ldo, ncols);
+  } else {
+    kp_combine_rows_mma<4><<<grid, 256, 0, ctx->stream>>>(bo, b1, b2, T1, ldt1, T2, ldt2, alpha2, Y, ldy, V2, ldv, OUT, ldo, ncols);
+  }
   ROM_HIP(hipGetLastError());
   return ROM_OK;
 }
