@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256) void kp_combine_rows_mma(int bo, int b1, int b
 // Rayleigh-Ritz rounds on a tall factor given TRANSPOSED, Tt (b x M, ld M, b <= 32), one workgroup of 256 threads:
 // per round  H = Tt Tt^T (MFMA, one 16 x 16 output block per wave),  H = S^T diag(sig2) S (jacobi32_run),  Tt <- S Tt,
 // Rt <- S Rt.  The first round rotates the rows towards the singular directions; from then on H is graded and nearly
-// diagonal, where Jacobi resolves the small eigenvalues to high relative accuracy.  Out: Rt (b x b), sig2 (b), Tt rotated.
+// diagonal, where Jacobi resolves the small eigenvalues to high relative accuracy.  Out: Rt (b x b), sig2 (b); Tt is scratch:
+// rotated by every round but the last one executed (a one-round call does not write it).
 __global__ __launch_bounds__(256) void kp_tall_svd(int b, int M, double* __restrict__ Tt, int rounds, double* __restrict__ Rt,
                                                    double* __restrict__ sig2) {
   __shared__ Jacobi32Lds L;
@@ -351,8 +352,10 @@ __global__ __launch_bounds__(256) void kp_tall_svd(int b, int M, double* __restr
       Rn[r * J32_LD + c] = s;
     }
     // Tt <- S Tt on the matrix cores: a wave owns 16-column blocks of Tt (all b rows of them: read before written), the
-    // A operand (S, from LDS) is the same for every block and stays in registers, two blocks in flight
-    {
+    // A operand (S, from LDS) is the same for every block and stays in registers, two blocks in flight.  Only for the sake
+    // of a further round: the last one leaves Tt as it found it (the caller gets the rotation in Rt; a one-round call does
+    // not write Tt at all)
+    if (rotated && round + 1 < rounds) {
       double sa[2][8];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
@@ -701,8 +704,11 @@ int lowdin_rows(rom_ctx* ctx, double* X, int b, int64_t dim, double* G, double* 
 // Gram matrix is graded and nearly diagonal, where Jacobi resolves the small eigenvalues to high relative accuracy --
 // nothing is lost to the squaring that a single eigen-decomposition of an ungraded Gram matrix would lose.
 // Rt (b x b): accumulated rotation (rows = right singular vectors in the coordinates Tt came in); sig2: b values.
+// (whether the one-workgroup kernel takes the call: it rotates Tt for the sake of a further round only -- a one-round call
+// leaves Tt as it was; the parallel path rotates it in every round)
+static bool tall_svd_is_fused(int b, int M) { return b <= FUSED_ROWS && M <= 4096; }
 int tall_svd_rotation(rom_ctx* ctx, double* Tt, int b, int M, double* Rt, double* sig2, int rounds = 3) {
-  if (b <= FUSED_ROWS && M <= 4096) {   // one workgroup from the first round to the last (beyond: its reads of the b x M factor, ~80 GB/s for ONE workgroup, outweigh the launches saved)
+  if (tall_svd_is_fused(b, M)) {   // one workgroup from the first round to the last (beyond: its reads of the b x M factor, ~80 GB/s for ONE workgroup, outweigh the launches saved)
     ROM_PROF(ctx, "tall_svd", rounds * (4.0 * b * b * M + 30.0 * b * b * b), 8.0 * rounds * 2.0 * b * M);
     kp_tall_svd<<<1, 256, 0, ctx->stream>>>(b, M, Tt, rounds, Rt, sig2);
     ROM_HIP(hipGetLastError());
@@ -821,7 +827,12 @@ int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double*
     // block and on spectra of 1 and 3 modes per decade over 13 orders -- tools/dev/pod_synth.py); the accepted modes are
     // orthonormalised again by the caller
     ROM_TRY(whiten_rows(ctx, Q, b, dim, 1e-26, 1, Tm, lam));
-    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, dim, 1.0, Q, dim, X, dim, 0.0, Traw, M, "gemm_nt"));    // Q X^T  (b, M)
+    // Q X^T (b, M).  Without deflation it IS the factor of the step: before the power step it goes straight to Tt (nobody
+    // needs the undeflated copy of that step); at the end to Traw, which the one-workgroup Rayleigh-Ritz kernel reads without
+    // writing (one round), so that no copy is needed there either
+    const bool last = it == power;
+    double* Tout = (!found && !last) ? Tt.p() : Traw;
+    ROM_TRY(rom_launch_gemm_nt(ctx, b, M, dim, 1.0, Q, dim, X, dim, 0.0, Tout, M, "gemm_nt"));
     if (found) {                                                                                  // Q X_d^T = Q X^T - (Q V^T) Bt
       ROM_TRY(rom_launch_gemm_nt(ctx, b, found, dim, 1.0, Q, dim, V, dim, 0.0, Cc, found, "gemm_nt"));
       if (fused && b <= 64) {
@@ -830,11 +841,11 @@ int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double*
         ROM_HIP(hipMemcpyAsync(Tt.p(), Traw, size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         ROM_TRY(rom_launch_gemm_nn(ctx, b, M, found, -1.0, Cc, found, Bt, M, 1.0, Tt, M));
       }
-    } else {
+    } else if (last && !tall_svd_is_fused(b, M)) {
       ROM_HIP(hipMemcpyAsync(Tt.p(), Traw, size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     }
     info.executed += 2.0 * b * M * double(dim) + 4.0 * b * b * double(dim);
-    if (it == power) break;
+    if (last) break;
     // the coefficient rows orthonormalised in M space BEFORE the second product: a row dominated by its own direction (see
     // SKETCH_ACCEPT) is cleaned of the strong directions to eps here, so the second product leaves eps r of them instead of
     // the eps r^3 that limited a pass to four orders of magnitude -- one pass now reaches seven
@@ -844,10 +855,10 @@ int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double*
     info.executed += 2.0 * b * M * double(dim);
   }
   ROM_TRY(before_rotation());   // (the last pass over the block is enqueued: what may run beside the small problems starts here)
-  // X_d ~ T Q: the right singular vectors of the small factor rotate Q into the modes (Tt is rotated along, not used again)
+  // X_d ~ T Q: the right singular vectors of the small factor rotate Q into the modes
   // (one round: the pass only has to separate its leading directions from the rest and to rank them for the accept rule --
   // the Rayleigh-Ritz step over ALL collected modes at the end of rom_pod_ex iterates to convergence)
-  ROM_TRY(tall_svd_rotation(ctx, Tt, b, M, Rt, s2, 1));
+  ROM_TRY(tall_svd_rotation(ctx, (!found && tall_svd_is_fused(b, M)) ? Traw : Tt.p(), b, M, Rt, s2, 1));
   ss_host.resize(b);
   ROM_TRY(download(ctx, s2, ss_host.data(), b));
   for (double& v : ss_host) v = std::sqrt(std::max(v, 0.0));
