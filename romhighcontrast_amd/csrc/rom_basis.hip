@@ -643,10 +643,176 @@ int romb_pivchol_whiten(rom_ctx* ctx, int n, const double* A, int lda, double* l
   return ROM_OK;
 }
 
+// =====================================================================================================================
+// Cyclic Jacobi of a symmetric matrix of order 97 ... SE_MAX over the WHOLE chip: one launch per round
+// =====================================================================================================================
+// kb_small_eig keeps a matrix beyond 96 rows in an L2-resident workspace and still runs it on ONE workgroup: 0.13 s at
+// n = 217, 6-8 s at n = 900-1000 (the whole-matrix diagonalisation that rom_pod falls back to for a flat spectrum).  The
+// rotations of a round act on disjoint index pairs, so a round is a grid: thread (k, l) of the first half * half threads owns
+// the 2 x 2 block rows (p_k, q_k) x columns (p_l, q_l) and computes the rotations of its two pairs itself from the pivot
+// blocks (jacobi_rotation of rom_small_dense.h: a pure function, the same bits in every thread -- no phase that computes
+// rotations for the others, hence no synchronisation inside a round), the other half * ne threads rotate the eigenvector rows;
+// everything is read from the buffers the previous round wrote and written to the other pair (every entry is written every
+// round).  Same criterion (relative, with the noise levels of a Gram matrix rotated along), same round-robin order as
+// jacobi32_run.  n = 1000: 999 launches of a few microseconds per sweep.
+__global__ __launch_bounds__(256) void kb_jgrid_round(int ne, int half, int r, const double* __restrict__ Ac, double* __restrict__ An,
+                                                      const double* __restrict__ Vc, double* __restrict__ Vn,
+                                                      const double* __restrict__ nuc, double* __restrict__ nun,
+                                                      const double* __restrict__ par, int* __restrict__ any) {
+  const long long gid = blockIdx.x * 256LL + threadIdx.x;
+  const int nm1 = ne - 1;
+  const double tol2 = par[1], floor_abs = par[2];
+  auto pair_of = [&](int k, int& p, int& q) {
+    p = r;
+    q = nm1;
+    if (k) {
+      p = r + k;
+      if (p >= nm1) p -= nm1;
+      q = r - k;
+      if (q < 0) q += nm1;
+      if (p > q) { const int x = p; p = q; q = x; }
+    }
+  };
+  if (gid < (long long)half * half) {
+    const int k = int(gid / half), l = int(gid - (long long)k * half);
+    int pk, qk, pl, ql;
+    pair_of(k, pk, qk);
+    pair_of(l, pl, ql);
+    const size_t rk = size_t(pk) * ne, sk = size_t(qk) * ne, rl = size_t(pl) * ne;
+    const double kpp = Ac[rk + pk], kqq = Ac[sk + qk], kpq = Ac[rk + qk];
+    const double lpp = Ac[rl + pl], lqq = Ac[size_t(ql) * ne + ql], lpq = Ac[rl + ql];
+    const double b00 = Ac[rk + pl], b01 = Ac[rk + ql], b10 = Ac[sk + pl], b11 = Ac[sk + ql];
+    double ck, s_k, cl, sl, nkpo, nkqo, nlpo, nlqo;
+    const bool rot = jacobi_rotation(kpp, kqq, kpq, nuc[pk], nuc[qk], tol2, floor_abs, ck, s_k, nkpo, nkqo);
+    (void)jacobi_rotation(lpp, lqq, lpq, nuc[pl], nuc[ql], tol2, floor_abs, cl, sl, nlpo, nlqo);
+    const double r00 = ck * b00 - s_k * b10, r01 = ck * b01 - s_k * b11;
+    const double r10 = s_k * b00 + ck * b10, r11 = s_k * b01 + ck * b11;
+    An[rk + pl] = cl * r00 - sl * r01;
+    An[rk + ql] = sl * r00 + cl * r01;
+    An[sk + pl] = cl * r10 - sl * r11;
+    An[sk + ql] = sl * r10 + cl * r11;
+    if (l == 0) {
+      nun[pk] = nkpo;
+      nun[qk] = nkqo;
+      if (rot) *any = 1;
+    }
+    return;
+  }
+  const long long idx = gid - (long long)half * half;
+  if (idx >= (long long)half * ne) return;
+  const int k = int(idx / ne), j = int(idx - (long long)k * ne);
+  int pk, qk;
+  pair_of(k, pk, qk);
+  const size_t rk = size_t(pk) * ne, sk = size_t(qk) * ne;
+  double ck, s_k, a, b;
+  (void)jacobi_rotation(Ac[rk + pk], Ac[sk + qk], Ac[rk + qk], nuc[pk], nuc[qk], tol2, floor_abs, ck, s_k, a, b);
+  const double vp = Vc[rk + j], vq = Vc[sk + j];
+  Vn[rk + j] = ck * vp - s_k * vq;
+  Vn[sk + j] = s_k * vp + ck * vq;
+}
+
+// A0 <- symmetrised copy of A with zero padding to the even order ne, V0 <- identity
+__global__ void kb_jgrid_init(int n, int ne, const double* __restrict__ A, int lda, double* __restrict__ A0, double* __restrict__ V0) {
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= (long long)ne * ne) return;
+  const int r = int(idx / ne), c = int(idx - (long long)r * ne);
+  A0[idx] = (r < n && c < n) ? 0.5 * (A[size_t(r) * lda + c] + A[size_t(c) * lda + r]) : 0.0;
+  V0[idx] = r == c ? 1.0 : 0.0;
+}
+
+// par[0] = max |a_ii|, par[1] = tol^2, par[2] = smallest entry that is rotated; nu^2 (noise levels) of the rows
+__global__ __launch_bounds__(256) void kb_jgrid_params(int n, int ne, const double* __restrict__ A0, int gram_like, double* __restrict__ par,
+                                                       double* __restrict__ nu) {
+  __shared__ double red[4];
+  const int t = threadIdx.x;
+  double dmax = 0.0;
+  for (int i = t; i < n; i += 256) dmax = fmax(dmax, fabs(A0[size_t(i) * ne + i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+  if ((t & 63) == 0) red[t >> 6] = dmax;
+  __syncthreads();
+  dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (t == 0) {
+    const double tol = double(n > 8 ? n : 8) * 1.1e-16;
+    par[0] = dmax;
+    par[1] = tol * tol;
+    par[2] = fmax(1e-300, 1e-40 * dmax);
+  }
+  for (int i = t; i < ne; i += 256) nu[i] = i < n ? (gram_like ? fabs(A0[size_t(i) * ne + i]) : dmax) : 0.0;
+}
+
+__global__ void kb_jgrid_diag(int n, int ne, const double* __restrict__ Ac, double* __restrict__ d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) d[i] = Ac[size_t(i) * ne + i];
+}
+
+// T[i, :] = V[perm[i], :], lam[i] = d[perm[i]]
+__global__ void kb_jgrid_gather(int n, int ne, const double* __restrict__ Vc, const double* __restrict__ d, const int* __restrict__ perm,
+                                double* __restrict__ T, int ldt, double* __restrict__ lam) {
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= (long long)n * n) return;
+  const int i = int(idx / n), c = int(idx - (long long)i * n);
+  const int src = perm[i];
+  T[size_t(i) * ldt + c] = Vc[size_t(src) * ne + c];
+  if (c == 0) lam[i] = d[src];
+}
+
+static int jacobi_grid(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, bool gram_like) {
+  const int ne = n + (n & 1), half = ne / 2;
+  const size_t nn = size_t(ne) * ne;
+  Tmp A0, A1, V0, V1, nu0, nu1, par, diag, anyb, permb;
+  ROM_TRY(A0.get(ctx, nn));
+  ROM_TRY(A1.get(ctx, nn));
+  ROM_TRY(V0.get(ctx, nn));
+  ROM_TRY(V1.get(ctx, nn));
+  ROM_TRY(nu0.get(ctx, ne));
+  ROM_TRY(nu1.get(ctx, ne));
+  ROM_TRY(par.get(ctx, 4));
+  ROM_TRY(diag.get(ctx, n));
+  ROM_TRY(anyb.get(ctx, 1));
+  ROM_TRY(permb.get(ctx, (size_t(n) + 1) / 2 + 1));
+  int* d_any = reinterpret_cast<int*>(anyb.p());
+  int* d_perm = reinterpret_cast<int*>(permb.p());
+  ROM_PROF(ctx, "jacobi_grid", 30.0 * n * double(n) * n, 16.0 * double(n) * n);
+  kb_jgrid_init<<<unsigned((nn + 255) / 256), 256, 0, ctx->stream>>>(n, ne, A, lda, A0, V0);
+  kb_jgrid_params<<<1, 256, 0, ctx->stream>>>(n, ne, A0, gram_like ? 1 : 0, par, nu0);
+  ROM_HIP(hipGetLastError());
+  double *Ac = A0, *An = A1, *Vc = V0, *Vn = V1, *nuc = nu0, *nun = nu1;
+  const long long threads = (long long)half * half + (long long)half * ne;
+  const unsigned grid = unsigned((threads + 255) / 256);
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    ROM_HIP(hipMemsetAsync(d_any, 0, sizeof(int), ctx->stream));
+    for (int r = 0; r < ne - 1; ++r) {
+      kb_jgrid_round<<<grid, 256, 0, ctx->stream>>>(ne, half, r, Ac, An, Vc, Vn, nuc, nun, par, d_any);
+      std::swap(Ac, An);
+      std::swap(Vc, Vn);
+      std::swap(nuc, nun);
+    }
+    ROM_HIP(hipGetLastError());
+    int any = 0;
+    ROM_HIP(hipMemcpyAsync(&any, d_any, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ROM_HIP(hipStreamSynchronize(ctx->stream));
+    if (!any) break;
+  }
+  kb_jgrid_diag<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(n, ne, Ac, diag);
+  ROM_HIP(hipGetLastError());
+  std::vector<double> d(n);
+  ROM_TRY(download(ctx, diag, d.data(), n));
+  std::vector<int> perm(n);
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return d[a] > d[b]; });   // (descending, first index first on ties)
+  ROM_HIP(hipMemcpyAsync(d_perm, perm.data(), size_t(n) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  kb_jgrid_gather<<<unsigned((size_t(n) * n + 255) / 256), 256, 0, ctx->stream>>>(n, ne, Vc, diag, d_perm, T, ldt, lam);
+  ROM_HIP(hipGetLastError());
+  ROM_HIP(hipStreamSynchronize(ctx->stream));   // (perm is host memory of this frame)
+  return ROM_OK;
+}
+
 int romb_small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, int mode, double rel_tol,
                      bool gram_like) {
   if (n <= 0) return ROM_OK;
   ROM_CHECK(n <= SE_MAX, "small symmetric eigenproblem: n = %d beyond %d", n, SE_MAX);
+  if (mode == SE_EIG && n > SE_LDS_MAX) return jacobi_grid(ctx, n, A, lda, lam, T, ldt, gram_like);   // (one launch per round, the whole chip)
   const int ld = n | 1, half = (n + (n & 1)) / 2;
   const size_t vec = (2 * size_t(half) + 2 * size_t(n) + 8) * sizeof(double) + (2 * size_t(half) + n + 2) * sizeof(int);
   double* gws = nullptr;

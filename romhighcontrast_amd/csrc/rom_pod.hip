@@ -446,7 +446,7 @@ constexpr double NOISE_FLOOR = 1e-13;    // modes below this fraction of sigma_1
 constexpr int PASS_MODES = 24;           // modes asked of one sketch pass (+ 8 rows of oversampling = 32: the one-workgroup small kernels)
 
 struct PodInfo {
-  int gram_passes = 0, sketch_passes = 0, completed = 0, resolved = 0, eig_iterations = 0, lowrank = 0;
+  int gram_passes = 0, sketch_passes = 0, completed = 0, resolved = 0, eig_iterations = 0, lowrank = 0, full_eig = 0, unconverged = 0;
   double executed = 0.0;
 };
 
@@ -554,12 +554,30 @@ int lowrank_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W,
 // b x b problems are solved on the device.  theta_host / theta_dev: nev values (host / device); W: (nev, M) rows = eigenvectors.
 int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std::vector<double>& theta_host, double* theta_dev,
                    PodInfo& info,
-                   int oversample = 12, double tol = 2e-14, int max_iter = 30, double accept = GRAM_ACCEPT) {
+                   int oversample = 12, double tol = 2e-14, int max_iter = 300, double accept = GRAM_ACCEPT) {
   {
     int done = 0;
     ROM_TRY(lowrank_eigenpairs(ctx, G, M, nev, W, theta_host, theta_dev, info, done));
     if (done) return ROM_OK;
   }
+  // the whole Gram matrix diagonalised at once (Jacobi: the eigenvalues to the accuracy of the matrix entries whatever the
+  // gaps): when the request is most of the spectrum -- an iteration would diagonalise a block of nearly that order EVERY
+  // step -- and as the last resort of an iteration that did not converge (below)
+  auto full_eig = [&]() -> int {
+    Tmp lamf, Tf;
+    ROM_TRY(lamf.get(ctx, M));
+    ROM_TRY(Tf.get(ctx, size_t(M) * M));
+    ROM_TRY(romb_small_eig(ctx, M, G, M, lamf, Tf, M, SE_EIG, 0.0, true));
+    std::vector<double> lf(M);
+    ROM_TRY(download(ctx, lamf, lf.data(), M));
+    theta_host.assign(lf.begin(), lf.begin() + nev);
+    ROM_HIP(hipMemcpyAsync(theta_dev, lamf.p(), size_t(nev) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ROM_HIP(hipMemcpyAsync(W, Tf.p(), size_t(nev) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ROM_HIP(hipStreamSynchronize(ctx->stream));   // (Tf / lamf go back to the pool when this scope ends)
+    info.full_eig = 1;
+    return ROM_OK;
+  };
+  if (M <= SE_MAX && 2 * (nev + oversample) >= M) return full_eig();
   const int b0 = std::min(M, nev + oversample);
   int b = b0;  // rows in play: shrinks once the spectrum shows how many pairs the caller can use (see below)
   Tmp Y, Z, H, St, lam, Yr, Zr, Res, res, Zs, scr, nrm;
@@ -577,7 +595,7 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
   double* d_res = lam.p() + b0;
   ROM_TRY(romb_fill_random(ctx, Y, size_t(b) * M, 0x5eed0000ull + unsigned(b) * 131u + unsigned(M), true));
   std::vector<double> th(2 * size_t(b0), 0.0);
-  double best = 1e300;
+  double best = 1e300, worst = 0.0;
   int stall = 0;
   if (b == M) {
     ROM_TRY(romb_gram_transform(ctx, Y, scr, b, M, SE_WHITEN, 1e-30, 2));  // (the full space: one exact Ritz step below)
@@ -611,11 +629,17 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
     ROM_TRY(download(ctx, lam, th.data(), size_t(b0) + ncheck));
     for (int i = b; i < b0; ++i) th[i] = 0.0;  // (pairs dropped from the block)
     const double t0 = std::max(std::fabs(th[0]), 1e-300);
-    double worst = 0.0;
+    worst = 0.0;
     for (int i = 0; i < ncheck; ++i)
       if (th[i] > accept * std::fabs(th[0])) worst = std::max(worst, th[b0 + i] / t0);
     if (worst < 0.7 * best) { best = worst; stall = 0; } else { ++stall; }
-    if (worst <= tol || stall >= 3 || it == max_iter - 1) break;
+    // (three steps without a gain of 30 % end the iteration only close to its tolerance -- the residual has reached the
+    // rounding level of the Gram matrix; further out a slow gain is a flat spectrum, (lambda_{b+1} / lambda_k) per step, and
+    // the iteration goes on: 300 steps cost less than one diagonalisation of the whole matrix)
+    if (worst <= tol || (stall >= 3 && worst <= 1e-10) || it == max_iter - 1) break;
+    // (a matrix that can be diagonalised whole -- 0.3 s at 900 rows -- is not iterated on for long: a dozen steps that have
+    // not brought the residual below 1e-8 mean a flat spectrum)
+    if (M <= SE_MAX && it >= 11 && worst > 1e-8) break;
     // The caller only takes pairs with theta_i > accept * theta_0.  Once a Rayleigh-Ritz step on an orthonormal block
     // has shown how many there can be (two orders of magnitude of slack on the threshold), the block is cut down to
     // those + the oversampling: the rows are Ritz vectors in descending order, so the cut keeps the leading ones.
@@ -629,6 +653,13 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
     ROM_HIP(hipGetLastError());
     ROM_TRY(romb_gram_transform(ctx, Zs, scr, b, M, SE_WHITEN, 1e-30, 1));  // (rows are rotated Ritz vectors: nearly orthonormal)
     ROM_HIP(hipMemcpyAsync(Y.p(), Zs.p(), size_t(b) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  if (b < M && worst > 1e-10) {
+    // The iteration ran out of steps far from its tolerance (a spectrum so flat that 300 steps of (lambda_{b+1} / lambda_k)
+    // do not get there: a large block of independent random rows).  Up to SE_MAX rows the whole matrix is diagonalised
+    // instead; beyond, the caller is told (info.unconverged -> stop reason 2).
+    if (M <= SE_MAX) return full_eig();
+    info.unconverged = 1;
   }
   theta_host.assign(th.begin(), th.begin() + nev);
   for (int i = b; i < nev; ++i) theta_host[i] = 0.0;
@@ -1048,7 +1079,9 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
         // ~(1/4)^3), at least one; the rest is left for the next pass, where it sits at the top
         int k = 0;
         while (k < take && ss[k] >= 4.0 * ss[b - 1]) ++k;
-        take = std::max(1, k);
+        // (none: a plateau -- typically the rounding noise of a block with a large mean, above the floor because the floor
+        // is relative to sigma_1 of the CENTRED block -- whose directions no method tells apart: a quarter of the sketch per pass)
+        take = k > 0 ? k : std::max(1, std::min(take, b / 4));
         power = 2;   // (and the passes from here on take a second power step: (1/4)^5 instead of (1/4)^3)
       }
     }
@@ -1092,7 +1125,10 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
         ROM_HIP(hipMemcpyAsync(Bn, B2.p(), size_t(take) * M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
       }
     }
-    const bool at_floor = take < b && ss[take] <= floor_rel * sigma_1;
+    // the first value NOT accepted says "floor reached" only if the pass resolves values that small: below 1e-8 of its top
+    // (eps r^2 ~ 1, see SKETCH_ACCEPT) a Ritz value is rounding noise -- a cliff of more than eight orders behind the accepted
+    // modes hides whatever lies between the cliff's foot and the floor, and the next pass, on the deflated block, looks there
+    const bool at_floor = take < b && ss[take] <= floor_rel * sigma_1 && floor_rel * sigma_1 >= 1e-8 * ss[0];
     found += take;
     if (at_floor) {  // the spectrum has reached the floor: nothing left to find
       at_floor_stop = true;
@@ -1155,7 +1191,7 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
     info_host[6] = info.eig_iterations;
     // why the call stopped short of n modes: 0 request filled, 1 the spectrum reached the floor (the completed modes are
     // not determined by the data), 2 no accepted mode in a pass / pass budget (modes above the floor may be missing)
-    info_host[7] = found >= n ? 0.0 : (at_floor_stop || sigma_1 == 0.0 ? 1.0 : 2.0);
+    info_host[7] = found >= n ? (info.unconverged ? 2.0 : 0.0) : (at_floor_stop || sigma_1 == 0.0 ? 1.0 : 2.0);
   }
   return ROM_OK;
 }

@@ -269,6 +269,9 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, rel_floor=
     pod_modes.resolved = info["resolved_modes"]
     if info["completed_modes"]:
         warn_completed_modes(info, n, rel_floor)
+    elif info["stop_reason"] == "budget":
+        warning("POD: the eigenpairs of the Gram matrix did not converge (a spectrum so flat that the subspace iteration "
+                f"stalls, with more than 1024 snapshots: M = {M}); the trailing modes of the request are approximate")
     if n == 0:
         return (np.zeros((0, dim)) if download else DeviceArray(V, 0, dim)), sig
     return (V.download(n * dim, shape=(n, dim)) if download else DeviceArray(V, n, dim)), sig

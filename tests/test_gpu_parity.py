@@ -524,6 +524,56 @@ def test_pod_awkward_blocks(api):
         observed("  ... orthonormality", np.abs(comps @ comps.T - np.eye(n_)), 1e-13)
 
 
+def test_pod_fuzz_vs_lapack(api):
+    """rom_pod against numpy.linalg.svd on random shapes (2 ... 400 rows, 2 ... 5000 columns), requests (a few modes ... all of
+    them), centring and spectra: geometric decay at a random rate, a plateau and a cliff of nine orders, independent random rows
+    (a flat spectrum: the Gram route, whose subspace iteration stalls there -- the whole Gram matrix is then diagonalised by
+    the grid-wide Jacobi, rom_basis.hip jacobi_grid), exact low rank.  Every singular value within 1e-7 relative + 50 eps ||X||_2
+    (what the stored numbers determine) of LAPACK's; a mode the POD completes with sigma = 0 must be below its floor there."""
+    SM, RB = api
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    rng = np.random.default_rng(20251005)
+    worst_v, worst_o = 0.0, 0.0
+    for case in range(60):
+        M = int(rng.integers(2, 400))
+        dim = int(rng.integers(2, 5000))
+        r = min(M, dim)
+        n = int(rng.integers(1, r + 1)) if rng.random() < 0.3 else int(rng.integers(1, min(r, 60) + 1))
+        center = bool(rng.integers(0, 2))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            s = 10.0 ** (-np.arange(r) * rng.uniform(0.02, 1.5))
+        elif kind == 1:
+            k = int(rng.integers(1, r + 1))
+            s = np.concatenate([np.ones(k), 1e-9 * np.ones(r - k)])
+        elif kind == 3:
+            k = int(rng.integers(1, min(r, 12) + 1))
+            s = np.concatenate([10.0 ** -rng.uniform(0, 6, k), np.zeros(r - k)])
+        if kind == 2:
+            Xh = rng.standard_normal((M, dim))
+        else:
+            Q1, _ = np.linalg.qr(rng.standard_normal((M, r)))
+            Q2, _ = np.linalg.qr(rng.standard_normal((dim, r)))
+            Xh = (Q1 * s) @ Q2.T
+        if center:
+            Xh = Xh + rng.uniform(0, 3) * rng.standard_normal(dim)[None, :]
+        sv = np.linalg.svd(Xh - Xh.mean(axis=0) if center else Xh, compute_uv=False)
+        comps, sig = RB.pod_modes(ctx, SM.DeviceArray(ctx.upload(Xh), M, dim), n, center=center)
+        info = RB.pod_modes.last_info
+        noise = 50 * 1.1e-16 * np.linalg.norm(Xh, 2)
+        m = min(n, len(sv))
+        err = np.abs(sig[:m] - sv[:m]) / (1e-7 * sv[:m] + noise)
+        completed_ok = (sig[:m] == 0) & (sv[:m] <= 2e-13 * sv[0] + noise)
+        err = np.where(completed_ok, 0.0, err)
+        assert err.max() <= 1.0, (case, M, dim, n, center, kind, int(err.argmax()), float(sv[err.argmax()]), float(sig[err.argmax()]), info)
+        orth = np.abs(comps @ comps.T - np.eye(n)).max()
+        assert orth < 1e-12, (case, M, dim, n, center, kind, orth, info)
+        worst_v, worst_o = max(worst_v, float(err.max())), max(worst_o, float(orth))
+    observed("POD fuzz, 60 random blocks: |sigma - LAPACK's| / (1e-7 sigma + 50 eps ||X||_2), worst", worst_v, 1.0)
+    observed("POD fuzz: orthonormality of the rows, worst", worst_o, 1e-12)
+
+
 def test_pod_slowly_decaying_spectrum_many_modes(api):
     """a request of hundreds of modes from a spectrum that decays slowly -- 320 modes over 12 orders of
     magnitude, 195 of them below the reach of the Gram matrix -- must be FILLED by the sketch passes (the round-3 loop gave
