@@ -746,18 +746,21 @@ __global__ void kb_jgrid_diag(int n, int ne, const double* __restrict__ Ac, doub
   if (i < n) d[i] = Ac[size_t(i) * ne + i];
 }
 
-// T[i, :] = V[perm[i], :], lam[i] = d[perm[i]]
+// T[i, :] = scale[i] V[perm[i], :], lam[i] = d[perm[i]]
 __global__ void kb_jgrid_gather(int n, int ne, const double* __restrict__ Vc, const double* __restrict__ d, const int* __restrict__ perm,
-                                double* __restrict__ T, int ldt, double* __restrict__ lam) {
+                                const double* __restrict__ scale, double* __restrict__ T, int ldt, double* __restrict__ lam) {
   const long long idx = blockIdx.x * 256LL + threadIdx.x;
   if (idx >= (long long)n * n) return;
   const int i = int(idx / n), c = int(idx - (long long)i * n);
   const int src = perm[i];
-  T[size_t(i) * ldt + c] = Vc[size_t(src) * ne + c];
+  T[size_t(i) * ldt + c] = scale[i] * Vc[size_t(src) * ne + c];
   if (c == 0) lam[i] = d[src];
 }
 
-static int jacobi_grid(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, bool gram_like) {
+// (mode / rel_tol as kb_small_eig: SE_EIG rows = eigenvectors, SE_WHITEN rows / sqrt(lam) -- zero rows below rel_tol x the
+// largest eigenvalue --, SE_LOWDIN the symmetric inverse square root over the same eigenpairs)
+static int jacobi_grid(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, int mode, double rel_tol,
+                       bool gram_like) {
   const int ne = n + (n & 1), half = ne / 2;
   const size_t nn = size_t(ne) * ne;
   Tmp A0, A1, V0, V1, nu0, nu1, par, diag, anyb, permb;
@@ -802,9 +805,32 @@ static int jacobi_grid(rom_ctx* ctx, int n, const double* A, int lda, double* la
   for (int i = 0; i < n; ++i) perm[i] = i;
   std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return d[a] > d[b]; });   // (descending, first index first on ties)
   ROM_HIP(hipMemcpyAsync(d_perm, perm.data(), size_t(n) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  kb_jgrid_gather<<<unsigned((size_t(n) * n + 255) / 256), 256, 0, ctx->stream>>>(n, ne, Vc, diag, d_perm, T, ldt, lam);
-  ROM_HIP(hipGetLastError());
-  ROM_HIP(hipStreamSynchronize(ctx->stream));   // (perm is host memory of this frame)
+  const double lmax = d[perm[0]];
+  std::vector<double> scale(n, 1.0);
+  if (mode != SE_EIG)
+    for (int i = 0; i < n; ++i) {
+      const double l = d[perm[i]];
+      const bool keep = l > rel_tol * lmax && l > 0.0;
+      scale[i] = !keep ? 0.0 : mode == SE_WHITEN ? 1.0 / std::sqrt(l) : 1.0 / std::sqrt(std::sqrt(l));
+    }
+  Tmp scb;
+  ROM_TRY(scb.get(ctx, n));
+  ROM_HIP(hipMemcpyAsync(scb.p(), scale.data(), size_t(n) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const unsigned gg = unsigned((size_t(n) * n + 255) / 256);
+  if (mode != SE_LOWDIN) {
+    kb_jgrid_gather<<<gg, 256, 0, ctx->stream>>>(n, ne, Vc, diag, d_perm, scb, T, ldt, lam);
+    ROM_HIP(hipGetLastError());
+  } else {
+    // sum_i q_i q_i^T / sqrt(lam_i) = S^T S with S = rows q_i^T lam_i^(-1/4): gathered into one ping-pong buffer, transposed
+    // into the other, one small product
+    double* S = An;
+    double* St = Vn;
+    kb_jgrid_gather<<<gg, 256, 0, ctx->stream>>>(n, ne, Vc, diag, d_perm, scb, S, n, lam);
+    kb_transpose<<<gg, 256, 0, ctx->stream>>>(St, n, S, n, n, n);
+    ROM_HIP(hipGetLastError());
+    ROM_TRY(rom_launch_gemm_nt(ctx, n, n, n, 1.0, St, n, St, n, 0.0, T, ldt, "gemm_nt"));
+  }
+  ROM_HIP(hipStreamSynchronize(ctx->stream));   // (perm / scale are host memory of this frame)
   return ROM_OK;
 }
 
@@ -812,7 +838,7 @@ int romb_small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, d
                      bool gram_like) {
   if (n <= 0) return ROM_OK;
   ROM_CHECK(n <= SE_MAX, "small symmetric eigenproblem: n = %d beyond %d", n, SE_MAX);
-  if (mode == SE_EIG && n > SE_LDS_MAX) return jacobi_grid(ctx, n, A, lda, lam, T, ldt, gram_like);   // (one launch per round, the whole chip)
+  if (n > SE_LDS_MAX) return jacobi_grid(ctx, n, A, lda, lam, T, ldt, mode, rel_tol, gram_like);   // (one launch per round, the whole chip)
   const int ld = n | 1, half = (n + (n & 1)) / 2;
   const size_t vec = (2 * size_t(half) + 2 * size_t(n) + 8) * sizeof(double) + (2 * size_t(half) + n + 2) * sizeof(int);
   double* gws = nullptr;
