@@ -841,15 +841,9 @@ int romb_small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, d
   if (n > SE_LDS_MAX) return jacobi_grid(ctx, n, A, lda, lam, T, ldt, mode, rel_tol, gram_like);   // (one launch per round, the whole chip)
   const int ld = n | 1, half = (n + (n & 1)) / 2;
   const size_t vec = (2 * size_t(half) + 2 * size_t(n) + 8) * sizeof(double) + (2 * size_t(half) + n + 2) * sizeof(int);
-  double* gws = nullptr;
-  size_t lds = vec + 16;
+  size_t lds = vec + 16 + 2 * size_t(n) * ld * sizeof(double);   // (n <= SE_LDS_MAX here: matrix + eigenvector rows in LDS)
   double* ns_ws = nullptr;
-  if (n <= SE_LDS_MAX) {
-    lds += 2 * size_t(n) * ld * sizeof(double);
-    ROM_TRY(rom_ctx_scratch(ctx, 2 * size_t(n) * n, &ns_ws));   // Newton-Schulz fast path: next iterates
-  } else {
-    ROM_TRY(rom_ctx_scratch(ctx, 2 * size_t(n) * ld, &gws));
-  }
+  ROM_TRY(rom_ctx_scratch(ctx, 2 * size_t(n) * n, &ns_ws));   // Newton-Schulz fast path: next iterates
   if (lds > 64 * 1024 && !ctx->lds_optin_small_eig) {
     ROM_HIP(hipSetDevice(ctx->device));
     ROM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kb_small_eig<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -863,8 +857,7 @@ int romb_small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, d
     // n <= 32: ONE wave -- no barrier between the phases of a round and the item map divided out once: 5x the rounds per
     // microsecond of the 512-thread form on the same rotations (same results)
     if (n <= 32 && mode == SE_EIG) kb_jacobi32<<<1, 256, 0, ctx->stream>>>(n, A, lda, lam, T, ldt, gram_like ? 1 : 0);
-    else if (!gws) kb_small_eig<512, false><<<1, 512, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws, ns_ws);
-    else kb_small_eig<512, true><<<1, 512, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, gws, ns_ws);
+    else kb_small_eig<512, false><<<1, 512, lds, ctx->stream>>>(n, A, lda, lam, T, ldt, mode, rel_tol, gram_like ? 1 : 0, nullptr, ns_ws);
   }
   ROM_HIP(hipGetLastError());
   return ROM_OK;
