@@ -30,6 +30,8 @@ int read_status(rom_ctx* ctx, const char* who) {
   ROM_HIP(hipMemcpyAsync(&status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   ROM_HIP(hipStreamSynchronize(ctx->stream));
   if (status) {
+    // (reported once: the word is cleared, or the next call on this context -- whatever it is -- would report this failure again)
+    ROM_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
     rom_set_error("%s: reduced matrix not positive definite", who);
     return ROM_ERR_NOT_SPD;
   }

@@ -475,6 +475,25 @@ def test_pod_slow_decay_takes_the_gram_route(api):
     observed("  ... orthonormality of the rows", np.abs(comps @ comps.T - np.eye(n)), 1e-13)
 
 
+def test_a_reported_failure_is_not_reported_again(api):
+    """Found by tests/dev/gpu_api_fuzz.py in round 5: a projection onto dependent basis rows raises LinAlgError -- like
+    scipy.linalg.solve(assume_a='pos') in the reference (src/lib/SolutionsManagers.py:28) -- and the NEXT call on the
+    context, a sweep with perfectly good parameters, raised it again: the device status word was read but not cleared
+    (read_status, csrc/rom_basis_int.h).  A failure is reported once."""
+    SM, RB = api
+    sm = SolutionsManagerFEM_cached(SM, (2, 2), 8)
+    a = 10.0 ** np.random.default_rng(2).uniform(0, 2, size=(6, 2, 2))
+    U = sm.generate_solutions(a)
+    C = np.vstack([U[0], U[1], U[0] + U[1]])          # dependent rows: C A_1 C^T is singular
+    for call in (lambda: sm.project_solutions(U, C), lambda: sm.generate_fm_solutions(a, C)):
+        with pytest.raises(np.linalg.LinAlgError):
+            call()
+        U2 = sm.generate_solutions(a)                 # (raised "interface matrix not positive definite" before the fix)
+        assert np.array_equal(U2, U)
+        P = sm.project_solutions(U, U[:2])
+        assert np.all(np.isfinite(P))
+
+
 def test_pod_awkward_blocks(api):
     """Blocks the sketch passes could stumble over: a mean a million times the variation (the first product of the first
     pass runs on the uncentred block -- its last row is the mean, rom_pod.hip kp_zero_sum_rows), clusters of ten equal
