@@ -39,11 +39,6 @@ __global__ void kb_inv(const double* __restrict__ x, double* __restrict__ out, i
   if (i < n) out[i] = x[i] > 0.0 ? 1.0 / x[i] : 0.0;
 }
 
-// out[i] = lam[i] > 0 ? 1 / sqrt(lam[i]) : 0
-__global__ void kb_inv_sqrt(const double* __restrict__ lam, double* __restrict__ out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = lam[i] > 0.0 ? 1.0 / sqrt(lam[i]) : 0.0;
-}
 
 
 // ---------------------------------------------------------------------------------------------------------------------
