@@ -310,11 +310,22 @@ __global__ __launch_bounds__(256) void kf_small_dots(int na, int nb, int n, cons
   if (pair >= na * nb) return;
   const double* a = A + size_t(pair / nb) * n;
   const double* b = B + size_t(pair % nb) * n;
-  double s = 0.0;
-  for (int c = lane; c < n; c += 64) s += a[c] * b[c];
+  // compensated: the products exactly (fma), the running sum with its rounding error carried along (TwoSum)
+  double s = 0.0, comp = 0.0;
+  for (int c = lane; c < n; c += 64) {
+    const double pr = a[c] * b[c], pe = fma(a[c], b[c], -pr);
+    const double t = s + pr, bb = t - s;
+    comp += ((s - (t - bb)) + (pr - bb)) + pe;
+    s = t;
+  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  if (lane == 0) out[pair] = s;
+  for (int off = 32; off > 0; off >>= 1) {
+    const double os = __shfl_xor(s, off), oc = __shfl_xor(comp, off);
+    const double t = s + os, bb = t - s;
+    comp += ((s - (t - bb)) + (os - bb)) + oc;
+    s = t;
+  }
+  if (lane == 0) out[pair] = s + comp;
 }
 
 // One pass over the residuals: p_m = <R_m, q>, R_m -= p_m q, err2[m] = |R_m|^2 (a sum of squares: exact to rounding).
@@ -357,16 +368,22 @@ __global__ __launch_bounds__(256) void kf_sb_apply(int Kc, const double* __restr
   __shared__ double ws[256];
   const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   const double* S = Sb + size_t(b) * Kc * Kc;
-  double acc = 0.0;
+  double acc = 0.0, comp = 0.0;   // (compensated like kf_small_dots)
   for (int k0 = 0; k0 < Kc; k0 += 256) {
     __syncthreads();
     ws[threadIdx.x] = k0 + int(threadIdx.x) < Kc ? w[k0 + threadIdx.x] : 0.0;
     __syncthreads();
     const int kn = min(256, Kc - k0);
     if (i < Kc)
-      for (int k = 0; k < kn; ++k) acc += S[size_t(k0 + k) * Kc + i] * ws[k];
+      for (int k = 0; k < kn; ++k) {
+        const double x = S[size_t(k0 + k) * Kc + i], y = ws[k];
+        const double pr = x * y, pe = fma(x, y, -pr);
+        const double t = acc + pr, bb = t - acc;
+        comp += ((acc - (t - bb)) + (pr - bb)) + pe;
+        acc = t;
+      }
   }
-  if (i < Kc) T[size_t(b) * Kc + i] = acc;
+  if (i < Kc) T[size_t(b) * Kc + i] = acc + comp;
 }
 
 // equilibrated pivoted Cholesky of the n x n matrix S (blocked, see kf_pivchol_panel): LT (n x n scratch), piv, d on the
@@ -685,7 +702,8 @@ extern "C" int rom_greedy_factored(rom_fem* f, rom_buf* Yc, int64_t c_row0, int 
       ROM_HIP(hipGetLastError());
       kb_grow_ahat<<<unsigned(((j + 1) * k + 255) / 256), 256, 0, ctx->stream>>>(Ahat, k, nb, j, col, d_dead, it - 1);
       ROM_HIP(hipGetLastError());
-      ROM_TRY(rom_launch_rowdot(ctx, wj, 1, Kc, mp->bt, bhat.p() + j));                                               // w_j . B^T B_total
+      kf_small_dots<<<1, 256, 0, ctx->stream>>>(1, 1, Kc, wj, mp->bt, bhat.p() + j);                                      // w_j . B^T B_total (compensated)
+      ROM_HIP(hipGetLastError());
       ROM_TRY(rom_launch_reduced_solve(ctx, j + 1, nb, k, M, Ahat, a->p, bhat, 0, cg));
       kb_galerkin_gap<<<unsigned((M + 255) / 256), 256, 0, ctx->stream>>>(M, j + 1, P, cg, extra);
       ROM_HIP(hipGetLastError());

@@ -161,13 +161,14 @@ class ReducedBasisGreedy(BaseReducedBasis):
         U = _as_device(ctx, solutions2train, dim)  # training set stays in HBM for the whole build
         M = U.rows
         fs = getattr(U, "factored", None)
-        if fs is not None and fs.M == M and (self.greedy_for == GREEDY_FOR_H10 or kwargs.get("galerkin_on_interface_vectors", False)):
-            # A block that sm.generate_solutions_device has just produced carries its interface vectors: the H^1_0 greedy
-            # runs on them (rom_greedy_factored: M x ~300 numbers per pass instead of M x dim; same picks, curves within
-            # 1e-12 of the row path's and 3e-13 of the reference arithmetic's on the same rows: tests/test_gpu_parity.py, C4).  The Galerkin mode
-            # stays on the rows: against the 80-bit truth of the reduced systems (tests/referee.py) its factored form is
-            # 1.2e-9 off at contrast 1e8 where the row form is 1.9e-10 and the reference's own arithmetic 6.5e-10 -- unless the
-            # caller opts in (build(..., galerkin_on_interface_vectors=True): 11.6 ms instead of 65 at C4, n = 50).
+        if fs is not None and fs.M == M and (self.greedy_for == GREEDY_FOR_H10 or kwargs.get("galerkin_on_interface_vectors", True)):
+            # A block that sm.generate_solutions_device has just produced carries its interface vectors: the greedy runs on
+            # them (rom_greedy_factored: M x ~300 numbers per pass instead of M x dim; same picks; H^1_0 curves within 1e-12 of
+            # the row path's and 3e-13 of the reference arithmetic's on the same rows: tests/test_gpu_parity.py, C4).  In
+            # Galerkin mode two exact fp64 routes differ by contrast x eps; against the 80-bit truth of the reduced systems
+            # (tests/referee.py, contrast 1e8) the factored form -- its quadratic forms w_i^T S_b w_j in compensated
+            # arithmetic since round 5 -- is 6.2e-10 off, the reference's own arithmetic 6.5e-10, the row form 1.9e-10:
+            # build(..., galerkin_on_interface_vectors=False) keeps the rows (65 ms instead of 12 at C4, n = 50).
             self.picks, self.max_errors = greedy_factored(fs, a2train, n, self.greedy_for == GREEDY_FOR_GALERKIN,
                                                           solutions2train_h1norm)
             basis = ctx.alloc(max(len(self.picks) * dim, 1)).gather_rows_from(U.buf, np.asarray(self.picks), dim)

@@ -6,6 +6,7 @@ import bench
 from romhighcontrast_amd import _ffi, factored
 from romhighcontrast_amd.lib import ReducedBasis as RB
 from romhighcontrast_amd.lib.SolutionsManagers import SolutionsManagerFEM
+from romhighcontrast_amd.lib import SolutionsManagers as SM_
 blocks, N, M, n = (3, 3), 171, 1024, 50
 sm = SolutionsManagerFEM(blocks, N)
 ctx, fem, dim = sm._ctx, sm._fem, sm.vspace_dim
@@ -19,7 +20,7 @@ fs = factored.FactoredSnapshots(sm, Yf, M)
 for mode in (RB.GREEDY_FOR_H10, RB.GREEDY_FOR_GALERKIN):
     er, ef = [], []
     for rep in range(3):
-        er.append(np.array(RB.ReducedBasisGreedy(mode).build(n, sm, Ud, a, h1).max_errors))
+        er.append(np.array(RB.ReducedBasisGreedy(mode).build(n, sm, SM_.DeviceArray(Ud.buf, M, dim), a, h1).max_errors))   # (a plain block: the row route)
         ef.append(np.array(RB.ReducedBasisGreedy(mode).build(n, sm, fs, a, h1).max_errors))
     print(mode, "rows: calls identical", all(np.array_equal(er[0], e) for e in er), " factored: calls identical", all(np.array_equal(ef[0], e) for e in ef),
           " max |rows - factored|", np.abs(er[0] - ef[0]).max(), "at n =", int(np.argmax(np.abs(er[0] - ef[0]))) + 1,
