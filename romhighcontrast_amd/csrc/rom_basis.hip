@@ -837,7 +837,7 @@ static int jacobi_grid(rom_ctx* ctx, int n, const double* A, int lda, double* la
 int romb_small_eig(rom_ctx* ctx, int n, const double* A, int lda, double* lam, double* T, int ldt, int mode, double rel_tol,
                      bool gram_like) {
   if (n <= 0) return ROM_OK;
-  ROM_CHECK(n <= SE_MAX, "small symmetric eigenproblem: n = %d beyond %d", n, SE_MAX);
+  ROM_CHECK(n <= SE_GRID_MAX, "small symmetric eigenproblem: n = %d beyond %d", n, SE_GRID_MAX);
   if (n > SE_LDS_MAX) return jacobi_grid(ctx, n, A, lda, lam, T, ldt, mode, rel_tol, gram_like);   // (one launch per round, the whole chip)
   const int ld = n | 1, half = (n + (n & 1)) / 2;
   const size_t vec = (2 * size_t(half) + 2 * size_t(n) + 8) * sizeof(double) + (2 * size_t(half) + n + 2) * sizeof(int);

@@ -58,6 +58,9 @@ __global__ void kb_ints_to_doubles(const int* __restrict__ src, double* __restri
 // ---- small dense problems and orthonormalisation helpers of rom_basis.hip, shared with rom_pod.hip ------------------
 enum { SE_EIG = 0, SE_WHITEN = 1, SE_LOWDIN = 2 };
 constexpr int SE_LDS_MAX = 96, SE_MAX = 1024;
+// (the grid-wide Jacobi takes larger orders -- four buffers of n^2 doubles, n launches per sweep: ~1 s at 2048 -- as the
+// whole-matrix fallback of the POD's Gram route; SE_MAX stays the limit of the public entries and of the modes per request)
+constexpr int SE_GRID_MAX = 2048;
 __global__ void kb_rows_axpy(double* __restrict__ out, const double* __restrict__ x, const double* __restrict__ y,
                              const double* __restrict__ f, double s, long long dim);
 int romb_fill_random(rom_ctx* ctx, double* p, size_t n, unsigned long long seed, bool gaussian);

@@ -572,7 +572,7 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
     info.full_eig = 1;
     return ROM_OK;
   };
-  if (M <= SE_MAX && 2 * (nev + oversample) >= M) return full_eig();
+  if (M <= SE_GRID_MAX && 2 * (nev + oversample) >= M) return full_eig();
   const int b0 = std::min(M, nev + oversample);
   int b = b0;  // rows in play: shrinks once the spectrum shows how many pairs the caller can use (see below)
   Tmp Y, Z, H, St, lam, Yr, Zr, Res, res, Zs, scr, nrm;
@@ -592,6 +592,7 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
   std::vector<double> th(2 * size_t(b0), 0.0);
   double best = 1e300, worst = 0.0;
   int stall = 0;
+  std::vector<double> hist;   // the residual after every step
   if (b == M) {
     ROM_TRY(romb_gram_transform(ctx, Y, scr, b, M, SE_WHITEN, 1e-30, 2));  // (the full space: one exact Ritz step below)
   } else {
@@ -632,9 +633,15 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
     // rounding level of the Gram matrix; further out a slow gain is a flat spectrum, (lambda_{b+1} / lambda_k) per step, and
     // the iteration goes on: 300 steps cost less than one diagonalisation of the whole matrix)
     if (worst <= tol || (stall >= 3 && worst <= 1e-10) || it == max_iter - 1) break;
-    // (a matrix that can be diagonalised whole -- 0.3 s at 900 rows -- is not iterated on for long: a dozen steps that have
-    // not brought the residual below 1e-8 mean a flat spectrum)
-    if (M <= SE_MAX && it >= 11 && worst > 1e-8) break;
+    // (a matrix that can be diagonalised whole -- 0.3 s at 900 rows, 0.85 s at 2048 -- is not iterated on in vain: after a dozen
+    // steps the gain per step of the last six says how many more the tolerance would take; more than the budget, or steps that
+    // each diagonalise a block too large for the one-workgroup kernel, and the iteration ends here)
+    hist.push_back(worst);
+    if (M <= SE_GRID_MAX && it >= 11 && worst > 1e-10) {
+      const double rate = std::pow(worst / hist[hist.size() - 7], 1.0 / 6.0);
+      const double more = rate < 1.0 ? std::log(1e-10 / worst) / std::log(rate) : 1e9;
+      if (it + more > max_iter || (b > SE_LDS_MAX && more > 20)) break;
+    }
     // The caller only takes pairs with theta_i > accept * theta_0.  Once a Rayleigh-Ritz step on an orthonormal block
     // has shown how many there can be (two orders of magnitude of slack on the threshold), the block is cut down to
     // those + the oversampling: the rows are Ritz vectors in descending order, so the cut keeps the leading ones.
@@ -651,9 +658,9 @@ int top_eigenpairs(rom_ctx* ctx, const double* G, int M, int nev, double* W, std
   }
   if (b < M && worst > 1e-10) {
     // The iteration ran out of steps far from its tolerance (a spectrum so flat that 300 steps of (lambda_{b+1} / lambda_k)
-    // do not get there: a large block of independent random rows).  Up to SE_MAX rows the whole matrix is diagonalised
+    // do not get there: a large block of independent random rows).  Up to SE_GRID_MAX rows the whole matrix is diagonalised
     // instead; beyond, the caller is told (info.unconverged -> stop reason 2).
-    if (M <= SE_MAX) return full_eig();
+    if (M <= SE_GRID_MAX) return full_eig();
     info.unconverged = 1;
   }
   theta_host.assign(th.begin(), th.begin() + nev);
