@@ -814,7 +814,7 @@ def extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim, factored_to
             rb, t = _timed(ctx, lambda: RB.ReducedBasisGreedy(mode).build(n, sm, Ud_api, a_loc, h1), reps=2)
             rec[f"api_{tag}"] = {"seconds": round(t, 4), "route": "interface vectors" if Ud_api.factored is not None else "rows",
                                  "picks_equal_to_rows": int(sum(p == q for p, q in zip(rb.picks, picks[tag])))}
-        # (the Galerkin greedy kept on the rows by the caller: 1.9e-10 from the 80-bit truth where the factored form is 6.2e-10 and the
+        # (the Galerkin greedy kept on the rows by the caller: 1.9e-10 from the 80-bit truth where the factored form is 4.5e-10 and the
         # reference's arithmetic 6.5e-10)
         rb, t = _timed(ctx, lambda: RB.ReducedBasisGreedy(RB.GREEDY_FOR_GALERKIN).build(n, sm, Ud_api, a_loc, h1, galerkin_on_interface_vectors=False), reps=2)
         rec["api_galerkin_rows"] = {"seconds": round(t, 4), "route": "rows (build(..., galerkin_on_interface_vectors=False))",

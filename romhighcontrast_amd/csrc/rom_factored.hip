@@ -362,29 +362,6 @@ __global__ __launch_bounds__(256) void kf_pass(int k1, double* __restrict__ R, c
   }
 }
 
-// T[b][i] = sum_k Sb[b][k][i] w[k]   (S_b symmetric: the column walk is the coalesced one)
-__global__ __launch_bounds__(256) void kf_sb_apply(int Kc, const double* __restrict__ Sb, const double* __restrict__ w,
-                                                   double* __restrict__ T) {
-  __shared__ double ws[256];
-  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-  const double* S = Sb + size_t(b) * Kc * Kc;
-  double acc = 0.0, comp = 0.0;   // (compensated like kf_small_dots)
-  for (int k0 = 0; k0 < Kc; k0 += 256) {
-    __syncthreads();
-    ws[threadIdx.x] = k0 + int(threadIdx.x) < Kc ? w[k0 + threadIdx.x] : 0.0;
-    __syncthreads();
-    const int kn = min(256, Kc - k0);
-    if (i < Kc)
-      for (int k = 0; k < kn; ++k) {
-        const double x = S[size_t(k0 + k) * Kc + i], y = ws[k];
-        const double pr = x * y, pe = fma(x, y, -pr);
-        const double t = acc + pr, bb = t - acc;
-        comp += ((acc - (t - bb)) + (pr - bb)) + pe;
-        acc = t;
-      }
-  }
-  if (i < Kc) T[size_t(b) * Kc + i] = acc + comp;
-}
 
 // equilibrated pivoted Cholesky of the n x n matrix S (blocked, see kf_pivchol_panel): LT (n x n scratch), piv, d on the
 // device; returns the rank.  No limit on n beyond memory.
@@ -696,7 +673,9 @@ extern "C" int rom_greedy_factored(rom_fem* f, rom_buf* Yc, int64_t c_row0, int 
     ROM_HIP(hipGetLastError());
     if (mode == 1) {
       const double* wj = W.p() + size_t(j) * Kc;
-      kf_sb_apply<<<dim3(unsigned((Kc + 255) / 256), unsigned(k)), 256, 0, ctx->stream>>>(Kc, mp->Sb, wj, T);      // T[b] = S_b w_j
+      // T[b] = S_b w_j: S_b is symmetric, so entry i is the product of ROW i with w_j -- a wave per entry, compensated
+      // (kf_small_dots; the column walk of a thread per entry read the same 43 MB at a third of the rate)
+      kf_small_dots<<<unsigned((k * Kc + 3) / 4), 256, 0, ctx->stream>>>(k * Kc, 1, Kc, mp->Sb, wj, T);
       ROM_HIP(hipGetLastError());
       kf_small_dots<<<unsigned(((j + 1) * k + 3) / 4), 256, 0, ctx->stream>>>(j + 1, k, Kc, W, T, col);                // col[i, b] = w_i . S_b w_j
       ROM_HIP(hipGetLastError());

@@ -167,8 +167,8 @@ class ReducedBasisGreedy(BaseReducedBasis):
             # the row path's and 3e-13 of the reference arithmetic's on the same rows: tests/test_gpu_parity.py, C4).  In
             # Galerkin mode two exact fp64 routes differ by contrast x eps; against the 80-bit truth of the reduced systems
             # (tests/referee.py, contrast 1e8) the factored form -- its quadratic forms w_i^T S_b w_j in compensated
-            # arithmetic since round 5 -- is 6.2e-10 off, the reference's own arithmetic 6.5e-10, the row form 1.9e-10:
-            # build(..., galerkin_on_interface_vectors=False) keeps the rows (65 ms instead of 12 at C4, n = 50).
+            # arithmetic since round 5 -- is 4.5e-10 off, the reference's own arithmetic 6.5e-10, the row form 1.9e-10:
+            # build(..., galerkin_on_interface_vectors=False) keeps the rows (65 ms instead of 8 at C4, n = 50).
             self.picks, self.max_errors = greedy_factored(fs, a2train, n, self.greedy_for == GREEDY_FOR_GALERKIN,
                                                           solutions2train_h1norm)
             basis = ctx.alloc(max(len(self.picks) * dim, 1)).gather_rows_from(U.buf, np.asarray(self.picks), dim)
