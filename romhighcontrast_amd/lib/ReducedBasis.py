@@ -36,6 +36,7 @@ def _orthonormalize_device(ctx: _ffi.Context, X: DeviceArray) -> DeviceArray:
     """Rows of X -> Euclidean-orthonormal rows spanning the same nested subspaces (rom_orthonormalize_rows: device
     CGS2, no host round trip per row)."""
     n, dim = X.rows, X.dim
+    n = min(n, dim)   # (more rows than dimensions: the thin QR of the reference, np.linalg.qr(rb.T) at :19, returns dim of them)
     Q = ctx.alloc(max(n * dim, 1))
     if n:
         ctx.orthonormalize_rows(X.buf, n, dim, Q)

@@ -475,6 +475,18 @@ def test_pod_slow_decay_takes_the_gram_route(api):
     observed("  ... orthonormality of the rows", np.abs(comps @ comps.T - np.eye(n)), 1e-13)
 
 
+def test_orthonormalize_base_more_rows_than_dimensions(api):
+    """(tests/dev/gpu_api_fuzz.py, round 5) The reference's thin QR, np.linalg.qr(rb.T) at src/lib/ReducedBasis.py:19,
+    returns min(rows, dim) orthonormal rows; so does the device call."""
+    SM, RB = api
+    rng = np.random.default_rng(4)
+    C = rng.standard_normal((12, 4))
+    Q, Qo = RB.orthonormalize_base(C), ro.orthonormalize_base(C)
+    assert Q.shape == Qo.shape == (4, 4)
+    sgn = np.sign(np.sum(Q * Qo, axis=1))
+    assert np.abs(Q * sgn[:, None] - Qo).max() < 1e-13
+
+
 def test_a_reported_failure_is_not_reported_again(api):
     """Found by tests/dev/gpu_api_fuzz.py in round 5: a projection onto dependent basis rows raises LinAlgError -- like
     scipy.linalg.solve(assume_a='pos') in the reference (src/lib/SolutionsManagers.py:28) -- and the NEXT call on the
