@@ -824,10 +824,12 @@ int sketch_ahead_take(rom_ctx* ctx, SketchAhead& sa, int b, int seed, bool& hit)
 // Out: Q (b x dim): orthonormal rows spanning the sketch; Rt (b x b): rows = right singular vectors of Q X_d^T in Q's
 // coordinates (mode i = row i of Rt Q); Traw (b x M) = Q X^T, the coefficients of the UNDEFLATED block (mode i's
 // coefficient row X v_i = row i of Rt Traw: the caller's next deflation needs no pass over X); ss_host: b singular values.
-template <class Hook>
+// `pilot` (first pass only; returns true to abandon the pass -- ss_host then comes back empty): called after the first two
+// products with estimates of the sketch's singular values, the pivots of the M-space orthonormalisation.
+template <class Hook, class Pilot>
 int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double* V, const double* Bt, int found, int b, int seed,
                 double* Q, const double* Om_ready, double* Rt, double* Traw, std::vector<double>& ss_host, PodInfo& info,
-                Hook before_rotation, int power = 1) {
+                Hook before_rotation, int power, Pilot pilot) {
   Tmp Om_own, Tt, Cc, Tm, lam, s2;
   if (!Om_ready) ROM_TRY(Om_own.get(ctx, size_t(b) * M));
   const double* Om = Om_ready ? Om_ready : Om_own.p();
@@ -883,6 +885,17 @@ int sketch_pass(rom_ctx* ctx, const double* X, int M, int64_t dim, const double*
     // SKETCH_ACCEPT) is cleaned of the strong directions to eps here, so the second product leaves eps r of them instead of
     // the eps r^3 that limited a pass to four orders of magnitude -- one pass now reaches seven
     ROM_TRY(whiten_rows(ctx, Tdefl, b, M, 1e-26, 1, Tm, lam));
+    if (it == 0) {
+      // (lam: the squared pivots of that orthonormalisation, in pivot order = the squared norms of the coefficient rows with
+      // the stronger rows taken out: sigma_k^2 of the sketch to a small factor, before any power step)
+      std::vector<double> est(b);
+      bool abandon = false;
+      ROM_TRY(pilot(lam, est, abandon));
+      if (abandon) {
+        ss_host.clear();
+        return ROM_OK;
+      }
+    }
     ROM_TRY(rom_launch_gemm_nn(ctx, b, dim, M, 1.0, Tdefl, M, X, dim, 0.0, Q, dim));              // Q X_d^T X_d (Q is rebuilt)
     ROM_TRY(correct_rows(Q, Tdefl));
     info.executed += 2.0 * b * M * double(dim);
@@ -1047,7 +1060,31 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
         return sketch_ahead_start(ctx, ahead, X, M, dim, int(std::min<int64_t>(std::min<int64_t>(M, dim), PASS_MODES + 8)), p + 1);
       return ROM_OK;
     };
-    ROM_TRY(sketch_pass(ctx, X, M, dim, V, Bt, found, b, p, Q, hit ? Om.p() : nullptr, Rt, Traw, ss, info, start_next, power));
+    // The first pass is a PILOT as well: after its first two products the pivots of the M-space orthonormalisation estimate the
+    // sketch's singular values.  If by them NO mode would meet the convergence rule (even without its safety factor) and the
+    // cost model prefers the Gram route, the pass is abandoned there -- its other two products over the block would be wasted
+    // (C5: 15 ms of 380).  A spectrum that decays fast never gets here: one read-back of b numbers.
+    auto pilot = [&](const double* d_lam, std::vector<double>& est, bool& abandon) -> int {
+      abandon = false;
+      if (p != 1 || found != 0 || gram_done || b + found >= std::min<int64_t>(M, dim) - (center ? 1 : 0)) return ROM_OK;
+      const double t_prod = double(M) * double(dim) * 8.0 / 4.5e12 + 30e-6, t_pass = 4.0 * t_prod + 0.5e-3;
+      const double t_gram = double(M) * double(M) * double(dim) / 55e12 + 1.5e-3;
+      if (2.0 * t_prod < 1e-3 || t_gram > 50.0 * t_pass) return ROM_OK;   // (nothing to save / the Gram route is not an option)
+      ROM_TRY(download(ctx, d_lam, est.data(), b));
+      for (double& v : est) v = std::sqrt(std::max(v, 0.0));
+      std::sort(est.begin(), est.end(), std::greater<double>());
+      if (!(est[0] > 0.0)) return ROM_OK;
+      const double rho = est[b - 1] / est[0];
+      abandon = rho * rho * rho > std::max(1e-10, 10.0 * 1.1e-16);   // (the rule of converged_prefix for the STRONGEST mode, no safety factor)
+      return ROM_OK;
+    };
+    ROM_TRY(sketch_pass(ctx, X, M, dim, V, Bt, found, b, p, Q, hit ? Om.p() : nullptr, Rt, Traw, ss, info, start_next, power, pilot));
+    if (ss.empty()) {   // the pilot said: a slowly decaying spectrum
+      gram_done = true;
+      ROM_TRY(gram_route());
+      if (found == 0) break;
+      continue;
+    }
     info.sketch_passes += 1;
     if (found == 0) sigma_1 = ss.empty() ? 0.0 : ss[0];
     int take = 0;
