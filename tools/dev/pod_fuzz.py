@@ -10,7 +10,7 @@ rng = np.random.default_rng(int(os.environ.get("SEED", "0")))
 bad = 0
 for case in range(int(os.environ.get("CASES", "60"))):
     M = int(rng.integers(2, int(os.environ.get("MMAX", "400"))))
-    dim = int(rng.integers(2, 5000))
+    dim = int(rng.integers(2, int(os.environ.get("DMAX", "5000"))))
     r = min(M, dim)
     n = int(rng.integers(1, r + 1)) if rng.random() < 0.3 else int(rng.integers(1, min(r, 60) + 1))
     center = bool(rng.integers(0, 2))
