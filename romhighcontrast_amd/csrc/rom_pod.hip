@@ -405,6 +405,18 @@ __global__ __launch_bounds__(256) void kp_tall_svd(int b, int M, double* __restr
   if (t < b) sig2[t] = L.ev[L.perm[t]];
 }
 
+// out[0] = bits of the largest |x| among the finite entries, out[1] = number of entries that are not finite
+__global__ void kp_block_amax(const double* __restrict__ X, size_t count, unsigned long long* __restrict__ out) {
+  unsigned long long best = 0ull, bad = 0ull;
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < count; i += size_t(gridDim.x) * blockDim.x) {
+    const double v = fabs(X[i]);
+    if (v <= 1.7976931348623157e308) best = max(best, (unsigned long long)__double_as_longlong(v));   // (positive doubles order like their bits)
+    else ++bad;
+  }
+  atomicMax(&out[0], best);
+  if (bad) atomicAdd(&out[1], bad);
+}
+
 // Sketch rows for a block that is still to be centred: rows 0 .. b - 2 of Om (b x M) lose their own mean -- a row with zero
 // sum gives the same product with the block as with its centred rows, Om' X = Om' (X - 1 mu^T), and nothing of the sketch
 // is lost: the columns of the centred block are orthogonal to the vector of ones -- and row b - 1 becomes 1 / M, so that the
@@ -1086,6 +1098,30 @@ extern "C" int rom_pod_ex(rom_ctx* ctx, rom_buf* Xb, int64_t x_row0, int M, int6
       continue;
     }
     info.sketch_passes += 1;
+    if (found == 0 && !gram_done && !(ss[0] > 0.0 && ss[0] <= 1.7976931348623157e308)) {
+      // nothing came out of the first pass.  A block of zeros is one reason (the floor logic below deals with it); the others
+      // are not silent: NaN / Inf entries (scikit-learn's PCA raises on those) and entries so large or small that their
+      // squares leave the range of fp64 -- every inner product of the passes is then Inf or 0.  One more look at the block
+      // tells them apart; no call with a first singular value pays for it.
+      Tmp st;
+      ROM_TRY(st.get(ctx, 2));
+      unsigned long long* d_st = reinterpret_cast<unsigned long long*>(st.p());
+      ROM_HIP(hipMemsetAsync(d_st, 0, 2 * sizeof(unsigned long long), ctx->stream));
+      kp_block_amax<<<1024, 256, 0, ctx->stream>>>(X, size_t(M) * dim, d_st);
+      ROM_HIP(hipGetLastError());
+      unsigned long long h_st[2] = {0, 0};
+      ROM_HIP(hipMemcpyAsync(h_st, d_st, sizeof(h_st), hipMemcpyDeviceToHost, ctx->stream));
+      ROM_HIP(hipStreamSynchronize(ctx->stream));
+      double amax;
+      memcpy(&amax, &h_st[0], sizeof(double));
+      ROM_CHECK(h_st[1] == 0, "rom_pod: the block contains %llu NaN / Inf entries", h_st[1]);
+      ROM_CHECK(amax == 0.0 || (amax < 1e140 && amax > 1e-140),
+                "rom_pod: entries of magnitude %.3g -- their squares leave the range of fp64; rescale the block", amax);
+    }
+    // (the small eigenproblems compare squares of entries of Gram matrices, sigma^4: outside 1e-70 ... 1e70 those leave the
+    // range of fp64 and the rotations stop silently -- LAPACK would rescale; this library says so)
+    ROM_CHECK(found > 0 || gram_done || ss[0] == 0.0 || (ss[0] < 1e70 && ss[0] > 1e-70),
+              "rom_pod: singular values of magnitude %.3g -- their fourth powers leave the range of fp64; rescale the block", ss[0]);
     if (found == 0) sigma_1 = ss.empty() ? 0.0 : ss[0];
     int take = 0;
     while (take < std::min(b, want) && ss[take] > SKETCH_ACCEPT * ss[0] && ss[take] > floor_rel * sigma_1) ++take;

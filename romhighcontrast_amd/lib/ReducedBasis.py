@@ -266,7 +266,12 @@ def pod_modes(ctx: _ffi.Context, X: DeviceArray, n: int, center=True, rel_floor=
     n = min(n, M, dim)
     V = ctx.alloc(max(n * dim, 1))
     X.factored = None  # (the rows are about to be centred in place: they stop being the image of their interface vectors)
-    sig, info = ctx.pod(X.buf, M, dim, n, V, center=center, rel_floor=rel_floor)
+    try:
+        sig, info = ctx.pod(X.buf, M, dim, n, V, center=center, rel_floor=rel_floor)
+    except _ffi.RomLibraryError as e:
+        if "NaN / Inf" in str(e) or "rescale the block" in str(e):   # (scikit-learn's PCA raises ValueError on such input)
+            raise ValueError(str(e)) from None
+        raise
     pod_modes.last_info = info
     pod_modes.resolved = info["resolved_modes"]
     if info["completed_modes"]:

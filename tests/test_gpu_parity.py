@@ -506,6 +506,38 @@ def test_a_reported_failure_is_not_reported_again(api):
         assert np.all(np.isfinite(P))
 
 
+def test_pod_says_so_when_the_block_has_no_svd_in_fp64(api):
+    """NaN / Inf entries (scikit-learn's PCA, src/lib/ReducedBasis.py:196, raises ValueError on those) and entries whose
+    squares leave the range of fp64: rom_pod used to return zeros and 'floor' for them (tools/dev/pod_nan.py, round 5);
+    now the call says what is wrong (LAPACK would rescale such a block; this library asks the caller to).  A block of
+    zeros is still a block of zeros; blocks scaled by 1e60 / 1e-60 work."""
+    SM, RB = api
+    from romhighcontrast_amd import _ffi
+    ctx = _ffi.get_context()
+    rng = np.random.default_rng(0)
+    X0 = rng.standard_normal((60, 900))
+    for bad in (np.nan, np.inf, -np.inf):
+        X = X0.copy()
+        X[3, 7] = bad
+        with pytest.raises(ValueError, match="NaN / Inf"):
+            RB.pod_modes(ctx, SM.DeviceArray(ctx.upload(X), 60, 900), 5)
+    for scale in (1e200, 1e-200):
+        with pytest.raises(ValueError, match="rescale"):
+            RB.pod_modes(ctx, SM.DeviceArray(ctx.upload(X0 * scale), 60, 900), 5, center=False)
+    comps, sig = RB.pod_modes(ctx, SM.DeviceArray(ctx.upload(np.zeros((60, 900))), 60, 900), 5)
+    assert np.all(sig == 0) and np.abs(comps @ comps.T - np.eye(5)).max() < 1e-13
+    sv = np.linalg.svd(X0, compute_uv=False)
+    for scale in (1e100, 1e-100):   # (squares fine, fourth powers not: the small eigenproblems would stop rotating)
+        with pytest.raises(ValueError, match="rescale"):
+            RB.pod_modes(ctx, SM.DeviceArray(ctx.upload(X0 * scale), 60, 900), 5, center=False)
+    for scale in (1e60, 1e-60):
+        comps, sig = RB.pod_modes(ctx, SM.DeviceArray(ctx.upload(X0 * scale), 60, 900), 5, center=False)
+        np.testing.assert_allclose(sig / scale, sv[:5], rtol=1e-9)   # (a flat spectrum: the Gram route, diagonalised whole)
+    # the context is usable afterwards
+    comps, sig = RB.pod_modes(ctx, SM.DeviceArray(ctx.upload(X0), 60, 900), 5, center=False)
+    np.testing.assert_allclose(sig, sv[:5], rtol=1e-9)
+
+
 def test_pod_awkward_blocks(api):
     """Blocks the sketch passes could stumble over: a mean a million times the variation (the first product of the first
     pass runs on the uncentred block -- its last row is the mean, rom_pod.hip kp_zero_sum_rows), clusters of ten equal
