@@ -85,6 +85,9 @@ int rom_host_alloc(size_t n, int pooled_only, double** out);
 int rom_host_free(double* p);
 int rom_buf_fill(rom_buf* b, size_t offset, size_t n, double value);
 int rom_buf_copy(rom_buf* dst, size_t dst_off, rom_buf* src, size_t src_off, size_t n);
+/* *equal_host = 1 if the n doubles A[a_off ...] and B[b_off ...] have the same bits (how the Python layer checks that rows
+ * handed back to it are still the image of the interface vectors it kept for them), else 0 */
+int rom_buf_equal(rom_buf* A, size_t a_off, rom_buf* B, size_t b_off, size_t n, int* equal_host);
 /* dst[i, :] = src[rows[i], :] for row length `dim` (host index list; used by the greedy) */
 int rom_buf_gather_rows(rom_buf* dst, rom_buf* src, const int64_t* rows, int n_rows, size_t dim);
 

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "rom_buf_download": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t]),
     "rom_buf_fill": (C.c_int, [_vp, C.c_size_t, C.c_size_t, C.c_double]),
     "rom_buf_copy": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t]),
+    "rom_buf_equal": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]),
     "rom_buf_gather_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_size_t]),
     "rom_fem_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "rom_fem_destroy": (C.c_int, [_vp]),
@@ -365,6 +366,11 @@ class Buffer:
     def copy_from(self, src: "Buffer", n, dst_off=0, src_off=0):
         check(self.ctx.lib.rom_buf_copy(self.h, dst_off, src.h, src_off, n))
         return self
+
+    def same_bits_as(self, other: "Buffer", n, off=0, other_off=0) -> bool:
+        eq = C.c_int(0)
+        check(self.ctx.lib.rom_buf_equal(self.h, off, other.h, other_off, n, C.byref(eq)))
+        return bool(eq.value)
 
     def gather_rows_from(self, src: "Buffer", rows, dim):
         rows = np.ascontiguousarray(rows, dtype=np.int64)

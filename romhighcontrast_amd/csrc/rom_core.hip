@@ -428,6 +428,34 @@ extern "C" int rom_buf_copy(rom_buf* dst, size_t dst_off, rom_buf* src, size_t s
   return ROM_OK;
 }
 
+// flag <- 1 if any of the n doubles differs in its bits (NaNs with equal bits count as equal: this compares storage)
+__global__ void k_buf_differ(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b, size_t n, int* __restrict__ flag) {
+  bool d = false;
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) d = d || a[i] != b[i];
+  if (d) *flag = 1;
+}
+
+extern "C" int rom_buf_equal(rom_buf* A, size_t a_off, rom_buf* B, size_t b_off, size_t n, int* equal_host) {
+  ROM_CHECK(A && B && equal_host, "rom_buf_equal: null argument");
+  ROM_CHECK(A->ctx == B->ctx, "rom_buf_equal: buffers of different contexts");
+  ROM_CHECK(a_off + n <= A->n && b_off + n <= B->n, "rom_buf_equal: range exceeds buffer");
+  *equal_host = 1;
+  if (n == 0) return ROM_OK;
+  rom_ctx* ctx = A->ctx;
+  int* d_flag = nullptr;
+  ROM_HIP(hipMalloc(&d_flag, sizeof(int)));
+  ROM_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
+  k_buf_differ<<<unsigned(std::min<size_t>((n + 255) / 256, 8192)), 256, 0, ctx->stream>>>(
+      reinterpret_cast<const unsigned long long*>(A->p + a_off), reinterpret_cast<const unsigned long long*>(B->p + b_off), n, d_flag);
+  int differ = 0;
+  hipError_t e = hipMemcpyAsync(&differ, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_flag);
+  ROM_HIP(e);
+  *equal_host = differ ? 0 : 1;
+  return ROM_OK;
+}
+
 extern "C" int rom_buf_gather_rows(rom_buf* dst, rom_buf* src, const int64_t* rows, int n_rows, size_t dim) {
   ROM_CHECK(dst && src && (rows || n_rows == 0), "bad arguments");
   ROM_CHECK(size_t(n_rows) * dim <= dst->n, "rom_buf_gather_rows: destination too small");

@@ -162,6 +162,11 @@ class ReducedBasisGreedy(BaseReducedBasis):
         U = _as_device(ctx, solutions2train, dim)  # training set stays in HBM for the whole build
         M = U.rows
         fs = getattr(U, "factored", None)
+        if fs is None and isinstance(solutions2train, np.ndarray) and hasattr(sm, "factored_of_host_rows"):
+            # the reference's own pattern: solutions = sm.generate_solutions(a) -> a host array -> build(n, sm, solutions, ...).
+            # The manager kept the interface vectors of the arrays it returned; if this is one of them and nobody has written
+            # into it (checked bit for bit on the device), the build runs on them
+            fs = sm.factored_of_host_rows(solutions2train, U)
         if fs is not None and fs.M == M and (self.greedy_for == GREEDY_FOR_H10 or kwargs.get("galerkin_on_interface_vectors", True)):
             # A block that sm.generate_solutions_device has just produced carries its interface vectors: the greedy runs on
             # them (rom_greedy_factored: M x ~300 numbers per pass instead of M x dim; same picks; H^1_0 curves within 1e-12 of

@@ -108,7 +108,30 @@ class SolutionsManager:
         d = dict(self.__dict__)
         d.pop("_fem", None)
         d.pop("_ctx", None)
+        d.pop("_host_blocks", None)
         return d
+
+    # -- host arrays that generate_solutions returned: their interface vectors stay on the device --------------------
+    def _remember_host_block(self, arr, fs):
+        """``arr`` (what generate_solutions is about to return) is the image of the interface vectors ``fs``: remembered by
+        identity (a weak reference; the two most recent blocks), so that a builder handed the same array back can work on
+        the interface vectors -- after checking on the device that the rows still are that image, bit for bit."""
+        import weakref
+        blocks = [b for b in getattr(self, "_host_blocks", []) if b[0]() is not None][-1:]
+        blocks.append((weakref.ref(arr), fs))
+        self._host_blocks = blocks
+
+    def factored_of_host_rows(self, arr, U: "DeviceArray"):
+        """The interface vectors remembered for the host array ``arr`` (uploaded as ``U``) -- None unless ``arr`` IS an array
+        generate_solutions returned and its rows are unchanged (the expansion of the interface vectors and the uploaded rows
+        are compared bit for bit on the device: a caller may have written into the array)."""
+        for ref, fs in getattr(self, "_host_blocks", []):
+            if ref() is arr and fs.M == U.rows and U.dim == self.vspace_dim:
+                Ue = fs.rows()
+                same = Ue.buf.same_bits_as(U.buf, U.rows * U.dim)
+                del Ue
+                return fs if same else None
+        return None
 
     # -- norms ----------------------------------------------------------------------------------------
     def H10norm(self, solutions: Union[List[np.ndarray], DeviceArray]):
@@ -165,7 +188,11 @@ class SolutionsManager:
 
     def generate_solutions(self, a2try):
         """``generate_solutions`` (:64-68): (M, dim) ndarray, row m = A(a_m)^-1 B_total."""
-        return self.generate_solutions_device(a2try).numpy()
+        Ud = self.generate_solutions_device(a2try)
+        arr = Ud.numpy()
+        if Ud.factored is not None:
+            self._remember_host_block(arr, Ud.factored)
+        return arr
 
     def generate_riesz(self, x, norm="h10"):
         """(:70-86) -- l2 branch only, as in the reference (h10 raises there too)."""

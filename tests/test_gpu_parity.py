@@ -487,6 +487,40 @@ def test_orthonormalize_base_more_rows_than_dimensions(api):
     assert np.abs(Q * sgn[:, None] - Qo).max() < 1e-13
 
 
+def test_host_rows_from_generate_solutions_take_the_interface_vector_route(api, monkeypatch):
+    """The reference's own pattern -- solutions = sm.generate_solutions(a) (a host array), then
+    ReducedBasisGreedy(...).build(n, sm, solutions, a, h1), src/lib/ReducedBasis.py:112 -- runs on the interface vectors the
+    manager kept for the array it returned, after a bit-for-bit check on the device that the rows are still their image
+    (rom_buf_equal); an array the caller has written into, a copy, or a slice takes the row route."""
+    SM, RB = api
+    from romhighcontrast_amd import factored
+    sm = SM.SolutionsManagerFEM((2, 2), 24)
+    if not sm._fem.expansion_is_linear:
+        pytest.skip("this geometry does not keep interface vectors")
+    a = 10.0 ** np.random.default_rng(8).uniform(0, 2, size=(40, 2, 2))
+    U = sm.generate_solutions(a)
+    h1 = sm.H10norm(U)
+    calls = []
+    real = factored.greedy_factored
+    monkeypatch.setattr(factored, "greedy_factored", lambda *args, **kw: (calls.append(1), real(*args, **kw))[1])   # (build imports it per call)
+    for mode in (RB.GREEDY_FOR_H10, RB.GREEDY_FOR_GALERKIN):
+        calls.clear()
+        rb_f = RB.ReducedBasisGreedy(mode).build(8, sm, U, a, h1)          # the array generate_solutions returned
+        assert len(calls) == 1, mode
+        rb_c = RB.ReducedBasisGreedy(mode).build(8, sm, U.copy(), a, h1)   # a copy: not that array
+        rb_s = RB.ReducedBasisGreedy(mode).build(8, sm, U[:30], a[:30], h1[:30])   # a slice
+        assert len(calls) == 1, mode
+        assert rb_f.picks == rb_c.picks
+        np.testing.assert_allclose(rb_f.max_errors, rb_c.max_errors, rtol=1e-8, atol=1e-11)
+        assert np.array_equal(rb_f.basis, rb_c.basis)
+    # written into: the check on the device sees it
+    U[3, 5] += 1e-9
+    calls.clear()
+    rb_w = RB.ReducedBasisGreedy(RB.GREEDY_FOR_H10).build(8, sm, U, a, sm.H10norm(U))
+    assert len(calls) == 0
+    assert rb_w.picks[0] == 0
+
+
 def test_a_reported_failure_is_not_reported_again(api):
     """Found by tests/dev/gpu_api_fuzz.py in round 5: a projection onto dependent basis rows raises LinAlgError -- like
     scipy.linalg.solve(assume_a='pos') in the reference (src/lib/SolutionsManagers.py:28) -- and the NEXT call on the
