@@ -820,6 +820,15 @@ def extras_greedy_c4(out, ctx, sm, fem, a_loc, a_dev, U_loc, M, dim, factored_to
         rec["api_galerkin_rows"] = {"seconds": round(t, 4), "route": "rows (build(..., galerkin_on_interface_vectors=False))",
                                     "picks_equal_to_rows": int(sum(p == q for p, q in zip(rb.picks, picks["galerkin"])))}
         del Ud_api
+        # the reference's literal pattern: solutions = sm.generate_solutions(a) -- a HOST array -- then build(n, sm, solutions, a, h1):
+        # the manager kept the interface vectors of the array it returned; build() uploads the rows (PCIe: most of the time below),
+        # checks bit for bit on the device that they are still the image of those vectors and runs on them
+        Uh = sm.generate_solutions(a_loc)
+        for tag, mode in (("h10", RB.GREEDY_FOR_H10), ("galerkin", RB.GREEDY_FOR_GALERKIN)):
+            rb, t = _timed(ctx, lambda: RB.ReducedBasisGreedy(mode).build(n, sm, Uh, a_loc, h1), reps=2)
+            rec[f"api_host_{tag}"] = {"seconds": round(t, 4), "route": "host rows -> upload -> interface vectors (verified on the device)",
+                                      "picks_equal_to_rows": int(sum(p == q for p, q in zip(rb.picks, picks[tag])))}
+        del Uh
         for tag, mode in (("h10", RB.GREEDY_FOR_H10), ("galerkin", RB.GREEDY_FOR_GALERKIN)):
             rb, t = _timed(ctx, lambda: RB.ReducedBasisGreedy(mode).build(n, sm, fs, a_loc, h1), reps=2)
             rec[f"factored_{tag}"] = {"seconds": round(t, 4),
