@@ -1,5 +1,6 @@
 # k_diag_factor with its pivots / solved entries through LDS (new build) against the build before (libromhc_prev.so):
 # bits of the rows, C4 / C5 bench lines alternating (dev tool; logs under gpurun_out/abdf)
+# (libromhc_prev.so: the object of the commit before, linked with the current other objects -- `git show HEAD~:.../rom_fem_kernels.hip`, same flags as the Makefile; not kept in the tree)
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/abdf
