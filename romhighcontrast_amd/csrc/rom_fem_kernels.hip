@@ -780,6 +780,16 @@ __device__ inline void chol_panel_regs(int lane, int c0, double (&v)[4], double&
                   readlane_f64(v[1], c0 + 3), readlane_f64(v[2], c0 + 3), readlane_f64(v[3], c0 + 3));
 }
 
+// A [64][LDC] tile from LDS to a [64][64] tile in HBM, a row (512 B) per store instruction.  In-kernel stamps
+// (tools/dev/gpu_diagf_stamps.py) put each of k_diag_factor's two tile stores at 5-6 k of its cycles: all systems store at the
+// same time, 33 MB in ~2.5 us.  Sixteen LDS reads in flight before the stores: the same; two rows per instruction
+// (16 bytes per lane): 21 k cycles -- four times slower; the rows of L stored panel by panel while the factorisation runs:
+// the same cycles move into the panels (a store instruction holds the wave's issue ~80 cycles wherever it stands).
+// The plain loop it is (profiles/r05_tile_cholesky_probes.txt).
+__device__ inline void tile_rows_to_global(double* __restrict__ dst, const double* Ls, int lane) {
+  for (int i = 0; i < 64; ++i) dst[i * 64 + lane] = Ls[i * LDC + lane];
+}
+
 // Diagonal tile j, steps 2 and 3 in one kernel on the matrix cores (one wave per system, LDS 36 KB: all 1024 systems
 // of a step resident at once):
 //   rank-4 blocked right-looking Cholesky of the tile held in MFMA accumulator layout (the scheme of k_solve1: a
@@ -790,7 +800,17 @@ __device__ inline void chol_panel_regs(int lane, int c0, double (&v)[4], double&
 //   broadcast from LDS), the six blocks below them as  X_ij = -sum_{k=j+1..i} X_ik (L_kj X_jj)  on MFMA.
 // (A column-by-column version on the vector pipe, two kernels, took 2 x 32 us per 1024 systems against 33 us.)
 // (one wave; Ls: 64 * LDC, Pn: 256, rinv: 64 doubles of LDS; the only synchronisation is between the lanes of the wave)
+// (dev build -DROMHC_DIAGF_STAMPS: cycle stamps of the kernel's phases, printed by two of the waves -- tools/dev/gpu_diagf_stamps.py)
+#ifdef ROMHC_DIAGF_STAMPS
+#define DF_STAMP(i) df_stamp[i] = __builtin_readcyclecounter()
+#else
+#define DF_STAMP(i)
+#endif
 __device__ inline void diag_factor_body(const FemDev& f, int m, int slot, int j, double* Ls, double* Pn, double* rinv) {
+#ifdef ROMHC_DIAGF_STAMPS
+  unsigned long long df_stamp[8];
+#endif
+  DF_STAMP(0);
   const int lane = threadIdx.x & 63;
   const int l16 = lane & 15, l4 = lane >> 4;
   double* Lt = f.L + (size_t(m) * f.nslots + slot) * 4096;
@@ -807,6 +827,10 @@ __device__ inline void diag_factor_body(const FemDev& f, int m, int slot, int j,
       }
   double y = f.y[size_t(m) * f.nGp + j * 64 + lane];
   double myrs = 0.0;
+#ifdef ROMHC_DIAGF_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  DF_STAMP(1);
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
     const int jb = p >> 2, co = 4 * (p & 3), c0 = 4 * p;
@@ -837,12 +861,14 @@ __device__ inline void diag_factor_body(const FemDev& f, int m, int slot, int j,
     }
     __builtin_amdgcn_wave_barrier();
   }
+  DF_STAMP(2);
   if (chol_pivots_bad(myrs) && lane == 0) atomicOr(f.status, 1);
   f.y[size_t(m) * f.nGp + j * 64 + lane] = y;
   rinv[lane] = myrs;  // 1 / L[lane][lane]
   __builtin_amdgcn_wave_barrier();
   // L (lower, zero above the diagonal) to HBM, coalesced
-  for (int i = 0; i < 64; ++i) Lt[i * 64 + lane] = Ls[i * LDC + lane];
+  tile_rows_to_global(Lt, Ls, lane);
+  DF_STAMP(3);
   // ---- X = L^-1 in place ----
   // (1) diagonal blocks: lane = (block bi, row r) sweeps the columns c = 15 .. 0 of its block:
   //     X[r][c] = -rinv_c * sum_{k=c+1..r} X[r][k] L[k][c]  (r > c),  X[c][c] = rinv_c
@@ -852,11 +878,18 @@ __device__ inline void diag_factor_body(const FemDev& f, int m, int slot, int j,
     double xr[16];
 #pragma unroll
     for (int c = 15; c >= 0; --c) {
+      // (column c of L is fetched whole, for every lane, before the sums, and the sums run over all k: xr[k] = 0 for k > r, a
+      //  term that adds nothing.  With `if (k <= r)` around each term the compiler emitted a branch, an LDS read and a wait per
+      //  term -- 120 LDS latencies in a row, 14 k of the kernel's 67 k cycles.  Same operations in the same order on the terms
+      //  that count: same bits.)
+      double lc[16];
+#pragma unroll
+      for (int k = c + 1; k < 16; ++k) lc[k] = Lb[k * LDC + c];
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int k = c + 1; k < 16; k += 2) {
-        if (k <= r) s0 += xr[k] * Lb[k * LDC + c];
-        if (k + 1 < 16 && k + 1 <= r) s1 += xr[k + 1] * Lb[(k + 1) * LDC + c];
+        s0 = __builtin_fma(xr[k], lc[k], s0);
+        if (k + 1 < 16) s1 = __builtin_fma(xr[k + 1], lc[k + 1], s1);
       }
       const double rc = rinv[16 * bi + c];
       xr[c] = r == c ? rc : (r > c ? -rc * (s0 + s1) : 0.0);
@@ -866,6 +899,7 @@ __device__ inline void diag_factor_body(const FemDev& f, int m, int slot, int j,
     for (int c = 0; c < 16; c += 2) *reinterpret_cast<double2*>(&Ls[lane * LDC + 16 * bi + c]) = double2{xr[c], xr[c + 1]};
     __builtin_amdgcn_wave_barrier();
   }
+  DF_STAMP(4);
   // (2) blocks below the diagonal, block column jb = 2, 1, 0: W_i = L_i,jb X_jb,jb (in place of L_i,jb), then
   //     X_i,jb = -sum_{k=jb+1..i} X_ik W_k.  Fragments: A(row = l16, k = l4), B(k = l4, col = l16).
 #pragma unroll
@@ -908,9 +942,20 @@ __device__ inline void diag_factor_body(const FemDev& f, int m, int slot, int j,
     __builtin_amdgcn_wave_barrier();
   }
   __builtin_amdgcn_wave_barrier();
+  DF_STAMP(5);
   double* It = f.invL + (size_t(m) * f.T + j) * 4096;
-  for (int i = 0; i < 64; ++i) It[i * 64 + lane] = Ls[i * LDC + lane];
+  tile_rows_to_global(It, Ls, lane);
+  DF_STAMP(6);
+#ifdef ROMHC_DIAGF_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DF_STAMP(7);
+  if (lane == 0 && (m == 0 || m == 513))
+    printf("diagf m %d j %d: load %llu panels %llu store_L %llu inv_diag %llu inv_offdiag %llu store_X_issue %llu store_X_drain %llu total %llu\n", m, j,
+           df_stamp[1] - df_stamp[0], df_stamp[2] - df_stamp[1], df_stamp[3] - df_stamp[2], df_stamp[4] - df_stamp[3],
+           df_stamp[5] - df_stamp[4], df_stamp[6] - df_stamp[5], df_stamp[7] - df_stamp[6], df_stamp[7] - df_stamp[0]);
+#endif
 }
+#undef DF_STAMP
 constexpr int DIAGF_LDS_DOUBLES = 64 * LDC + 64 * 4 + 64;
 __global__ __launch_bounds__(64) void k_diag_factor(FemDev f, int slot, int j) {
   __shared__ __align__(16) double lds[DIAGF_LDS_DOUBLES];
