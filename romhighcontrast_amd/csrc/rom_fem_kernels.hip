@@ -314,6 +314,39 @@ __device__ inline void s_tile_to_lds(double* const (&T)[NS], const TileStream<NS
 }
 
 // T (LDS tile holding S) -= acc
+// The lower triangle of a symmetric 64 x 64 tile as ten 16 x 16 blocks dealt to the four waves 3 / 3 / 2 / 2 (k_diag_update: with
+// the quadrants of `Acc` the wave of the upper-right quadrant idles and two others compute an upper block nobody reads -- 4 / 4 / 4 / 0
+// MFMAs per k-step; the k-loop is two thirds of that kernel and runs at the rate of the matrix pipe, in-kernel stamps,
+// profiles/r05_tile_cholesky_probes.txt).  Wave w, pair p -> block (row block, column block):
+//   w = 0: (0,0) (1,0) (1,1)    w = 1: (2,0) (2,1) (2,2)    w = 2: (3,0) (3,1)    w = 3: (3,2) (3,3)
+// (a wave with two pairs repeats its second one as pair 2: addresses stay valid, the MFMA is skipped)
+// `ws`: the wave's place in that deal = its index.  (Reversed in every other group of 256 workgroups -- workgroups that share a
+// CU are mostly 256 apart in launch order, a SIMD would then hold a 3-block and a 2-block wave instead of two of a kind --
+// measured: no difference at C4, slower at C5; profiles/r05_tile_cholesky_probes.txt)
+struct SymAcc {
+  d4_t c[3];
+  int ws;
+};
+__device__ inline int sym_pairs(int w) { return w < 2 ? 3 : 2; }
+__device__ inline int sym_ib(int w, int p) { return w == 0 ? (p == 0 ? 0 : 1) : w == 1 ? 2 : 3; }
+__device__ inline int sym_jb(int w, int p) { return w == 0 ? (p == 2 ? 1 : 0) : w == 1 ? p : w == 2 ? min(p, 1) : 2 + min(p, 1); }
+__device__ inline void sym_acc_zero(SymAcc& a) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) a.c[p] = d4_t{0.0, 0.0, 0.0, 0.0};
+  a.ws = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+}
+// Cb (lower blocks only) -= acc; the blocks above the diagonal keep what the assembly left there: nobody reads them
+__device__ inline void tile_minus_acc_sym(double* Cb, const SymAcc& acc, const WavePos& wp) {
+  const int w = acc.ws;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    if (p >= sym_pairs(w)) break;
+    const int r0 = 16 * sym_ib(w, p) + (wp.lane >> 4), c = 16 * sym_jb(w, p) + (wp.lane & 15);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) Cb[(r0 + 4 * g) * LDC + c] -= acc.c[p][g];
+  }
+  __syncthreads();
+}
 __device__ inline void tile_minus_acc(double* Cb, const Acc& acc, const WavePos& wp) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -355,8 +388,10 @@ __device__ inline unsigned long long x128_uniform(unsigned long long v) {
 constexpr int TD_SLOT = 2 * 64 * 128;     // bytes
 constexpr int TD_NSLOT = 2;
 constexpr int TD_LDS_BYTES = TD_NSLOT * TD_SLOT;  // 32,768
-template <class FP>
-__device__ inline void accumulate_klist_dma(const FemDev& f, int slot, const double* Lm, FP active, Acc& acc, char* lds,
+// SYM (AccT = SymAcc): the product is a symmetric tile (both operands the same tile pairs), the waves own the lower blocks
+// as dealt by sym_ib / sym_jb; every block sees the same MFMAs in the same order as in the quadrant form: same bits.
+template <bool SYM = false, class FP, class AccT>
+__device__ inline void accumulate_klist_dma(const FemDev& f, int slot, const double* Lm, FP active, AccT& acc, char* lds,
                                             const WavePos& wp) {
   const int e0 = f.kptr[slot], np = f.kptr[slot + 1] - e0;
   const int n = 4 * np;  // chunks
@@ -371,6 +406,19 @@ __device__ inline void accumulate_klist_dma(const FemDev& f, int slot, const dou
     const unsigned uo = unsigned((((2 * kki) ^ (kq >> 1) ^ (fr >> 1)) << 4) + (kq & 1) * 8);
     fa[kki] = unsigned((wp.wr * 32 + fr) * 128) + uo;
     fb[kki] = unsigned(8192 + (wp.wc * 32 + fr) * 128) + uo;
+  }
+  // SYM: block row ib of A at ib * 2048, block column jb of B at 8192 + jb * 2048, + the lane's (fr * 128 + unit) below
+  unsigned ua[4], offA[3], offB[3];
+  int npairs = 0;
+#pragma unroll
+  for (int kki = 0; kki < 4; ++kki) ua[kki] = unsigned(fr * 128) + unsigned((((2 * kki) ^ (kq >> 1) ^ (fr >> 1)) << 4) + (kq & 1) * 8);
+  if constexpr (SYM) {
+    npairs = sym_pairs(acc.ws);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      offA[q] = unsigned(sym_ib(acc.ws, q) * 2048);
+      offB[q] = unsigned(8192 + sym_jb(acc.ws, q) * 2048);
+    }
   }
   // DMA addressing: lane -> row 16 w + 8 q + (lane >> 3) of the tile (512-byte rows), stored unit lane & 7 = logical
   // unit (lane & 7) ^ ((4 q + (lane >> 4)) & 7)
@@ -410,7 +458,31 @@ __device__ inline void accumulate_klist_dma(const FemDev& f, int slot, const dou
     // chunk ch has landed for everybody, and everybody has left the slot of chunk ch - 1 (= that of chunk ch + 1)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (ch + 1 < n) issue(ch + 1, s_nxt);
-    if (active(ch)) {
+    if constexpr (SYM) {
+      if (active(ch)) {
+        const char* sp = lds + s_cur;
+        double af[2][3], bf[2][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          af[0][q] = *reinterpret_cast<const double*>(sp + offA[q] + ua[0]);
+          bf[0][q] = *reinterpret_cast<const double*>(sp + offB[q] + ua[0]);
+        }
+#pragma unroll
+        for (int kki = 0; kki < 4; ++kki) {
+          const int pb = kki & 1;
+          if (kki < 3) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              af[pb ^ 1][q] = *reinterpret_cast<const double*>(sp + offA[q] + ua[kki + 1]);
+              bf[pb ^ 1][q] = *reinterpret_cast<const double*>(sp + offB[q] + ua[kki + 1]);
+            }
+          }
+          acc.c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][0], bf[pb][0], acc.c[0], 0, 0, 0);
+          acc.c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][1], bf[pb][1], acc.c[1], 0, 0, 0);
+          if (npairs > 2) acc.c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[pb][2], bf[pb][2], acc.c[2], 0, 0, 0);
+        }
+      }
+    } else if (active(ch)) {
       const char* sp = lds + s_cur;
       double af[2][2], bf[2][2];
 #pragma unroll
@@ -613,13 +685,13 @@ __device__ inline void diag_update_body(const FemDev& f, const double* __restric
     // straight into their LDS tiles, minus the accumulators, out
     TileStream<NS> ts;
     s_tile_stream_begin<NS>(ts, slot, d, f, am0, nsys);
-    Acc acc[NS];
+    SymAcc acc[NS];  // (the ten lower blocks over the four waves: no idle quadrant)
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-      acc_zero(acc[q]);
+      sym_acc_zero(acc[q]);
       if (q >= nsys) continue;
       if (q > 0) __syncthreads();  // (the previous k-loop's slots)
-      accumulate_klist_dma(f, slot, f.L + size_t(m0 + q) * f.nslots * 4096, [&](int) { return lower; }, acc[q], reinterpret_cast<char*>(lds), wp);
+      accumulate_klist_dma<true>(f, slot, f.L + size_t(m0 + q) * f.nslots * 4096, [](int) { return true; }, acc[q], reinterpret_cast<char*>(lds), wp);
     }
     __syncthreads();
     double* T[NS];
@@ -629,7 +701,7 @@ __device__ inline void diag_update_body(const FemDev& f, const double* __restric
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       if (q >= nsys) break;
-      tile_minus_acc(T[q], acc[q], wp);
+      tile_minus_acc_sym(T[q], acc[q], wp);
       double* Lout = f.L + (size_t(m0 + q) * f.nslots + slot) * 4096;
       for (int idx = threadIdx.x; idx < 4096; idx += 256) Lout[idx] = T[q][(idx >> 6) * LDC + (idx & 63)];
     }
