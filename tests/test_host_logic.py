@@ -547,3 +547,59 @@ def test_plain_c_caller_builds_against_the_header(tmp_path):
     out = r.stdout.decode()
     assert r.returncode == 0 and "libromhc version" in out and "rom_device_count ->" in out, out
 
+
+
+def test_host_array_registry_is_by_identity_and_verified():
+    """`generate_solutions` remembers the interface vectors of the (two most recent) host arrays it returned; a builder handed
+    such an array back gets them only if it IS that array (not a copy) and the uploaded rows still equal their expansion bit
+    for bit.  The bookkeeping is host logic: exercised here with stand-ins for the device objects."""
+    import gc
+    import pickle
+    from romhighcontrast_amd.lib import SolutionsManagers as SM
+
+    class Buf:
+        def __init__(self, same):
+            self.same, self.asked = same, 0
+
+        def same_bits_as(self, other, n):
+            self.asked += 1
+            return self.same
+
+    class Rows:
+        def __init__(self, same):
+            self.buf = Buf(same)
+
+    class Interface:
+        def __init__(self, M, same=True):
+            self.M, self.same, self.expanded = M, same, 0
+
+        def rows(self):
+            self.expanded += 1
+            return Rows(self.same)
+
+    class Uploaded:
+        def __init__(self, rows, dim):
+            self.rows, self.dim, self.buf = rows, dim, object()
+
+    sm = object.__new__(SM.SolutionsManagerFEM)
+    sm.vspace_dim = 9
+    a1, a2, a3 = np.zeros((4, 9)), np.zeros((4, 9)), np.zeros((5, 9))
+    f1, f2, f3 = Interface(4), Interface(4, same=False), Interface(5)
+    assert sm.factored_of_host_rows(a1, Uploaded(4, 9)) is None          # nothing remembered yet
+    sm._remember_host_block(a1, f1)
+    assert sm.factored_of_host_rows(a1, Uploaded(4, 9)) is f1 and f1.expanded == 1
+    assert sm.factored_of_host_rows(a1.copy(), Uploaded(4, 9)) is None   # a copy is not the array
+    assert sm.factored_of_host_rows(a1[:3], Uploaded(3, 9)) is None      # nor is a slice
+    assert sm.factored_of_host_rows(a1, Uploaded(4, 8)) is None          # another space
+    sm._remember_host_block(a2, f2)
+    assert sm.factored_of_host_rows(a2, Uploaded(4, 9)) is None and f2.expanded == 1   # rows were written into: verified, refused
+    assert sm.factored_of_host_rows(a1, Uploaded(4, 9)) is f1            # the one before is still there
+    sm._remember_host_block(a3, f3)
+    assert sm.factored_of_host_rows(a1, Uploaded(4, 9)) is None          # two most recent only
+    assert sm.factored_of_host_rows(a3, Uploaded(5, 9)) is f3
+    del a2
+    gc.collect()
+    sm._remember_host_block(a1, f1)                                      # dead arrays leave the list
+    assert all(ref() is not None for ref, _ in sm._host_blocks) and len(sm._host_blocks) <= 2
+    assert "_host_blocks" not in sm.__getstate__()                       # device state is not pickled
+    pickle.dumps(sm.__getstate__())
